@@ -1,0 +1,131 @@
+"""Oracle (TEST INFRASTRUCTURE): DINOv2 ViT teacher, CPU fp32 restatement.  PARITY UNPINNED.
+
+The reference obtains the teacher with ``torch.hub.load('facebookresearch/dinov2', name)``
+(/root/reference/models/backbones/dinov2.py:20); that dependency is unpinned and absent from
+/root/reference, and fetching it was denied, so this file restates the *published* DINOv2 ViT
+architecture (pre-norm blocks, LayerScale, qkv bias, head_dim 64, GELU MLP x4, LN eps 1e-6, patch 14,
+learned 37x37 position table bicubically resized).  What IS anchored on the reference:
+  * I/O contract of ``DINOv2ViT.forward``  (models/backbones/dinov2.py:27-46): last-layer tokens after the
+    final LayerNorm, CLS dropped, returned as a permuted ``[B,D,P,P]`` *view* of token-major memory.
+  * block re-use on student tokens (train/distillation_module.py:169-177): ``blocks[i]`` maps
+    ``[B,N,D] -> [B,N,D]`` and autograd flows to the input.
+
+Parameter names follow the public DINOv2 checkpoints (``blocks.{i}.attn.qkv.weight`` ...).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# teacher table: /root/reference/train.py:103-108 (embed dims); depth/heads from the published models.
+VIT_CONFIGS = {
+    "dinov2_vits14": dict(embed_dim=384, depth=12, num_heads=6, ffn="mlp"),
+    "dinov2_vitb14": dict(embed_dim=768, depth=12, num_heads=12, ffn="mlp"),
+    "dinov2_vitl14": dict(embed_dim=1024, depth=24, num_heads=16, ffn="mlp"),
+    "dinov2_vitg14": dict(embed_dim=1536, depth=40, num_heads=24, ffn="swiglu"),
+}
+PATCH = 14
+POS_GRID = 37  # 518 // 14: the resolution the published position table is stored at
+
+
+def init_vit_params(cfg, seed=0, depth=None, dtype=torch.float32):
+    """Synthetic teacher weights: trunc-normal(0.02) linears, zero bias,
+    LayerScale 1.0, LN (1, 0).  No pretrained weights are reachable (no network)."""
+    g = torch.Generator().manual_seed(seed)
+    D = cfg["embed_dim"]
+    depth = cfg["depth"] if depth is None else depth
+
+    def tn(*shape):
+        t = torch.empty(*shape, dtype=dtype)
+        torch.nn.init.trunc_normal_(t, std=0.02, generator=g)
+        return t
+
+    p = {
+        "cls_token": tn(1, 1, D),
+        "pos_embed": tn(1, 1 + POS_GRID * POS_GRID, D),
+        "patch_embed.proj.weight": tn(D, 3, PATCH, PATCH),
+        "patch_embed.proj.bias": torch.zeros(D, dtype=dtype),
+        "norm.weight": torch.ones(D, dtype=dtype),
+        "norm.bias": torch.zeros(D, dtype=dtype),
+    }
+    hidden = 4 * D
+    for i in range(depth):
+        b = f"blocks.{i}."
+        p[b + "norm1.weight"] = torch.ones(D, dtype=dtype)
+        p[b + "norm1.bias"] = torch.zeros(D, dtype=dtype)
+        p[b + "attn.qkv.weight"] = tn(3 * D, D)
+        p[b + "attn.qkv.bias"] = torch.zeros(3 * D, dtype=dtype)
+        p[b + "attn.proj.weight"] = tn(D, D)
+        p[b + "attn.proj.bias"] = torch.zeros(D, dtype=dtype)
+        p[b + "ls1.gamma"] = torch.ones(D, dtype=dtype)
+        p[b + "norm2.weight"] = torch.ones(D, dtype=dtype)
+        p[b + "norm2.bias"] = torch.zeros(D, dtype=dtype)
+        p[b + "mlp.fc1.weight"] = tn(hidden, D)
+        p[b + "mlp.fc1.bias"] = torch.zeros(hidden, dtype=dtype)
+        p[b + "mlp.fc2.weight"] = tn(D, hidden)
+        p[b + "mlp.fc2.bias"] = torch.zeros(D, dtype=dtype)
+        p[b + "ls2.gamma"] = torch.ones(D, dtype=dtype)
+    return p
+
+
+def vit_block(p, prefix, x, num_heads, eps=1e-6):
+    """One pre-norm block: x += ls1*proj(MHSA(LN(x))); x += ls2*MLP(LN(x)).
+    Call site in the reference: train/distillation_module.py:177 (``blocks[i](feat)``)."""
+    B, N, D = x.shape
+    hd = D // num_heads
+    y = F.layer_norm(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps)
+    qkv = F.linear(y, p[prefix + "attn.qkv.weight"], p[prefix + "attn.qkv.bias"])
+    qkv = qkv.view(B, N, 3, num_heads, hd)
+    q = qkv[:, :, 0].transpose(1, 2)  # [B,h,N,hd]
+    k = qkv[:, :, 1].transpose(1, 2)
+    v = qkv[:, :, 2].transpose(1, 2)
+    logits = (q * hd ** -0.5) @ k.transpose(-1, -2)
+    ctx = torch.softmax(logits, dim=-1) @ v
+    ctx = ctx.transpose(1, 2).reshape(B, N, D)
+    a = F.linear(ctx, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"])
+    x = x + a * p[prefix + "ls1.gamma"]
+    y = F.layer_norm(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps)
+    m = F.linear(y, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"])
+    m = F.gelu(m)
+    m = F.linear(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"])
+    return x + m * p[prefix + "ls2.gamma"]
+
+
+def resize_pos_table(pos_embed, ph, pw, offset=0.1):
+    """Bicubic resize of the stored 37x37 patch position table to (ph, pw) (published recipe:
+    scale_factor = (P + 0.1) / 37, antialias off).  Identity when the grid already matches."""
+    cls_pos, patch_pos = pos_embed[:, :1], pos_embed[:, 1:]
+    n = patch_pos.shape[1]
+    m = int(math.isqrt(n))
+    if ph * pw == n and ph == pw:
+        return pos_embed
+    D = patch_pos.shape[-1]
+    grid = patch_pos.reshape(1, m, m, D).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=((ph + offset) / m, (pw + offset) / m), mode="bicubic", antialias=False)
+    assert grid.shape[-2:] == (ph, pw)
+    patch_pos = grid.permute(0, 2, 3, 1).reshape(1, ph * pw, D)
+    return torch.cat([cls_pos, patch_pos], dim=1)
+
+
+def vit_tokens(p, x, cfg, depth=None):
+    """Patch-embed + CLS + position + all blocks + final LN; returns [B, 1+P*P, D]."""
+    B, _, H, W = x.shape
+    ph, pw = H // PATCH, W // PATCH
+    depth = cfg["depth"] if depth is None else depth
+    t = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=PATCH)
+    t = t.flatten(2).transpose(1, 2)  # [B, P*P, D]
+    t = torch.cat([p["cls_token"].expand(B, -1, -1), t], dim=1)
+    t = t + resize_pos_table(p["pos_embed"], ph, pw)
+    for i in range(depth):
+        t = vit_block(p, f"blocks.{i}.", t, cfg["num_heads"])
+    return F.layer_norm(t, (t.shape[-1],), p["norm.weight"], p["norm.bias"], 1e-6)
+
+
+def teacher_feature_map(p, x, cfg, depth=None):
+    """``DINOv2ViT.forward`` contract (models/backbones/dinov2.py:32-40): tokens of the last layer
+    (``get_intermediate_layers(n=1, return_class_token=True)`` applies the final norm and strips CLS),
+    reshaped [B,P,P,D] and permuted to [B,D,P,P] without copying."""
+    B, _, H, W = x.shape
+    ph, pw = H // PATCH, W // PATCH
+    tok = vit_tokens(p, x, cfg, depth)[:, 1:]
+    return tok.reshape(B, ph, pw, tok.shape[-1]).permute(0, 3, 1, 2)

@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE's own modules.
+
+Run in the build container only (needs /root/reference; the GPU box has no reference):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is imported from the reference:
+    losses/scalekd.py                  -> ScaleKD, AttentionProjector   (forward + backward)
+    train/distillation_module.py       -> DistillationModule.training_step with stand-in teacher/student
+    models/backbones/convnext.py       -> D2ConvNextV2
+The DINOv2 teacher is NOT imported (external torch.hub dependency, fetch denied): the step fixture uses a
+stand-in teacher whose ``.model.blocks`` are this repo's own oracle ViT blocks with seeded weights.
+
+Packages absent from this image (torchvision, timm, lightning, termcolor) are replaced by minimal stand-in
+modules below; none of them contributes arithmetic on the captured paths (torchvision.resize is only
+referenced by dead code, DropPath is Identity at rate 0, trunc_normal_ is torch's own).
+
+Only data (inputs, weights by state-dict name, outputs, gradients) is written to the .npz files.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+
+def _install_standins():
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+
+    def resize(*a, **k):  # only reachable from dead code (losses/scalekd.py:160)
+        raise RuntimeError("torchvision stand-in: resize is not available")
+
+    tvf.resize = resize
+    tv.transforms = tvt
+    tvt.functional = tvf
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+
+    timm = types.ModuleType("timm")
+    tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers")
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            assert p == 0.0
+
+        def forward(self, x):
+            return x
+
+    tl.DropPath = DropPath
+    tl.trunc_normal_ = torch.nn.init.trunc_normal_
+    tl.to_2tuple = lambda v: (v, v) if not isinstance(v, (tuple, list)) else tuple(v)
+    timm.models = tm
+    tm.layers = tl
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl})
+
+    lightning = types.ModuleType("lightning")
+
+    class LightningModule(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.logged = {}
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, name, value, **k):
+            self.logged[name] = float(value.detach()) if torch.is_tensor(value) else float(value)
+
+        def optimizers(self):
+            return types.SimpleNamespace(param_groups=[{"lr": 1e-3}])
+
+    lightning.LightningModule = LightningModule
+    sys.modules["lightning"] = lightning
+
+    tc = types.ModuleType("termcolor")
+    tc.colored = lambda s, *a, **k: s
+    sys.modules["termcolor"] = tc
+
+
+_install_standins()
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float32) if t.dtype.is_floating_point else t.detach().cpu().numpy()
+
+
+def _save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}: {len(arrays)} arrays, {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def _load_file(modname, relpath):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_scalekd():
+    skd = _load_file("ref_scalekd", "losses/scalekd.py")
+    cases = {
+        # name: (student_dims, teacher_dims, P, heads, self_query, window, with_queries)
+        "scalekd_selfq": (40, 48, 4, 6, True, (1, 1), False),
+        "scalekd_extq": (24, 48, 4, 4, False, (1, 1), True),
+        "scalekd_win22": (24, 32, 4, 4, True, (2, 2), False),
+        "scalekd_p6": (16, 32, 6, 2, True, (1, 1), False),
+    }
+    for idx, (name, (cs, d, P, heads, selfq, win, withq)) in enumerate(cases.items()):
+        torch.manual_seed(7 + idx)
+        m = skd.ScaleKD(name="scalekd_res5", alpha=[0.08, 0.06], student_dims=cs, teacher_dims=d,
+                        query_hw=[P, P], pos_hw=[P, P], pos_dims=d, window_shapes=win, self_query=selfq,
+                        softmax_scale=[5.0, 5.0], num_heads=heads)
+        m.train()
+        # make every parameter non-trivial (LN/BN affine default to 1/0, biases to small values)
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if p_.dim() == 1:
+                    p_.add_(0.1 * torch.randn_like(p_))
+        B = 3
+        arrays = {}
+        for k, v in m.state_dict().items():
+            arrays["param/" + k] = _np(v)
+        x = torch.randn(B, cs, P, P, requires_grad=True)
+        t = torch.randn(B, d, P, P)
+        qs = qf = None
+        if withq:
+            qs = torch.randn(B, P * P, d, requires_grad=True)
+            qf = torch.randn(B, P * P, d, requires_grad=True)
+        out = m(x, t, query_s=qs, query_f=qf)
+        out["loss"].backward()
+        arrays["in/preds_S"] = _np(x)
+        arrays["in/preds_T"] = _np(t)
+        if withq:
+            arrays["in/query_s"], arrays["in/query_f"] = _np(qs), _np(qf)
+            arrays["grad/query_s"], arrays["grad/query_f"] = _np(qs.grad), _np(qf.grad)
+        for k, v in out.items():
+            arrays["out/" + k] = _np(v)
+        arrays["grad/preds_S"] = _np(x.grad)
+        for k, p_ in m.named_parameters():
+            arrays["pgrad/" + k] = _np(p_.grad)
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                arrays["after/" + k] = _np(v)
+        arrays["meta"] = np.array([cs, d, P, heads, int(selfq), win[0], win[1], B], dtype=np.int64)
+        # projector tokens on their own (pins AttentionProjector.forward)
+        with torch.no_grad():
+            m2 = skd.ScaleKD(name="x", alpha=[0.08, 0.06], student_dims=cs, teacher_dims=d, query_hw=[P, P],
+                             pos_hw=[P, P], pos_dims=d, window_shapes=win, self_query=selfq,
+                             softmax_scale=[5.0, 5.0], num_heads=heads)
+            m2.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in arrays.items() if k.startswith("param/")})
+            m2.train()
+            arrays["out/tokens_spat"] = _np(m2.project_feat_spat(x, query=qs))
+        _save(name, **arrays)
+
+
+def gen_loss_tail():
+    skd = _load_file("ref_scalekd", "losses/scalekd.py")
+    m = skd.ScaleKD(name="x", alpha=[0.08, 0.06], student_dims=8, teacher_dims=8, query_hw=[2, 2], pos_hw=[2, 2],
+                    pos_dims=8, num_heads=2)
+    for P, C, B in ((16, 24, 2), (37, 8, 2), (5, 16, 3)):
+        torch.manual_seed(100 + P)
+        s = torch.randn(B, P * P, C, requires_grad=True)
+        t = torch.randn(B, C, P, P) + 0.3
+        arrays = {"in/tok_s": _np(s), "in/feat_t": _np(t)}
+        ls, ss = m.get_spat_loss(s, t)
+        ls.backward()
+        arrays["out/spat_loss"], arrays["out/spat_sim"], arrays["grad/spat"] = _np(ls), _np(ss), _np(s.grad)
+        s.grad = None
+        lf, sf = m.get_freq_loss(s, t)
+        lf.backward()
+        arrays["out/freq_loss"], arrays["out/freq_sim"], arrays["grad/freq"] = _np(lf), _np(sf), _np(s.grad)
+        _save(f"loss_tail_p{P}", **arrays)
+
+
+def gen_convnext():
+    cn = _load_file("ref_convnext", "models/backbones/convnext.py")
+    torch.manual_seed(11)
+    depths, dims = [1, 1, 2, 1], [8, 16, 32, 64]
+    net = cn.D2ConvNextV2(depths=depths, embed_dims=dims, drop_path_rate=0.0, out_features=["res4", "res5"])
+    net.train()
+    with torch.no_grad():  # reference init leaves GRN gamma/beta and all biases at zero: perturb so they matter
+        for n_, p_ in net.named_parameters():
+            if "grn" in n_ or p_.dim() == 1:
+                p_.add_(0.2 * torch.randn_like(p_))
+            else:
+                p_.mul_(8.0)
+    x = torch.randn(2, 3, 64, 64, requires_grad=True)
+    feats = net.forward_features(x)
+    arrays = {"in/x": _np(x), "meta/depths": np.array(depths), "meta/dims": np.array(dims)}
+    for k, v in net.state_dict().items():
+        arrays["param/" + k] = _np(v)
+    loss = 0
+    for k in ("res2", "res3", "res4", "res5"):
+        arrays["out/" + k] = _np(feats[k])
+    P = (5, 5)  # ModelWrapper resize (models/model_zoo.py:123-128)
+    for k in ("res4", "res5"):
+        r = torch.nn.functional.interpolate(feats[k], size=P, mode="bilinear", align_corners=False)
+        ct = torch.randn_like(r)
+        arrays["out/resized_" + k] = _np(r)
+        arrays["in/cotangent_" + k] = _np(ct)
+        loss = loss + (r * ct).sum()
+    loss.backward()
+    arrays["grad/x"] = _np(x.grad)
+    for k, p_ in net.named_parameters():
+        arrays["pgrad/" + k] = _np(p_.grad)
+    _save("convnext_small", **arrays)
+
+
+def gen_step():
+    """DistillationModule.training_step (train/distillation_module.py:247-276) with stand-ins."""
+    from oracle import vit_oracle as vit
+    import train.distillation_module as dm  # the reference's module (imports reference losses/ and utils/)
+
+    D, heads, depth, P = 48, 3, 12, 4
+    c4, c5, B = 24, 40, 2
+    torch.manual_seed(5)
+    tcfg = dict(embed_dim=D, depth=depth, num_heads=heads)
+    tp = vit.init_vit_params(tcfg, seed=3)
+    with torch.no_grad():
+        for k in tp:  # non-trivial LayerScale/bias so the block arithmetic is exercised
+            if k.endswith("gamma"):
+                tp[k] = 0.5 + torch.rand_like(tp[k])
+            elif k.endswith("bias"):
+                tp[k] = 0.05 * torch.randn_like(tp[k])
+            elif k.endswith("weight") and tp[k].dim() == 2:
+                tp[k] = tp[k] * 5
+
+    class Blk(nn.Module):
+        def __init__(self, i):
+            super().__init__()
+            self.i = i
+
+        def forward(self, x):
+            return vit.vit_block(tp, f"blocks.{self.i}.", x, heads)
+
+    feat_t = torch.randn(B, P * P, D).reshape(B, P, P, D).permute(0, 3, 1, 2)
+
+    class Teacher(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = nn.Module()
+            self.model.blocks = nn.ModuleList([Blk(i) for i in range(depth)])
+
+        def forward(self, x):
+            return {"feature_map": feat_t}
+
+    s4 = torch.randn(B, c4, P, P, requires_grad=True)
+    s5 = torch.randn(B, c5, P, P, requires_grad=True)
+
+    class Student(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = types.SimpleNamespace(ckpt_dir="unused.pth")
+
+        def forward(self, x):
+            return {"res4": s4, "res5": s5}
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    def loss_spec(name, heads_, selfq, cs):
+        return Cfg(type="scalekd", weight=1.0 if name.endswith("5") else 0.7, kwargs=Cfg(
+            alpha=[0.08, 0.06], window_shapes=[1, 1], self_query=selfq, softmax_scale=[5.0, 5.0],
+            num_heads=heads_, name=name, teacher_dims=D, pos_dims=D, pos_hw=[P, P], query_hw=[P, P], student_dims=cs))
+
+    cfg = Cfg(student=Cfg(model_name="convnext_tiny", checkpoint_path=None),
+              teacher=Cfg(model_name="dinov2_vits14", teacher_key="feature_map"),
+              loss=Cfg(losses=[loss_spec("scalekd_res4", 4, True, c4), loss_spec("scalekd_res5", 6, False, c5)]),
+              optimizer=Cfg(type="AdamW", kwargs=Cfg(lr=1e-3)))
+    dm.DistillationModule._load_student_checkpoint = lambda self, path: None  # no checkpoint files exist
+    mod = dm.DistillationModule(student=Student(), teacher=Teacher(), cfg=cfg)
+    mod.train()
+    mod.teacher.eval()
+    with torch.no_grad():
+        for n_, p_ in mod.losses.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    arrays = {}
+    for k, v in mod.losses.state_dict().items():
+        arrays["param/" + k] = _np(v)
+    for k, v in tp.items():
+        if k.startswith("blocks.9.") or k.startswith("blocks.10."):
+            arrays["teacher/" + k] = _np(v)
+    loss = mod.training_step(torch.zeros(B, 3, 56, 56), 0)
+    loss.backward()
+    for k, v in mod.logged.items():
+        arrays["log/" + k] = np.float32(v)
+    arrays["in/res4"], arrays["in/res5"], arrays["in/feat_t"] = _np(s4), _np(s5), _np(feat_t)
+    arrays["grad/res4"], arrays["grad/res5"] = _np(s4.grad), _np(s5.grad)
+    for k, p_ in mod.losses.named_parameters():
+        arrays["pgrad/" + k] = _np(p_.grad)
+    arrays["meta"] = np.array([D, heads, depth, P, c4, c5, B], dtype=np.int64)
+    _save("step_res45", **arrays)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "step"]
+    for w in which:
+        globals()["gen_" + w]()

@@ -1,0 +1,147 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors captured from the reference's own modules
+(tests/golden/make_golden.py).  This is what PINS the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import convnext_oracle as cno
+from oracle import scalekd_oracle as skd
+from oracle import step_oracle as so
+
+TOL = dict(rtol=2e-4, atol=2e-6)
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def params_of(g, prefix="param/", add_prefix=""):
+    return {add_prefix + k[len(prefix):]: v.clone() for k, v in g.items() if k.startswith(prefix)}
+
+
+def close(a, b, what, rtol=2e-4, atol=2e-6):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * scale, f"{what}: max|diff|={err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("name", ["scalekd_selfq", "scalekd_extq", "scalekd_win22", "scalekd_p6"])
+def test_scalekd_forward_backward(golden_dir, name):
+    g = load(golden_dir, name)
+    cs, d, P, heads, selfq, wh, ww, B = [int(v) for v in g["meta"]]
+    p = params_of(g, add_prefix="L.")
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = g["in/preds_S"].clone().requires_grad_(True)
+    qs = g["in/query_s"].clone().requires_grad_(True) if "in/query_s" in g else None
+    qf = g["in/query_f"].clone().requires_grad_(True) if "in/query_f" in g else None
+    cfg = dict(alpha=[0.08, 0.06], hw=(P, P), num_heads=heads, softmax_scale=[5.0, 5.0], window_shapes=(wh, ww))
+    tok = skd.attention_projector({k: v.detach().clone() for k, v in p.items()}, "L.projector_0.", x.detach(),
+                                  None if qs is None else qs.detach(), (P, P), heads, 5.0, (wh, ww))
+    close(tok, g["out/tokens_spat"], "projector tokens")
+    out = skd.scalekd_forward(p, "L.", x, g["in/preds_T"], cfg, qs, qf, training=True)
+    for k in ("spatial_loss", "frequency_loss", "spatial_similarity", "frequency_similarity", "loss"):
+        close(out[k], g["out/" + k], k)
+    out["loss"].backward()
+    close(x.grad, g["grad/preds_S"], "grad preds_S")
+    if qs is not None:
+        close(qs.grad, g["grad/query_s"], "grad query_s")
+        close(qf.grad, g["grad/query_f"], "grad query_f")
+    for k, v in g.items():
+        if k.startswith("pgrad/"):
+            close(p["L." + k[6:]].grad, v, k)
+        if k.startswith("after/") and "num_batches" not in k:
+            close(p["L." + k[6:]], v, k)
+
+
+@pytest.mark.parametrize("P", [16, 37, 5])
+def test_loss_tails(golden_dir, P):
+    g = load(golden_dir, f"loss_tail_p{P}")
+    s = g["in/tok_s"].clone().requires_grad_(True)
+    t = g["in/feat_t"]
+    l, sim = skd.spat_loss(s, t, 0.08)
+    close(l, g["out/spat_loss"], "spat loss")
+    close(sim, g["out/spat_sim"], "spat sim")
+    l.backward()
+    close(s.grad, g["grad/spat"], "spat grad")
+    s.grad = None
+    l, sim = skd.freq_loss(s, t, 0.06)
+    close(l, g["out/freq_loss"], "freq loss")
+    close(sim, g["out/freq_sim"], "freq sim", atol=2e-5)
+    l.backward()
+    close(s.grad, g["grad/freq"], "freq grad")
+
+
+def test_freq_loss_is_spatial_mean_removal(golden_dir):
+    """DCT -> zero DC -> IDCT == subtracting each (n,c) map's spatial mean.  The HIP kernel relies
+    on this identity, so pin it on the oracle's own DCT restatement."""
+    torch.manual_seed(0)
+    for P in (16, 37):
+        m = torch.randn(2, 6, P, P)
+        close(skd.drop_dc(m), m - m.mean(dim=(-1, -2), keepdim=True), f"drop_dc P={P}", atol=5e-6)
+
+
+def test_convnext(golden_dir):
+    g = load(golden_dir, "convnext_small")
+    depths = [int(v) for v in g["meta/depths"]]
+    p = params_of(g)
+    for v in p.values():
+        v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = cno.forward_features(p, x, depths)
+    for k in ("res2", "res3", "res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+    loss = 0
+    for k in ("res4", "res5"):
+        r = torch.nn.functional.interpolate(feats[k], size=(5, 5), mode="bilinear", align_corners=False)
+        close(r, g["out/resized_" + k], "resized " + k)
+        loss = loss + (r * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x")
+    for k, v in g.items():
+        if k.startswith("pgrad/"):
+            close(p[k[6:]].grad, v, k, rtol=5e-4)
+
+
+def test_step_compute_losses(golden_dir):
+    g = load(golden_dir, "step_res45")
+    D, heads, depth, P, c4, c5, B = [int(v) for v in g["meta"]]
+    lp = params_of(g)
+    for k, v in lp.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    tp = params_of(g, "teacher/")
+    s4 = g["in/res4"].clone().requires_grad_(True)
+    s5 = g["in/res5"].clone().requires_grad_(True)
+    cfgs = {
+        "scalekd_res4": dict(alpha=[0.08, 0.06], hw=(P, P), num_heads=4, softmax_scale=[5.0, 5.0]),
+        "scalekd_res5": dict(alpha=[0.08, 0.06], hw=(P, P), num_heads=6, softmax_scale=[5.0, 5.0]),
+    }
+    w = {"scalekd_res4": 0.7, "scalekd_res5": 1.0}
+    out = so.compute_losses(lp, cfgs, w, {"res4": s4, "res5": s5}, g["in/feat_t"], tp, depth, heads)
+    n_checked = 0
+    for k, v in g.items():
+        if k.startswith("log/train_"):
+            close(out[k[len("log/train_"):]], v, k, rtol=3e-4)
+            n_checked += 1
+    assert n_checked == 11
+    out["loss"].backward()
+    close(s4.grad, g["grad/res4"], "grad res4", rtol=5e-4)
+    close(s5.grad, g["grad/res5"], "grad res5", rtol=5e-4)
+    for k, v in g.items():
+        if k.startswith("pgrad/"):
+            close(lp[k[6:]].grad, v, k, rtol=5e-4)
+
+
+def test_stage_block_range():
+    assert list(so.stage_block_range(12, "res4")) == [9, 10]
+    assert list(so.stage_block_range(24, "res4")) == [18, 19, 20, 21, 22]
+    assert list(so.stage_block_range(40, "res4")) == list(range(30, 39))
+    for n in (12, 24, 40):
+        assert list(so.stage_block_range(n, "res2")) == []
+        assert list(so.stage_block_range(n, "res3")) == []
