@@ -1,0 +1,110 @@
+"""ctypes binding of libdkd_hip.so, generated from include/dkd_hip.h at import time.
+
+The header is the single source of truth for the C ABI: prototypes and argument structs are parsed from it, so the
+Python side can never drift from what the library exports.  There is NO fallback: if the library is missing or a
+call fails, a RuntimeError is raised (the product path must fail loudly without the HIP extension).
+"""
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(_ROOT, "include", "dkd_hip.h")
+LIB_PATH = os.path.join(_PKG, "lib", "libdkd_hip.so")
+
+_SCALARS = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "int32_t": ctypes.c_int32,
+    "int64_t": ctypes.c_int64, "void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "constfloat*": ctypes.c_void_p,
+    "constvoid*": ctypes.c_void_p,
+}
+
+
+def _strip_comments(src):
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
+def parse_header(path=HEADER):
+    """-> (structs: {name: [(field, ctype)]}, funcs: {name: (restype, [(argname, ctype_or_structname)])}, defines)"""
+    src = _strip_comments(open(path).read())
+    defines = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(DKD_\w+)\s+(-?\d+)\s*$", src, flags=re.M)}
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            mm = re.match(r"((?:const\s+)?\w+)\s*(.*)", decl)
+            base, rest = mm.group(1), mm.group(2)
+            for d in rest.split(","):
+                d = d.strip()
+                ptr = d.startswith("*")
+                name = d.lstrip("* ")
+                key = (base.replace(" ", "") + ("*" if ptr else ""))
+                fields.append((name, _SCALARS[key]))
+        structs[m.group(3)] = fields
+    funcs = {}
+    body = re.sub(r"typedef\s+struct.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    for m in re.finditer(r"^\s*(int|long)\s+(dkd_\w+)\s*\((.*?)\)\s*;", body, flags=re.S | re.M):
+        args = []
+        argstr = m.group(3).strip()
+        if argstr and argstr != "void":
+            for a in argstr.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                ty, name = mm.group(1).replace(" ", ""), mm.group(2)
+                if ty.endswith("_args*"):
+                    args.append((name, ty.replace("const", "").rstrip("*")))
+                else:
+                    args.append((name, _SCALARS[ty]))
+        funcs[m.group(2)] = (ctypes.c_int if m.group(1) == "int" else ctypes.c_long, args)
+    return structs, funcs, defines
+
+
+_STRUCT_DEFS, _FUNC_DEFS, DEFINES = parse_header()
+
+
+def _make_struct(name, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
+STRUCTS = {n: _make_struct(n, f) for n, f in _STRUCT_DEFS.items()}
+GemmArgs = STRUCTS["dkd_gemm_args"]
+AttnArgs = STRUCTS["dkd_attn_args"]
+
+_lib = None
+
+
+class DkdError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DkdError(f"{LIB_PATH} is missing: build it with `python -m dinov2_distillation_amd.build` "
+                       "(there is no CPU fallback for the distillation step)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, args) in _FUNC_DEFS.items():
+        fn = getattr(lib, name)  # AttributeError if the header declares something the library lacks
+        fn.restype = restype
+        fn.argtypes = [ctypes.POINTER(STRUCTS[t]) if isinstance(t, str) else t for _, t in args]
+    if lib.dkd_abi_version() != DEFINES["DKD_ABI_VERSION"]:
+        raise DkdError("libdkd_hip.so ABI version does not match include/dkd_hip.h - rebuild")
+    _lib = lib
+    return lib
+
+
+def declared_functions():
+    return dict(_FUNC_DEFS)
+
+
+_ERRS = {-1: "DKD_ERR_BAD_ARG", -2: "DKD_ERR_ALIGN", -3: "DKD_ERR_UNSUPPORTED"}
+
+
+def check(code, what):
+    if code != 0:
+        raise DkdError(f"{what} failed: {_ERRS.get(code, 'hipError_t ' + str(code))}")

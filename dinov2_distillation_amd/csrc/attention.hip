@@ -1,0 +1,355 @@
+// Flash-style multi-head attention in exact fp32 on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), forward and
+// backward, for (i) the DINOv2 teacher blocks (head_dim 64, N = P*P+1 tokens; dgrad-only reuse on student tokens,
+// train/distillation_module.py:176-177) and (ii) the ScaleKD cross-attention of positional queries over student
+// tokens (losses/scalekd.py:299-316; head_dim = D/num_heads = 16/24/32/48...).
+//
+// Formulation ("everything transposed", so nothing ever crosses lanes or LDS between the two products):
+//   S^T = K Q^T     A = K tile from LDS (key on lane), B = Q fragment in registers -> lane (half,q) holds 16 keys
+//   softmax over keys: 15 in-lane max/add + one lane^32 exchange (the query sits on the lane)
+//   O^T += V^T P^T  A = V tile from LDS (d on lane, key picked per register), B = the S^T accumulator registers AS
+//                   THEY ARE (register r of lane (half,q) is P[q][key(r,half)], key(r,h) = (r&3)+8(r>>2)+4h)
+// The backward kernels reuse the same trick: dQ^T += K^T dS^T (queries resident, keys streamed) and
+// dK^T += Q^T dS, dV^T += dO^T P (keys resident, queries streamed): no atomics, deterministic.
+// k-index convention for the 32x32x2 products over head_dim: lane half h covers d in [h*HD/2, (h+1)*HD/2).
+#include "common.h"
+#include "dkd_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int HD>
+struct Cfg {
+    static constexpr int DCH = (HD + 31) / 32;   // 32-wide output chunks along head_dim
+    static constexpr int HDP = DCH * 32;          // padded head_dim (zero filled)
+    static constexpr int LDW = HDP + 1;           // odd row stride: column reads are conflict-free
+    static constexpr int KH = HD / 2;             // k-steps per lane half
+    static_assert(HD % 8 == 0, "head_dim must be a multiple of 8");
+};
+
+// Cooperative copy of a [32 x HD] tile (rows row0.., global row stride rs) into LDS [32][LDW]; rows >= nrows -> 0.
+template <int HD, int NT>
+__device__ __forceinline__ void stage_tile(float* __restrict__ S, const float* __restrict__ base, long rs, int row0,
+                                           int nrows, int tid) {
+    constexpr int LDW = Cfg<HD>::LDW, V4 = HD / 4;
+    for (int idx = tid; idx < 32 * V4; idx += NT) {
+        const int r = idx / V4, c4 = idx % V4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < nrows) x = *reinterpret_cast<const float4*>(base + (long)(row0 + r) * rs + 4 * c4);
+        float* d = S + r * LDW + 4 * c4;
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+    }
+}
+template <int HD, int NT>
+__device__ __forceinline__ void zero_pad_cols(float* __restrict__ S, int tid) {
+    constexpr int LDW = Cfg<HD>::LDW, HDP = Cfg<HD>::HDP;
+    if (HDP > HD)
+        for (int idx = tid; idx < 32 * (HDP - HD); idx += NT) S[(idx / (HDP - HD)) * LDW + HD + idx % (HDP - HD)] = 0.f;
+}
+
+// load this lane's B-operand fragment of row `row` (HD/2 contiguous floats starting at half*HD/2), scaled
+template <int HD>
+__device__ __forceinline__ void load_frag(float (&f)[HD / 2], const float* __restrict__ base, long rs, int row, int nrows,
+                                          int half, float scale) {
+    constexpr int KH = HD / 2;
+    if (row < nrows) {
+        const float4* p = reinterpret_cast<const float4*>(base + (long)row * rs + half * KH);
+#pragma unroll
+        for (int i = 0; i < KH / 4; ++i) {
+            const float4 x = p[i];
+            f[4 * i + 0] = x.x * scale; f[4 * i + 1] = x.y * scale; f[4 * i + 2] = x.z * scale; f[4 * i + 3] = x.w * scale;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KH; ++i) f[i] = 0.f;
+    }
+}
+
+// acc[r] (lane (half, j)) = sum_d T[lane&31][d] * frag_j[d]   : "column" product, T tile in LDS, frag in registers
+template <int HD>
+__device__ __forceinline__ f32x16 tile_times_frag(const float* __restrict__ T, const float (&f)[HD / 2], int l31, int half) {
+    constexpr int LDW = Cfg<HD>::LDW, KH = HD / 2;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* row = T + l31 * LDW + half * KH;
+#pragma unroll
+    for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(row[s], f[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// out[c] += T^T(chunk c) * P : A = T[frag_row(r,half)][32c + lane&31], B = p[r]
+template <int HD>
+__device__ __forceinline__ void tileT_times_regs(f32x16 (&out)[Cfg<HD>::DCH], const float* __restrict__ T,
+                                                 const f32x16& p, int l31, int half) {
+    constexpr int LDW = Cfg<HD>::LDW, DCH = Cfg<HD>::DCH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* row = T + frag_row(r, half) * LDW + l31;
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) out[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32 * c], p[r], out[c], 0, 0, 0);
+    }
+}
+
+// store a transposed accumulator (rows = d, cols = token on lane) to X[token][head_off + d]
+template <int HD>
+__device__ __forceinline__ void store_T(const f32x16 (&acc)[Cfg<HD>::DCH], float* __restrict__ base, long rs, int tok,
+                                        int ntok, int half, float mul) {
+    if (tok >= ntok) return;
+    float* row = base + (long)tok * rs;
+#pragma unroll
+    for (int c = 0; c < Cfg<HD>::DCH; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 32 * c + 8 * g + 4 * half;
+            if (d < HD)
+                *reinterpret_cast<float4*>(row + d) = make_float4(acc[c][4 * g] * mul, acc[c][4 * g + 1] * mul,
+                                                                  acc[c][4 * g + 2] * mul, acc[c][4 * g + 3] * mul);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
+    using C = Cfg<HD>;
+    constexpr int NT = NW * 64;
+    __shared__ float Ks[32 * C::LDW], Vs[32 * C::LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = (blockIdx.x * NW + wid) * 32 + l31;
+    const float* Qb = a.q + b * a.q_bs + h * HD;
+    const float* Kb = a.k + b * a.k_bs + h * HD;
+    const float* Vb = a.v + b * a.v_bs + h * HD;
+
+    float qf[HD / 2];
+    load_frag<HD>(qf, Qb, a.q_rs, q, a.Nq, half, a.scale * LOG2E);
+    f32x16 o[C::DCH];
+#pragma unroll
+    for (int c = 0; c < C::DCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    zero_pad_cols<HD, NT>(Ks, tid);
+    zero_pad_cols<HD, NT>(Vs, tid);
+
+    const int nkt = (a.Nk + 31) / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_tile<HD, NT>(Ks, Kb, a.k_rs, kt * 32, a.Nk, tid);
+        stage_tile<HD, NT>(Vs, Vb, a.v_rs, kt * 32, a.Nk, tid);
+        __syncthreads();
+        f32x16 s = tile_times_frag<HD>(Ks, qf, l31, half);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (kt * 32 + frag_row(r, half) >= a.Nk) s[r] = -INFINITY;
+            mt = fmaxf(mt, s[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m, mt);
+        const float alpha = exp2f(m - mn);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = exp2f(s[r] - mn);
+            ls += s[r];
+        }
+        l = l * alpha + ls;
+        m = mn;
+#pragma unroll
+        for (int c = 0; c < C::DCH; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+        tileT_times_regs<HD>(o, Vs, s, l31, half);
+    }
+    l += __shfl_xor(l, 32, 64);
+    store_T<HD>(o, a.o + b * a.o_bs + h * HD, a.o_rs, q, a.Nq, half, 1.f / l);
+    if (a.lse && half == 0 && q < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + q] = m + log2f(l);  // log2 units
+}
+
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ void attn_delta_kernel(dkd_attn_args a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * a.H * a.Nq;
+    if (i >= total) return;
+    const int q = (int)(i % a.Nq), h = (int)((i / a.Nq) % a.H), b = (int)(i / ((long)a.Nq * a.H));
+    const float* o = a.o + b * a.o_bs + (long)q * a.o_rs + h * a.hd;
+    const float* d = a.d_o + b * a.do_bs + (long)q * a.do_rs + h * a.hd;
+    float s = 0.f;
+    for (int c = 0; c < a.hd; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(o + c), y = *reinterpret_cast<const float4*>(d + c);
+        s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    a.delta[i] = s;
+}
+
+// dQ: queries resident (one wave = 32 queries), keys/values streamed through LDS.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(dkd_attn_args a) {
+    using C = Cfg<HD>;
+    constexpr int NT = NW * 64;
+    __shared__ float Ks[32 * C::LDW], Vs[32 * C::LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = (blockIdx.x * NW + wid) * 32 + l31;
+    const float* Kb = a.k + b * a.k_bs + h * HD;
+    const float* Vb = a.v + b * a.v_bs + h * HD;
+    float qf[HD / 2], dof[HD / 2];
+    load_frag<HD>(qf, a.q + b * a.q_bs + h * HD, a.q_rs, q, a.Nq, half, a.scale * LOG2E);
+    load_frag<HD>(dof, a.d_o + b * a.do_bs + h * HD, a.do_rs, q, a.Nq, half, 1.f);
+    const long sidx = ((long)b * a.H + h) * a.Nq + q;
+    const float lse = q < a.Nq ? a.lse[sidx] : 0.f;
+    const float dl = q < a.Nq ? a.delta[sidx] : 0.f;
+    f32x16 dq[C::DCH];
+#pragma unroll
+    for (int c = 0; c < C::DCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[c][r] = 0.f;
+    zero_pad_cols<HD, NT>(Ks, tid);
+    zero_pad_cols<HD, NT>(Vs, tid);
+    const int nkt = (a.Nk + 31) / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_tile<HD, NT>(Ks, Kb, a.k_rs, kt * 32, a.Nk, tid);
+        stage_tile<HD, NT>(Vs, Vb, a.v_rs, kt * 32, a.Nk, tid);
+        __syncthreads();
+        f32x16 s = tile_times_frag<HD>(Ks, qf, l31, half);    // S^T (log2 units)
+        f32x16 dp = tile_times_frag<HD>(Vs, dof, l31, half);  // dP^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool valid = kt * 32 + frag_row(r, half) < a.Nk;
+            const float p = valid ? exp2f(s[r] - lse) : 0.f;
+            s[r] = p * (dp[r] - dl) * a.scale;  // dS^T
+        }
+        tileT_times_regs<HD>(dq, Ks, s, l31, half);
+    }
+    store_T<HD>(dq, a.dq + b * a.dq_bs + h * HD, a.dq_rs, q, a.Nq, half, 1.f);
+}
+
+// dK, dV: keys resident (one wave = 32 keys), queries / dO streamed through LDS.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(dkd_attn_args a) {
+    using C = Cfg<HD>;
+    constexpr int NT = NW * 64;
+    __shared__ float Qs[32 * C::LDW], Os[32 * C::LDW];
+    __shared__ float lse_s[32], dl_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int key = (blockIdx.x * NW + wid) * 32 + l31;
+    const float* Qb = a.q + b * a.q_bs + h * HD;
+    const float* Ob = a.d_o + b * a.do_bs + h * HD;
+    float kf[HD / 2], vf[HD / 2];
+    load_frag<HD>(kf, a.k + b * a.k_bs + h * HD, a.k_rs, key, a.Nk, half, 1.f);
+    load_frag<HD>(vf, a.v + b * a.v_bs + h * HD, a.v_rs, key, a.Nk, half, 1.f);
+    f32x16 dk[C::DCH], dv[C::DCH];
+#pragma unroll
+    for (int c = 0; c < C::DCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[c][r] = dv[c][r] = 0.f;
+    zero_pad_cols<HD, NT>(Qs, tid);
+    zero_pad_cols<HD, NT>(Os, tid);
+    const float sc2 = a.scale * LOG2E;
+    const long sbase = ((long)b * a.H + h) * a.Nq;
+    const int nqt = (a.Nq + 31) / 32;
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        stage_tile<HD, NT>(Qs, Qb, a.q_rs, qt * 32, a.Nq, tid);
+        stage_tile<HD, NT>(Os, Ob, a.do_rs, qt * 32, a.Nq, tid);
+        if (tid < 32) {
+            const int qq = qt * 32 + tid;
+            lse_s[tid] = qq < a.Nq ? a.lse[sbase + qq] : INFINITY;  // +inf -> p = 0 for padded queries
+            dl_s[tid] = qq < a.Nq ? a.delta[sbase + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x16 s = tile_times_frag<HD>(Qs, kf, l31, half);   // S[q(r,half)][key]
+        f32x16 dp = tile_times_frag<HD>(Os, vf, l31, half);  // dP[q][key]
+        f32x16 ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = frag_row(r, half);
+            const float p = exp2f(s[r] * sc2 - lse_s[qr]);
+            s[r] = p;
+            ds[r] = p * (dp[r] - dl_s[qr]) * a.scale;
+        }
+        tileT_times_regs<HD>(dv, Os, s, l31, half);
+        tileT_times_regs<HD>(dk, Qs, ds, l31, half);
+    }
+    store_T<HD>(dk, a.dk + b * a.dk_bs + h * HD, a.dk_rs, key, a.Nk, half, 1.f);
+    store_T<HD>(dv, a.dv + b * a.dv_bs + h * HD, a.dv_rs, key, a.Nk, half, 1.f);
+}
+
+int pick_nw(int n) {  // waves per workgroup (32 rows each): least padded rows, prefer larger
+    const int w4 = (n + 127) / 128 * 128 - n, w2 = (n + 63) / 64 * 64 - n;
+    return w2 < w4 ? 2 : 4;
+}
+
+bool strides_ok(const dkd_attn_args* a, bool bwd) {
+    const int64_t s[] = {a->q_bs, a->q_rs, a->k_bs, a->k_rs, a->v_bs, a->v_rs, a->o_bs, a->o_rs};
+    for (int64_t x : s)
+        if (x & 3) return false;
+    if (bwd) {
+        const int64_t t[] = {a->do_bs, a->do_rs, a->dq_bs, a->dq_rs, a->dk_bs, a->dk_rs, a->dv_bs, a->dv_rs};
+        for (int64_t x : t)
+            if (x & 3) return false;
+    }
+    return true;
+}
+
+template <int HD>
+int launch_fwd(const dkd_attn_args* a, hipStream_t st) {
+    const int nw = pick_nw(a->Nq);
+    dim3 grid((a->Nq + 32 * nw - 1) / (32 * nw), a->H, a->B);
+    if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(128), 0, st, *a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<HD, 4>), grid, dim3(256), 0, st, *a);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+template <int HD>
+int launch_bwd(const dkd_attn_args* a, hipStream_t st) {
+    const long total = (long)a->B * a->H * a->Nq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, *a);
+    DKD_LAUNCH_CHECK();
+    int nw = pick_nw(a->Nq);
+    dim3 gq((a->Nq + 32 * nw - 1) / (32 * nw), a->H, a->B);
+    if (nw == 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 2>), gq, dim3(128), 0, st, *a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4>), gq, dim3(256), 0, st, *a);
+    DKD_LAUNCH_CHECK();
+    nw = pick_nw(a->Nk);
+    dim3 gk((a->Nk + 32 * nw - 1) / (32 * nw), a->H, a->B);
+    if (nw == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 2>), gk, dim3(128), 0, st, *a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4>), gk, dim3(256), 0, st, *a);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+}  // namespace
+
+#define DKD_HD_DISPATCH(FN, a, st)                     \
+    switch ((a)->hd) {                                 \
+        case 16: return FN<16>(a, st);                 \
+        case 24: return FN<24>(a, st);                 \
+        case 32: return FN<32>(a, st);                 \
+        case 48: return FN<48>(a, st);                 \
+        case 64: return FN<64>(a, st);                 \
+        case 96: return FN<96>(a, st);                 \
+        default: return DKD_ERR_UNSUPPORTED;           \
+    }
+
+extern "C" int dkd_attn_fwd_f32(const dkd_attn_args* a, void* stream) {
+    if (!a || !a->q || !a->k || !a->v || !a->o || a->B <= 0 || a->H <= 0 || a->Nq <= 0 || a->Nk <= 0)
+        return DKD_ERR_BAD_ARG;
+    if (!strides_ok(a, false)) return DKD_ERR_ALIGN;
+    DKD_HD_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+}
+
+extern "C" int dkd_attn_bwd_f32(const dkd_attn_args* a, void* stream) {
+    if (!a || !a->q || !a->k || !a->v || !a->o || !a->d_o || !a->lse || !a->delta || !a->dq || !a->dk || !a->dv ||
+        a->B <= 0 || a->H <= 0 || a->Nq <= 0 || a->Nk <= 0)
+        return DKD_ERR_BAD_ARG;
+    if (!strides_ok(a, true)) return DKD_ERR_ALIGN;
+    DKD_HD_DISPATCH(launch_bwd, a, (hipStream_t)stream);
+}

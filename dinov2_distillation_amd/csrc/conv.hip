@@ -1,0 +1,322 @@
+// Spatial kernels of the ConvNeXt-V2 student and of the feature plumbing, all on NHWC (token-major) fp32 tensors:
+//   * depthwise 7x7 (pad 3) forward / dgrad (same kernel, flipped taps) / wgrad   (models/backbones/convnext.py:62-64)
+//   * patchify / unpatchify for the non-overlapping convs (stem 4x4 s4, downsample 2x2 s2, DINOv2 patch-embed 14x14
+//     s14), which turn those convs into plain GEMMs                                (convnext.py:116-126)
+//   * bilinear resize, align_corners=False, forward and (gather-form, deterministic) backward
+//                                                                                  (models/model_zoo.py:123-128)
+// Channel is the fastest index, so consecutive lanes read consecutive channels: every access is a dense 16 B/lane run.
+#include "common.h"
+#include "dkd_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void fma4(float4& a, const float4 w, const float4 x) {
+    a.x = fmaf(w.x, x.x, a.x); a.y = fmaf(w.y, x.y, a.y); a.z = fmaf(w.z, x.z, a.z); a.w = fmaf(w.w, x.w, a.w);
+}
+
+// thread = (channel quad, 7 consecutive x, one y, one image).  wt is tap-major [49][C].
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias, const float* __restrict__ add,
+                                                      float* __restrict__ out, int B, int H, int W, int C) {
+    const int cq = C >> 2, xt = W / 7;
+    const long total = (long)B * H * xt * cq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % cq);
+        long r = idx / cq;
+        const int x0 = (int)(r % xt) * 7;
+        r /= xt;
+        const int y = (int)(r % H), b = (int)(r / H);
+        float4 acc[7];
+        const float4 bv = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k] = bv;
+        const float4* inb = reinterpret_cast<const float4*>(in) + (long)b * H * W * cq + c4;
+        const float4* w4 = reinterpret_cast<const float4*>(wt) + c4;
+#pragma unroll 1
+        for (int i = 0; i < 7; ++i) {
+            const int yy = y + i - 3;
+            if (yy < 0 || yy >= H) continue;
+            float4 v[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                const int xx = x0 + k - 3;
+                v[k] = (xx >= 0 && xx < W) ? inb[((long)yy * W + xx) * cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int tap = FLIP ? 48 - (i * 7 + j) : i * 7 + j;
+                const float4 wv = w4[(long)tap * cq];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) fma4(acc[k], wv, v[k + j]);
+            }
+        }
+        float4* ob = reinterpret_cast<float4*>(out) + ((long)(b * H + y) * W + x0) * cq + c4;
+        const float4* ab = add ? reinterpret_cast<const float4*>(add) + ((long)(b * H + y) * W + x0) * cq + c4 : nullptr;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            float4 o = acc[k];
+            if (ab) {
+                const float4 a = ab[(long)k * cq];
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            ob[(long)k * cq] = o;
+        }
+    }
+}
+
+// wgrad partials: thread = one channel, one image, RY consecutive output rows; 49 running sums in registers.
+// part[(b*ny + yc)][tap][c]
+__global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                            float* __restrict__ part, int B, int H, int W, int C,
+                                                            int RY) {
+    const int ny = (H + RY - 1) / RY;
+    const long total = (long)B * ny * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long r = idx / C;
+        const int yc = (int)(r % ny), b = (int)(r / ny);
+        float acc[49];
+#pragma unroll
+        for (int t = 0; t < 49; ++t) acc[t] = 0.f;
+        const float* inb = in + (long)b * H * W * C + c;
+        const float* db = dout + (long)b * H * W * C + c;
+        const int y1 = min(H, (yc + 1) * RY);
+        for (int y = yc * RY; y < y1; ++y) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int yy = y + i - 3;
+                if (yy < 0 || yy >= H) continue;
+                const float* irow = inb + (long)yy * W * C;
+                const float* drow = db + (long)y * W * C;
+                float win[7];  // in[yy][x-3 .. x+3]
+#pragma unroll
+                for (int j = 0; j < 6; ++j) win[j + 1] = (j - 3 >= 0 && j - 3 < W) ? irow[(long)(j - 3) * C] : 0.f;
+                for (int x = 0; x < W; ++x) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) win[j] = win[j + 1];
+                    win[6] = (x + 3 < W) ? irow[(long)(x + 3) * C] : 0.f;
+                    const float d = drow[(long)x * C];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc[i * 7 + j] = fmaf(d, win[j], acc[i * 7 + j]);
+                }
+            }
+        }
+        float* p = part + r * 49 * C + c;
+#pragma unroll
+        for (int t = 0; t < 49; ++t) p[(long)t * C] = acc[t];
+    }
+}
+
+// ---- patchify -------------------------------------------------------------------------------------------------
+// NCHW image -> rows [(b,py,px)][(c,ky,kx)]  (matches conv weight [O][c][ky][kx] flattened); V floats per access.
+template <int V>
+__global__ void patchify_nchw_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Cin, int H, int W,
+                                     int k) {
+    const int ph = H / k, pw = W / k, kv = k / V, K = Cin * k * k;
+    const long total = (long)B * ph * pw * Cin * k * kv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int kx = (int)(r % kv) * V; r /= kv;
+        const int ky = (int)(r % k); r /= k;
+        const int c = (int)(r % Cin); r /= Cin;
+        const int px = (int)(r % pw); r /= pw;
+        const int py = (int)(r % ph);
+        const int b = (int)(r / ph);
+        const float* src = img + (((long)b * Cin + c) * H + py * k + ky) * W + px * k + kx;
+        float* dst = out + ((long)(b * ph + py) * pw + px) * K + (c * k + ky) * k + kx;
+        if (V == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        else if (V == 2) *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(src);
+        else *dst = *src;
+    }
+}
+
+// NHWC feature <-> rows [(b,py,px)][(ky,kx,c)] for a k x k stride-k conv (weights permuted to [O][ky][kx][c]).
+template <bool INVERSE>
+__global__ void patchify_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int C,
+                                     int k) {
+    const int ph = H / k, pw = W / k, cq = C >> 2;
+    const long total = (long)B * H * W * cq;  // H, W multiples of k: every pixel belongs to exactly one patch
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int c4 = (int)(r % cq); r /= cq;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const long feat = (((long)b * H + y) * W + x) * cq + c4;
+        const long prow = ((long)b * ph + y / k) * pw + x / k;
+        const long pat = (prow * k * k + (y % k) * k + (x % k)) * cq + c4;
+        if (INVERSE) reinterpret_cast<float4*>(dst)[feat] = reinterpret_cast<const float4*>(src)[pat];
+        else reinterpret_cast<float4*>(dst)[pat] = reinterpret_cast<const float4*>(src)[feat];
+    }
+}
+
+// ---- bilinear resize (align_corners = False) -------------------------------------------------------------------
+__device__ __forceinline__ void src_index(int o, float scale, int in_size, int& i0, int& i1, float& lam) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    lam = s - (float)i0;
+}
+
+__global__ void resize_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int Hi, int Wi, int Ho,
+                                  int Wo, int C) {
+    const int cq = C >> 2;
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    const long total = (long)B * Ho * Wo * cq;
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int c4 = (int)(r % cq); r /= cq;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index(oy, sy, Hi, y0, y1, ly);
+        src_index(ox, sx, Wi, x0, x1, lx);
+        const long base = (long)b * Hi * Wi;
+        const float4 a = in4[(base + (long)y0 * Wi + x0) * cq + c4], bq = in4[(base + (long)y0 * Wi + x1) * cq + c4];
+        const float4 c = in4[(base + (long)y1 * Wi + x0) * cq + c4], d = in4[(base + (long)y1 * Wi + x1) * cq + c4];
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+        float4 o;
+        o.x = w00 * a.x + w01 * bq.x + w10 * c.x + w11 * d.x;
+        o.y = w00 * a.y + w01 * bq.y + w10 * c.y + w11 * d.y;
+        o.z = w00 * a.z + w01 * bq.z + w10 * c.z + w11 * d.z;
+        o.w = w00 * a.w + w01 * bq.w + w10 * c.w + w11 * d.w;
+        reinterpret_cast<float4*>(out)[idx] = o;
+    }
+}
+
+// gather form of the adjoint: every input pixel sums the output pixels whose 2x2 footprint touches it
+__global__ void resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int Hi, int Wi, int Ho,
+                                  int Wo, int C) {
+    const int cq = C >> 2;
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    const long total = (long)B * Hi * Wi * cq;
+    const float4* d4 = reinterpret_cast<const float4*>(dout);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int c4 = (int)(r % cq); r /= cq;
+        const int ix = (int)(r % Wi); r /= Wi;
+        const int iy = (int)(r % Hi);
+        const int b = (int)(r / Hi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = 0; oy < Ho; ++oy) {
+            int y0, y1; float ly;
+            src_index(oy, sy, Hi, y0, y1, ly);
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = 0; ox < Wo; ++ox) {
+                int x0, x1; float lx;
+                src_index(ox, sx, Wi, x0, x1, lx);
+                const float w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
+                if (w == 0.f) continue;
+                const float4 g = d4[(((long)b * Ho + oy) * Wo + ox) * cq + c4];
+                acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+            }
+        }
+        reinterpret_cast<float4*>(din)[idx] = acc;
+    }
+}
+
+__global__ void set_rows_kernel(float* __restrict__ out, const float* __restrict__ vec, int B, long row_stride, int D) {
+    const long total = (long)B * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        out[(i / D) * row_stride + i % D] = vec[i % D];
+}
+
+inline int blocks_for(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+}  // namespace
+
+extern "C" int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, const float* bias, const float* add,
+                                   float* out, int B, int H, int W, int C, int flip, void* stream) {
+    if (!in || !w_tap_major || !out || B <= 0 || H <= 0 || W <= 0) return DKD_ERR_BAD_ARG;
+    if ((C & 3) || (W % 7)) return DKD_ERR_UNSUPPORTED;
+    const long total = (long)B * H * (W / 7) * (C / 4);
+    if (flip)
+        hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, w_tap_major,
+                           bias, add, out, B, H, W, C);
+    else
+        hipLaunchKernelGGL(dwconv7_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                           w_tap_major, bias, add, out, B, H, W, C);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+static int dw_ry(int H) { return H >= 28 ? 4 : (H >= 14 ? 2 : 1); }
+extern "C" long dkd_dwconv7_wgrad_f32_parts(int B, int H) { return (long)B * ((H + dw_ry(H) - 1) / dw_ry(H)); }
+
+extern "C" int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* partials, int B, int H, int W, int C,
+                                     void* stream) {
+    if (!in || !dout || !partials || B <= 0) return DKD_ERR_BAD_ARG;
+    const int RY = dw_ry(H);
+    const long total = (long)B * ((H + RY - 1) / RY) * C;
+    hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, dout, partials,
+                       B, H, W, C, RY);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_patchify_nchw_f32(const float* img, float* out, int B, int Cin, int H, int W, int k, void* stream) {
+    if (!img || !out || B <= 0 || k <= 0 || H % k || W % k) return DKD_ERR_BAD_ARG;
+    const int V = (k % 4 == 0 && W % 4 == 0) ? 4 : ((k % 2 == 0 && W % 2 == 0) ? 2 : 1);
+    const long total = (long)B * Cin * H * W / V;
+    dim3 grid(blocks_for(total)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (V == 4) hipLaunchKernelGGL(patchify_nchw_kernel<4>, grid, block, 0, st, img, out, B, Cin, H, W, k);
+    else if (V == 2) hipLaunchKernelGGL(patchify_nchw_kernel<2>, grid, block, 0, st, img, out, B, Cin, H, W, k);
+    else hipLaunchKernelGGL(patchify_nchw_kernel<1>, grid, block, 0, st, img, out, B, Cin, H, W, k);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_patchify_nhwc_f32(const float* src, float* dst, int B, int H, int W, int C, int k, int inverse,
+                                     void* stream) {
+    if (!src || !dst || B <= 0 || k <= 0 || H % k || W % k) return DKD_ERR_BAD_ARG;
+    if (C & 3) return DKD_ERR_ALIGN;
+    const long total = (long)B * H * W * (C / 4);
+    if (inverse)
+        hipLaunchKernelGGL(patchify_nhwc_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                           B, H, W, C, k);
+    else
+        hipLaunchKernelGGL(patchify_nhwc_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                           dst, B, H, W, C, k);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_resize_bilinear_fwd_f32(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                           void* stream) {
+    if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return DKD_ERR_BAD_ARG;
+    if (C & 3) return DKD_ERR_ALIGN;
+    const long total = (long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, Hi, Wi,
+                       Ho, Wo, C);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_resize_bilinear_bwd_f32(const float* dout, float* din, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                           void* stream) {
+    if (!dout || !din || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return DKD_ERR_BAD_ARG;
+    if (C & 3) return DKD_ERR_ALIGN;
+    const long total = (long)B * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dout, din, B, Hi, Wi,
+                       Ho, Wo, C);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_set_rows_f32(float* out, const float* vec, int B, long row_stride, int D, void* stream) {
+    if (!out || !vec || B <= 0 || D <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(set_rows_kernel, dim3(blocks_for((long)B * D)), dim3(256), 0, (hipStream_t)stream, out, vec, B,
+                       row_stride, D);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}

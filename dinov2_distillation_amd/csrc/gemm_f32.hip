@@ -1,0 +1,284 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 == fmaf chain).
+//
+//   C[m][n] = epilogue( alpha * sum_k Aop[m][k] * Bop[n][k] )
+//
+// Operand layouts (one kernel family covers forward / dgrad / wgrad of every dense layer on the path):
+//   a_layout 0 "MK": Aop[m][k] = A[m*lda + k]        a_layout 1 "KM": Aop[m][k] = A[k*lda + m]
+//   b_layout 0 "NK": Bop[n][k] = B[n*ldb + k]        b_layout 1 "KN": Bop[n][k] = B[k*ldb + n]
+//   forward  y = x W^T   : A = x  (MK), B = W (NK)
+//   dgrad    dx = dy W   : A = dy (MK), B = W (KN)          (K := out features)
+//   wgrad    dW = dy^T x : A = dy (KM), B = x (KN), split-K (K := rows of the batch)
+//
+// Structure: BMxBNx16 LDS tiles stored k-major ([k][m], [k][n]) so every MFMA fragment read is a
+// conflict-free ds_read_b32 with lanes along m (or n); global->register->LDS staging with the next tile's
+// loads issued before the MFMA block of the current one (double-buffered LDS, one barrier per k-tile).
+// fp32 MFMA is 64 cycles per 32x32x2 issue per SIMD, so LDS/VMEM bandwidth is far from limiting; what
+// matters is keeping 4 waves x (TM x TN) independent accumulators busy and the launch XCD-aware.
+#include "common.h"
+#include "dkd_hip.h"
+
+namespace {
+
+struct Epilogue {
+    const float* bias;
+    const float* colscale;
+    const float* residual;
+    float* preact;
+    long ldr;
+    int res_mod;
+    int act;
+    int row_grp, row_grp_stride, row_off;
+    float alpha;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == DKD_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DKD_ACT_GELU) return gelu_f(v);
+    return v;
+}
+
+__device__ __forceinline__ void epilogue_store(const Epilogue& e, float* C, long ldc, int m, int n,
+                                               float acc) {
+    float v = acc * e.alpha;
+    if (e.bias) v += e.bias[n];
+    long orow = m;
+    if (e.row_grp > 0) orow = (long)(m / e.row_grp) * e.row_grp_stride + (m % e.row_grp) + e.row_off;
+    if (e.preact) e.preact[orow * ldc + n] = v;
+    v = apply_act(v, e.act);
+    if (e.colscale) v *= e.colscale[n];
+    if (e.residual) {
+        const long rr = e.res_mod > 0 ? (long)(m % e.res_mod) : orow;
+        v += e.residual[rr * e.ldr + n];
+    }
+    C[orow * ldc + n] = v;
+}
+
+// ---- tile staging -------------------------------------------------------------------------------
+// EXT = tile extent along the non-reduction index (BM or BN); KC = source is contiguous along k.
+template <int EXT, int BK, bool KC, int NT>
+struct Stager {
+    static constexpr int TOTAL = EXT * BK / 4;               // float4 in the tile
+    static constexpr int NV = (TOTAL + NT - 1) / NT;          // float4 per thread
+    static constexpr int LDS_LD = KC ? EXT + 2 : EXT + 4;    // see conflict analysis in DESIGN.md
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int rows, int k0, int kend,
+                                         int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TOTAL % NT != 0 && idx >= TOTAL) {
+            } else if (KC) {
+                const int r = idx / (BK / 4), kq = idx % (BK / 4);
+                const int gr = row0 + r, gk = k0 + 4 * kq;
+                if (gr < rows && gk < kend) x = *reinterpret_cast<const float4*>(P + (long)gr * ld + gk);
+            } else {
+                const int k = idx / (EXT / 4), mq = idx % (EXT / 4);
+                const int gk = k0 + k, gr = row0 + 4 * mq;
+                if (gk < kend && gr < rows) x = *reinterpret_cast<const float4*>(P + (long)gk * ld + gr);
+            }
+            v[i] = x;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT;
+            if (TOTAL % NT != 0 && idx >= TOTAL) continue;
+            if (KC) {
+                const int r = idx / (BK / 4), kq = idx % (BK / 4);
+                S[(4 * kq + 0) * LDS_LD + r] = v[i].x;
+                S[(4 * kq + 1) * LDS_LD + r] = v[i].y;
+                S[(4 * kq + 2) * LDS_LD + r] = v[i].z;
+                S[(4 * kq + 3) * LDS_LD + r] = v[i].w;
+            } else {
+                const int k = idx / (EXT / 4), mq = idx % (EXT / 4);
+                *reinterpret_cast<float4*>(S + k * LDS_LD + 4 * mq) = v[i];
+            }
+        }
+    }
+};
+
+// XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of
+// logical tiles (bn fastest) -> the tiles that share an A row-panel hit the same L2.  Bijective for any grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+template <int WM, int WN, int TM, int TN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __restrict__ A, long lda,
+                                                                const float* __restrict__ B, long ldb,
+                                                                float* C, long ldc, int M, int N, int K,
+                                                                int kchunk, Epilogue epi, float* __restrict__ ws) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16, NT = WM * WN * 64;
+    using SA = Stager<BM, BK, A_KC, NT>;
+    using SB = Stager<BN, BK, B_KC, NT>;
+    constexpr int A_SZ = BK * SA::LDS_LD, B_SZ = BK * SB::LDS_LD;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    SA sa;
+    SB sb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        sa.load(A, lda, bm0, M, kbeg, kend, tid);
+        sb.load(B, ldb, bn0, N, kbeg, kend, tid);
+        sa.store(smem, tid);
+        sb.store(smem + A_SZ, tid);
+    }
+    __syncthreads();
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            sa.load(A, lda, bm0, M, kbeg + (kt + 1) * BK, kend, tid);
+            sb.load(B, ldb, bn0, N, kbeg + (kt + 1) * BK, kend, tid);
+        }
+        const float* As = smem + cur * (A_SZ + B_SZ);
+        const float* Bs = As + A_SZ;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(2 * s + half) * SA::LDS_LD + (wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * s + half) * SB::LDS_LD + (wn * TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
+            sa.store(An, tid);
+            sb.store(An + A_SZ, tid);
+        }
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 MFMA: col = lane & 31 (B's index n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    const bool partial = ws != nullptr;
+    float* out = partial ? ws + (long)blockIdx.y * M * N : C;
+    const long ldo = partial ? N : ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn0 + (wn * TN + j) * 32 + l31;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                if (partial)
+                    out[(long)m * ldo + n] = acc[i][j][r];
+                else
+                    epilogue_store(epi, C, ldc, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* C,
+                                     long ldc, Epilogue epi) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += ws[(long)z * total + i];
+        epilogue_store(epi, C, ldc, (int)(i / N), (int)(i % N), s);
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
+    float* ws = splits > 1 ? g->workspace : nullptr;
+#define DKD_GEMM_LAUNCH(AKC, BKC)                                                                                  \
+    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AKC, BKC>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, \
+                       g->C, g->ldc, g->M, g->N, g->K, kchunk, epi, ws)
+    if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH(true, true);
+    else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH(true, false);
+    else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH(false, true);
+    else DKD_GEMM_LAUNCH(false, false);
+#undef DKD_GEMM_LAUNCH
+    DKD_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long total = (long)g->M * g->N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g->workspace, splits, g->M, g->N,
+                           g->C, g->ldc, epi);
+        DKD_LAUNCH_CHECK();
+    }
+    return DKD_OK;
+}
+
+}  // namespace
+
+extern "C" long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout) {
+    int splits = dkd_gemm_f32_splits(M, N, K);
+    (void)a_layout;
+    (void)b_layout;
+    return splits > 1 ? (long)splits * M * N * sizeof(float) : 0;
+}
+
+// Split the reduction only when the output grid alone cannot fill the 256 CUs (weight gradients: tiny
+// M x N, reduction over all B*H*W rows).
+extern "C" int dkd_gemm_f32_splits(int M, int N, int K) {
+    const long tiles = (long)dkd_cdiv(M, 128) * dkd_cdiv(N, N <= 96 || N == 192 ? 96 : 128);
+    if (tiles >= 256 || K < 2048) return 1;
+    long want = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
+    long maxs = K / 256;                      // at least 16 k-tiles per split
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want > 512) want = 512;
+    return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
+    if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || !g->A || !g->B || !g->C) return DKD_ERR_BAD_ARG;
+    // float4 staging: contiguous extent of each operand and its leading dimension must be multiples of 4
+    const int a_contig = g->a_layout == 0 ? g->K : g->M;
+    const int b_contig = g->b_layout == 0 ? g->K : g->N;
+    if ((a_contig & 3) || (b_contig & 3) || (g->lda & 3) || (g->ldb & 3)) return DKD_ERR_ALIGN;
+    if (!dkd_aligned16(g->A) || !dkd_aligned16(g->B)) return DKD_ERR_ALIGN;
+    Epilogue epi;
+    epi.bias = g->bias;
+    epi.colscale = g->colscale;
+    epi.residual = g->residual;
+    epi.preact = g->preact;
+    epi.ldr = g->ldr;
+    epi.res_mod = g->res_mod;
+    epi.act = g->act;
+    epi.row_grp = g->row_grp;
+    epi.row_grp_stride = g->row_grp_stride;
+    epi.row_off = g->row_off;
+    epi.alpha = g->alpha;
+    int splits = dkd_gemm_f32_splits(g->M, g->N, g->K);
+    if (splits > 1 && !g->workspace) splits = 1;
+    int kchunk = g->K;
+    if (splits > 1) {
+        kchunk = ((g->K + splits - 1) / splits + 15) / 16 * 16;
+        splits = (g->K + kchunk - 1) / kchunk;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (g->N <= 96 || g->N == 192) return launch_cfg<4, 1, 1, 3>(g, epi, splits, kchunk, st);  // 128 x 96
+    return launch_cfg<2, 2, 2, 2>(g, epi, splits, kchunk, st);                                   // 128 x 128
+}

@@ -1,0 +1,307 @@
+// Element-wise HBM-bound kernels (16 B per lane, grid-stride): activations and their derivatives, train-mode
+// BatchNorm apply / backward for the ScaleKD projector input, GRN, small helpers.
+#include "common.h"
+#include "dkd_hip.h"
+
+namespace {
+
+inline int ew_blocks(long nvec) {
+    long b = (nvec + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+#define EW_LOOP(i, nvec) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (nvec); i += (long)gridDim.x * blockDim.x)
+
+__global__ void gelu_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 v = x[i];
+        y[i] = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+    }
+}
+__global__ void gelu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ x, float4* __restrict__ dx,
+                                long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 v = x[i], g = dy[i];
+        dx[i] = make_float4(g.x * gelu_grad_f(v.x), g.y * gelu_grad_f(v.y), g.z * gelu_grad_f(v.z), g.w * gelu_grad_f(v.w));
+    }
+}
+__global__ void relu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ dx,
+                                long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 v = y[i], g = dy[i];
+        dx[i] = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+    }
+}
+__global__ void axpby_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out,
+                             float alpha, float beta, long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 u = a[i], v = b[i];
+        out[i] = make_float4(alpha * u.x + beta * v.x, alpha * u.y + beta * v.y, alpha * u.z + beta * v.z,
+                             alpha * u.w + beta * v.w);
+    }
+}
+// out[r][:] = x[r][:] - vec[r / rows_per_group][:]
+__global__ void sub_group_vec_kernel(const float4* __restrict__ x, const float4* __restrict__ vec,
+                                     float4* __restrict__ out, long rows_per_group, int nv, long nvec) {
+    EW_LOOP(i, nvec) {
+        const long r = i / nv;
+        const int c = (int)(i % nv);
+        const float4 a = x[i], m = vec[(r / rows_per_group) * nv + c];
+        out[i] = make_float4(a.x - m.x, a.y - m.y, a.z - m.z, a.w - m.w);
+    }
+}
+
+// ---- BatchNorm (train mode) ------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int N, float count,
+                                   float momentum, float eps) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    rstd[n] = rsqrtf(var[n] + eps);
+    if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * mean[n];
+    if (running_var) running_var[n] = (1.f - momentum) * running_var[n] + momentum * var[n] * (count / (count - 1.f));
+}
+
+// out = act(gamma * (z - mean) * rstd + beta) + pos[row % period]
+__global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4* __restrict__ mean,
+                                      const float4* __restrict__ rstd, const float4* __restrict__ gamma,
+                                      const float4* __restrict__ beta, const float4* __restrict__ pos,
+                                      float4* __restrict__ out, int nv, int period, int relu, long nvec) {
+    EW_LOOP(i, nvec) {
+        const long r = i / nv;
+        const int c = (int)(i % nv);
+        const float4 x = z[i], mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
+        float4 o = make_float4(g.x * (x.x - mu.x) * rs.x + b.x, g.y * (x.y - mu.y) * rs.y + b.y,
+                               g.z * (x.z - mu.z) * rs.z + b.z, g.w * (x.w - mu.w) * rs.w + b.w);
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        if (pos) {
+            const float4 p = pos[(r % period) * nv + c];
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        out[i] = o;
+    }
+}
+
+// dbn = dt * [bn > 0] (bn recomputed), xhat = (z - mean) * rstd
+__global__ void bn_bwd_prep_kernel(const float4* __restrict__ dt, const float4* __restrict__ z,
+                                   const float4* __restrict__ mean, const float4* __restrict__ rstd,
+                                   const float4* __restrict__ gamma, const float4* __restrict__ beta,
+                                   float4* __restrict__ dbn, float4* __restrict__ xhat, int nv, int relu, long nvec) {
+    EW_LOOP(i, nvec) {
+        const int c = (int)(i % nv);
+        const float4 x = z[i], mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c], d = dt[i];
+        const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
+        float4 o = d;
+        if (relu) {
+            o.x = g.x * xh.x + b.x > 0.f ? d.x : 0.f;
+            o.y = g.y * xh.y + b.y > 0.f ? d.y : 0.f;
+            o.z = g.z * xh.z + b.z > 0.f ? d.z : 0.f;
+            o.w = g.w * xh.w + b.w > 0.f ? d.w : 0.f;
+        }
+        dbn[i] = o;
+        xhat[i] = xh;
+    }
+}
+
+// dz = gamma * rstd * (dbn - sum_dbn / M - xhat * sum_dbn_xhat / M)
+__global__ void bn_bwd_apply_kernel(const float4* __restrict__ dbn, const float4* __restrict__ xhat,
+                                    const float4* __restrict__ s1, const float4* __restrict__ s2,
+                                    const float4* __restrict__ gamma, const float4* __restrict__ rstd,
+                                    float4* __restrict__ dz, int nv, float inv_count, long nvec) {
+    EW_LOOP(i, nvec) {
+        const int c = (int)(i % nv);
+        const float4 d = dbn[i], xh = xhat[i], a = s1[c], b = s2[c], g = gamma[c], rs = rstd[c];
+        dz[i] = make_float4(g.x * rs.x * (d.x - a.x * inv_count - xh.x * b.x * inv_count),
+                            g.y * rs.y * (d.y - a.y * inv_count - xh.y * b.y * inv_count),
+                            g.z * rs.z * (d.z - a.z * inv_count - xh.z * b.z * inv_count),
+                            g.w * rs.w * (d.w - a.w * inv_count - xh.w * b.w * inv_count));
+    }
+}
+
+// ---- GRN (ConvNeXt-V2), NHWC: rows grouped per image ------------------------------------------------------
+// nx[b][c] = sqrt(sumsq[b][c]) / (mean_c sqrt(sumsq[b][:]) + 1e-6); one block per image
+__global__ __launch_bounds__(256) void grn_stats_kernel(const float* __restrict__ sumsq, float* __restrict__ gx,
+                                                        float* __restrict__ nx, float* __restrict__ denom, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g = sqrtf(sumsq[(long)b * C + c]);
+        gx[(long)b * C + c] = g;
+        s += g;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float d = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C + 1e-6f;
+    if (threadIdx.x == 0) denom[b] = d;
+    for (int c = threadIdx.x; c < C; c += 256) nx[(long)b * C + c] = gx[(long)b * C + c] / d;
+}
+
+// y = g * (gamma * nx[b] + 1) + beta
+__global__ void grn_apply_kernel(const float4* __restrict__ g, const float4* __restrict__ nx,
+                                 const float4* __restrict__ gamma, const float4* __restrict__ beta,
+                                 float4* __restrict__ y, long rows_per_img, int nv, long nvec) {
+    EW_LOOP(i, nvec) {
+        const long r = i / nv;
+        const int c = (int)(i % nv);
+        const float4 v = g[i], n = nx[(r / rows_per_img) * nv + c], ga = gamma[c], be = beta[c];
+        y[i] = make_float4(v.x * (ga.x * n.x + 1.f) + be.x, v.y * (ga.y * n.y + 1.f) + be.y,
+                           v.z * (ga.z * n.z + 1.f) + be.z, v.w * (ga.w * n.w + 1.f) + be.w);
+    }
+}
+
+// GRN backward, per image b and channel c, given A[b][c] = sum_hw dy*g :
+//   dnx = gamma * A;  dgx = dnx / denom - (1/C) * sum_c'(dnx[c'] * gx[c']) / denom^2;  coef = dgx / gx (0 if gx == 0)
+// one block per image; writes coef[b][c] (so that dg = dy*(gamma*nx+1) + coef*g) and dnx*nx partials for dgamma.
+__global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restrict__ A, const float* __restrict__ gx,
+                                                            const float* __restrict__ nx, const float* __restrict__ denom,
+                                                            const float* __restrict__ gamma, float* __restrict__ coef,
+                                                            float* __restrict__ dgamma_part, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float d = denom[b];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += gamma[c] * A[(long)b * C + c] * gx[(long)b * C + c];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float corr = ((red[0] + red[1]) + (red[2] + red[3])) / ((float)C * d * d);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const long i = (long)b * C + c;
+        const float a = A[i], g = gx[i];
+        const float dgx = gamma[c] * a / d - corr;
+        coef[i] = g > 0.f ? dgx / g : 0.f;
+        dgamma_part[i] = a * nx[i];  // dgamma[c] = sum_b A[b][c] * nx[b][c]
+    }
+}
+
+// dh = (dy * (gamma*nx + 1) + coef * g) * gelu'(h)      (g = gelu(h) is re-read, not recomputed)
+__global__ void grn_gelu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ g,
+                                    const float4* __restrict__ h, const float4* __restrict__ nx,
+                                    const float4* __restrict__ coef, const float4* __restrict__ gamma,
+                                    float4* __restrict__ dh, long rows_per_img, int nv, long nvec) {
+    EW_LOOP(i, nvec) {
+        const long r = i / nv;
+        const int c = (int)(i % nv);
+        const long bi = (r / rows_per_img) * nv + c;
+        const float4 d = dy[i], gv = g[i], hv = h[i], n = nx[bi], cf = coef[bi], ga = gamma[c];
+        dh[i] = make_float4((d.x * (ga.x * n.x + 1.f) + cf.x * gv.x) * gelu_grad_f(hv.x),
+                            (d.y * (ga.y * n.y + 1.f) + cf.y * gv.y) * gelu_grad_f(hv.y),
+                            (d.z * (ga.z * n.z + 1.f) + cf.z * gv.z) * gelu_grad_f(hv.z),
+                            (d.w * (ga.w * n.w + 1.f) + cf.w * gv.w) * gelu_grad_f(hv.w));
+    }
+}
+
+}  // namespace
+
+#define EW_CHECK(n) if ((n) <= 0) return DKD_ERR_BAD_ARG; if ((n) & 3) return DKD_ERR_ALIGN;
+#define F4(p) reinterpret_cast<const float4*>(p)
+#define F4W(p) reinterpret_cast<float4*>(p)
+
+extern "C" int dkd_gelu_fwd_f32(const float* x, float* y, long n, void* stream) {
+    EW_CHECK(n);
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, F4(x), F4W(y), n / 4);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_gelu_bwd_f32(const float* dy, const float* x, float* dx, long n, void* stream) {
+    EW_CHECK(n);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, F4(dy), F4(x), F4W(dx),
+                       n / 4);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream) {
+    EW_CHECK(n);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, F4(dy), F4(y), F4W(dx),
+                       n / 4);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, long n, void* stream) {
+    EW_CHECK(n);
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, F4(a), F4(b), F4W(out),
+                       alpha, beta, n / 4);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_sub_group_vec_f32(const float* x, const float* vec, float* out, long rows_per_group, int groups, int N,
+                                     void* stream) {
+    EW_CHECK(N);
+    const long nvec = rows_per_group * groups * (N / 4);
+    hipLaunchKernelGGL(sub_group_vec_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(x), F4(vec),
+                       F4W(out), rows_per_group, N / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_bn_finalize_f32(const float* mean, const float* var, float* rstd, float* running_mean,
+                                   float* running_var, int N, long count, float momentum, float eps, void* stream) {
+    if (!mean || !var || !rstd || N <= 0 || count < 2) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, var, rstd,
+                       running_mean, running_var, N, (float)count, momentum, eps);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_bn_act_pos_fwd_f32(const float* z, const float* mean, const float* rstd, const float* gamma,
+                                      const float* beta, const float* pos, float* out, long rows, int N, int period,
+                                      int relu, void* stream) {
+    EW_CHECK(N);
+    if (rows <= 0 || (pos && period <= 0)) return DKD_ERR_BAD_ARG;
+    const long nvec = rows * (N / 4);
+    hipLaunchKernelGGL(bn_act_pos_fwd_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(z), F4(mean),
+                       F4(rstd), F4(gamma), F4(beta), F4(pos), F4W(out), N / 4, period, relu, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_bn_bwd_prep_f32(const float* dt, const float* z, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, float* dbn, float* xhat, long rows, int N,
+                                   int relu, void* stream) {
+    EW_CHECK(N);
+    const long nvec = rows * (N / 4);
+    hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(dt), F4(z),
+                       F4(mean), F4(rstd), F4(gamma), F4(beta), F4W(dbn), F4W(xhat), N / 4, relu, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_bn_bwd_apply_f32(const float* dbn, const float* xhat, const float* sum_dbn, const float* sum_dbn_xhat,
+                                    const float* gamma, const float* rstd, float* dz, long rows, int N, void* stream) {
+    EW_CHECK(N);
+    const long nvec = rows * (N / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(dbn), F4(xhat),
+                       F4(sum_dbn), F4(sum_dbn_xhat), F4(gamma), F4(rstd), F4W(dz), N / 4, 1.0f / (float)rows, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_grn_stats_f32(const float* sumsq, float* gx, float* nx, float* denom, int B, int C, void* stream) {
+    if (!sumsq || !gx || !nx || !denom || B <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(grn_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sumsq, gx, nx, denom, C);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_grn_apply_f32(const float* g, const float* nx, const float* gamma, const float* beta, float* y, int B,
+                                 long rows_per_img, int C, void* stream) {
+    EW_CHECK(C);
+    const long nvec = (long)B * rows_per_img * (C / 4);
+    hipLaunchKernelGGL(grn_apply_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(g), F4(nx), F4(gamma),
+                       F4(beta), F4W(y), rows_per_img, C / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_grn_bwd_stats_f32(const float* A, const float* gx, const float* nx, const float* denom,
+                                     const float* gamma, float* coef, float* dgamma_part, int B, int C, void* stream) {
+    if (!A || !gx || !nx || !denom || !gamma || !coef || !dgamma_part || B <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, A, gx, nx, denom, gamma, coef,
+                       dgamma_part, C);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const float* nx, const float* coef,
+                                    const float* gamma, float* dh, int B, long rows_per_img, int C, void* stream) {
+    EW_CHECK(C);
+    const long nvec = (long)B * rows_per_img * (C / 4);
+    hipLaunchKernelGGL(grn_gelu_bwd_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(dy), F4(g), F4(h),
+                       F4(nx), F4(coef), F4(gamma), F4W(dh), rows_per_img, C / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}

@@ -1,0 +1,399 @@
+"""Tensor-level wrappers over the C ABI (include/dkd_hip.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream, autograd bookkeeping.  Every
+function validates its tensors (cuda, fp32, layout), allocates outputs, and launches the HIP kernels through ctypes on
+`torch.cuda.current_stream()`.  Nothing in this module computes with ATen ops and nothing falls back to the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs, GemmArgs, check
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF = 0, 1, 2, 3
+
+_ws = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, contiguous=True):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.DkdError(f"{name}: expected a CUDA(HIP) float32 tensor, got {t.device} {t.dtype} "
+                            "(the distillation step has no CPU path)")
+    if contiguous and not t.is_contiguous():
+        raise _lib.DkdError(f"{name}: expected a contiguous tensor, got strides {t.stride()}")
+
+
+def workspace(nbytes, device, slot=0):
+    """Stream-ordered scratch: one growing buffer per (device, slot)."""
+    key = (device.index, slot)
+    w = _ws.get(key)
+    if w is None or w.numel() * 4 < nbytes:
+        w = torch.empty(max(int(nbytes) // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+        _ws[key] = w
+    return w
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, colscale=None, residual=None, res_mod=0,
+         preact=None, alpha=1.0, row_map=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None):
+    """C = epi(alpha * Aop @ Bop^T).  a/b are 2-D (or flattened-leading-dims) dense tensors:
+    a_layout 0: a is [M,K]; 1: a is [K,M].   b_layout 0: b is [N,K]; 1: b is [K,N]."""
+    lib = _lib.load()
+    _chk(a, "a"), _chk(b, "b"), _chk(bias, "bias"), _chk(colscale, "colscale"), _chk(residual, "residual")
+    a2 = a.reshape(-1, a.shape[-1])
+    b2 = b.reshape(-1, b.shape[-1])
+    if M is None:
+        M, K_a = (a2.shape[0], a2.shape[1]) if a_layout == 0 else (a2.shape[1], a2.shape[0])
+        N, K_b = (b2.shape[0], b2.shape[1]) if b_layout == 0 else (b2.shape[1], b2.shape[0])
+        if K_a != K_b:
+            raise _lib.DkdError(f"gemm: reduction extents differ: {K_a} vs {K_b}")
+        K = K_a
+    lda = a2.shape[1] if lda is None else lda
+    ldb = b2.shape[1] if ldb is None else ldb
+    out_rows = M
+    g = GemmArgs()
+    if row_map is not None:
+        g.row_grp, g.row_grp_stride, g.row_off, out_rows = row_map
+    if out is None:
+        out = torch.empty((out_rows, N), dtype=torch.float32, device=a.device)
+    _chk(out, "out")
+    ldc = N if ldc is None else ldc
+    wsb = lib.dkd_gemm_f32_workspace_bytes(M, N, K, a_layout, b_layout)
+    ws = workspace(wsb, a.device) if wsb else None
+    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), lda, _p(b2), ldb, _p(out), ldc
+    g.bias, g.colscale, g.residual, g.preact, g.workspace = _p(bias), _p(colscale), _p(residual), _p(preact), _p(ws)
+    g.ldr = (N if ldr is None else ldr)
+    g.a_layout, g.b_layout, g.M, g.N, g.K = a_layout, b_layout, M, N, K
+    g.act, g.res_mod, g.alpha = act, res_mod, alpha
+    check(lib.dkd_gemm_f32(ctypes.byref(g), _stream()), f"dkd_gemm_f32[{M}x{N}x{K} a{a_layout} b{b_layout}]")
+    return out
+
+
+def linear_fwd(x, w, bias=None, act=ACT_NONE, residual=None, colscale=None, preact=None, out=None):
+    """y[..., N] = act(x[..., K] @ w[N, K]^T + bias) * colscale + residual"""
+    y = gemm(x, w, bias=bias, act=act, residual=residual, colscale=colscale, preact=preact,
+             out=None if out is None else out.reshape(-1, w.shape[0]))
+    return y.reshape(*x.shape[:-1], w.shape[0])
+
+
+def linear_dgrad(dy, w, accumulate_into=None):
+    """dx[..., K] = dy[..., N] @ w[N, K]  (+= accumulate_into)"""
+    K = w.shape[1]
+    out = None if accumulate_into is None else accumulate_into.reshape(-1, K)
+    dx = gemm(dy, w, b_layout=1, out=out, residual=out)
+    return dx.reshape(*dy.shape[:-1], K)
+
+
+def linear_wgrad(dy, x):
+    """dW[N, K] = dy[M, N]^T @ x[M, K]"""
+    return gemm(dy, x, a_layout=1, b_layout=1)
+
+
+def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):
+    """x viewed as [groups, rows_per_group, N] -> out[groups, N]."""
+    lib = _lib.load()
+    _chk(x, "x"), _chk(y, "y"), _chk(aux, "aux")
+    N = x.shape[-1]
+    rows = x.numel() // N
+    rpg = rows // groups
+    if out is None:
+        out = torch.empty((groups, N), dtype=torch.float32, device=x.device)
+    wsb = lib.dkd_colreduce_f32_workspace_bytes(rpg, groups, N)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.dkd_colreduce_f32(_p(x), _p(y), _p(aux), _p(out), _p(ws), rpg, groups, N, N, op, scale, _stream()),
+          "dkd_colreduce_f32")
+    return out
+
+
+def transpose(x, out=None):
+    """[..., R, C] -> [..., C, R] (dense copy)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    R, C = x.shape[-2:]
+    batch = x.numel() // (R * C)
+    if out is None:
+        out = torch.empty((*x.shape[:-2], C, R), dtype=torch.float32, device=x.device)
+    check(lib.dkd_transpose_f32(_p(x), _p(out), R, C, batch, _stream()), "dkd_transpose_f32")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, need_stats=True):
+    lib = _lib.load()
+    _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    mean = rstd = None
+    if need_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.dkd_layernorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps, _stream()),
+          "dkd_layernorm_fwd_f32")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True):
+    lib = _lib.load()
+    _chk(dy, "dy"), _chk(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    dg = db = ws = None
+    if affine:
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.dkd_layernorm_bwd_f32_workspace_bytes(rows, C), x.device)
+    check(lib.dkd_layernorm_bwd_f32(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dg), _p(db), _p(ws), rows,
+                                    C, _stream()), "dkd_layernorm_bwd_f32")
+    return dx, dg, db
+
+
+def _ew(fn, name, *tensors, n):
+    check(fn(*[_p(t) for t in tensors], n, _stream()), name)
+
+
+def gelu_fwd(x):
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    _ew(_lib.load().dkd_gelu_fwd_f32, "dkd_gelu_fwd_f32", x, y, n=x.numel())
+    return y
+
+
+def gelu_bwd(dy, x):
+    _chk(dy, "dy"), _chk(x, "x")
+    dx = torch.empty_like(x)
+    _ew(_lib.load().dkd_gelu_bwd_f32, "dkd_gelu_bwd_f32", dy, x, dx, n=x.numel())
+    return dx
+
+
+def relu_bwd(dy, y):
+    _chk(dy, "dy"), _chk(y, "y")
+    dx = torch.empty_like(y)
+    _ew(_lib.load().dkd_relu_bwd_f32, "dkd_relu_bwd_f32", dy, y, dx, n=y.numel())
+    return dx
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out=None):
+    _chk(a, "a"), _chk(b, "b")
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.load().dkd_axpby_f32(_p(a), _p(b), _p(out), alpha, beta, a.numel(), _stream()), "dkd_axpby_f32")
+    return out
+
+
+def sub_group_vec(x, vec, groups, out=None):
+    _chk(x, "x"), _chk(vec, "vec")
+    N = x.shape[-1]
+    rpg = x.numel() // N // groups
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().dkd_sub_group_vec_f32(_p(x), _p(vec), _p(out), rpg, groups, N, _stream()), "dkd_sub_group_vec_f32")
+    return out
+
+
+# ---- attention -------------------------------------------------------------------------------------------------
+def _attn_args(q, k, v, o, H, hd, scale, strides):
+    a = AttnArgs()
+    a.q, a.k, a.v, a.o = _p(q), _p(k), _p(v), _p(o)
+    (a.q_bs, a.q_rs), (a.k_bs, a.k_rs), (a.v_bs, a.v_rs), (a.o_bs, a.o_rs) = strides
+    a.H, a.hd, a.scale = H, hd, scale
+    return a
+
+
+def attention_forward(q, k, v, H, hd, scale, B, Nq, Nk, q_st, k_st, v_st):
+    lib = _lib.load()
+    D = H * hd
+    o = torch.empty((B, Nq, D), dtype=torch.float32, device=k.device)
+    lse = torch.empty((B, H, Nq), dtype=torch.float32, device=k.device)
+    a = _attn_args(q, k, v, o, H, hd, scale, (q_st, k_st, v_st, (Nq * D, D)))
+    a.B, a.Nq, a.Nk, a.lse = B, Nq, Nk, _p(lse)
+    check(lib.dkd_attn_fwd_f32(ctypes.byref(a), _stream()), f"dkd_attn_fwd_f32[hd={hd}]")
+    return o, lse
+
+
+def attention_backward(do, q, k, v, o, lse, H, hd, scale, B, Nq, Nk, q_st, k_st, v_st, dq, dk, dv, dq_st, dk_st, dv_st):
+    lib = _lib.load()
+    D = H * hd
+    _chk(do, "do")
+    delta = torch.empty((B, H, Nq), dtype=torch.float32, device=k.device)
+    a = _attn_args(q, k, v, o, H, hd, scale, (q_st, k_st, v_st, (Nq * D, D)))
+    a.B, a.Nq, a.Nk, a.lse, a.delta, a.d_o = B, Nq, Nk, _p(lse), _p(delta), _p(do)
+    a.do_bs, a.do_rs = Nq * D, D
+    a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
+    (a.dq_bs, a.dq_rs), (a.dk_bs, a.dk_rs), (a.dv_bs, a.dv_rs) = dq_st, dk_st, dv_st
+    check(lib.dkd_attn_bwd_f32(ctypes.byref(a), _stream()), f"dkd_attn_bwd_f32[hd={hd}]")
+
+
+# ---- ScaleKD loss tail -----------------------------------------------------------------------------------------
+def kd_loss_fwd(s, t, rows_per_img, alpha, mean_s=None, mean_t=None):
+    lib = _lib.load()
+    _chk(s, "s"), _chk(t, "t"), _chk(mean_s, "mean_s"), _chk(mean_t, "mean_t")
+    D = s.shape[-1]
+    rows = s.numel() // D
+    out = torch.empty(2, dtype=torch.float32, device=s.device)
+    ws = workspace(lib.dkd_kd_loss_f32_workspace_bytes(rows), s.device)
+    check(lib.dkd_kd_loss_fwd_f32(_p(s), _p(t), _p(mean_s), _p(mean_t), _p(out), _p(ws), rows, rows_per_img, D, alpha,
+                                  _stream()), "dkd_kd_loss_fwd_f32")
+    return out
+
+
+def kd_loss_bwd(s, t, rows_per_img, alpha, grad_out=None, mean_s=None, mean_t=None):
+    lib = _lib.load()
+    D = s.shape[-1]
+    rows = s.numel() // D
+    ds = torch.empty_like(s)
+    check(lib.dkd_kd_loss_bwd_f32(_p(s), _p(t), _p(mean_s), _p(mean_t), _p(grad_out), _p(ds), rows, rows_per_img, D, alpha,
+                                  _stream()), "dkd_kd_loss_bwd_f32")
+    return ds
+
+
+# ---- BatchNorm / GRN helpers -----------------------------------------------------------------------------------
+def bn_stats(z, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """Train-mode batch statistics of z [rows, N] (two-pass: mean, centred variance) -> mean, rstd [N]."""
+    lib = _lib.load()
+    N = z.shape[-1]
+    rows = z.numel() // N
+    mean = colreduce(z, RED_SUM, scale=1.0 / rows).reshape(N)
+    var = colreduce(z, RED_SQDIFF, aux=mean, scale=1.0 / rows).reshape(N)
+    rstd = torch.empty_like(mean)
+    check(lib.dkd_bn_finalize_f32(_p(mean), _p(var), _p(rstd), _p(running_mean), _p(running_var), N, rows, momentum, eps,
+                                  _stream()), "dkd_bn_finalize_f32")
+    return mean, rstd
+
+
+def bn_act_pos_fwd(z, mean, rstd, gamma, beta, pos=None, relu=True):
+    lib = _lib.load()
+    N = z.shape[-1]
+    rows = z.numel() // N
+    out = torch.empty_like(z)
+    period = pos.numel() // N if pos is not None else 0
+    check(lib.dkd_bn_act_pos_fwd_f32(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(pos), _p(out), rows, N, period,
+                                     int(relu), _stream()), "dkd_bn_act_pos_fwd_f32")
+    return out
+
+
+def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True):
+    """-> dz, dgamma, dbeta for out = relu(bn(z)) (+ pos)."""
+    lib = _lib.load()
+    N = z.shape[-1]
+    rows = z.numel() // N
+    dbn = torch.empty_like(z)
+    xhat = torch.empty_like(z)
+    check(lib.dkd_bn_bwd_prep_f32(_p(dt), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dbn), _p(xhat), rows, N,
+                                  int(relu), _stream()), "dkd_bn_bwd_prep_f32")
+    dbeta = colreduce(dbn, RED_SUM).reshape(N)
+    dgamma = colreduce(dbn, RED_DOT, y=xhat).reshape(N)
+    dz = torch.empty_like(z)
+    check(lib.dkd_bn_bwd_apply_f32(_p(dbn), _p(xhat), _p(dbeta), _p(dgamma), _p(gamma), _p(rstd), _p(dz), rows, N,
+                                   _stream()), "dkd_bn_bwd_apply_f32")
+    return dz, dgamma, dbeta
+
+
+# ---- ConvNeXt spatial ops (NHWC) -----------------------------------------------------------------------------------
+def dwconv7(x, w_tap, bias=None, add=None, flip=False):
+    """x [B,H,W,C]; w_tap tap-major [49,C]."""
+    _chk(x, "x"), _chk(w_tap, "w_tap"), _chk(bias, "bias"), _chk(add, "add")
+    B, H, W, C = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().dkd_dwconv7_fwd_f32(_p(x), _p(w_tap), _p(bias), _p(add), _p(out), B, H, W, C, int(flip), _stream()),
+          "dkd_dwconv7_fwd_f32")
+    return out
+
+
+def dwconv7_wgrad(x, dout):
+    """-> dW tap-major [49, C]"""
+    lib = _lib.load()
+    _chk(x, "x"), _chk(dout, "dout")
+    B, H, W, C = x.shape
+    parts = lib.dkd_dwconv7_wgrad_f32_parts(B, H)
+    part = workspace(parts * 49 * C * 4, x.device, slot=1)
+    check(lib.dkd_dwconv7_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_f32")
+    return colreduce(part[: parts * 49 * C].view(parts, 49 * C)).view(49, C)
+
+
+def patchify_nchw(img, k):
+    _chk(img, "img")
+    B, Cin, H, W = img.shape
+    out = torch.empty((B * (H // k) * (W // k), Cin * k * k), dtype=torch.float32, device=img.device)
+    check(_lib.load().dkd_patchify_nchw_f32(_p(img), _p(out), B, Cin, H, W, k, _stream()), "dkd_patchify_nchw_f32")
+    return out
+
+
+def patchify_nhwc(x, k):
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    out = torch.empty((B * (H // k) * (W // k), k * k * C), dtype=torch.float32, device=x.device)
+    check(_lib.load().dkd_patchify_nhwc_f32(_p(x), _p(out), B, H, W, C, k, 0, _stream()), "dkd_patchify_nhwc_f32")
+    return out
+
+
+def unpatchify_nhwc(rows, B, H, W, C, k):
+    _chk(rows, "rows")
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=rows.device)
+    check(_lib.load().dkd_patchify_nhwc_f32(_p(rows), _p(out), B, H, W, C, k, 1, _stream()), "dkd_patchify_nhwc_f32(inv)")
+    return out
+
+
+def resize_fwd(x, Ho, Wo):
+    _chk(x, "x")
+    B, Hi, Wi, C = x.shape
+    out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().dkd_resize_bilinear_fwd_f32(_p(x), _p(out), B, Hi, Wi, Ho, Wo, C, _stream()), "dkd_resize_fwd")
+    return out
+
+
+def resize_bwd(dout, Hi, Wi):
+    _chk(dout, "dout")
+    B, Ho, Wo, C = dout.shape
+    din = torch.empty((B, Hi, Wi, C), dtype=torch.float32, device=dout.device)
+    check(_lib.load().dkd_resize_bilinear_bwd_f32(_p(dout), _p(din), B, Hi, Wi, Ho, Wo, C, _stream()), "dkd_resize_bwd")
+    return din
+
+
+def set_rows(out, vec, B, row_stride):
+    check(_lib.load().dkd_set_rows_f32(_p(out), _p(vec), B, row_stride, vec.numel(), _stream()), "dkd_set_rows_f32")
+    return out
+
+
+def grn_fwd(g, gamma, beta, B):
+    """g [B*HW, C] (post-GELU) -> y, (gx, nx, denom)"""
+    lib = _lib.load()
+    C = g.shape[-1]
+    rpi = g.numel() // C // B
+    sumsq = colreduce(g, RED_SUMSQ, groups=B)
+    gx, nx = torch.empty_like(sumsq), torch.empty_like(sumsq)
+    denom = torch.empty(B, dtype=torch.float32, device=g.device)
+    check(lib.dkd_grn_stats_f32(_p(sumsq), _p(gx), _p(nx), _p(denom), B, C, _stream()), "dkd_grn_stats_f32")
+    y = torch.empty_like(g)
+    check(lib.dkd_grn_apply_f32(_p(g), _p(nx), _p(gamma), _p(beta), _p(y), B, rpi, C, _stream()), "dkd_grn_apply_f32")
+    return y, (gx, nx, denom)
+
+
+def grn_gelu_bwd(dy, g, h, stats, gamma, B):
+    """-> dh (through GRN and GELU), dgamma, dbeta"""
+    lib = _lib.load()
+    gx, nx, denom = stats
+    C = g.shape[-1]
+    rpi = g.numel() // C // B
+    A = colreduce(dy, RED_DOT, y=g, groups=B)  # [B, C] sum_hw dy*g
+    dbeta = colreduce(dy, RED_SUM).reshape(C)
+    coef, dgp = torch.empty_like(A), torch.empty_like(A)
+    check(lib.dkd_grn_bwd_stats_f32(_p(A), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgp), B, C, _stream()),
+          "dkd_grn_bwd_stats_f32")
+    dgamma = colreduce(dgp, RED_SUM).reshape(C)
+    dh = torch.empty_like(g)
+    check(lib.dkd_grn_gelu_bwd_f32(_p(dy), _p(g), _p(h), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
+          "dkd_grn_gelu_bwd_f32")
+    return dh, dgamma, dbeta

@@ -1,0 +1,187 @@
+/* dkd_hip.h - C ABI of libdkd_hip.so: the MI355X (gfx950) kernels of the DINOv2->CNN distillation step.
+ *
+ * The reference (ardaerendogru/dinov2_distillation) is pure Python/PyTorch and has no FFI of its own; every
+ * entry point below replaces the ATen op sequence at the cited reference call site (paths relative to
+ * /root/reference).  This library has NO torch dependency: plain device pointers, sizes, and a hipStream_t
+ * passed as void*.  Ownership: the caller owns every buffer; kernels borrow pointers for the duration of the
+ * launch.  All tensors are fp32, dense, "token-major" (channels-last: [rows, C] with C contiguous) unless a
+ * stride argument says otherwise.  Every function returns 0 on success, a positive hipError_t if the launch
+ * failed, or a negative DKD_ERR_* for an argument it refuses (nothing launched).  All launches are asynchronous
+ * on `stream`; nothing here allocates, frees or synchronises, so every call is hipGraph-capturable.
+ * `ws` arguments are caller-provided scratch (size from the matching *_workspace_bytes query, may be reused by
+ * the next call on the same stream).
+ */
+#ifndef DKD_HIP_H
+#define DKD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DKD_ABI_VERSION 1
+int dkd_abi_version(void);
+
+/* activation codes for fused epilogues */
+#define DKD_ACT_NONE 0
+#define DKD_ACT_RELU 1
+#define DKD_ACT_GELU 2 /* exact erf GELU (nn.GELU default) */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense layers: fp32 MFMA GEMM   C[m][n] = epi(alpha * sum_k Aop[m][k] * Bop[n][k])
+ * Replaces every nn.Linear / 1x1 / patchify conv on the path, forward, dgrad and wgrad:
+ *   losses/scalekd.py:199 (proj_student 1x1 conv), :299-301 (q,k,v), :316 (proj), :455-459 (FFN);
+ *   models/backbones/convnext.py:66-72 (pwconv1/2), :117,:124 (stem / downsample convs as patch GEMMs);
+ *   external DINOv2 block (qkv, proj, fc1, fc2, patch_embed) reached from models/backbones/dinov2.py:32 and
+ *   train/distillation_module.py:177.
+ *   a_layout 0: Aop[m][k]=A[m*lda+k]   1: Aop[m][k]=A[k*lda+m]
+ *   b_layout 0: Bop[n][k]=B[n*ldb+k]   1: Bop[n][k]=B[k*ldb+n]
+ * Epilogue order: v=alpha*acc (+bias[n]); preact[.]=v (optional); v=act(v); v*=colscale[n]; v+=residual; store.
+ *   residual row = res_mod>0 ? m % res_mod : output row (residual may alias C => C += ...).
+ *   output row remap (row_grp>0): orow = (m / row_grp) * row_grp_stride + m % row_grp + row_off
+ *   (used to drop the patch tokens of image b behind its CLS slot).
+ * Requirements: contiguous extent and leading dimension of A and B multiples of 4 floats, 16-byte aligned bases.
+ * `workspace` (dkd_gemm_f32_workspace_bytes) enables split-K for small-output / long-reduction shapes (wgrad).
+ */
+typedef struct dkd_gemm_args {
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    const float* bias;
+    const float* colscale;
+    const float* residual;
+    int64_t ldr;
+    float* preact;
+    float* workspace;
+    int32_t a_layout, b_layout;
+    int32_t M, N, K;
+    int32_t act;
+    int32_t res_mod;
+    int32_t row_grp, row_grp_stride, row_off;
+    float alpha;
+} dkd_gemm_args;
+int dkd_gemm_f32(const dkd_gemm_args* args, void* stream);
+int dkd_gemm_f32_splits(int M, int N, int K);
+long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis of token-major rows (one wavefront per row, C <= 2048, C % 4 == 0).
+ * Replaces: DINOv2 block norm1/norm2/final norm (eps 1e-6; external, via models/backbones/dinov2.py:32),
+ * ScaleKD norm / norm_2 (eps 1e-5; losses/scalekd.py:215-216,244-245), ConvNeXt LayerNorm channels_last AND
+ * channels_first (models/backbones/convnext.py:26-36: in NHWC both are the same row reduction).
+ * mean/rstd (per row) may be NULL when no backward is needed.  bwd: dgamma/dbeta may both be NULL (frozen
+ * teacher: dgrad only); otherwise ws must hold dkd_layernorm_bwd_f32_workspace_bytes.
+ */
+int dkd_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                          long rows, int C, float eps, void* stream);
+int dkd_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          float* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, void* stream);
+long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C);
+
+/* Grouped column reduction  out[g][n] = scale * sum_{r<rows_per_group} f(X[g*rows_per_group+r][n], ...)
+ * (bias gradients, BatchNorm batch statistics losses/scalekd.py:200, GRN energies convnext.py:48, pos_embed / query
+ * gradients, spatial means for the frequency loss losses/scalekd.py:111-118). */
+#define DKD_RED_SUM 0    /* x            */
+#define DKD_RED_DOT 1    /* x * y        */
+#define DKD_RED_SUMSQ 2  /* x * x        */
+#define DKD_RED_SQDIFF 3 /* (x - aux[n])^2 */
+int dkd_colreduce_f32(const float* X, const float* Y, const float* aux, float* out, float* ws, long rows_per_group,
+                      int groups, int N, long ldx, int op, float scale, void* stream);
+long dkd_colreduce_f32_workspace_bytes(long rows_per_group, int groups, int N);
+/* out[b] = in[b]^T for `batch` dense [rows, cols] matrices (pos_embed [D,P*P] <-> token-major [P*P,D]) */
+int dkd_transpose_f32(const float* in, float* out, int rows, int cols, int batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Element-wise kernels (n, N, C multiples of 4).
+ */
+int dkd_gelu_fwd_f32(const float* x, float* y, long n, void* stream);                  /* convnext.py:70, DINOv2 MLP */
+int dkd_gelu_bwd_f32(const float* dy, const float* x, float* dx, long n, void* stream);
+int dkd_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream); /* FFN ReLU losses/scalekd.py:448 */
+int dkd_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, long n, void* stream);
+int dkd_sub_group_vec_f32(const float* x, const float* vec, float* out, long rows_per_group, int groups, int N,
+                          void* stream);
+/* train-mode BatchNorm2d of the projector input (losses/scalekd.py:199-201,238): statistics come from
+ * dkd_colreduce_f32 (mean, then centred variance); finalize makes rstd and updates the running stats
+ * (momentum 0.1, unbiased running_var); apply fuses BN + ReLU + pos_embed add (pos is [period, N] token-major). */
+int dkd_bn_finalize_f32(const float* mean, const float* var, float* rstd, float* running_mean, float* running_var,
+                        int N, long count, float momentum, float eps, void* stream);
+int dkd_bn_act_pos_fwd_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           const float* pos, float* out, long rows, int N, int period, int relu, void* stream);
+int dkd_bn_bwd_prep_f32(const float* dt, const float* z, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* dbn, float* xhat, long rows, int N, int relu, void* stream);
+int dkd_bn_bwd_apply_f32(const float* dbn, const float* xhat, const float* sum_dbn, const float* sum_dbn_xhat,
+                         const float* gamma, const float* rstd, float* dz, long rows, int N, void* stream);
+/* ConvNeXt-V2 GRN on NHWC rows (models/backbones/convnext.py:39-50): sumsq[b][c] from dkd_colreduce_f32 */
+int dkd_grn_stats_f32(const float* sumsq, float* gx, float* nx, float* denom, int B, int C, void* stream);
+int dkd_grn_apply_f32(const float* g, const float* nx, const float* gamma, const float* beta, float* y, int B,
+                      long rows_per_img, int C, void* stream);
+int dkd_grn_bwd_stats_f32(const float* A, const float* gx, const float* nx, const float* denom, const float* gamma,
+                          float* coef, float* dgamma_part, int B, int C, void* stream);
+int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const float* nx, const float* coef,
+                         const float* gamma, float* dh, int B, long rows_per_img, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ScaleKD loss tail (losses/scalekd.py:67-92 get_spat_loss, :95-127 get_freq_loss).  S, T: token-major [rows, D].
+ * out2[0] = alpha/B * sum |s^ - t^|^2, out2[1] = mean cosine.  mean_s/mean_t: NULL (spatial) or [B, D] spatial
+ * means (frequency variant == DCT / zero DC / IDCT).  bwd writes d loss / d (centred) S scaled by *grad_out
+ * (device scalar, NULL = 1).
+ */
+int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* mean_s, const float* mean_t, float* out2, float* ws,
+                        long rows, long rows_per_img, int D, float alpha, void* stream);
+int dkd_kd_loss_bwd_f32(const float* S, const float* T, const float* mean_s, const float* mean_t, const float* grad_out,
+                        float* dS, long rows, long rows_per_img, int D, float alpha, void* stream);
+long dkd_kd_loss_f32_workspace_bytes(long rows);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-head attention, flash-style, exact fp32 MFMA.  softmax(scale * q k^T) v per (batch, head).
+ * Replaces the DINOv2 block attention (external; reused with autograd at train/distillation_module.py:176-177)
+ * and WindowMultiheadPosAttention's core (losses/scalekd.py:308-314, window_shapes (1,1)).
+ * Element (b, token, head, d) of x lives at x[b*x_bs + token*x_rs + head*hd + d]; strides in floats, % 4 == 0;
+ * q_bs may be 0 (batch-invariant self-query).  lse/delta: [B, H, Nq] scratch kept between fwd and bwd.
+ * hd in {16,24,32,48,64,96}.
+ */
+typedef struct dkd_attn_args {
+    const float *q, *k, *v;
+    float* o;
+    float* lse;
+    const float* d_o;
+    float* delta;
+    float *dq, *dk, *dv;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    int64_t do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    int32_t B, H, Nq, Nk, hd;
+    float scale;
+} dkd_attn_args;
+int dkd_attn_fwd_f32(const dkd_attn_args* args, void* stream);
+int dkd_attn_bwd_f32(const dkd_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ConvNeXt-V2 student spatial ops on NHWC tensors (models/backbones/convnext.py).
+ * dwconv7: depthwise 7x7, pad 3 (:62-64).  Weights arrive TAP-MAJOR [49][C] (dkd_transpose_f32 of the [C,1,7,7]
+ * parameter).  flip=1 applies the 180-degree-rotated taps == dgrad wrt the input; `add` (nullable, same shape as out)
+ * is summed into the result (residual branch of Block.forward :86 in the backward pass).  W % 7 == 0, C % 4 == 0.
+ * wgrad writes per-(image,row-chunk) partial sums [parts][49][C] (parts from dkd_dwconv7_wgrad_f32_parts), to be
+ * folded with dkd_colreduce_f32 -> tap-major [49][C].
+ */
+int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, const float* bias, const float* add, float* out, int B,
+                        int H, int W, int C, int flip, void* stream);
+int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* partials, int B, int H, int W, int C, void* stream);
+long dkd_dwconv7_wgrad_f32_parts(int B, int H);
+/* Non-overlapping k x k stride-k convs as GEMMs: stem 4x4 s4 (:117), downsample 2x2 s2 (:124), DINOv2 patch-embed
+ * 14x14 s14.  nchw: image [B,Cin,H,W] -> rows [(b,py,px)][(c,ky,kx)].  nhwc: feature [B,H,W,C] <-> rows
+ * [(b,py,px)][(ky,kx,c)] (inverse=1 scatters rows back = the conv's dgrad layout step). */
+int dkd_patchify_nchw_f32(const float* img, float* out, int B, int Cin, int H, int W, int k, void* stream);
+int dkd_patchify_nhwc_f32(const float* src, float* dst, int B, int H, int W, int C, int k, int inverse, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) of every student feature to the teacher grid
+ * (models/model_zoo.py:123-128), NHWC, forward and its adjoint (gather form: deterministic, no atomics). */
+int dkd_resize_bilinear_fwd_f32(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+int dkd_resize_bilinear_bwd_f32(const float* dout, float* din, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+/* out[b*row_stride + d] = vec[d]: the CLS(+pos[0]) token row of every image in the teacher token buffer */
+int dkd_set_rows_f32(float* out, const float* vec, int B, long row_stride, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DKD_HIP_H */

@@ -1,0 +1,293 @@
+"""GPU parity of every HIP kernel (called through the C ABI via dinov2_distillation_amd.ops) against a plain fp32
+PyTorch CPU computation of the same op / the oracle.  Tolerance: 1e-3 relative to the tensor's max magnitude is the
+north-star bound; kernels are held to a tighter 2e-5..2e-4 here (fp32 accumulate-order noise only)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from dinov2_distillation_amd import ops as o
+    return o
+
+
+def close(a, b, what, rtol=1e-4):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max|diff| {err:.3e} > {rtol:g} * {scale:.3e}"
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(257 * 3, 384, 384), (512, 1152, 384), (300, 96, 384), (1000, 192, 96),
+                                   (256, 384, 588), (130, 1536, 384), (64, 48, 96)])
+def test_gemm_forward_layouts(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    close(ops.gemm(dev(x), dev(w)), x @ w.t(), "NT")
+    dy = torch.randn(M, N, generator=g)
+    close(ops.gemm(dev(dy), dev(w), b_layout=1), dy @ w, "dgrad NN")
+    close(ops.gemm(dev(dy), dev(x), a_layout=1, b_layout=1), dy.t() @ x, "wgrad TN")
+    if M % 4 == 0:
+        close(ops.gemm(dev(x.t().contiguous()), dev(w), a_layout=1), x @ w.t(), "A km / B nk")
+
+
+def test_gemm_splitk_wgrad(ops):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 20000, 96, 384  # rows of the batch are the reduction
+    dy, x = torch.randn(M, K, generator=g) * 0.1, torch.randn(M, N, generator=g)
+    from dinov2_distillation_amd import _lib
+    assert _lib.load().dkd_gemm_f32_splits(K, N, M) > 1
+    close(ops.linear_wgrad(dev(dy), dev(x)), dy.t() @ x, "split-K wgrad", rtol=2e-4)
+
+
+def test_gemm_epilogues(ops):
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 514, 384, 96
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    cs, res = torch.rand(N, generator=g) + 0.5, torch.randn(M, N, generator=g)
+    ref_pre = x @ w.t() + b
+    pre = torch.empty(M, N, device="cuda")
+    out = ops.gemm(dev(x), dev(w), bias=dev(b), act=ops.ACT_GELU, colscale=dev(cs), residual=dev(res), preact=pre)
+    close(pre, ref_pre, "preact")
+    close(out, F.gelu(ref_pre) * cs + res, "bias+gelu+colscale+residual")
+    close(ops.gemm(dev(x), dev(w), bias=dev(b), act=ops.ACT_RELU), torch.relu(ref_pre), "relu")
+    # accumulate into C (residual aliases C) and alpha
+    c = dev(res.clone())
+    ops.gemm(dev(x), dev(w), out=c, residual=c, alpha=0.5)
+    close(c, 0.5 * (x @ w.t()) + res, "accumulate")
+    # row remap (CLS slot) + periodic residual (position table): M = B*P2 rows -> [B, P2+1] rows
+    Bn, P2 = 2, 257
+    x2 = torch.randn(Bn * P2, K, generator=g)
+    pos = torch.randn(P2 + 1, N, generator=g)
+    outb = torch.zeros(Bn * (P2 + 1), N, device="cuda")
+    ops.gemm(dev(x2), dev(w), bias=dev(b), out=outb, residual=dev(pos)[1:], res_mod=P2, row_map=(P2, P2 + 1, 1, Bn * (P2 + 1)))
+    ref = torch.zeros(Bn, P2 + 1, N)
+    ref[:, 1:] = (x2 @ w.t() + b).reshape(Bn, P2, N) + pos[1:]
+    close(outb, ref.reshape(-1, N), "row remap + periodic residual")
+
+
+@pytest.mark.parametrize("C", [96, 384, 768, 1536])
+def test_layernorm(ops, C):
+    g = torch.Generator().manual_seed(C)
+    rows = 531
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).requires_grad_(True)
+    ga, be = (torch.randn(C, generator=g) + 1).requires_grad_(True), torch.randn(C, generator=g).requires_grad_(True)
+    y_ref = F.layer_norm(x, (C,), ga, be, 1e-6)
+    dy = torch.randn(rows, C, generator=g)
+    y_ref.backward(dy)
+    y, mean, rstd = ops.layernorm_fwd(dev(x.detach()), dev(ga.detach()), dev(be.detach()), 1e-6)
+    close(y, y_ref, "ln fwd")
+    dx, dg, db = ops.layernorm_bwd(dev(dy), dev(x.detach()), mean, rstd, dev(ga.detach()))
+    close(dx, x.grad, "ln dx")
+    close(dg, ga.grad, "ln dgamma")
+    close(db, be.grad, "ln dbeta")
+    dx2, _, _ = ops.layernorm_bwd(dev(dy), dev(x.detach()), mean, rstd, dev(ga.detach()), affine=False)
+    close(dx2, x.grad, "ln dx (dgrad only)")
+
+
+def test_colreduce_transpose_pointwise(ops):
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(6, 49, 384, generator=g), torch.randn(6, 49, 384, generator=g)
+    aux = torch.randn(384, generator=g)
+    close(ops.colreduce(dev(x)), x.sum((0, 1))[None], "sum")
+    close(ops.colreduce(dev(x), ops.RED_DOT, y=dev(y), groups=6), (x * y).sum(1), "dot grouped")
+    close(ops.colreduce(dev(x), ops.RED_SUMSQ, groups=6, scale=0.5), 0.5 * (x * x).sum(1), "sumsq grouped")
+    close(ops.colreduce(dev(x), ops.RED_SQDIFF, aux=dev(aux)), ((x - aux) ** 2).sum((0, 1))[None], "sqdiff")
+    big = torch.randn(40000, 96, generator=g)
+    close(ops.colreduce(dev(big)), big.sum(0)[None], "tall sum", rtol=2e-4)
+    wide = torch.randn(8, 256 * 384, generator=g)
+    close(ops.colreduce(dev(wide)), wide.sum(0)[None], "wide sum")
+    t = torch.randn(3, 100, 37, generator=g)
+    close(ops.transpose(dev(t)), t.transpose(-1, -2), "transpose")
+    h = torch.randn(1000, 384, generator=g) * 2
+    close(ops.gelu_fwd(dev(h)), F.gelu(h), "gelu")
+    hh = h.clone().requires_grad_(True)
+    dh = torch.randn(1000, 384, generator=g)
+    F.gelu(hh).backward(dh)
+    close(ops.gelu_bwd(dev(dh), dev(h)), hh.grad, "gelu bwd")
+    close(ops.relu_bwd(dev(y), dev(torch.relu(x))), y * (x > 0), "relu bwd")
+    close(ops.axpby(dev(x), dev(y), 2.0, -0.5), 2 * x - 0.5 * y, "axpby")
+    v = torch.randn(6, 384, generator=g)
+    close(ops.sub_group_vec(dev(x), dev(v), 6), x - v[:, None], "sub group vec")
+
+
+@pytest.mark.parametrize("hd,H,Nq,Nk,B,shared_q", [(64, 3, 257, 257, 2, False), (16, 6, 256, 256, 2, True),
+                                                  (24, 4, 256, 256, 3, False), (32, 2, 100, 70, 2, False),
+                                                  (48, 2, 64, 64, 1, True), (64, 2, 33, 1369, 1, False)])
+def test_attention(ops, hd, H, Nq, Nk, B, shared_q):
+    g = torch.Generator().manual_seed(hd * 7 + Nq)
+    D = H * hd
+    scale = hd ** -0.5 * (5.0 if hd < 64 else 1.0)
+    q = torch.randn(1 if shared_q else B, Nq, D, generator=g).requires_grad_(True)
+    k = torch.randn(B, Nk, D, generator=g).requires_grad_(True)
+    v = torch.randn(B, Nk, D, generator=g).requires_grad_(True)
+
+    def heads(t, n):
+        return t.expand(B, -1, -1).reshape(B, n, H, hd).transpose(1, 2)
+
+    w = torch.softmax(heads(q, Nq) @ heads(k, Nk).transpose(-1, -2) * scale, -1)
+    o_ref = (w @ heads(v, Nk)).transpose(1, 2).reshape(B, Nq, D)
+    do = torch.randn(B, Nq, D, generator=g)
+    o_ref.backward(do)
+    qd, kd, vd = dev(q.detach()), dev(k.detach()), dev(v.detach())
+    q_st = (0 if shared_q else Nq * D, D)
+    kv_st = (Nk * D, D)
+    o, lse = ops.attention_forward(qd, kd, vd, H, hd, scale, B, Nq, Nk, q_st, kv_st, kv_st)
+    close(o, o_ref, "attn fwd", rtol=2e-4)
+    dq = torch.empty(B, Nq, D, device="cuda")
+    dk, dv = torch.empty_like(kd), torch.empty_like(vd)
+    ops.attention_backward(dev(do), qd, kd, vd, o, lse, H, hd, scale, B, Nq, Nk, q_st, kv_st, kv_st, dq, dk, dv,
+                           (Nq * D, D), kv_st, kv_st)
+    close(dk, k.grad, "attn dk", rtol=3e-4)
+    close(dv, v.grad, "attn dv", rtol=3e-4)
+    dq_ref = q.grad if not shared_q else None
+    if shared_q:
+        close(dq.sum(0, keepdim=True), q.grad, "attn dq (summed over batch)", rtol=3e-4)
+    else:
+        close(dq, dq_ref, "attn dq", rtol=3e-4)
+
+
+def test_attention_packed_qkv(ops):
+    """teacher layout: one [B, N, 3, H, hd] buffer, q/k/v addressed by strides; gradients written packed."""
+    g = torch.Generator().manual_seed(5)
+    B, N, H, hd = 2, 257, 6, 64
+    D = H * hd
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    q, k, v = (qkv[..., i * D:(i + 1) * D].reshape(B, N, H, hd).transpose(1, 2) for i in range(3))
+    o_ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, D)
+    d = dev(qkv)
+    st = (N * 3 * D, 3 * D)
+    o, _ = ops.attention_forward(d, d[..., D:], d[..., 2 * D:], H, hd, hd ** -0.5, B, N, N, st, st, st)
+    close(o, o_ref, "packed attn fwd", rtol=2e-4)
+
+
+@pytest.mark.parametrize("P,D,B", [(16, 384, 4), (37, 64, 2), (5, 768, 3)])
+def test_kd_loss(ops, P, D, B):
+    from oracle import scalekd_oracle as skd
+    g = torch.Generator().manual_seed(P)
+    s = (torch.randn(B, P * P, D, generator=g) + 0.2).requires_grad_(True)
+    tmap = (torch.randn(B, P * P, D, generator=g) + 0.3).reshape(B, P, P, D).permute(0, 3, 1, 2)  # token-major view
+    ttok = tmap.permute(0, 2, 3, 1).reshape(B, P * P, D)
+    l_ref, sim_ref = skd.spat_loss(s, tmap, 0.08)
+    gout = torch.tensor(1.7)
+    (l_ref * gout).backward()
+    out = ops.kd_loss_fwd(dev(s.detach()), dev(ttok), P * P, 0.08)
+    close(out[0], l_ref, "spat loss", rtol=2e-5)
+    close(out[1], sim_ref, "spat sim", rtol=2e-5)
+    ds = ops.kd_loss_bwd(dev(s.detach()), dev(ttok), P * P, 0.08, grad_out=dev(gout.reshape(1)))
+    close(ds, s.grad, "spat grad", rtol=1e-4)
+    s.grad = None
+    l_ref, sim_ref = skd.freq_loss(s, tmap, 0.06)
+    l_ref.backward()
+    sd, td = dev(s.detach()), dev(ttok)
+    ms = ops.colreduce(sd, groups=B, scale=1.0 / (P * P))
+    mt = ops.colreduce(td, groups=B, scale=1.0 / (P * P))
+    out = ops.kd_loss_fwd(sd, td, P * P, 0.06, ms, mt)
+    close(out[0], l_ref, "freq loss", rtol=5e-5)
+    close(out[1], sim_ref, "freq sim", rtol=5e-4)
+    dsc = ops.kd_loss_bwd(sd, td, P * P, 0.06, None, ms, mt)
+    ds = ops.sub_group_vec(dsc, ops.colreduce(dsc, groups=B, scale=1.0 / (P * P)), B)
+    close(ds, s.grad, "freq grad", rtol=2e-4)
+
+
+def test_batchnorm_relu_pos(ops):
+    g = torch.Generator().manual_seed(2)
+    B, HW, N = 3, 64, 96
+    z = (torch.randn(B * HW, N, generator=g) * 2 + 1).requires_grad_(True)
+    ga, be = (torch.rand(N, generator=g) + 0.5).requires_grad_(True), torch.randn(N, generator=g).requires_grad_(True)
+    pos = torch.randn(HW, N, generator=g).requires_grad_(True)
+    rm, rv = torch.zeros(N), torch.ones(N)
+    ref = torch.relu(F.batch_norm(z, rm, rv, ga, be, True, 0.1, 1e-5)).reshape(B, HW, N) + pos
+    dt = torch.randn(B, HW, N, generator=g)
+    ref.backward(dt)
+    zd = dev(z.detach())
+    rmd, rvd = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    mean, rstd = ops.bn_stats(zd, rmd, rvd)
+    out = ops.bn_act_pos_fwd(zd, mean, rstd, dev(ga.detach()), dev(be.detach()), dev(pos.detach()))
+    close(out.reshape(B, HW, N), ref, "bn fwd")
+    close(rmd, rm, "running mean")
+    close(rvd, rv, "running var")
+    dz, dg, db = ops.bn_bwd(dev(dt), zd, mean, rstd, dev(ga.detach()), dev(be.detach()))
+    close(dz, z.grad, "bn dz", rtol=2e-4)
+    close(dg, ga.grad, "bn dgamma", rtol=2e-4)
+    close(db, be.grad, "bn dbeta", rtol=2e-4)
+
+
+@pytest.mark.parametrize("B,H,C", [(2, 56, 96), (3, 14, 384), (2, 7, 768), (1, 28, 192)])
+def test_dwconv7(ops, B, H, C):
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, C, H, H, generator=g).requires_grad_(True)
+    w = torch.randn(C, 1, 7, 7, generator=g).requires_grad_(True)
+    b = torch.randn(C, generator=g).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=3, groups=C)
+    dy = torch.randn(B, C, H, H, generator=g)
+    y.backward(dy)
+    xn = dev(x.detach().permute(0, 2, 3, 1))
+    wt = ops.transpose(dev(w.detach().reshape(C, 49)))
+    out = ops.dwconv7(xn, wt, dev(b.detach()))
+    close(out.permute(0, 3, 1, 2), y, "dwconv fwd")
+    dyn = dev(dy.permute(0, 2, 3, 1))
+    dx = ops.dwconv7(dyn, wt, None, add=dyn, flip=True)
+    close(dx.permute(0, 3, 1, 2), x.grad + dy, "dwconv dgrad (+residual)")
+    dw = ops.dwconv7_wgrad(xn, dyn)
+    close(ops.transpose(dw).reshape(C, 1, 7, 7), w.grad, "dwconv wgrad", rtol=3e-4)
+
+
+def test_patchify_and_resize(ops):
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(2, 3, 56, 56, generator=g)
+    for k in (4, 14):
+        w = torch.randn(8, 3, k, k, generator=g)
+        ref = F.conv2d(img, w, stride=k).permute(0, 2, 3, 1).reshape(-1, 8)
+        rows = ops.patchify_nchw(dev(img), k)
+        close(rows.cpu() @ w.reshape(8, -1).t(), ref, f"patchify nchw k={k}")
+    x = torch.randn(2, 16, 8, 8, generator=g)
+    w = torch.randn(24, 16, 2, 2, generator=g)
+    ref = F.conv2d(x, w, stride=2).permute(0, 2, 3, 1).reshape(-1, 24)
+    xn = dev(x.permute(0, 2, 3, 1))
+    rows = ops.patchify_nhwc(xn, 2)
+    wp = w.permute(0, 2, 3, 1).reshape(24, -1)  # [O][ky][kx][c]
+    close(rows.cpu() @ wp.t(), ref, "patchify nhwc")
+    close(ops.unpatchify_nhwc(rows, 2, 8, 8, 16, 2), xn, "unpatchify roundtrip")
+    for (hi, ho) in ((14, 16), (7, 16), (33, 37), (17, 37), (16, 16), (20, 9)):
+        f = torch.randn(2, 8, hi, hi, generator=g).requires_grad_(True)
+        r = F.interpolate(f, size=(ho, ho), mode="bilinear", align_corners=False)
+        ct = torch.randn(2, 8, ho, ho, generator=g)
+        r.backward(ct)
+        out = ops.resize_fwd(dev(f.detach().permute(0, 2, 3, 1)), ho, ho)
+        close(out.permute(0, 3, 1, 2), r, f"resize {hi}->{ho}")
+        din = ops.resize_bwd(dev(ct.permute(0, 2, 3, 1)), hi, hi)
+        close(din.permute(0, 3, 1, 2), f.grad, f"resize bwd {hi}->{ho}")
+
+
+def test_grn(ops):
+    from oracle import convnext_oracle as cno
+    g = torch.Generator().manual_seed(4)
+    B, HW, C = 3, 49, 384
+    h = torch.randn(B, 7, 7, C, generator=g).requires_grad_(True)
+    ga = torch.randn(1, 1, 1, C, generator=g).requires_grad_(True)
+    be = torch.randn(1, 1, 1, C, generator=g).requires_grad_(True)
+    y = cno.grn(F.gelu(h), ga, be)
+    dy = torch.randn(B, 7, 7, C, generator=g)
+    y.backward(dy)
+    hd = dev(h.detach().reshape(B * HW, C))
+    gd = ops.gelu_fwd(hd)
+    yd, stats = ops.grn_fwd(gd, dev(ga.detach().reshape(C)), dev(be.detach().reshape(C)), B)
+    close(yd.reshape(B, 7, 7, C), y, "grn fwd")
+    dh, dga, dbe = ops.grn_gelu_bwd(dev(dy.reshape(B * HW, C)), gd, hd, stats, dev(ga.detach().reshape(C)), B)
+    close(dh.reshape(B, 7, 7, C), h.grad, "grn+gelu dh", rtol=2e-4)
+    close(dga, ga.grad.reshape(C), "grn dgamma", rtol=2e-4)
+    close(dbe, be.grad.reshape(C), "grn dbeta", rtol=2e-4)
