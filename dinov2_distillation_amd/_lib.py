@@ -105,6 +105,12 @@ def declared_functions():
 _ERRS = {-1: "DKD_ERR_BAD_ARG", -2: "DKD_ERR_ALIGN", -3: "DKD_ERR_UNSUPPORTED"}
 
 
+_DEBUG_SYNC = bool(os.environ.get("DKD_DEBUG_SYNC"))
+
+
 def check(code, what):
+    if _DEBUG_SYNC:  # debugging aid: serialise every launch so that a fault / race is attributed to its op
+        import torch
+        torch.cuda.synchronize()
     if code != 0:
         raise DkdError(f"{what} failed: {_ERRS.get(code, 'hipError_t ' + str(code))}")

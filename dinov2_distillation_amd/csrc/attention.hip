@@ -330,6 +330,7 @@ int launch_bwd(const dkd_attn_args* a, hipStream_t st) {
 
 #define DKD_HD_DISPATCH(FN, a, st)                     \
     switch ((a)->hd) {                                 \
+        case 8: return FN<8>(a, st);                   \
         case 16: return FN<16>(a, st);                 \
         case 24: return FN<24>(a, st);                 \
         case 32: return FN<32>(a, st);                 \

@@ -19,7 +19,7 @@ template <bool FLIP>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                       const float* __restrict__ bias, const float* __restrict__ add,
                                                       float* __restrict__ out, int B, int H, int W, int C) {
-    const int cq = C >> 2, xt = W / 7;
+    const int cq = C >> 2, xt = (W + 6) / 7;
     const long total = (long)B * H * xt * cq;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % cq);
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
         const float4* ab = add ? reinterpret_cast<const float4*>(add) + ((long)(b * H + y) * W + x0) * cq + c4 : nullptr;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
+            if (x0 + k >= W) break;
             float4 o = acc[k];
             if (ab) {
                 const float4 a = ab[(long)k * cq];
@@ -237,8 +238,8 @@ inline int blocks_for(long n) {
 extern "C" int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, const float* bias, const float* add,
                                    float* out, int B, int H, int W, int C, int flip, void* stream) {
     if (!in || !w_tap_major || !out || B <= 0 || H <= 0 || W <= 0) return DKD_ERR_BAD_ARG;
-    if ((C & 3) || (W % 7)) return DKD_ERR_UNSUPPORTED;
-    const long total = (long)B * H * (W / 7) * (C / 4);
+    if (C & 3) return DKD_ERR_UNSUPPORTED;
+    const long total = (long)B * H * ((W + 6) / 7) * (C / 4);
     if (flip)
         hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, w_tap_major,
                            bias, add, out, B, H, W, C);

@@ -12,12 +12,14 @@ template <bool WRITE_STATS>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            long rows, int C, float eps) {
+                                                            long rows, int C, float eps, int in_grp, int in_grp_stride,
+                                                            int in_off) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nv = C >> 2;
     const float invC = 1.f / (float)C;
     for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
-        const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+        const long irow = in_grp > 0 ? (row / in_grp) * in_grp_stride + row % in_grp + in_off : row;
+        const float4* xr = reinterpret_cast<const float4*>(x + irow * C);
         float4 v[LN_MAXV];
         float s = 0.f;
 #pragma unroll
@@ -65,7 +67,8 @@ template <bool AFFINE>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ add, float* __restrict__ dx,
                                                             float* __restrict__ ws, long rows, int C) {
     __shared__ float red[AFFINE ? 4 * LN_MAXV * 256 : 4];  // [wave][C <= 2048]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -109,6 +112,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 o.y = rs * (g[i].y - s1 - xh[i].y * s2);
                 o.z = rs * (g[i].z - s1 - xh[i].z * s2);
                 o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+                if (add) {
+                    const float4 a = reinterpret_cast<const float4*>(add + row * C)[c];
+                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                }
                 oxr[c] = o;
             }
         }
@@ -237,16 +244,17 @@ void colreduce_plan(long rows_per_group, int groups, int N, int* CL, int* nsplit
 }  // namespace
 
 extern "C" int dkd_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                     float* rstd, long rows, int C, float eps, void* stream) {
+                                     float* rstd, long rows, int C, float eps, int in_row_grp, int in_row_grp_stride,
+                                     int in_row_off, void* stream) {
     if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
     if ((C & 3) || C > LN_MAXV * 256) return DKD_ERR_UNSUPPORTED;
     const int blocks = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
     if (mean && rstd)
         hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, rows, C, eps);
+                           mean, rstd, rows, C, eps, in_row_grp, in_row_grp_stride, in_row_off);
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                           y, mean, rstd, rows, C, eps);
+                           y, mean, rstd, rows, C, eps, in_row_grp, in_row_grp_stride, in_row_off);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
@@ -258,22 +266,22 @@ extern "C" long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C) {
 }
 
 extern "C" int dkd_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
-                                     const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, long rows,
-                                     int C, void* stream) {
+                                     const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
+                                     float* ws, long rows, int C, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || rows <= 0) return DKD_ERR_BAD_ARG;
     if ((C & 3) || C > LN_MAXV * 256) return DKD_ERR_UNSUPPORTED;
     const int blocks = ln_bwd_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     if (dgamma && dbeta) {
         if (!ws) return DKD_ERR_BAD_ARG;
-        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, dx, ws,
-                           rows, C);
+        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx,
+                           ws, rows, C);
         DKD_LAUNCH_CHECK();
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, blocks, 2 * C, dgamma,
                            dbeta, C, 1.0f);
     } else {
-        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, dx, ws,
-                           rows, C);
+        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx,
+                           ws, rows, C);
     }
     DKD_LAUNCH_CHECK();
     return DKD_OK;

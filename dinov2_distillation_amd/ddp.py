@@ -1,0 +1,119 @@
+"""Data-parallel gradient exchange for the distillation step: one process per GPU, RCCL over xGMI
+(torch.distributed backend "nccl" IS RCCL on ROCm; "gloo" on CPU for tests).
+
+Replaces Lightning's ``strategy: ddp`` (train.py:256-270, config/config.yaml:62-69) for this path:
+  * only student + projector gradients are exchanged (the teacher is frozen and identical on every rank by
+    construction: same seed / same checkpoint; ``broadcast_parameters`` sends the trainable arena once);
+  * gradients live in FusedAdamW's flat arena, so a bucket is a contiguous slice - no flatten/unflatten copies;
+  * buckets are launched from post-accumulate-grad hooks as soon as every parameter of the bucket has its gradient,
+    on a side HIP stream, so the all-reduce overlaps the rest of the backward pass;
+  * xGMI is point-to-point (7 links/GPU): few large buckets (default 32 MiB) keep every ring step per-link
+    bandwidth-bound rather than latency-bound;
+  * BatchNorm buffers are rank-local exactly as in the reference (no SyncBN for in-scope students), so the per-step
+    buffer broadcast of torch DDP is dropped;
+  * the reference never sets it on ROCm, but NCCL_P2P_DISABLE=1 (train.py:23) must NOT be inherited: it would turn
+    xGMI peer-to-peer off.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend=None):
+    if dist.is_initialized():
+        return
+    os.environ.pop("NCCL_P2P_DISABLE", None)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend)
+
+
+class GradBucketReducer:
+    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None):
+        self.opt = optimizer
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.flat_g = optimizer.flat_g
+        self.cuda = self.flat_g.is_cuda
+        self.side = torch.cuda.Stream() if self.cuda else None
+        cap = max(1, bucket_bytes // 4)
+        # buckets over the arena, filled in arena order; gradients become ready roughly in REVERSE arena order
+        self.buckets = []  # [start, end, n_params]
+        self.param_bucket = {}
+        cur = None
+        for p, off, n in optimizer.layout:
+            if cur is None or (off + n - cur[0]) > cap:
+                cur = [off, off + n, 0]
+                self.buckets.append(cur)
+            cur[1] = off + n
+            cur[2] += 1
+            self.param_bucket[id(p)] = len(self.buckets) - 1
+        self.pending = [0] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+        self.hooks = []
+        if self.world > 1:
+            for p, _, _ in optimizer.layout:
+                self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def reset(self):
+        self.pending = [b[2] for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+
+    def _launch(self, bi):
+        start, end, _ = self.buckets[bi]
+        buf = self.flat_g[start:end]
+        self.launched[bi] = True
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                buf.div_(self.world)  # SUM of pre-divided grads == AVG (no ReduceOp.AVG on gloo)
+                self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
+        else:
+            buf.div_(self.world)
+            self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
+
+    def _on_grad(self, p):
+        bi = self.param_bucket[id(p)]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0 and not self.launched[bi]:
+            self._launch(bi)
+
+    def finish(self):
+        """call after backward, before the optimiser: reduces buckets whose hooks never all fired (unused
+        parameters) and makes the compute stream wait for the exchange."""
+        if self.world > 1:
+            for bi in range(len(self.buckets)):
+                if not self.launched[bi]:
+                    self._launch(bi)
+            for h in self.handles:
+                h.wait()
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self.side)
+        self.reset()
+
+    def broadcast_parameters(self, src=0):
+        """once, at start-up (C2 of SURVEY 2.1): trainable arena from rank 0; teacher weights are frozen and seeded
+        identically, so nothing else moves."""
+        if self.world > 1:
+            dist.broadcast(self.opt.flat_p, src=src, group=self.pg)
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []
+
+
+def allreduce_metrics(values, process_group=None):
+    """C5: the step's scalar metrics packed in ONE vector, ONE all-reduce (mean) instead of 12 sync_dist logs."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return values
+    keys = sorted(values)
+    vec = torch.stack([values[k].detach().float().reshape(()) for k in keys])
+    vec /= dist.get_world_size(process_group)
+    dist.all_reduce(vec, group=process_group)
+    return {k: vec[i] for i, k in enumerate(keys)}

@@ -1,0 +1,350 @@
+"""Autograd nodes of the distillation step.  Each node is a coarse, hand-scheduled sequence of HIP kernel launches
+(forward) with a hand-written backward - torch.autograd only records the nodes and routes gradients between them.
+All activations are fp32, channels-last / token-major.  No ATen arithmetic happens inside these nodes.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+F32 = torch.float32
+
+
+def _c(t):
+    """gradients may arrive as expanded / strided tensors; kernels want dense ones"""
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def colsum(x2d):
+    return ops.colreduce(x2d, ops.RED_SUM).reshape(-1)
+
+
+# =====================================================================================================================
+class LinearFn(Function):
+    """y = act(x W^T + b) (+ residual).  Replaces nn.Linear / 1x1 conv call sites (include/dkd_hip.h, GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, residual):
+        x = _c(x)
+        y = ops.linear_fwd(x, w, b, act=act, residual=None if residual is None else _c(residual))
+        ctx.act = act
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, w, y if act == ops.ACT_RELU else None)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        dres = dy if ctx.has_res else None
+        if ctx.act == ops.ACT_RELU:
+            assert not ctx.has_res
+            dy = ops.relu_bwd(dy, y)
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_wgrad(dy2, x2) if ctx.needs_input_grad[1] else None
+        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, dres
+
+
+def linear(x, w, b=None, act=ops.ACT_NONE, residual=None):
+    return LinearFn.apply(x, w, b, act, residual)
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dg, db = ops.layernorm_bwd(_c(dy), x, mean, rstd, gamma, affine=affine)
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# =====================================================================================================================
+class ResizeFn(Function):
+    """F.interpolate(bilinear, align_corners=False) on NHWC (models/model_zoo.py:123-128)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x = _c(x)
+        ctx.hw = x.shape[1:3]
+        return ops.resize_fwd(x, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.resize_bwd(_c(dy), *ctx.hw), None, None
+
+
+class PatchConvFn(Function):
+    """k x k stride-k convolution as patchify + GEMM.  src_nchw: input is the NCHW image (stem, convnext.py:117) and
+    needs no gradient; otherwise input is an NHWC feature (downsample conv, convnext.py:124)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, src_nchw):
+        O = w.shape[0]
+        x = _c(x)
+        if src_nchw:
+            B, _, H, W = x.shape
+            rows = ops.patchify_nchw(x, k)
+            w2 = w.reshape(O, -1)
+        else:
+            B, H, W, C = x.shape
+            rows = ops.patchify_nhwc(x, k)
+            w2 = ops.transpose(w.reshape(O, C, k * k)).reshape(O, k * k * C)  # [O][ky][kx][c]
+        y = ops.gemm(rows, w2, bias=b)
+        ctx.save_for_backward(rows, w2)
+        ctx.meta = (k, src_nchw, tuple(x.shape), tuple(w.shape))
+        return y.reshape(B, H // k, W // k, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, w2 = ctx.saved_tensors
+        k, src_nchw, xshape, wshape = ctx.meta
+        O = wshape[0]
+        dy2 = _c(dy).reshape(-1, O)
+        dw2 = ops.linear_wgrad(dy2, rows)
+        db = colsum(dy2)
+        dx = None
+        if src_nchw:
+            dw = dw2.reshape(wshape)
+        else:
+            B, H, W, C = xshape
+            dw = ops.transpose(dw2.reshape(O, k * k, C)).reshape(wshape)
+            if ctx.needs_input_grad[0]:
+                drows = ops.gemm(dy2, w2, b_layout=1)
+                dx = ops.unpatchify_nhwc(drows, B, H, W, C, k)
+        return dx, dw, db, None, None
+
+
+# =====================================================================================================================
+class ConvNeXtBlockFn(Function):
+    """ConvNeXt-V2 block on NHWC (models/backbones/convnext.py:75-87):
+    dw7x7 -> LN(1e-6) -> Linear(4C) -> GELU -> GRN -> Linear(C) -> + input."""
+
+    @staticmethod
+    def forward(ctx, x, dw_w, dw_b, ln_w, ln_b, w1, b1, grn_g, grn_b, w2, b2):
+        x = _c(x)
+        B, H, W, C = x.shape
+        M = B * H * W
+        wt = ops.transpose(dw_w.reshape(C, 49))  # tap-major [49, C]
+        d = ops.dwconv7(x, wt, dw_b)
+        n, mean, rstd = ops.layernorm_fwd(d, ln_w, ln_b, 1e-6)
+        h = torch.empty((M, 4 * C), dtype=F32, device=x.device)
+        g = ops.gemm(n.reshape(M, C), w1, bias=b1, act=ops.ACT_GELU, preact=h)
+        gg, gb = grn_g.reshape(-1), grn_b.reshape(-1)
+        y, stats = ops.grn_fwd(g, gg, gb, B)
+        out = ops.gemm(y, w2, bias=b2, residual=x.reshape(M, C))
+        ctx.save_for_backward(x, wt, d, mean, rstd, n, h, g, y, w1, w2, ln_w, gg, *stats)
+        ctx.shapes = (B, H, W, C, tuple(dw_w.shape), tuple(grn_g.shape))
+        return out.reshape(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wt, d, mean, rstd, n, h, g, y, w1, w2, ln_w, gg, gx, nx, denom = ctx.saved_tensors
+        B, H, W, C, dw_shape, grn_shape = ctx.shapes
+        M = B * H * W
+        dout = _c(dout)
+        do2 = dout.reshape(M, C)
+        dw2 = ops.linear_wgrad(do2, y)
+        db2 = colsum(do2)
+        dy = ops.gemm(do2, w2, b_layout=1)  # [M, 4C]
+        dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, g, h, (gx, nx, denom), gg, B)
+        n2 = n.reshape(M, C)
+        dw1 = ops.linear_wgrad(dh, n2)
+        db1 = colsum(dh)
+        dn = ops.gemm(dh, w1, b_layout=1)  # [M, C]
+        dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w)
+        dd = dd.reshape(B, H, W, C)
+        dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
+        ddw = ops.transpose(ops.dwconv7_wgrad(x, dd)).reshape(dw_shape)
+        ddb = colsum(dd.reshape(M, C))
+        return (dx, ddw, ddb, dln_w, dln_b, dw1, db1, dgrn_g.reshape(grn_shape), dgrn_b.reshape(grn_shape), dw2, db2)
+
+
+# =====================================================================================================================
+def vit_block_forward(x, p, H, save):
+    """DINOv2 pre-norm block with LayerScale folded into the (frozen) projection weights.
+    x [B,N,D]; p: dict of prepared tensors.  Returns (out, saved-tuple or None)."""
+    B, N, D = x.shape
+    M, hd = B * N, D // H
+    x2 = x.reshape(M, D)
+    h1, m1, r1 = ops.layernorm_fwd(x2, p["n1w"], p["n1b"], 1e-6, need_stats=save)
+    qkv = ops.gemm(h1, p["wqkv"], bias=p["bqkv"])  # [M, 3D] packed (3, H, hd)
+    st = (N * 3 * D, 3 * D)
+    o, lse = ops.attention_forward(qkv, qkv[:, D:], qkv[:, 2 * D:], H, hd, hd ** -0.5, B, N, N, st, st, st)
+    x1 = ops.gemm(o.reshape(M, D), p["wproj"], bias=p["bproj"], residual=x2)
+    h2, m2, r2 = ops.layernorm_fwd(x1, p["n2w"], p["n2b"], 1e-6, need_stats=save)
+    u = torch.empty((M, p["w1"].shape[0]), dtype=F32, device=x.device) if save else None
+    a = ops.gemm(h2, p["w1"], bias=p["b1"], act=ops.ACT_GELU, preact=u)
+    x2o = ops.gemm(a, p["w2"], bias=p["b2"], residual=x1)
+    saved = (x2, m1, r1, qkv, o, lse, x1, m2, r2, u) if save else None
+    return x2o.reshape(B, N, D), saved
+
+
+class ViTBlockFrozenFn(Function):
+    """A frozen teacher block applied to student tokens with gradient to the INPUT only
+    (train/distillation_module.py:176-177: ``feat = self.teacher.model.blocks[i](feat)``)."""
+
+    @staticmethod
+    def forward(ctx, x, blk):
+        x = _c(x)
+        out, saved = vit_block_forward(x, blk.prepared(), blk.num_heads, save=True)
+        ctx.blk = blk
+        ctx.save_for_backward(*saved)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, m1, r1, qkv, o, lse, x1, m2, r2, u = ctx.saved_tensors
+        p, H = ctx.blk.prepared(), ctx.blk.num_heads
+        B, N, D = ctx.shape
+        M, hd = B * N, D // H
+        d2 = _c(dout).reshape(M, D)
+        da = ops.gemm(d2, p["w2"], b_layout=1)
+        du = ops.gelu_bwd(da, u)
+        dh2 = ops.gemm(du, p["w1"], b_layout=1)
+        dx1, _, _ = ops.layernorm_bwd(dh2, x1, m2, r2, p["n2w"], affine=False, add=d2)
+        do = ops.gemm(dx1, p["wproj"], b_layout=1).reshape(B, N, D)
+        dqkv = torch.empty_like(qkv)
+        st = (N * 3 * D, 3 * D)
+        ops.attention_backward(do, qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, H, hd, hd ** -0.5, B, N, N, st, st, st,
+                               dqkv, dqkv[:, D:], dqkv[:, 2 * D:], st, st, st)
+        dh1 = ops.gemm(dqkv, p["wqkv"], b_layout=1)
+        dx, _, _ = ops.layernorm_bwd(dh1, x2, m1, r1, p["n1w"], affine=False, add=dx1)
+        return dx.reshape(B, N, D), None
+
+
+# =====================================================================================================================
+PROJ_PARAM_NAMES = (
+    "pos_embed", "proj_student.0.weight", "proj_student.0.bias", "proj_student.1.weight", "proj_student.1.bias",
+    "pos_attention.q.weight", "pos_attention.q.bias", "pos_attention.k.weight", "pos_attention.k.bias",
+    "pos_attention.v.weight", "pos_attention.v.bias", "pos_attention.proj.weight", "pos_attention.proj.bias",
+    "ffn.layers.0.0.weight", "ffn.layers.0.0.bias", "ffn.layers.1.weight", "ffn.layers.1.bias",
+    "norm.weight", "norm.bias", "norm_2.weight", "norm_2.bias",
+)
+
+
+class AttentionProjectorFn(Function):
+    """losses/scalekd.py:228-245 as one node: 1x1 conv + BatchNorm(train) + ReLU + pos_embed -> cross attention of the
+    positional / incoming queries over the student tokens (+ residual) -> LN -> FFN(ReLU, residual = normalised input)
+    -> LN.  x is NHWC [B,P,P,Cs]; ext_query is [B,N,D] or None (then self_query [N,D] is used, batch-invariant)."""
+
+    @staticmethod
+    def forward(ctx, x, ext_query, self_query, bn_state, num_heads, softmax_scale, training, *params):
+        (pos_embed, wc, bc, bn_w, bn_b, wq, bq, wk, bk, wv, bv, wp, bp, w1, b1, w2, b2, n1w, n1b, n2w, n2b) = params
+        x = _c(x)
+        B, Ph, Pw, Cs = x.shape
+        N, D = Ph * Pw, wc.shape[0]
+        M, hd = B * N, D // num_heads
+        scale = hd ** -0.5 * softmax_scale
+        x2 = x.reshape(M, Cs)
+        z = ops.gemm(x2, wc.reshape(D, Cs), bias=bc)
+        running_mean, running_var = bn_state
+        if training:
+            mean, rstd = ops.bn_stats(z, running_mean, running_var, 0.1, 1e-5)
+        else:
+            raise NotImplementedError("AttentionProjector eval-mode BatchNorm is not on the training hot path yet")
+        pos_t = ops.transpose(pos_embed.reshape(D, N))  # [N, D]
+        tok = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, pos_t, relu=True)
+        shared = ext_query is None
+        qin = _c(self_query) if shared else _c(ext_query).reshape(M, D)
+        q = ops.gemm(qin, wq, bias=bq)
+        k = ops.gemm(tok, wk, bias=bk)
+        v = ops.gemm(tok, wv, bias=bv)
+        st = (N * D, D)
+        o, lse = ops.attention_forward(q, k, v, num_heads, hd, scale, B, N, N, (0 if shared else N * D, D), st, st)
+        y = ops.gemm(o.reshape(M, D), wp, bias=bp, residual=tok)
+        zn, m1, r1 = ops.layernorm_fwd(y, n1w, n1b, 1e-5)
+        f1 = ops.gemm(zn, w1, bias=b1, act=ops.ACT_RELU)
+        f2 = ops.gemm(f1, w2, bias=b2, residual=zn)
+        out, m2, r2 = ops.layernorm_fwd(f2, n2w, n2b, 1e-5)
+        ctx.save_for_backward(x2, z, mean, rstd, tok, qin, q, k, v, o, lse, y, m1, r1, zn, f1, f2, m2, r2, *params)
+        ctx.meta = (B, N, D, Cs, num_heads, hd, scale, shared, tuple(pos_embed.shape), tuple(wc.shape), tuple(x.shape))
+        return out.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, z, mean, rstd, tok, qin, q, k, v, o, lse, y, m1, r1, zn, f1, f2, m2, r2,
+         pos_embed, wc, bc, bn_w, bn_b, wq, bq, wk, bk, wv, bv, wp, bp, w1, b1, w2, b2, n1w, n1b, n2w, n2b) = ctx.saved_tensors
+        B, N, D, Cs, H, hd, scale, shared, pos_shape, wc_shape, xshape = ctx.meta
+        M = B * N
+        df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w)
+        dw2 = ops.linear_wgrad(df2, f1)
+        db2 = colsum(df2)
+        df1 = ops.relu_bwd(ops.gemm(df2, w2, b_layout=1), f1)
+        dw1 = ops.linear_wgrad(df1, zn)
+        db1 = colsum(df1)
+        dzn = ops.gemm(df1, w1, b_layout=1, residual=df2)  # + FFN residual branch
+        dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w)
+        dwp = ops.linear_wgrad(dy, o.reshape(M, D))
+        dbp = colsum(dy)
+        do = ops.gemm(dy, wp, b_layout=1).reshape(B, N, D)
+        dq = torch.empty((B, N, D), dtype=F32, device=dy.device)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        st = (N * D, D)
+        ops.attention_backward(do, q, k, v, o, lse, H, hd, scale, B, N, N, (0 if shared else N * D, D), st, st,
+                               dq, dk, dv, st, st, st)
+        dwk, dbk = ops.linear_wgrad(dk, tok), colsum(dk)
+        dwv, dbv = ops.linear_wgrad(dv, tok), colsum(dv)
+        dtok = ops.gemm(dk, wk, b_layout=1, residual=dy)  # + attention residual branch
+        ops.gemm(dv, wv, b_layout=1, out=dtok, residual=dtok)
+        if shared:
+            dq2 = ops.colreduce(dq.reshape(B, N * D), ops.RED_SUM).reshape(N, D)
+        else:
+            dq2 = dq.reshape(M, D)
+        dwq, dbq = ops.linear_wgrad(dq2, qin), colsum(dq2)
+        dqin = ops.gemm(dq2, wq, b_layout=1)
+        dext = None if shared else dqin.reshape(B, N, D)
+        dself = dqin if shared else None
+        dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D)).reshape(pos_shape)
+        dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True)
+        dwc = ops.linear_wgrad(dz, x2).reshape(wc_shape)
+        dbc = colsum(dz)
+        dx = ops.gemm(dz, wc.reshape(D, Cs), b_layout=1).reshape(xshape) if ctx.needs_input_grad[0] else None
+        return (dx, dext, dself, None, None, None, None,
+                dpos, dwc, dbc, dbn_w, dbn_b, dwq, dbq, dwk, dbk, dwv, dbv, dwp, dbp, dw1, db1, dw2, db2,
+                dn1w, dn1b, dn2w, dn2b)
+
+
+# =====================================================================================================================
+class KDLossFn(Function):
+    """losses/scalekd.py:67-92 (spatial) / :95-127 (frequency == spatial-mean removal, see csrc/loss.hip).
+    s, t: token-major [B, N, D]; returns (loss, similarity) 0-dim tensors."""
+
+    @staticmethod
+    def forward(ctx, s, t, alpha, freq):
+        s, t = _c(s), _c(t)
+        B, N, D = s.shape
+        ms = mt = None
+        if freq:
+            ms = ops.colreduce(s, groups=B, scale=1.0 / N)
+            mt = ops.colreduce(t, groups=B, scale=1.0 / N)
+        out = ops.kd_loss_fwd(s, t, N, alpha, ms, mt)
+        ctx.save_for_backward(s, t, ms, mt)
+        ctx.meta = (alpha, freq, B, N)
+        loss, sim = out.unbind(0)
+        ctx.mark_non_differentiable(sim)
+        return loss, sim
+
+    @staticmethod
+    def backward(ctx, gloss, _gsim):
+        s, t, ms, mt = ctx.saved_tensors
+        alpha, freq, B, N = ctx.meta
+        g = _c(gloss).reshape(1)
+        ds = ops.kd_loss_bwd(s, t, N, alpha, g, ms, mt)
+        if freq:  # adjoint of the mean removal
+            ds = ops.sub_group_vec(ds, ops.colreduce(ds, groups=B, scale=1.0 / N), B, out=ds)
+        return ds, None, None, None

@@ -1,0 +1,109 @@
+"""ScaleKD loss on MI355X kernels - same surface and state-dict names as /root/reference/losses/scalekd.py.
+
+torch.nn layers are used ONLY as parameter / buffer containers with the reference's names and default
+initialisations (``proj_student.0`` Conv2d, ``proj_student.1`` BatchNorm2d, ``pos_attention.{q,k,v,proj}`` Linear,
+``ffn.layers.0.0`` / ``ffn.layers.1`` Linear, ``norm`` / ``norm_2`` LayerNorm, ``query`` Embedding); their forward is
+never called - the arithmetic runs in functional.AttentionProjectorFn / KDLossFn.
+"""
+import torch
+import torch.nn as nn
+from torch.nn.init import trunc_normal_
+
+from .. import functional as Fn
+
+
+def _tokens_of_map(feat):
+    """[B,C,H,W] -> token-major [B,HW,C]; free when feat is a permuted view of NHWC memory (the teacher's
+    ``feature_map``, models/backbones/dinov2.py:40, and ModelWrapper outputs)."""
+    B, C, H, W = feat.shape
+    return feat.permute(0, 2, 3, 1).reshape(B, H * W, C)
+
+
+class _PosAttentionParams(nn.Module):  # WindowMultiheadPosAttention parameters (losses/scalekd.py:277-282)
+    def __init__(self, dims, pos_dims):
+        super().__init__()
+        self.q = nn.Linear(pos_dims, dims)
+        self.k = nn.Linear(dims, dims)
+        self.v = nn.Linear(dims, dims)
+        self.proj = nn.Linear(dims, dims)
+
+
+class _FFNParams(nn.Module):  # FFN parameters (losses/scalekd.py:450-460): layers.0.0 and layers.1
+    def __init__(self, dims, hidden):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Sequential(nn.Linear(dims, hidden), nn.ReLU(inplace=True), nn.Dropout(0.0)),
+                                    nn.Linear(hidden, dims))
+
+
+class AttentionProjector(nn.Module):
+    """losses/scalekd.py:177-245"""
+
+    def __init__(self, student_dims, teacher_dims, hw_dims, pos_dims, window_shapes=(1, 1), self_query=True,
+                 softmax_scale=1.0, num_heads=8):
+        super().__init__()
+        if tuple(window_shapes) != (1, 1):
+            raise NotImplementedError("window_shapes != (1,1) has no MI355X kernel yet (config default is [1,1])")
+        if teacher_dims % num_heads:
+            raise ValueError(f"num_heads={num_heads} must divide teacher_dims={teacher_dims} (scalekd.py:273,299)")
+        self.hw_dims, self.student_dims, self.teacher_dims = tuple(hw_dims), student_dims, teacher_dims
+        self.num_heads, self.softmax_scale = num_heads, float(softmax_scale)
+        self.proj_student = nn.Sequential(nn.Conv2d(student_dims, teacher_dims, 1), nn.BatchNorm2d(teacher_dims), nn.ReLU())
+        self.pos_embed = nn.Parameter(torch.zeros(1, teacher_dims, hw_dims[0], hw_dims[1]))
+        self.pos_attention = _PosAttentionParams(teacher_dims, pos_dims)
+        self.ffn = _FFNParams(teacher_dims, teacher_dims * 4)
+        self.norm = nn.LayerNorm([teacher_dims])
+        self.norm_2 = nn.LayerNorm([teacher_dims])
+        self.query = nn.Embedding(hw_dims[0] * hw_dims[1], teacher_dims) if self_query else None
+        trunc_normal_(self.pos_embed, std=0.02)
+
+    def _params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in Fn.PROJ_PARAM_NAMES]
+
+    def forward(self, x, query=None):
+        """x [B,Cs,H,W] -> tokens [B,HW,D]"""
+        if query is None and self.query is None:
+            raise NotImplementedError("There is no query!")  # scalekd.py:236
+        bn = self.proj_student[1]
+        x_nhwc = x.permute(0, 2, 3, 1)
+        if self.training:
+            bn.num_batches_tracked += 1
+        return Fn.AttentionProjectorFn.apply(x_nhwc, query, None if query is not None else self.query.weight,
+                                             (bn.running_mean, bn.running_var), self.num_heads, self.softmax_scale,
+                                             self.training, *self._params())
+
+
+class ScaleKD(nn.Module):
+    """losses/scalekd.py:12-127"""
+
+    def __init__(self, name, alpha, student_dims, teacher_dims, query_hw, pos_hw, pos_dims, window_shapes=(1, 1),
+                 self_query=True, softmax_scale=(1, 1), num_heads=8):
+        super().__init__()
+        self.alpha = [float(a) for a in alpha]
+        self.self_query = self_query
+        kw = dict(window_shapes=tuple(window_shapes), self_query=self_query, num_heads=num_heads)
+        self.projector_0 = AttentionProjector(student_dims, teacher_dims, query_hw, pos_dims, softmax_scale=softmax_scale[0], **kw)
+        self.projector_1 = AttentionProjector(student_dims, teacher_dims, query_hw, pos_dims, softmax_scale=softmax_scale[1], **kw)
+
+    def project_feat_spat(self, preds_S, query=None):
+        return self.projector_0(preds_S, query=query)
+
+    def project_feat_freq(self, preds_S, query=None):
+        return self.projector_1(preds_S, query=query)
+
+    def get_spat_loss(self, preds_S, preds_T):
+        """preds_S tokens [B,HW,C]; preds_T [B,C,H,W] -> (alpha0 * sum|s^-t^|^2 / B, mean cosine)"""
+        return Fn.KDLossFn.apply(preds_S, _tokens_of_map(preds_T), self.alpha[0], False)
+
+    def get_freq_loss(self, preds_S, preds_T):
+        if preds_T.shape[-1] != preds_T.shape[-2]:
+            raise ValueError("frequency loss needs a square grid (DCT(resolution=H) on both axes, scalekd.py:107)")
+        return Fn.KDLossFn.apply(preds_S, _tokens_of_map(preds_T), self.alpha[1], True)
+
+    def forward(self, preds_S, preds_T, query_s=None, query_f=None):
+        tok_s = self.project_feat_spat(preds_S, query=query_s)
+        tok_f = self.project_feat_freq(preds_S, query=query_f)
+        spat_loss, spat_sim = self.get_spat_loss(tok_s, preds_T)
+        freq_loss, freq_sim = self.get_freq_loss(tok_f, preds_T)
+        return {"spatial_loss": spat_loss, "frequency_loss": freq_loss, "spatial_similarity": spat_sim,
+                "frequency_similarity": freq_sim, "loss": spat_loss + freq_loss}

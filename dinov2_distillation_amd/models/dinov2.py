@@ -1,0 +1,163 @@
+"""DINOv2 ViT teacher on MI355X kernels - same module surface as /root/reference/models/backbones/dinov2.py:
+``DINOv2ViT(model_name)``, ``forward(x) -> {'feature_map': [B, D, P, P]}`` (a permuted view of token-major memory,
+dinov2.py:40), ``.model.blocks[i]`` callable ``[B,N,D] -> [B,N,D]`` with autograd to the input
+(train/distillation_module.py:169-177).
+
+The reference pulls architecture + weights from torch.hub (dinov2.py:20); there is no network here, so the published
+architecture is built locally with synthetic (seeded) weights under the public checkpoint's parameter names -
+``load_state_dict`` of a real DINOv2 checkpoint therefore works unchanged.  Teacher parity vs upstream is unpinned
+(see DESIGN.md).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import ops
+
+VIT_CONFIGS = {  # embed dims: train.py:103-108; depth / heads: published models (head_dim 64 everywhere)
+    "dinov2_vits14": dict(embed_dim=384, depth=12, num_heads=6, ffn="mlp"),
+    "dinov2_vitb14": dict(embed_dim=768, depth=12, num_heads=12, ffn="mlp"),
+    "dinov2_vitl14": dict(embed_dim=1024, depth=24, num_heads=16, ffn="mlp"),
+    "dinov2_vitg14": dict(embed_dim=1536, depth=40, num_heads=24, ffn="swiglu"),
+}
+PATCH, POS_GRID = 14, 37
+
+
+def _tn(*shape, gen):
+    t = torch.empty(*shape)
+    nn.init.trunc_normal_(t, std=0.02, generator=gen)
+    return nn.Parameter(t, requires_grad=False)
+
+
+class _Holder(nn.Module):
+    pass
+
+
+class Block(nn.Module):
+    """Parameter names of a DINOv2 block: norm1, attn.{qkv,proj}, ls1.gamma, norm2, mlp.{fc1,fc2}, ls2.gamma."""
+
+    def __init__(self, dim, num_heads, gen):
+        super().__init__()
+        self.num_heads = num_heads
+        z = lambda n: nn.Parameter(torch.zeros(n), requires_grad=False)
+        o = lambda n: nn.Parameter(torch.ones(n), requires_grad=False)
+        self.norm1, self.norm2, self.attn, self.mlp, self.ls1, self.ls2 = (_Holder() for _ in range(6))
+        self.norm1.weight, self.norm1.bias = o(dim), z(dim)
+        self.norm2.weight, self.norm2.bias = o(dim), z(dim)
+        self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2 = (_Holder() for _ in range(4))
+        self.attn.qkv.weight, self.attn.qkv.bias = _tn(3 * dim, dim, gen=gen), z(3 * dim)
+        self.attn.proj.weight, self.attn.proj.bias = _tn(dim, dim, gen=gen), z(dim)
+        self.ls1.gamma, self.ls2.gamma = o(dim), o(dim)
+        self.mlp.fc1.weight, self.mlp.fc1.bias = _tn(4 * dim, dim, gen=gen), z(4 * dim)
+        self.mlp.fc2.weight, self.mlp.fc2.bias = _tn(dim, 4 * dim, gen=gen), z(dim)
+        self._prep = None
+
+    def prepared(self):
+        """Kernel-ready frozen weights; LayerScale is folded into the projections once (the teacher never trains):
+        x + ls * (a W^T + b) == x + a (ls[:,None] * W)^T + ls * b."""
+        w = self.attn.qkv.weight
+        if self._prep is None or self._prep["wqkv"].data_ptr() != w.data_ptr() or self._prep["_ver"] != w._version:
+            with torch.no_grad():
+                ls1, ls2 = self.ls1.gamma, self.ls2.gamma
+                self._prep = {
+                    "n1w": self.norm1.weight, "n1b": self.norm1.bias, "n2w": self.norm2.weight, "n2b": self.norm2.bias,
+                    "wqkv": w, "bqkv": self.attn.qkv.bias,
+                    "wproj": (self.attn.proj.weight * ls1[:, None]).contiguous(), "bproj": self.attn.proj.bias * ls1,
+                    "w1": self.mlp.fc1.weight, "b1": self.mlp.fc1.bias,
+                    "w2": (self.mlp.fc2.weight * ls2[:, None]).contiguous(), "b2": self.mlp.fc2.bias * ls2,
+                    "_ver": w._version,
+                }
+        return self._prep
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return Fn.ViTBlockFrozenFn.apply(x, self)
+        return Fn.vit_block_forward(x.contiguous(), self.prepared(), self.num_heads, save=False)[0]
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, cfg, seed=0):
+        super().__init__()
+        if cfg.get("ffn", "mlp") != "mlp":
+            raise NotImplementedError("SwiGLU FFN (dinov2_vitg14) is not built yet")
+        gen = torch.Generator().manual_seed(seed)
+        D = cfg["embed_dim"]
+        self.embed_dim, self.num_heads, self.patch_size = D, cfg["num_heads"], PATCH
+        self.cls_token = _tn(1, 1, D, gen=gen)
+        self.pos_embed = _tn(1, 1 + POS_GRID * POS_GRID, D, gen=gen)
+        self.mask_token = nn.Parameter(torch.zeros(1, D), requires_grad=False)  # present in the public checkpoints
+        self.patch_embed = _Holder()
+        self.patch_embed.proj = _Holder()
+        self.patch_embed.proj.weight = _tn(D, 3, PATCH, PATCH, gen=gen)
+        self.patch_embed.proj.bias = nn.Parameter(torch.zeros(D), requires_grad=False)
+        self.blocks = nn.ModuleList([Block(D, cfg["num_heads"], gen) for _ in range(cfg["depth"])])
+        self.norm = _Holder()
+        self.norm.weight = nn.Parameter(torch.ones(D), requires_grad=False)
+        self.norm.bias = nn.Parameter(torch.zeros(D), requires_grad=False)
+        self._pos_cache = {}
+
+    def _apply(self, fn, *a, **k):
+        self._pos_cache = {}
+        return super()._apply(fn, *a, **k)
+
+    def _pos_table(self, ph, pw):
+        """[1+ph*pw, D] table for this grid (one-time set-up, cached): bicubic resize of the stored 37x37 table with
+        the published recipe (scale_factor = (P + 0.1) / 37, antialias off); row 0 additionally carries the CLS token."""
+        key = (ph, pw, self.pos_embed.data_ptr(), self.pos_embed._version)
+        if key not in self._pos_cache:
+            with torch.no_grad():
+                pe = self.pos_embed.float()
+                patch = pe[:, 1:]
+                m = int(math.isqrt(patch.shape[1]))
+                if not (ph * pw == patch.shape[1] and ph == pw):
+                    grid = patch.reshape(1, m, m, -1).permute(0, 3, 1, 2)
+                    grid = torch.nn.functional.interpolate(grid, scale_factor=((ph + 0.1) / m, (pw + 0.1) / m),
+                                                           mode="bicubic", antialias=False)
+                    assert grid.shape[-2:] == (ph, pw)
+                    patch = grid.permute(0, 2, 3, 1).reshape(1, ph * pw, -1)
+                table = torch.cat([pe[:, :1] + self.cls_token, patch], dim=1)[0].contiguous()
+            self._pos_cache = {key: table}
+        return self._pos_cache[key]
+
+    def forward_tokens(self, x):
+        """-> final-norm patch tokens [B, P*P, D], dense (CLS dropped by the norm kernel's row gather)."""
+        B, _, Himg, Wimg = x.shape
+        ph, pw = Himg // PATCH, Wimg // PATCH
+        n, D = ph * pw, self.embed_dim
+        table = self._pos_table(ph, pw)
+        rows = ops.patchify_nchw(x.contiguous(), PATCH)
+        tok = torch.empty((B * (n + 1), D), dtype=torch.float32, device=x.device)
+        ops.gemm(rows, self.patch_embed.proj.weight.reshape(D, -1), bias=self.patch_embed.proj.bias, out=tok,
+                 residual=table[1:], res_mod=n, row_map=(n, n + 1, 1, B * (n + 1)))
+        ops.set_rows(tok, table[0], B, (n + 1) * D)
+        t = tok.view(B, n + 1, D)
+        for blk in self.blocks:
+            t = blk(t)
+        out, _, _ = ops.layernorm_fwd(t.reshape(B * (n + 1), D), self.norm.weight, self.norm.bias, 1e-6,
+                                      need_stats=False, in_rows=(n, n + 1, 1, B * n))
+        return out.view(B, n, D)
+
+
+class DINOv2ViT(nn.Module):
+    def __init__(self, model_name="dinov2_vitg14", seed=0):
+        super().__init__()
+        self.model = VisionTransformer(VIT_CONFIGS[model_name], seed=seed)
+        self.model.eval()
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.H = None
+        self.W = None
+
+    def forward(self, x):
+        with torch.no_grad():
+            tok = self.model.forward_tokens(x)
+        if self.H is None:  # cached from the first batch like the reference (dinov2.py:34-36)
+            self.H, self.W = x.shape[2] // PATCH, x.shape[3] // PATCH
+        self.B, _, self.D = tok.shape
+        return {"feature_map": tok.reshape(self.B, self.H, self.W, self.D).permute(0, 3, 1, 2)}

@@ -1,0 +1,73 @@
+"""Student factory - same surface as /root/reference/models/model_zoo.py (ModelWrapper) and
+models/wrappers/convnext_wrapper.py (ConvNextWrapper)."""
+import os
+
+import torch.nn as nn
+
+from .. import functional as Fn
+from .convnext import D2ConvNextV2
+
+CONVNEXT_CONFIGS = {  # models/wrappers/convnext_wrapper.py:19-49
+    "convnext_atto": ([2, 2, 6, 2], [40, 80, 160, 320], "convnextv2_atto_1k_224_ema.pkl"),
+    "convnext_pico": ([2, 2, 6, 2], [64, 128, 256, 512], "convnextv2_pico_1k_224_ema.pkl"),
+    "convnext_nano": ([2, 2, 8, 2], [80, 160, 320, 640], "convnextv2_nano_1k_224_ema.pkl"),
+    "convnext_tiny": ([3, 3, 9, 3], [96, 192, 384, 768], "convnextv2_tiny_1k_224_ema.pkl"),
+    "convnext_base": ([3, 3, 27, 3], [128, 256, 512, 1024], "convnextv2_base_1k_224_ema.pkl"),
+}
+
+
+class ConvNextWrapper(nn.Module):
+    def __init__(self, model_name="convnext_tiny", out_features=None):
+        super().__init__()
+        if model_name not in CONVNEXT_CONFIGS:
+            raise NotImplementedError(f"There is not a ConvNext_{model_name}. Please, check the backbone name.")
+        depths, dims, ckpt = CONVNEXT_CONFIGS[model_name]
+        self._out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", ckpt)
+        self.model = D2ConvNextV2(depths=depths, embed_dims=dims, drop_path_rate=0.0, out_features=self._out_features)
+        self._out_feature_channels = {f"res{i + 2}": dims[i] for i in range(4)}
+
+    def get_features(self, x):
+        return self.model.forward_features(x)
+
+    def get_features_nhwc(self, x):
+        return self.model.forward_features_nhwc(x)
+
+    @property
+    def feature_channels(self):
+        return self._out_feature_channels
+
+
+class ModelWrapper(nn.Module):
+    """models/model_zoo.py:18-145.  Only the student families built on the MI355X kernels are registered; asking for
+    another one fails loudly (no silent fallback to an ATen implementation)."""
+
+    MODEL_MAP = {"convnext": ConvNextWrapper}
+
+    def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
+        super().__init__()
+        model_id = model_name.split("_")[0].lower()
+        if model_id == "mobilenet":
+            model_id = model_id + "_" + model_name.split("_")[1].lower()
+        if model_id not in self.MODEL_MAP:
+            raise NotImplementedError(f"student family '{model_id}' has no MI355X-native backbone yet "
+                                      f"(available: {sorted(self.MODEL_MAP)})")
+        self.model = self.MODEL_MAP[model_id](model_name=model_name, out_features=list(target_feature))
+        self.n_patches = n_patches
+        self.target_features = list(target_feature)
+        self.patch_size = n_patches
+
+    def forward(self, x):
+        """every target feature bilinearly resized (align_corners=False) to the teacher grid (model_zoo.py:116-129);
+        returned as [B,C,P,P] views of NHWC memory."""
+        feats = self.model.get_features_nhwc(x)
+        out = {}
+        for k in self.target_features:
+            if k in feats:
+                r = Fn.ResizeFn.apply(feats[k], int(self.patch_size[0]), int(self.patch_size[1]))
+                out[k] = r.permute(0, 3, 1, 2)
+        return out
+
+    @property
+    def feature_channels(self):
+        return self.model.feature_channels

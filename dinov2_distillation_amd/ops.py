@@ -129,22 +129,28 @@ def transpose(x, out=None):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, need_stats=True):
+def layernorm_fwd(x, gamma, beta, eps, need_stats=True, in_rows=None):
+    """in_rows=(grp, grp_stride, off, n_out_rows): gather input rows (see dkd_hip.h); output is dense [n_out_rows, C]."""
     lib = _lib.load()
     _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty_like(x)
+    grp = gst = off = 0
+    if in_rows is None:
+        y = torch.empty_like(x)
+    else:
+        grp, gst, off, rows = in_rows
+        y = torch.empty((rows, C), dtype=torch.float32, device=x.device)
     mean = rstd = None
     if need_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(lib.dkd_layernorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps, _stream()),
-          "dkd_layernorm_fwd_f32")
+    check(lib.dkd_layernorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps, grp, gst, off,
+                                    _stream()), "dkd_layernorm_fwd_f32")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True):
+def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True, add=None):
     lib = _lib.load()
     _chk(dy, "dy"), _chk(x, "x")
     C = x.shape[-1]
@@ -155,8 +161,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(lib.dkd_layernorm_bwd_f32_workspace_bytes(rows, C), x.device)
-    check(lib.dkd_layernorm_bwd_f32(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dg), _p(db), _p(ws), rows,
-                                    C, _stream()), "dkd_layernorm_bwd_f32")
+    check(lib.dkd_layernorm_bwd_f32(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(add), _p(dx), _p(dg), _p(db), _p(ws),
+                                    rows, C, _stream()), "dkd_layernorm_bwd_f32")
     return dx, dg, db
 
 

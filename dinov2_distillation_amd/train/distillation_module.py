@@ -1,0 +1,190 @@
+"""The distillation step module - same surface as /root/reference/train/distillation_module.py.
+
+If ``lightning`` is importable the class derives from ``L.LightningModule`` and drops into the reference's
+``train.py``; otherwise it is a plain nn.Module with the same hooks, driven by ``dinov2_distillation_amd.trainer``.
+"""
+import logging
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..losses import ScaleKD
+
+try:  # pragma: no cover - lightning is not installed in the build image
+    import lightning as L
+    _Base = L.LightningModule
+except Exception:  # noqa: BLE001
+    _Base = nn.Module
+
+logger = logging.getLogger("dinov2")
+
+LOSS_REGISTRY = {"scalekd": ScaleKD}
+
+
+def _get(cfg, key, default=None):
+    if hasattr(cfg, "get"):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class DistillationModule(_Base):
+    def __init__(self, student, teacher, cfg):
+        super().__init__()
+        self.cfg = cfg
+        if hasattr(self, "save_hyperparameters") and _Base is not nn.Module:
+            self.save_hyperparameters(cfg)
+        self.logged = {}
+        self._initialize_models(student, teacher)
+        self._initialize_loss()
+
+    # ---- set-up (train/distillation_module.py:68-137) ---------------------------------------------------------------
+    def _initialize_models(self, student, teacher):
+        self.student = student
+        self.teacher = teacher
+        self._freeze_teacher()
+        path = _get(self.cfg["student"], "checkpoint_path", None) or getattr(self.student.model, "ckpt_dir", None)
+        self._load_student_checkpoint(path)
+
+    def _freeze_teacher(self):
+        self.teacher.eval()
+        for p in self.teacher.parameters():
+            p.requires_grad = False
+
+    def _initialize_loss(self):
+        self.losses = nn.ModuleDict()
+        self.loss_weights = {}
+        for spec in self.cfg["loss"]["losses"]:
+            kwargs = dict(spec["kwargs"])
+            name = kwargs.get("name", spec["type"])
+            self.losses[name] = LOSS_REGISTRY[spec["type"]](**kwargs)
+            self.loss_weights[name] = spec["weight"]
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.teacher.eval()  # the teacher stays in eval during fit (run.ipynb:109)
+        return self
+
+    # ---- hot path -----------------------------------------------------------------------------------------------------
+    def _forward_specific_stage(self, feat, layer):
+        """train/distillation_module.py:139-178: res2/res3 run no block; res4 runs blocks floor(.75 n) .. n-2."""
+        layers = {"res2": 0.25, "res3": 0.50, "res4": 0.75}
+        n_total_blocks = len(self.teacher.model.blocks)
+        start_block = int(n_total_blocks * layers[layer])
+        end_block = int(n_total_blocks / 4) - 1
+        if layer == "res4":
+            end_block = n_total_blocks - 1
+        for i in range(start_block, end_block):
+            feat = self.teacher.model.blocks[i](feat)
+        return feat
+
+    def _compute_losses(self, features):
+        """train/distillation_module.py:180-246 (sorted level order, res5 ends the loop, intermediate levels use
+        get_spat_loss for both terms, queries are handed on without detaching)."""
+        total_loss = 0
+        loss_dict = {}
+        spatial_query = frequency_query = None
+        for name in sorted(self.losses.keys()):
+            layer_name = name.split("_")[1]
+            loss_fn, weight = self.losses[name], self.loss_weights[name]
+            if "res5" in name:
+                loss = loss_fn(features["student"][layer_name], features["teacher"], query_s=spatial_query,
+                               query_f=frequency_query)
+                loss_dict[f"{name}_total_loss"] = loss["loss"] * weight
+                loss_dict[f"{name}_frequency_loss"] = loss["frequency_loss"] * weight
+                loss_dict[f"{name}_spatial_loss"] = loss["spatial_loss"] * weight
+                loss_dict[f"{name}_spatial_similarity"] = loss["spatial_similarity"]
+                loss_dict[f"{name}_frequency_similarity"] = loss["frequency_similarity"]
+                total_loss = total_loss + loss["loss"] * weight
+                break
+            feat_S_spat = loss_fn.project_feat_spat(features["student"][layer_name], query=spatial_query)
+            feat_S_freq = loss_fn.project_feat_freq(features["student"][layer_name], query=frequency_query)
+            feat_S_spat = self._forward_specific_stage(feat_S_spat, layer_name)
+            feat_S_freq = self._forward_specific_stage(feat_S_freq, layer_name)
+            spatial_query, frequency_query = feat_S_spat, feat_S_freq
+            spatial_loss, spatial_similarity = loss_fn.get_spat_loss(feat_S_spat, features["teacher"])
+            frequency_loss, frequency_similarity = loss_fn.get_spat_loss(feat_S_freq, features["teacher"])
+            loss_dict[f"{name}_total_loss"] = (spatial_loss + frequency_loss) * weight
+            loss_dict[f"{name}_frequency_loss"] = frequency_loss * weight
+            loss_dict[f"{name}_spatial_loss"] = spatial_loss * weight
+            loss_dict[f"{name}_spatial_similarity"] = spatial_similarity
+            loss_dict[f"{name}_frequency_similarity"] = frequency_similarity
+            total_loss = total_loss + (spatial_loss + frequency_loss) * weight
+        loss_dict["loss"] = total_loss
+        return loss_dict
+
+    def _extract_features(self, batch):
+        with torch.no_grad():
+            teacher_features = self.teacher(batch)[_get(self.cfg["teacher"], "teacher_key", "feature_map")]
+        return {"student": self.student(batch), "teacher": teacher_features}
+
+    def training_step(self, batch, batch_idx):
+        losses = self._compute_losses(self._extract_features(batch))
+        self._log_training_metrics(losses)
+        return losses["loss"]
+
+    def validation_step(self, batch, batch_idx):
+        losses = self._compute_losses(self._extract_features(batch))
+        for k, v in losses.items():
+            self.log(f"val_{k}", v, sync_dist=True)
+        return losses["loss"]
+
+    # ---- logging ------------------------------------------------------------------------------------------------------
+    def log(self, name, value, **kwargs):
+        if _Base is not nn.Module:
+            return super().log(name, value, **kwargs)
+        self.logged[name] = value  # kept on the device: no host sync inside the step
+
+    def _log_training_metrics(self, losses):
+        for k, v in losses.items():
+            self.log(f"train_{k}", v, sync_dist=True)
+        if _Base is not nn.Module:
+            self.log("lr", self.optimizers().param_groups[0]["lr"], sync_dist=True, prog_bar=True)
+
+    # ---- optimiser (train/distillation_module.py:440-502) ------------------------------------------------------------
+    def configure_optimizers(self):
+        from ..optim import FusedAdamW
+        groups = [{"params": list(self.student.parameters()), "name": "student"}]
+        for name, mod in self.losses.items():
+            ps = list(mod.parameters())
+            if ps:
+                groups.append({"params": ps, "name": f"loss_{name}"})
+        ocfg = self.cfg["optimizer"]
+        kwargs = dict(_get(ocfg, "kwargs", {}) or {})
+        if ocfg["type"] == "AdamW":
+            optimizer = FusedAdamW(groups, **kwargs)
+        else:
+            optimizer = getattr(torch.optim, ocfg["type"])(groups, **kwargs)
+        sched = _get(ocfg, "scheduler", None)
+        if sched:
+            scheduler = getattr(torch.optim.lr_scheduler, sched["type"])(optimizer, **dict(_get(sched, "kwargs", {}) or {}))
+            return {"optimizer": optimizer,
+                    "lr_scheduler": {"scheduler": scheduler, "monitor": _get(sched, "monitor", "val_loss"),
+                                     "interval": _get(sched, "interval", "epoch"), "frequency": _get(sched, "frequency", 1)}}
+        return optimizer
+
+    # ---- student warm start (train/distillation_module.py:381-438) ---------------------------------------------------
+    def _load_student_checkpoint(self, checkpoint_path):
+        if not checkpoint_path or not os.path.exists(checkpoint_path):
+            logger.warning("student checkpoint %s not found - keeping the initialised weights", checkpoint_path)
+            return
+        if checkpoint_path.endswith(".pkl"):
+            with open(checkpoint_path, "rb") as f:
+                checkpoint = pickle.load(f)["model"]
+        elif checkpoint_path.endswith(".pth"):
+            checkpoint = torch.load(checkpoint_path, map_location="cpu")
+        else:
+            raise ValueError(f"Unsupported checkpoint format: {checkpoint_path}")
+        checkpoint = {k: torch.from_numpy(v) if isinstance(v, np.ndarray) else v for k, v in checkpoint.items()}
+        student_type = self.cfg["student"]["model_name"].split("_")[0].lower()
+        if student_type == "stdc":
+            checkpoint = {f"model.model.{k.replace('cp.backbone.', '')}": v for k, v in checkpoint.items()}
+        elif student_type in ("mit", "darknet", "presnet"):
+            checkpoint = {f"model.model.{k.replace('backbone.', '')}": v for k, v in checkpoint.items()}
+        else:
+            checkpoint = {f"model.model.{k}": v for k, v in checkpoint.items()}
+        result = self.student.load_state_dict(checkpoint, strict=False)
+        logger.info("student checkpoint loaded: %d missing, %d unexpected", len(result.missing_keys),
+                    len(result.unexpected_keys))

@@ -71,13 +71,18 @@ long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layou
  * Replaces: DINOv2 block norm1/norm2/final norm (eps 1e-6; external, via models/backbones/dinov2.py:32),
  * ScaleKD norm / norm_2 (eps 1e-5; losses/scalekd.py:215-216,244-245), ConvNeXt LayerNorm channels_last AND
  * channels_first (models/backbones/convnext.py:26-36: in NHWC both are the same row reduction).
+ * fwd input-row remap (in_row_grp > 0): output row r reads input row (r/grp)*grp_stride + r%grp + off - the final
+ * teacher norm reads only the patch tokens and writes them densely, dropping CLS (models/backbones/dinov2.py:32,40).
  * mean/rstd (per row) may be NULL when no backward is needed.  bwd: dgamma/dbeta may both be NULL (frozen
- * teacher: dgrad only); otherwise ws must hold dkd_layernorm_bwd_f32_workspace_bytes.
+ * teacher: dgrad only); otherwise ws must hold dkd_layernorm_bwd_f32_workspace_bytes.  `add` (nullable, [rows,C]) is
+ * summed into dx (the residual branch that bypasses the norm).
  */
 int dkd_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                          long rows, int C, float eps, void* stream);
+                          long rows, int C, float eps, int in_row_grp, int in_row_grp_stride, int in_row_off,
+                          void* stream);
 int dkd_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                          float* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, void* stream);
+                          const float* add, float* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
+                          void* stream);
 long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C);
 
 /* Grouped column reduction  out[g][n] = scale * sum_{r<rows_per_group} f(X[g*rows_per_group+r][n], ...)
@@ -140,7 +145,7 @@ long dkd_kd_loss_f32_workspace_bytes(long rows);
  * and WindowMultiheadPosAttention's core (losses/scalekd.py:308-314, window_shapes (1,1)).
  * Element (b, token, head, d) of x lives at x[b*x_bs + token*x_rs + head*hd + d]; strides in floats, % 4 == 0;
  * q_bs may be 0 (batch-invariant self-query).  lse/delta: [B, H, Nq] scratch kept between fwd and bwd.
- * hd in {16,24,32,48,64,96}.
+ * hd in {8,16,24,32,48,64,96}.
  */
 typedef struct dkd_attn_args {
     const float *q, *k, *v;
@@ -161,7 +166,7 @@ int dkd_attn_bwd_f32(const dkd_attn_args* args, void* stream);
  * ConvNeXt-V2 student spatial ops on NHWC tensors (models/backbones/convnext.py).
  * dwconv7: depthwise 7x7, pad 3 (:62-64).  Weights arrive TAP-MAJOR [49][C] (dkd_transpose_f32 of the [C,1,7,7]
  * parameter).  flip=1 applies the 180-degree-rotated taps == dgrad wrt the input; `add` (nullable, same shape as out)
- * is summed into the result (residual branch of Block.forward :86 in the backward pass).  W % 7 == 0, C % 4 == 0.
+ * is summed into the result (residual branch of Block.forward :86 in the backward pass).  C % 4 == 0.
  * wgrad writes per-(image,row-chunk) partial sums [parts][49][C] (parts from dkd_dwconv7_wgrad_f32_parts), to be
  * folded with dkd_colreduce_f32 -> tap-major [49][C].
  */
@@ -180,6 +185,19 @@ int dkd_resize_bilinear_fwd_f32(const float* in, float* out, int B, int Hi, int 
 int dkd_resize_bilinear_bwd_f32(const float* dout, float* din, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
 /* out[b*row_stride + d] = vec[d]: the CLS(+pos[0]) token row of every image in the teacher token buffer */
 int dkd_set_rows_f32(float* out, const float* vec, int B, long row_stride, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser tail over FLAT fp32 arenas (n % 4 == 0, 16-byte aligned): global grad norm, clip, AdamW.
+ * Replaces torch.optim.AdamW (train/distillation_module.py:476-479; config/config.yaml:24-30) and the Trainer's
+ * gradient_clip_val=1.0 / "norm" (train.py:267-268).  dkd_sumsq_f32 writes out2 = {sum x^2, sqrt(sum x^2)} on the
+ * device; dkd_adamw_f32 takes that pointer (or NULL) and scales every gradient by min(1, max_norm/(norm+1e-6))
+ * on the fly, then applies torch's AdamW update with bias corrections for `step` (>= 1).
+ */
+int dkd_sumsq_f32(const float* x, long n, float* out2, float* ws, void* stream);
+long dkd_sumsq_f32_workspace_bytes(long n);
+int dkd_adamw_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, const float* gnorm2, float max_norm, void* stream);
+int dkd_clip_grad_f32(float* g, long n, const float* gnorm2, float max_norm, void* stream);
 
 #ifdef __cplusplus
 }

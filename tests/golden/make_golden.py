@@ -116,7 +116,7 @@ def gen_scalekd():
     cases = {
         # name: (student_dims, teacher_dims, P, heads, self_query, window, with_queries)
         "scalekd_selfq": (40, 48, 4, 6, True, (1, 1), False),
-        "scalekd_extq": (24, 48, 4, 4, False, (1, 1), True),
+        "scalekd_extq": (24, 48, 4, 6, False, (1, 1), True),
         "scalekd_win22": (24, 32, 4, 4, True, (2, 2), False),
         "scalekd_p6": (16, 32, 6, 2, True, (1, 1), False),
     }
@@ -280,7 +280,7 @@ def gen_step():
 
     cfg = Cfg(student=Cfg(model_name="convnext_tiny", checkpoint_path=None),
               teacher=Cfg(model_name="dinov2_vits14", teacher_key="feature_map"),
-              loss=Cfg(losses=[loss_spec("scalekd_res4", 4, True, c4), loss_spec("scalekd_res5", 6, False, c5)]),
+              loss=Cfg(losses=[loss_spec("scalekd_res4", 6, True, c4), loss_spec("scalekd_res5", 3, False, c5)]),
               optimizer=Cfg(type="AdamW", kwargs=Cfg(lr=1e-3)))
     dm.DistillationModule._load_student_checkpoint = lambda self, path: None  # no checkpoint files exist
     mod = dm.DistillationModule(student=Student(), teacher=Teacher(), cfg=cfg)

@@ -119,8 +119,8 @@ def test_step_compute_losses(golden_dir):
     s4 = g["in/res4"].clone().requires_grad_(True)
     s5 = g["in/res5"].clone().requires_grad_(True)
     cfgs = {
-        "scalekd_res4": dict(alpha=[0.08, 0.06], hw=(P, P), num_heads=4, softmax_scale=[5.0, 5.0]),
-        "scalekd_res5": dict(alpha=[0.08, 0.06], hw=(P, P), num_heads=6, softmax_scale=[5.0, 5.0]),
+        "scalekd_res4": dict(alpha=[0.08, 0.06], hw=(P, P), num_heads=6, softmax_scale=[5.0, 5.0]),
+        "scalekd_res5": dict(alpha=[0.08, 0.06], hw=(P, P), num_heads=3, softmax_scale=[5.0, 5.0]),
     }
     w = {"scalekd_res4": 0.7, "scalekd_res5": 1.0}
     out = so.compute_losses(lp, cfgs, w, {"res4": s4, "res5": s5}, g["in/feat_t"], tp, depth, heads)
