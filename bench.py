@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of ONE full distillation step (teacher fwd + student fwd/bwd + ScaleKD fwd/bwd + gradient
+all-reduce + clip + AdamW) on N MI355X GPUs, BASELINE.json config[1]:
+dinov2_vits14 -> convnext_tiny, ScaleKD res4+res5, 224x224, bs=64/GPU, fp32, synthetic data.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job images/s, inputs resident in HBM,
+plus `roofline` for the dominant kernel family (fp32 MFMA GEMM; HIP events recorded live around every launch in the
+timed region, on the launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+
+
+class GemmProfiler:
+    """HIP-event pairs around every dkd_gemm_f32 launch (recorded on the stream the kernel is launched on)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def wrap(self, ops):
+        inner = ops.gemm
+
+        def gemm(a, b, **kw):
+            if not self.enabled:
+                return inner(a, b, **kw)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = inner(a, b, **kw)
+            e1.record(s)
+            al, bl = kw.get("a_layout", 0), kw.get("b_layout", 0)
+            a2, b2 = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+            M, K = (a2.shape[0], a2.shape[1]) if al == 0 else (a2.shape[1], a2.shape[0])
+            N = b2.shape[0] if bl == 0 else b2.shape[1]
+            self.records.append((e0, e1, 2.0 * M * N * K, (M, N, K, al, bl)))
+            return out
+
+        ops.gemm = gemm
+
+    def summary(self):
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
+        tot_fl = sum(f for _, _, f, _ in self.records)
+        n = len(self.records)
+        return n, tot_ms, tot_fl
+
+
+def cpu_baseline(seconds_budget=25.0, batch=2):
+    """The CPU oracle (oracle/, kind 'port') timed on the host cores on a bounded sample of the SAME workload:
+    full step = teacher fwd + student fwd/bwd + ScaleKD fwd/bwd + clip + AdamW, config[1] shapes at a small batch."""
+    from oracle import convnext_oracle as cno, step_oracle as so, vit_oracle as vo
+    from dinov2_distillation_amd.config import make_config
+    ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("DKD_CPU_THREADS", "16")))  # the box's CPU share
+    torch.set_num_threads(ncpu)
+    cfg = make_config()
+    tcfg = vo.VIT_CONFIGS["dinov2_vits14"]
+    depths, dims = cno.CONVNEXT_CONFIGS["convnext_tiny"]["depths"], cno.CONVNEXT_CONFIGS["convnext_tiny"]["dims"]
+    tp = vo.init_vit_params(tcfg, seed=0)
+    sp = cno.init_convnext_params(depths, dims, seed=1)
+    from dinov2_distillation_amd.losses import ScaleKD  # parameter containers / default init only (CPU tensors)
+    lp, cfgs, w = {}, {}, {}
+    for spec in cfg.loss.losses:
+        kw = dict(spec.kwargs)
+        kw["student_dims"] = dims[int(kw["name"][-1]) - 2]
+        m = ScaleKD(**kw)
+        for k, v in m.state_dict().items():
+            lp[kw["name"] + "." + k] = v.clone()
+        cfgs[kw["name"]] = dict(alpha=kw["alpha"], hw=tuple(kw["pos_hw"]), num_heads=kw["num_heads"],
+                                softmax_scale=kw["softmax_scale"])
+        w[kw["name"]] = spec.weight
+    train = [v.requires_grad_(True) for v in sp.values()]
+    train += [v.requires_grad_(True) for k, v in lp.items() if v.dtype.is_floating_point and "running" not in k]
+    m_ = [torch.zeros_like(v) for v in train]
+    v_ = [torch.zeros_like(v) for v in train]
+    x = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        for p in train:
+            p.grad = None
+        with torch.no_grad():
+            ft = vo.teacher_feature_map(tp, x, tcfg)
+        feats = cno.student_features(sp, x, depths, cfg.teacher.n_patches, cfg.student.student_keys)
+        out = so.compute_losses(lp, cfgs, w, feats, ft, tp, tcfg["depth"], tcfg["num_heads"])
+        out["loss"].backward()
+        with torch.no_grad():
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in train]
+            so.clip_grad_norm_(grads, 1.0)
+            so.adamw_step_(train, grads, m_, v_, steps + 1)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget * 0.6 or steps >= 8:
+            break
+    return {"value": round(steps * batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full steps (teacher fwd + student fwd/bwd + ScaleKD + clip + AdamW) of config[1] at batch "
+                      f"{batch} on the host CPU, fp32 torch oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config[1]: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the distillation step has no CPU path (only cpu_baseline uses the oracle)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        from dinov2_distillation_amd.ddp import init_process_group_from_env
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        init_process_group_from_env("nccl")
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    prof = GemmProfiler()
+    if not args.no_roofline:
+        prof.wrap(ops)
+    t_start = time.perf_counter()
+    stepper = DistillationStepper(device=f"cuda:{local}")
+    gen = torch.Generator().manual_seed(1234 + rank)
+    batch = torch.randn(args.batch, 3, 224, 224, generator=gen).cuda()  # resident in HBM before the timed region
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    note("model built")
+    for i in range(args.warmup):
+        stepper.step(batch)
+        torch.cuda.synchronize()
+        note(f"warmup step {i} done")
+    sync()
+    prof.enabled = not args.no_roofline
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = stepper.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    lossv = float(loss)
+    note(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = dt / args.steps * 1e3
+    res = {
+        "metric": "images/sec distillation step (teacher fwd + student fwd/bwd + ScaleKD) at 1/2/4/8 GPUs",
+        "value": round(args.batch * world * args.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dinov2_vits14 -> convnext_tiny, ScaleKD res4+res5, 224x224, bs=%d/GPU (BASELINE configs[1]); "
+                               "full step incl. grad all-reduce, clip 1.0, AdamW" % args.batch,
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+        "loss": round(lossv, 5),
+    }
+    if not args.no_roofline:
+        n, gemm_ms, gemm_fl = prof.summary()
+        ach = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel": "gemm_f32_kernel (fp32 MFMA 32x32x2), all launches of the timed region",
+                           "launches": n, "avg_launch_us": round(gemm_ms * 1e3 / max(n, 1), 2),
+                           "avg_flop_per_launch": round(gemm_fl / max(n, 1)),
+                           "gemm_share_of_step": round(gemm_ms / args.steps / ms, 3)}
+    if not args.no_cpu_baseline and world == 1:
+        note("timing the CPU oracle (cpu_baseline) ...")
+        res["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,11 @@ import ctypes
 import os
 import re
 
+# torch FIRST: its wheel bundles a HIP runtime with SONAME libamdhip64.so.7; once that copy is mapped, the dynamic loader
+# resolves libdkd_hip.so's own NEEDED libamdhip64.so.7 to it, so kernels, streams and device pointers share ONE runtime.
+# (Loading libdkd_hip.so before torch maps /opt/rocm's copy as well and every launch fails with hipErrorNoDevice.)
+import torch  # noqa: F401
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "dkd_hip.h")
