@@ -231,11 +231,12 @@ void colreduce_plan(long rows_per_group, int groups, int N, int* CL, int* nsplit
     while (cl < nv && cl < 64) cl <<= 1;
     const int RL = 256 / cl;
     const int cb = (nv + cl - 1) / cl;
-    long want = 2048 / ((long)cb * groups);  // ~8 blocks per CU in total
+    long want = 1024 / ((long)cb * groups);  // ~4 blocks per CU in total
     if (want < 1) want = 1;
     long maxs = rows_per_group / ((long)RL * 8);  // >= 8 rows per thread
     if (maxs < 1) maxs = 1;
     long ns = want < maxs ? want : maxs;
+    if (ns > 64) ns = 64;  // the second pass walks the partials serially per column: keep it short
     long rps = (rows_per_group + ns - 1) / ns;
     ns = (rows_per_group + rps - 1) / rps;
     *CL = cl; *nsplit = (int)ns; *rows_per_split = (int)rps; *colblocks = cb;
@@ -259,7 +260,7 @@ extern "C" int dkd_layernorm_fwd_f32(const float* x, const float* gamma, const f
     return DKD_OK;
 }
 
-static int ln_bwd_blocks(long rows) { return (int)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512); }
+static int ln_bwd_blocks(long rows) { return (int)((rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256); }
 
 extern "C" long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C) {
     return (long)ln_bwd_blocks(rows) * 2 * C * sizeof(float);

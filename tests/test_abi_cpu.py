@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dkd_hip.h declares (no compute without a GPU), the
+argument structs match the C layout, and the product path refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+import torch
+
+from dinov2_distillation_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from dinov2_distillation_amd import build
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    funcs = _lib.declared_functions()
+    assert len(funcs) >= 40
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    for name in funcs:
+        assert name in exported, f"{name} declared in include/dkd_hip.h but not exported"
+        assert getattr(lib, name) is not None
+    stray = {s for s in exported if s.startswith("dkd_")} - set(funcs)
+    assert not stray, f"exported but undeclared: {stray}"
+
+
+def test_abi_version_and_struct_layout(lib):
+    assert lib.dkd_abi_version() == _lib.DEFINES["DKD_ABI_VERSION"]
+    # compile a tiny C program against the header and compare sizeof / offsetof with the ctypes mirrors
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "dkd_hip.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu\n", sizeof(dkd_gemm_args), offsetof(dkd_gemm_args, a_layout), offsetof(dkd_gemm_args, alpha),
+             sizeof(dkd_attn_args), offsetof(dkd_attn_args, q_bs), offsetof(dkd_attn_args, scale));
+      return 0; }'''
+    tmp = os.path.join(ROOT, "build", "abi_check")
+    os.makedirs(tmp, exist_ok=True)
+    open(os.path.join(tmp, "t.c"), "w").write(src)
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(tmp, "t.c"), "-o", os.path.join(tmp, "t")], check=True)
+    vals = [int(v) for v in subprocess.run([os.path.join(tmp, "t")], capture_output=True, text=True).stdout.split()]
+    G, A = _lib.GemmArgs, _lib.AttnArgs
+    assert vals == [ctypes.sizeof(G), G.a_layout.offset, G.alpha.offset, ctypes.sizeof(A), A.q_bs.offset, A.scale.offset]
+
+
+def test_argument_errors_are_reported_not_launched(lib):
+    g = _lib.GemmArgs()
+    assert lib.dkd_gemm_f32(ctypes.byref(g), None) == -1  # DKD_ERR_BAD_ARG: null operands, nothing launched
+    assert lib.dkd_gemm_f32_splits(384, 96, 200704) > 1 and lib.dkd_gemm_f32_splits(16384, 1536, 384) == 1
+    assert lib.dkd_gemm_f32_workspace_bytes(384, 96, 200704, 1, 1) > 0
+    assert lib.dkd_layernorm_fwd_f32(None, None, None, None, None, None, 4, 384, 1e-6, 0, 0, 0, None) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_path_fails_loudly_without_gpu():
+    from dinov2_distillation_amd import ops
+    with pytest.raises(_lib.DkdError, match="no CPU path"):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))
+    from dinov2_distillation_amd.losses import ScaleKD
+    m = ScaleKD(name="scalekd_res5", alpha=[0.08, 0.06], student_dims=8, teacher_dims=16, query_hw=[2, 2], pos_hw=[2, 2],
+                pos_dims=16, num_heads=2)
+    with pytest.raises(_lib.DkdError):
+        m(torch.zeros(2, 8, 2, 2), torch.zeros(2, 16, 2, 2))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "dinov2_distillation_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)

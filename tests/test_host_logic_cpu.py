@@ -1,0 +1,163 @@
+"""CPU: host-side logic of the path - reference-compatible module surface / state-dict names, config derivation,
+block-range logic, error behaviour, and the data-parallel gradient exchange (gloo, world_size 2)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_names_match_reference_golden(golden_dir):
+    """the reference's own state-dict keys (captured in the golden files) load into our modules with strict=True"""
+    import numpy as np
+    from dinov2_distillation_amd.losses import ScaleKD
+    from dinov2_distillation_amd.models.convnext import D2ConvNextV2
+    z = np.load(os.path.join(golden_dir, "scalekd_selfq.npz"))
+    cs, d, P, heads, selfq, wh, ww, B = [int(v) for v in z["meta"]]
+    m = ScaleKD(name="x", alpha=[0.08, 0.06], student_dims=cs, teacher_dims=d, query_hw=[P, P], pos_hw=[P, P], pos_dims=d,
+                self_query=True, softmax_scale=[5.0, 5.0], num_heads=heads)
+    m.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+    z = np.load(os.path.join(golden_dir, "convnext_small.npz"))
+    net = D2ConvNextV2([int(v) for v in z["meta/depths"]], [int(v) for v in z["meta/dims"]])
+    net.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}, strict=True)
+
+
+def test_module_surface_and_param_counts():
+    from dinov2_distillation_amd.config import make_config, set_student_dims
+    from dinov2_distillation_amd.models import DINOv2ViT, ModelWrapper
+    from dinov2_distillation_amd.train import LOSS_REGISTRY, DistillationModule
+    cfg = make_config()
+    s = ModelWrapper("convnext_tiny", cfg.teacher.n_patches, cfg.student.student_keys)
+    assert s.feature_channels == {"res2": 96, "res3": 192, "res4": 384, "res5": 768}
+    assert s.model.ckpt_dir.endswith("convnextv2_tiny_1k_224_ema.pkl")
+    set_student_dims(cfg, s)
+    t = DINOv2ViT("dinov2_vits14")
+    mod = DistillationModule(s, t, cfg)
+    assert set(LOSS_REGISTRY) == {"scalekd"}
+    assert sorted(mod.losses) == ["scalekd_res4", "scalekd_res5"]
+    assert abs(sum(p.numel() for p in s.parameters()) / 1e6 - 27.86) < 0.01
+    assert abs(sum(p.numel() for p in mod.losses.parameters()) / 1e6 - 8.58) < 0.01
+    assert abs(sum(p.numel() for p in t.parameters()) / 1e6 - 22.06) < 0.01
+    assert all(not p.requires_grad for p in t.parameters()) and not t.training
+    mod.train()
+    assert not mod.teacher.training and mod.student.training  # teacher stays in eval during fit
+    keys = list(s.state_dict())
+    assert keys[0] == "model.model.downsample_layers.0.0.weight" and "model.model.stages.2.8.grn.gamma" in keys
+    assert len(t.model.blocks) == 12 and "blocks.11.ls2.gamma" in t.model.state_dict()
+
+
+def test_error_behaviour_matches_reference():
+    from dinov2_distillation_amd.losses.scalekd import AttentionProjector
+    from dinov2_distillation_amd.models import ModelWrapper
+    p = AttentionProjector(8, 16, (2, 2), 16, self_query=False, num_heads=2)
+    with pytest.raises(NotImplementedError, match="There is no query"):   # losses/scalekd.py:236
+        p(torch.zeros(1, 8, 2, 2))
+    with pytest.raises(ValueError):   # 24 does not divide 1024
+        AttentionProjector(8, 1024, (2, 2), 1024, num_heads=24)
+    with pytest.raises(NotImplementedError):
+        ModelWrapper("stdc_2", [16, 16])
+
+
+def test_stage_block_range_logic():
+    from dinov2_distillation_amd.train import DistillationModule
+
+    class T(torch.nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.model = torch.nn.Module()
+            self.calls = []
+            self.model.blocks = [(lambda x, i=i: (self.calls.append(i), x)[1]) for i in range(n)]
+
+    for n, expect in ((12, [9, 10]), (24, [18, 19, 20, 21, 22]), (40, list(range(30, 39)))):
+        t = T(n)
+        fake = type("M", (), {"teacher": t})()
+        DistillationModule._forward_specific_stage(fake, torch.zeros(1), "res4")
+        assert t.calls == expect
+        t.calls.clear()
+        DistillationModule._forward_specific_stage(fake, torch.zeros(1), "res2")
+        DistillationModule._forward_specific_stage(fake, torch.zeros(1), "res3")
+        assert t.calls == []
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from dinov2_distillation_amd.ddp import GradBucketReducer, allreduce_metrics, init_process_group_from_env
+    os.environ["NCCL_P2P_DISABLE"] = "1"  # must be dropped, never inherited (train.py:23)
+    init_process_group_from_env("gloo")
+    assert "NCCL_P2P_DISABLE" not in os.environ
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 70), torch.nn.Linear(70, 5))
+
+    class FlatOpt:  # the arena layout FusedAdamW builds, on CPU tensors
+        def __init__(self, params):
+            ps = [p for p in params]
+            offs, tot = [], 0
+            for p in ps:
+                offs.append(tot)
+                tot += (p.numel() + 63) // 64 * 64
+            self.flat_p, self.flat_g = torch.zeros(tot), torch.zeros(tot)
+            self.layout = []
+            for p, o in zip(ps, offs):
+                self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+                self.layout.append((p, o, p.numel()))
+
+    opt = FlatOpt(net.parameters())
+    if rank == 1:
+        with torch.no_grad():
+            opt.flat_p.add_(1.0)  # diverge on purpose: broadcast must restore rank 0's weights
+    red = GradBucketReducer(opt, bucket_bytes=4096 * 4)
+    assert len(red.buckets) >= 3
+    red.broadcast_parameters(0)
+    x = torch.randn(8, 40, generator=torch.Generator().manual_seed(100 + rank))
+    for _ in range(2):  # two steps: hooks re-arm
+        opt.flat_g.zero_()
+        net(x).pow(2).sum().backward()
+        assert any(red.launched), "buckets must be launched from the grad hooks during backward"
+        red.finish()
+    # reference: average of the per-rank gradients computed in one process
+    ref_net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 70), torch.nn.Linear(70, 5))
+    torch.manual_seed(0)
+    ref_net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 70), torch.nn.Linear(70, 5))
+    tot = [torch.zeros_like(p) for p in ref_net.parameters()]
+    for r in range(world):
+        ref_net.zero_grad()
+        xr = torch.randn(8, 40, generator=torch.Generator().manual_seed(100 + r))
+        ref_net(xr).pow(2).sum().backward()
+        for t, p in zip(tot, ref_net.parameters()):
+            t += p.grad / world
+    err = max((p.grad - t).abs().max().item() for p, t in zip(net.parameters(), tot))
+    m = allreduce_metrics({"a": torch.tensor(float(rank)), "b": torch.tensor(2.0)})
+    q.put((rank, err, float(m["a"]), float(m["b"])))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, a, b in res:
+        assert err < 1e-5, (rank, err)
+        assert abs(a - 0.5) < 1e-6 and abs(b - 2.0) < 1e-6
