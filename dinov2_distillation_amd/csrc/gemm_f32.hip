@@ -107,12 +107,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
-template <int WM, int WN, int TM, int TN, bool A_KC, bool B_KC>
+// SCHED 0: load(t+1) | compute(t) | store(t+1) | barrier        (store after the MFMA block)
+// SCHED 1: store(t+1) | load(t+2) | compute(t) | barrier        (store right after the barrier, loads one tile further ahead)
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int SCHED>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __restrict__ A, long lda,
                                                                 const float* __restrict__ B, long ldb,
                                                                 float* C, long ldc, int M, int N, int K,
-                                                                int kchunk, Epilogue epi, float* __restrict__ ws) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16, NT = WM * WN * 64;
+                                                                int kchunk, Epilogue epi, float* __restrict__ ws,
+                                                                float* __restrict__ rowsum) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     using SA = Stager<BM, BK, A_KC, NT>;
     using SB = Stager<BN, BK, B_KC, NT>;
     constexpr int A_SZ = BK * SA::LDS_LD, B_SZ = BK * SB::LDS_LD;
@@ -137,22 +140,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __re
     SA sa;
     SB sb;
     const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        sa.load(A, lda, bm0, M, kbeg, kend, tid);
-        sb.load(B, ldb, bn0, N, kbeg, kend, tid);
-        sa.store(smem, tid);
-        sb.store(smem + A_SZ, tid);
-    }
-    __syncthreads();
     const int half = lane >> 5, l31 = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            sa.load(A, lda, bm0, M, kbeg + (kt + 1) * BK, kend, tid);
-            sb.load(B, ldb, bn0, N, kbeg + (kt + 1) * BK, kend, tid);
+    // optional fused row sums of Aop (the bias gradient of a wgrad launch): column-tile 0 folds its LDS A tiles
+    const bool do_rowsum = rowsum != nullptr && bn0 == 0 && tid < BM;
+    float rs = 0.f;
+    auto compute = [&](const float* As, const float* Bs) {
+        if (do_rowsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += As[kk * SA::LDS_LD + tid];
         }
-        const float* As = smem + cur * (A_SZ + B_SZ);
-        const float* Bs = As + A_SZ;
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float a[TM], b[TN];
@@ -166,16 +162,52 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __re
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-            float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
-            sa.store(An, tid);
-            sb.store(An + A_SZ, tid);
+    };
+    if (nk > 0) {
+        sa.load(A, lda, bm0, M, kbeg, kend, tid);
+        sb.load(B, ldb, bn0, N, kbeg, kend, tid);
+        sa.store(smem, tid);
+        sb.store(smem + A_SZ, tid);
+        if (SCHED == 1 && nk > 1) {
+            sa.load(A, lda, bm0, M, kbeg + BK, kend, tid);
+            sb.load(B, ldb, bn0, N, kbeg + BK, kend, tid);
+        }
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        float* As = smem + cur * (A_SZ + B_SZ);
+        float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
+        if (SCHED == 1) {
+            if (kt + 1 < nk) {
+                sa.store(An, tid);
+                sb.store(An + A_SZ, tid);
+            }
+            if (kt + 2 < nk) {
+                sa.load(A, lda, bm0, M, kbeg + (kt + 2) * BK, kend, tid);
+                sb.load(B, ldb, bn0, N, kbeg + (kt + 2) * BK, kend, tid);
+            }
+            compute(As, As + A_SZ);
+        } else {
+            if (kt + 1 < nk) {
+                sa.load(A, lda, bm0, M, kbeg + (kt + 1) * BK, kend, tid);
+                sb.load(B, ldb, bn0, N, kbeg + (kt + 1) * BK, kend, tid);
+            }
+            compute(As, As + A_SZ);
+            if (kt + 1 < nk) {
+                sa.store(An, tid);
+                sb.store(An + A_SZ, tid);
+            }
         }
         __syncthreads();
     }
 
     // C/D map of the 32x32 MFMA: col = lane & 31 (B's index n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     const bool partial = ws != nullptr;
+    if (do_rowsum && bm0 + tid < M) {
+        if (partial) ws[(long)gridDim.y * M * N + (long)blockIdx.y * M + bm0 + tid] = rs;
+        else rowsum[bm0 + tid] = rs * epi.alpha;
+    }
     float* out = partial ? ws + (long)blockIdx.y * M * N : C;
     const long ldo = partial ? N : ldc;
 #pragma unroll
@@ -197,23 +229,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __re
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* C,
-                                     long ldc, Epilogue epi) {
+                                     long ldc, Epilogue epi, float* __restrict__ rowsum) {
     const long total = (long)M * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total + (rowsum ? M : 0);
+         i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += ws[(long)z * total + i];
-        epilogue_store(epi, C, ldc, (int)(i / N), (int)(i % N), s);
+        if (i < total) {
+            for (int z = 0; z < splits; ++z) s += ws[(long)z * total + i];
+            epilogue_store(epi, C, ldc, (int)(i / N), (int)(i % N), s);
+        } else {
+            const long m = i - total;
+            for (int z = 0; z < splits; ++z) s += ws[(long)splits * total + (long)z * M + m];
+            rowsum[m] = s * epi.alpha;
+        }
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BK, int SCHED>
 int launch_cfg(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
     float* ws = splits > 1 ? g->workspace : nullptr;
 #define DKD_GEMM_LAUNCH(AKC, BKC)                                                                                  \
-    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AKC, BKC>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, \
-                       g->C, g->ldc, g->M, g->N, g->K, kchunk, epi, ws)
+    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, BK, AKC, BKC, SCHED>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, \
+                       g->C, g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum)
     if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH(true, true);
     else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH(true, false);
     else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH(false, true);
@@ -224,7 +263,7 @@ int launch_cfg(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
         const long total = (long)g->M * g->N;
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g->workspace, splits, g->M, g->N,
-                           g->C, g->ldc, epi);
+                           g->C, g->ldc, epi, g->rowsum);
         DKD_LAUNCH_CHECK();
     }
     return DKD_OK;
@@ -232,24 +271,46 @@ int launch_cfg(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
 
 }  // namespace
 
-extern "C" long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout) {
-    int splits = dkd_gemm_f32_splits(M, N, K);
-    (void)a_layout;
-    (void)b_layout;
-    return splits > 1 ? (long)splits * M * N * sizeof(float) : 0;
-}
+// ---- automatic configuration --------------------------------------------------------------------------------------
+// Measured on MI355X (gpurun_out/tune*.log, fp32, random operands): the 32x64 / 64x32 per-wave tiles (2 accumulators,
+// ~90 registers, 5 waves/SIMD) beat 64x64 per wave everywhere; 128x128 blocks of 8 such waves win once the grid has
+// >= 4 tiles per CU, 64x128 blocks of 4 waves win on the 300-600-tile grids (N = 384 projections), 128x96 on N = 96/192.
+enum { CFG_128x128_8W = 2, CFG_64x128_4W = 3, CFG_128x96_4W = 4 };
 
-// Split the reduction only when the output grid alone cannot fill the 256 CUs (weight gradients: tiny
-// M x N, reduction over all B*H*W rows).
-extern "C" int dkd_gemm_f32_splits(int M, int N, int K) {
-    const long tiles = (long)dkd_cdiv(M, 128) * dkd_cdiv(N, N <= 96 || N == 192 ? 96 : 128);
-    if (tiles >= 256 || K < 2048) return 1;
-    long want = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
-    long maxs = K / 256;                      // at least 16 k-tiles per split
+static int pick_cfg(int M, int N, int variant) {
+    if (variant > 0) return variant;
+    if (N <= 96 || N == 192) return CFG_128x96_4W;
+    const long t128 = (long)dkd_cdiv(M, 128) * dkd_cdiv(N, 128);
+    return t128 >= 1024 ? CFG_128x128_8W : CFG_64x128_4W;
+}
+static void cfg_tile(int cfg, int* bm, int* bn) {
+    switch (cfg) {
+        case 1: case CFG_128x128_8W: *bm = 128; *bn = 128; break;
+        case CFG_128x96_4W: *bm = 128; *bn = 96; break;
+        default: *bm = 64; *bn = 128; break;
+    }
+}
+// Split the reduction only when the output grid alone cannot fill the chip (weight gradients: small M x N, reduction
+// over all B*H*W rows).  Aim at ~1024 workgroups, >= 32 k-tiles per split, <= 128 slabs.
+static int pick_splits(int M, int N, int K, int cfg) {
+    int bm, bn;
+    cfg_tile(cfg, &bm, &bn);
+    const long tiles = (long)dkd_cdiv(M, bm) * dkd_cdiv(N, bn);
+    if (tiles >= 384 || K < 1024) return 1;
+    long want = (1024 + tiles - 1) / tiles, maxs = K / 512;
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
-    if (want > 512) want = 512;
+    if (want > 128) want = 128;
     return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int dkd_gemm_f32_splits(int M, int N, int K) { return pick_splits(M, N, K, pick_cfg(M, N, 0)); }
+
+extern "C" long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout) {
+    (void)a_layout;
+    (void)b_layout;
+    const int splits = dkd_gemm_f32_splits(M, N, K);
+    return splits > 1 ? (long)splits * ((long)M * N + M) * sizeof(float) : 0;
 }
 
 extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
@@ -271,7 +332,11 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     epi.row_grp_stride = g->row_grp_stride;
     epi.row_off = g->row_off;
     epi.alpha = g->alpha;
-    int splits = dkd_gemm_f32_splits(g->M, g->N, g->K);
+    const int cfg = pick_cfg(g->M, g->N, g->variant);
+    // the workspace was sized for the automatic configuration: never use more slabs than that
+    int splits = pick_splits(g->M, g->N, g->K, cfg);
+    const int auto_splits = dkd_gemm_f32_splits(g->M, g->N, g->K);
+    if (splits > auto_splits) splits = auto_splits;
     if (splits > 1 && !g->workspace) splits = 1;
     int kchunk = g->K;
     if (splits > 1) {
@@ -279,6 +344,12 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         splits = (g->K + kchunk - 1) / kchunk;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (g->N <= 96 || g->N == 192) return launch_cfg<4, 1, 1, 3>(g, epi, splits, kchunk, st);  // 128 x 96
-    return launch_cfg<2, 2, 2, 2>(g, epi, splits, kchunk, st);                                   // 128 x 128
+    switch (cfg) {
+        case 1: return launch_cfg<2, 2, 2, 2, 16, 1>(g, epi, splits, kchunk, st);               // 128 x 128, 4 waves of 64 x 64
+        case CFG_128x128_8W: return launch_cfg<4, 2, 1, 2, 16, 1>(g, epi, splits, kchunk, st);  // 128 x 128, 8 waves of 32 x 64
+        case CFG_64x128_4W: return launch_cfg<1, 4, 2, 1, 16, 1>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 64 x 32
+        case CFG_128x96_4W: return launch_cfg<4, 1, 1, 3, 16, 1>(g, epi, splits, kchunk, st);   // 128 x 96, 4 waves of 32 x 96
+        case 5: return launch_cfg<2, 2, 1, 2, 16, 1>(g, epi, splits, kchunk, st);               // 64 x 128, 4 waves of 32 x 64
+        default: return DKD_ERR_BAD_ARG;
+    }
 }

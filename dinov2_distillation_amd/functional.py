@@ -43,8 +43,13 @@ class LinearFn(Function):
             dy = ops.relu_bwd(dy, y)
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_wgrad(dy2, x2) if ctx.needs_input_grad[1] else None
-        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = db = None
+        if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
+            dw, db = ops.linear_wgrad(dy2, x2, True)
+        elif ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy2, x2)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
         return dx, dw, db, None, dres
 
 
@@ -114,8 +119,7 @@ class PatchConvFn(Function):
         k, src_nchw, xshape, wshape = ctx.meta
         O = wshape[0]
         dy2 = _c(dy).reshape(-1, O)
-        dw2 = ops.linear_wgrad(dy2, rows)
-        db = colsum(dy2)
+        dw2, db = ops.linear_wgrad(dy2, rows, True)
         dx = None
         if src_nchw:
             dw = dw2.reshape(wshape)
@@ -157,13 +161,11 @@ class ConvNeXtBlockFn(Function):
         M = B * H * W
         dout = _c(dout)
         do2 = dout.reshape(M, C)
-        dw2 = ops.linear_wgrad(do2, y)
-        db2 = colsum(do2)
+        dw2, db2 = ops.linear_wgrad(do2, y, True)
         dy = ops.gemm(do2, w2, b_layout=1)  # [M, 4C]
         dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, g, h, (gx, nx, denom), gg, B)
         n2 = n.reshape(M, C)
-        dw1 = ops.linear_wgrad(dh, n2)
-        db1 = colsum(dh)
+        dw1, db1 = ops.linear_wgrad(dh, n2, True)
         dn = ops.gemm(dh, w1, b_layout=1)  # [M, C]
         dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w)
         dd = dd.reshape(B, H, W, C)
@@ -282,37 +284,34 @@ class AttentionProjectorFn(Function):
         B, N, D, Cs, H, hd, scale, shared, pos_shape, wc_shape, xshape = ctx.meta
         M = B * N
         df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w)
-        dw2 = ops.linear_wgrad(df2, f1)
-        db2 = colsum(df2)
+        dw2, db2 = ops.linear_wgrad(df2, f1, True)
         df1 = ops.relu_bwd(ops.gemm(df2, w2, b_layout=1), f1)
-        dw1 = ops.linear_wgrad(df1, zn)
-        db1 = colsum(df1)
+        dw1, db1 = ops.linear_wgrad(df1, zn, True)
         dzn = ops.gemm(df1, w1, b_layout=1, residual=df2)  # + FFN residual branch
         dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w)
-        dwp = ops.linear_wgrad(dy, o.reshape(M, D))
-        dbp = colsum(dy)
+        dwp, dbp = ops.linear_wgrad(dy, o.reshape(M, D), True)
         do = ops.gemm(dy, wp, b_layout=1).reshape(B, N, D)
         dq = torch.empty((B, N, D), dtype=F32, device=dy.device)
         dk, dv = torch.empty_like(k), torch.empty_like(v)
         st = (N * D, D)
         ops.attention_backward(do, q, k, v, o, lse, H, hd, scale, B, N, N, (0 if shared else N * D, D), st, st,
                                dq, dk, dv, st, st, st)
-        dwk, dbk = ops.linear_wgrad(dk, tok), colsum(dk)
-        dwv, dbv = ops.linear_wgrad(dv, tok), colsum(dv)
+        dwk, dbk = ops.linear_wgrad(dk, tok, True)
+        dwv, dbv = ops.linear_wgrad(dv, tok, True)
         dtok = ops.gemm(dk, wk, b_layout=1, residual=dy)  # + attention residual branch
         ops.gemm(dv, wv, b_layout=1, out=dtok, residual=dtok)
         if shared:
             dq2 = ops.colreduce(dq.reshape(B, N * D), ops.RED_SUM).reshape(N, D)
         else:
             dq2 = dq.reshape(M, D)
-        dwq, dbq = ops.linear_wgrad(dq2, qin), colsum(dq2)
+        dwq, dbq = ops.linear_wgrad(dq2, qin, True)
         dqin = ops.gemm(dq2, wq, b_layout=1)
         dext = None if shared else dqin.reshape(B, N, D)
         dself = dqin if shared else None
         dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D)).reshape(pos_shape)
         dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True)
-        dwc = ops.linear_wgrad(dz, x2).reshape(wc_shape)
-        dbc = colsum(dz)
+        dwc, dbc = ops.linear_wgrad(dz, x2, True)
+        dwc = dwc.reshape(wc_shape)
         dx = ops.gemm(dz, wc.reshape(D, Cs), b_layout=1).reshape(xshape) if ctx.needs_input_grad[0] else None
         return (dx, dext, dself, None, None, None, None,
                 dpos, dwc, dbc, dbn_w, dbn_b, dwq, dbq, dwk, dbk, dwv, dbv, dwp, dbp, dw1, db1, dw2, db2,

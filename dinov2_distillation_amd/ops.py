@@ -47,7 +47,8 @@ def workspace(nbytes, device, slot=0):
 
 # ---------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, colscale=None, residual=None, res_mod=0,
-         preact=None, alpha=1.0, row_map=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None):
+         preact=None, alpha=1.0, row_map=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None,
+         variant=0, rowsum=None):
     """C = epi(alpha * Aop @ Bop^T).  a/b are 2-D (or flattened-leading-dims) dense tensors:
     a_layout 0: a is [M,K]; 1: a is [K,M].   b_layout 0: b is [N,K]; 1: b is [K,N]."""
     lib = _lib.load()
@@ -74,9 +75,10 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     ws = workspace(wsb, a.device) if wsb else None
     g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), lda, _p(b2), ldb, _p(out), ldc
     g.bias, g.colscale, g.residual, g.preact, g.workspace = _p(bias), _p(colscale), _p(residual), _p(preact), _p(ws)
+    g.rowsum = _p(rowsum)
     g.ldr = (N if ldr is None else ldr)
     g.a_layout, g.b_layout, g.M, g.N, g.K = a_layout, b_layout, M, N, K
-    g.act, g.res_mod, g.alpha = act, res_mod, alpha
+    g.act, g.res_mod, g.alpha, g.variant = act, res_mod, alpha, variant
     check(lib.dkd_gemm_f32(ctypes.byref(g), _stream()), f"dkd_gemm_f32[{M}x{N}x{K} a{a_layout} b{b_layout}]")
     return out
 
@@ -96,9 +98,12 @@ def linear_dgrad(dy, w, accumulate_into=None):
     return dx.reshape(*dy.shape[:-1], K)
 
 
-def linear_wgrad(dy, x):
-    """dW[N, K] = dy[M, N]^T @ x[M, K]"""
-    return gemm(dy, x, a_layout=1, b_layout=1)
+def linear_wgrad(dy, x, with_bias_grad=False):
+    """dW[N, K] = dy[M, N]^T @ x[M, K]; optionally also db[N] = sum_m dy[m, :] from the same launch"""
+    if not with_bias_grad:
+        return gemm(dy, x, a_layout=1, b_layout=1)
+    db = torch.empty(dy.shape[-1], dtype=torch.float32, device=dy.device)
+    return gemm(dy, x, a_layout=1, b_layout=1, rowsum=db), db
 
 
 def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):

@@ -55,12 +55,14 @@ typedef struct dkd_gemm_args {
     int64_t ldr;
     float* preact;
     float* workspace;
+    float* rowsum; /* optional [M]: alpha * sum_k Aop[m][k] (bias gradient fused into a wgrad launch) */
     int32_t a_layout, b_layout;
     int32_t M, N, K;
     int32_t act;
     int32_t res_mod;
     int32_t row_grp, row_grp_stride, row_off;
     float alpha;
+    int32_t variant; /* 0 = automatic tile/schedule choice; >0 pins a kernel variant (tuning / A-B tests) */
 } dkd_gemm_args;
 int dkd_gemm_f32(const dkd_gemm_args* args, void* stream);
 int dkd_gemm_f32_splits(int M, int N, int K);

@@ -291,3 +291,13 @@ def test_grn(ops):
     close(dh.reshape(B, 7, 7, C), h.grad, "grn+gelu dh", rtol=2e-4)
     close(dga, ga.grad.reshape(C), "grn dgamma", rtol=2e-4)
     close(dbe, be.grad.reshape(C), "grn dbeta", rtol=2e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 96, 384), (3000, 384, 1536), (512, 768, 192), (200704, 96, 384)])
+def test_wgrad_with_fused_bias_grad(ops, M, N, K):
+    """dW = dy^T x and db = sum_rows dy from ONE launch (rowsum of the A operand), incl. the split-K path"""
+    g = torch.Generator().manual_seed(M)
+    dy, x = torch.randn(M, K, generator=g) * 0.1, torch.randn(M, N, generator=g)
+    dw, db = ops.linear_wgrad(dev(dy), dev(x), True)
+    close(dw, dy.double().t() @ x.double(), "wgrad", rtol=3e-4)
+    close(db, dy.double().sum(0), "fused bias grad", rtol=3e-4)
