@@ -66,46 +66,46 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
     }
 }
 
-// wgrad partials: thread = one channel, one image, RY consecutive output rows; 49 running sums in registers.
-// part[(b*ny + yc)][tap][c]
+// wgrad partials: thread = (channel quad, tap row i, image, RY consecutive output rows); 7 float4 running sums, the input
+// row slides through a 7-wide register window.  part[(b*ny + yc)][tap][c]
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dout,
                                                             float* __restrict__ part, int B, int H, int W, int C,
                                                             int RY) {
-    const int ny = (H + RY - 1) / RY;
-    const long total = (long)B * ny * C;
+    const int ny = (H + RY - 1) / RY, cq = C >> 2;
+    const long total = (long)B * ny * 7 * cq;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const long r = idx / C;
+        const int c4 = (int)(idx % cq);
+        long r = idx / cq;
+        const int i = (int)(r % 7);
+        r /= 7;  // r = b * ny + yc
         const int yc = (int)(r % ny), b = (int)(r / ny);
-        float acc[49];
+        float4 acc[7];
 #pragma unroll
-        for (int t = 0; t < 49; ++t) acc[t] = 0.f;
-        const float* inb = in + (long)b * H * W * C + c;
-        const float* db = dout + (long)b * H * W * C + c;
+        for (int j = 0; j < 7; ++j) acc[j] = zero;
+        const float4* inb = reinterpret_cast<const float4*>(in) + (long)b * H * W * cq + c4;
+        const float4* db = reinterpret_cast<const float4*>(dout) + (long)b * H * W * cq + c4;
         const int y1 = min(H, (yc + 1) * RY);
         for (int y = yc * RY; y < y1; ++y) {
+            const int yy = y + i - 3;
+            if (yy < 0 || yy >= H) continue;
+            const float4* irow = inb + (long)yy * W * cq;
+            const float4* drow = db + (long)y * W * cq;
+            float4 win[7];  // in[yy][x-3 .. x+3]
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const int yy = y + i - 3;
-                if (yy < 0 || yy >= H) continue;
-                const float* irow = inb + (long)yy * W * C;
-                const float* drow = db + (long)y * W * C;
-                float win[7];  // in[yy][x-3 .. x+3]
+            for (int j = 0; j < 6; ++j) win[j + 1] = (j - 3 >= 0 && j - 3 < W) ? irow[(long)(j - 3) * cq] : zero;
+            for (int x = 0; x < W; ++x) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) win[j + 1] = (j - 3 >= 0 && j - 3 < W) ? irow[(long)(j - 3) * C] : 0.f;
-                for (int x = 0; x < W; ++x) {
+                for (int j = 0; j < 6; ++j) win[j] = win[j + 1];
+                win[6] = (x + 3 < W) ? irow[(long)(x + 3) * cq] : zero;
+                const float4 d = drow[(long)x * cq];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) win[j] = win[j + 1];
-                    win[6] = (x + 3 < W) ? irow[(long)(x + 3) * C] : 0.f;
-                    const float d = drow[(long)x * C];
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) acc[i * 7 + j] = fmaf(d, win[j], acc[i * 7 + j]);
-                }
+                for (int j = 0; j < 7; ++j) fma4(acc[j], d, win[j]);
             }
         }
-        float* p = part + r * 49 * C + c;
+        float4* p = reinterpret_cast<float4*>(part + (r * 49 + i * 7) * C) + c4;
 #pragma unroll
-        for (int t = 0; t < 49; ++t) p[(long)t * C] = acc[t];
+        for (int j = 0; j < 7; ++j) p[(long)j * cq] = acc[j];
     }
 }
 
@@ -257,7 +257,8 @@ extern "C" int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* 
                                      void* stream) {
     if (!in || !dout || !partials || B <= 0) return DKD_ERR_BAD_ARG;
     const int RY = dw_ry(H);
-    const long total = (long)B * ((H + RY - 1) / RY) * C;
+    if (C & 3) return DKD_ERR_ALIGN;
+    const long total = (long)B * ((H + RY - 1) / RY) * 7 * (C / 4);
     hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, dout, partials,
                        B, H, W, C, RY);
     DKD_LAUNCH_CHECK();

@@ -139,16 +139,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ ws, int nparts, int n, float* __restrict__ out0,
-                                       float* __restrict__ out1, int split, float scale) {
-    // out[j] = scale * sum_p ws[p][j]; columns [0,split) go to out0, [split,n) to out1
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nparts, int n,
+                                                              float* __restrict__ out0, float* __restrict__ out1, int split,
+                                                              float scale) {
+    // out[j] = scale * sum_p ws[p][j]; columns [0,split) go to out0, [split,n) to out1.  64 columns x 4 part-lanes.
+    __shared__ float red[256];
+    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += ws[(long)p * n + j];
-    s *= scale;
-    if (j < split) out0[j] = s;
-    else out1[j - split] = s;
+    if (j < n)
+        for (int p = pl; p < nparts; p += 4) s += ws[(long)p * n + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && j < n) {
+        s = ((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c])) * scale;
+        if (j < split) out0[j] = s;
+        else out1[j - split] = s;
+    }
 }
 
 // ---- grouped column reduction -----------------------------------------------------------------------------
@@ -163,6 +170,7 @@ __device__ __forceinline__ float4 colop(const float4 x, const float4 y, const fl
     return make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w);
 }
 
+// OP == DKD_RED_DOT_SUM: two results per column, sum x*y -> out[.], sum x -> out[groups*nsplit*N + .]
 template <int OP>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                         const float* __restrict__ aux, float* __restrict__ out,
@@ -175,29 +183,35 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     const int g = blockIdx.z, sp = blockIdx.y;
     const long r0 = (long)sp * rows_per_split;
     const long r1 = min(rows_per_group, r0 + rows_per_split);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
+    constexpr bool TWO = OP == DKD_RED_DOT_SUM;
     if (4 * c4 < N) {
         const float4 a = OP == DKD_RED_SQDIFF ? reinterpret_cast<const float4*>(aux)[c4] : acc;
         const long base = (long)g * rows_per_group;
         for (long r = r0 + rl; r < r1; r += RL) {
             const float4 x = *reinterpret_cast<const float4*>(X + (base + r) * ldx + 4 * c4);
             float4 y = x;
-            if (OP == DKD_RED_DOT) y = *reinterpret_cast<const float4*>(Y + (base + r) * ldx + 4 * c4);
-            const float4 v = colop<OP>(x, y, a);
+            if (OP == DKD_RED_DOT || TWO) y = *reinterpret_cast<const float4*>(Y + (base + r) * ldx + 4 * c4);
+            const float4 v = colop<TWO ? DKD_RED_DOT : OP>(x, y, a);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            if (TWO) { acc2.x += x.x; acc2.y += x.y; acc2.z += x.z; acc2.w += x.w; }
         }
     }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (rl == 0 && 4 * c4 < N) {
-        for (int k = 1; k < RL; ++k) {
-            const float4 v = red[k * CL + cl];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const long second = (long)gridDim.z * nsplit * N;  // offset of the second result plane
+    for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
+        if (pass == 1) { __syncthreads(); acc = acc2; }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0 && 4 * c4 < N) {
+            for (int k = 1; k < RL; ++k) {
+                const float4 v = red[k * CL + cl];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            // partial layout [g][split][N]; with nsplit == 1 this IS the output
+            float4* o = reinterpret_cast<float4*>(out + pass * second + ((long)g * nsplit + sp) * N) + c4;
+            if (nsplit == 1) { acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale; }
+            *o = acc;
         }
-        // partial layout [g][split][N]; with nsplit == 1 this IS the output
-        float4* o = reinterpret_cast<float4*>(out + ((long)g * nsplit + sp) * N) + c4;
-        if (nsplit == 1) { acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale; }
-        *o = acc;
     }
 }
 
@@ -278,7 +292,7 @@ extern "C" int dkd_layernorm_bwd_f32(const float* dy, const float* x, const floa
         hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx,
                            ws, rows, C);
         DKD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, blocks, 2 * C, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, ws, blocks, 2 * C, dgamma,
                            dbeta, C, 1.0f);
     } else {
         hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx,
@@ -291,14 +305,14 @@ extern "C" int dkd_layernorm_bwd_f32(const float* dy, const float* x, const floa
 extern "C" long dkd_colreduce_f32_workspace_bytes(long rows_per_group, int groups, int N) {
     int cl, ns, rps, cb;
     colreduce_plan(rows_per_group, groups, N, &cl, &ns, &rps, &cb);
-    return ns > 1 ? (long)groups * ns * N * sizeof(float) : 0;
+    return ns > 1 ? 2L * groups * ns * N * sizeof(float) : 0;  // x2: DKD_RED_DOT_SUM keeps two planes
 }
 
 extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* aux, float* out, float* ws,
                                  long rows_per_group, int groups, int N, long ldx, int op, float scale, void* stream) {
     if (!X || !out || rows_per_group <= 0 || groups <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
     if ((N & 3) || (ldx & 3)) return DKD_ERR_ALIGN;
-    if (op == DKD_RED_DOT && !Y) return DKD_ERR_BAD_ARG;
+    if ((op == DKD_RED_DOT || op == DKD_RED_DOT_SUM) && !Y) return DKD_ERR_BAD_ARG;
     if (op == DKD_RED_SQDIFF && !aux) return DKD_ERR_BAD_ARG;
     int cl, ns, rps, cb;
     colreduce_plan(rows_per_group, groups, N, &cl, &ns, &rps, &cb);
@@ -314,6 +328,7 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
         case DKD_RED_DOT: DKD_CR(DKD_RED_DOT); break;
         case DKD_RED_SUMSQ: DKD_CR(DKD_RED_SUMSQ); break;
         case DKD_RED_SQDIFF: DKD_CR(DKD_RED_SQDIFF); break;
+        case DKD_RED_DOT_SUM: DKD_CR(DKD_RED_DOT_SUM); break;
         default: return DKD_ERR_BAD_ARG;
     }
 #undef DKD_CR
@@ -323,6 +338,11 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
         hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, ws, out, groups, ns,
                            N, scale);
         DKD_LAUNCH_CHECK();
+        if (op == DKD_RED_DOT_SUM) {
+            hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st,
+                               ws + (long)groups * ns * N, out + total, groups, ns, N, scale);
+            DKD_LAUNCH_CHECK();
+        }
     }
     return DKD_OK;
 }

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import AttnArgs, GemmArgs, check
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF = 0, 1, 2, 3
+RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM = 0, 1, 2, 3, 4
 
 _ws = {}
 
@@ -114,7 +114,7 @@ def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):
     rows = x.numel() // N
     rpg = rows // groups
     if out is None:
-        out = torch.empty((groups, N), dtype=torch.float32, device=x.device)
+        out = torch.empty((2, groups, N) if op == RED_DOT_SUM else (groups, N), dtype=torch.float32, device=x.device)
     wsb = lib.dkd_colreduce_f32_workspace_bytes(rpg, groups, N)
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.dkd_colreduce_f32(_p(x), _p(y), _p(aux), _p(out), _p(ws), rpg, groups, N, N, op, scale, _stream()),
@@ -398,8 +398,9 @@ def grn_gelu_bwd(dy, g, h, stats, gamma, B):
     gx, nx, denom = stats
     C = g.shape[-1]
     rpi = g.numel() // C // B
-    A = colreduce(dy, RED_DOT, y=g, groups=B)  # [B, C] sum_hw dy*g
-    dbeta = colreduce(dy, RED_SUM).reshape(C)
+    both = colreduce(dy, RED_DOT_SUM, y=g, groups=B)  # one pass: [0] = sum_hw dy*g, [1] = sum_hw dy, per image
+    A = both[0]
+    dbeta = colreduce(both[1], RED_SUM).reshape(C)
     coef, dgp = torch.empty_like(A), torch.empty_like(A)
     check(lib.dkd_grn_bwd_stats_f32(_p(A), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgp), B, C, _stream()),
           "dkd_grn_bwd_stats_f32")

@@ -94,6 +94,7 @@ long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C);
 #define DKD_RED_DOT 1    /* x * y        */
 #define DKD_RED_SUMSQ 2  /* x * x        */
 #define DKD_RED_SQDIFF 3 /* (x - aux[n])^2 */
+#define DKD_RED_DOT_SUM 4 /* two planes: out[0:G*N] = sum x*y, out[G*N:2*G*N] = sum x (one pass over x) */
 int dkd_colreduce_f32(const float* X, const float* Y, const float* aux, float* out, float* ws, long rows_per_group,
                       int groups, int N, long ldx, int op, float scale, void* stream);
 long dkd_colreduce_f32_workspace_bytes(long rows_per_group, int groups, int N);
