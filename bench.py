@@ -188,8 +188,15 @@ def main():
     if not args.no_roofline:
         n, gemm_ms, gemm_fl = prof.summary()
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # HBM-side bytes per launch of this kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH x2 gfx950 correction; scripts/pmc_summarize.py)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and args.batch == 64:
+            traffic = json.load(open(pmc))["kernels"].get("gemm_f32_kernel", {}).get("traffic_bytes")
         res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.md)",
                            "kernel": "gemm_f32_kernel (fp32 MFMA 32x32x2), all launches of the timed region",
                            "launches": n, "avg_launch_us": round(gemm_ms * 1e3 / max(n, 1), 2),
                            "avg_flop_per_launch": round(gemm_fl / max(n, 1)),
