@@ -347,3 +347,135 @@ class KDLossFn(Function):
         if freq:  # adjoint of the mean removal
             ds = ops.sub_group_vec(ds, ops.colreduce(ds, groups=B, scale=1.0 / N), B, out=ds)
         return ds, None, None, None
+
+
+# =====================================================================================================================
+# STDC / ResNet building blocks (NHWC)
+class ConvBNActFn(Function):
+    """conv(k in {1,3,7}, stride, pad=k//2, no bias) -> train-mode BatchNorm2d -> optional ReLU
+    (models/backbones/stdc.py:8-24 ``ConvX``).  src_nchw: the input is the NCHW image (first layer)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bn_w, bn_b, bn_state, k, stride, relu, training, src_nchw):
+        x = _c(x)
+        O = w.shape[0]
+        pad = k // 2
+        if src_nchw:
+            B, Cin, H, W = x.shape
+            rows = ops.im2col_nchw(x, k, stride, pad)
+            w2 = torch.zeros((O, rows.shape[1]), dtype=F32, device=x.device)
+            w2[:, : Cin * k * k] = w.reshape(O, -1)  # layout plumbing on < 10 K floats
+        else:
+            B, H, W, Cin = x.shape
+            if k == 1 and stride == 1:
+                rows = x.reshape(-1, Cin)
+                w2 = w.reshape(O, Cin)
+            else:
+                rows = ops.im2col_nhwc(x, k, stride, pad)
+                w2 = ops.transpose(w.reshape(O, Cin, k * k)).reshape(O, k * k * Cin)  # [O][ky][kx][c]
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        z = ops.gemm(rows, w2)
+        if not training:
+            raise NotImplementedError("eval-mode BatchNorm is not on the training hot path yet")
+        mean, rstd = ops.bn_stats(z, bn_state[0], bn_state[1], 0.1, 1e-5)
+        y = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, None, relu=relu)
+        ctx.save_for_backward(rows, w2, z, mean, rstd, bn_w, bn_b)
+        ctx.meta = (k, stride, pad, relu, src_nchw, tuple(x.shape), tuple(w.shape))
+        return y.reshape(B, Ho, Wo, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, w2, z, mean, rstd, bn_w, bn_b = ctx.saved_tensors
+        k, stride, pad, relu, src_nchw, xshape, wshape = ctx.meta
+        O = wshape[0]
+        dz, dg, db = ops.bn_bwd(_c(dy).reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu)
+        dw2 = ops.linear_wgrad(dz, rows)
+        dx = None
+        if src_nchw:
+            Cin = xshape[1]
+            dw = dw2[:, : Cin * k * k].reshape(wshape)
+        else:
+            B, H, W, Cin = xshape
+            if k == 1 and stride == 1:
+                dw = dw2.reshape(wshape)
+                if ctx.needs_input_grad[0]:
+                    dx = ops.gemm(dz, w2, b_layout=1).reshape(xshape)
+            else:
+                dw = ops.transpose(dw2.reshape(O, k * k, Cin)).reshape(wshape)
+                if ctx.needs_input_grad[0]:
+                    dx = ops.col2im_nhwc(ops.gemm(dz, w2, b_layout=1), B, H, W, Cin, k, stride, pad)
+        return dx, dw, dg, db, None, None, None, None, None, None
+
+
+class DepthwiseBNFn(Function):
+    """depthwise 3x3 stride-s conv (no bias) + train-mode BatchNorm2d, no activation (stdc.py:113-126 ``avd_layer``)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training):
+        x = _c(x)
+        C = x.shape[3]
+        wt = ops.transpose(w.reshape(C, 9))
+        y = ops.dwconv3(x, wt, stride)
+        if not training:
+            raise NotImplementedError("eval-mode BatchNorm is not on the training hot path yet")
+        y2 = y.reshape(-1, C)
+        mean, rstd = ops.bn_stats(y2, bn_state[0], bn_state[1], 0.1, 1e-5)
+        out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=False)
+        ctx.save_for_backward(x, wt, y2, mean, rstd, bn_w, bn_b)
+        ctx.meta = (stride, tuple(w.shape), tuple(y.shape))
+        return out.reshape(y.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wt, y2, mean, rstd, bn_w, bn_b = ctx.saved_tensors
+        stride, wshape, yshape = ctx.meta
+        C = x.shape[3]
+        dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=False)
+        dy = dy.reshape(yshape)
+        dx = ops.dwconv3(dy, wt, stride, dgrad_shape=x.shape[1:3]) if ctx.needs_input_grad[0] else None
+        dw = ops.transpose(ops.dwconv3_wgrad(x, dy, stride)).reshape(wshape)
+        return dx, dw, dg, db, None, None, None
+
+
+class AvgPool3Fn(Function):
+    """nn.AvgPool2d(kernel_size=3, stride=s, padding=1) (count_include_pad) == depthwise 3x3 with all taps 1/9."""
+
+    @staticmethod
+    def forward(ctx, x, stride):
+        x = _c(x)
+        ctx.meta = (stride, tuple(x.shape[1:3]))
+        return ops.dwconv3(x, None, stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, hw = ctx.meta
+        return ops.dwconv3(_c(dy), None, stride, dgrad_shape=hw), None
+
+
+class ConcatChannelsFn(Function):
+    """torch.cat(dim=1) of NCHW maps == channel-slice copies on NHWC rows (stdc.py:171)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_c(x) for x in xs]
+        B, H, W = xs[0].shape[:3]
+        cs = [x.shape[3] for x in xs]
+        out = torch.empty((B, H, W, sum(cs)), dtype=F32, device=xs[0].device)
+        rows, off = B * H * W, 0
+        for x, c in zip(xs, cs):
+            ops.copy2d(x, c, out.view(-1)[off:], sum(cs), rows, c)
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        B, H, W, Ct = dy.shape
+        rows, off, outs = B * H * W, 0, []
+        for c in ctx.cs:
+            g = torch.empty((B, H, W, c), dtype=F32, device=dy.device)
+            ops.copy2d(dy.view(-1)[off:], Ct, g, c, rows, c)
+            outs.append(g)
+            off += c
+        return tuple(outs)

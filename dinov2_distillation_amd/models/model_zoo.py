@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .convnext import D2ConvNextV2
+from .stdc import STDCNet
 
 CONVNEXT_CONFIGS = {  # models/wrappers/convnext_wrapper.py:19-49
     "convnext_atto": ([2, 2, 6, 2], [40, 80, 160, 320], "convnextv2_atto_1k_224_ema.pkl"),
@@ -38,11 +39,40 @@ class ConvNextWrapper(nn.Module):
         return self._out_feature_channels
 
 
+STDC_CONFIGS = {"stdc_1": ([2, 2, 2], "STDCNet1.pkl"), "stdc_2": ([4, 5, 3], "STDCNet2.pkl")}  # stdc_wrapper.py:8-11
+
+
+class STDCWrapper(nn.Module):
+    """models/wrappers/stdc_wrapper.py"""
+
+    def __init__(self, model_name="stdc_2", out_features=None):
+        super().__init__()
+        if model_name not in STDC_CONFIGS:
+            raise NotImplementedError(f"There is not a STDC config called {model_name}.")
+        layers, ckpt = STDC_CONFIGS[model_name]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", ckpt)
+        self.model = STDCNet(layers=layers)
+        self.model.init_params()
+        self.out_features = out_features if out_features else ["res2", "res3", "res4", "res5"]
+
+    def get_features(self, x):
+        feats = self.model(x)
+        return {k: feats[k] for k in self.out_features}
+
+    def get_features_nhwc(self, x):
+        feats = self.model.forward_features_nhwc(x)
+        return {k: feats[k] for k in self.out_features}
+
+    @property
+    def feature_channels(self):
+        return {"res2": 64, "res3": 256, "res4": 512, "res5": 1024}  # stdc_wrapper.py:106-111
+
+
 class ModelWrapper(nn.Module):
     """models/model_zoo.py:18-145.  Only the student families built on the MI355X kernels are registered; asking for
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
-    MODEL_MAP = {"convnext": ConvNextWrapper}
+    MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

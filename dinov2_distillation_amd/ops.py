@@ -409,3 +409,66 @@ def grn_gelu_bwd(dy, g, h, stats, gamma, B):
     check(lib.dkd_grn_gelu_bwd_f32(_p(dy), _p(g), _p(h), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
           "dkd_grn_gelu_bwd_f32")
     return dh, dgamma, dbeta
+
+
+# ---- general convolutions (STDC / ResNet students) ------------------------------------------------------------------
+def conv_out_hw(H, W, k, stride, pad):
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def im2col_nhwc(x, k, stride, pad):
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    rows = torch.empty((B * Ho * Wo, k * k * C), dtype=torch.float32, device=x.device)
+    check(_lib.load().dkd_im2col_nhwc_f32(_p(x), _p(rows), B, H, W, C, k, stride, pad, 0, _stream()), "dkd_im2col_nhwc_f32")
+    return rows
+
+
+def col2im_nhwc(drows, B, H, W, C, k, stride, pad):
+    _chk(drows, "drows")
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=drows.device)
+    check(_lib.load().dkd_im2col_nhwc_f32(_p(dx), _p(drows), B, H, W, C, k, stride, pad, 1, _stream()), "dkd_col2im_nhwc_f32")
+    return dx
+
+
+def im2col_nchw(img, k, stride, pad):
+    _chk(img, "img")
+    B, Cin, H, W = img.shape
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    Kp = (Cin * k * k + 3) // 4 * 4
+    rows = torch.empty((B * Ho * Wo, Kp), dtype=torch.float32, device=img.device)
+    check(_lib.load().dkd_im2col_nchw_f32(_p(img), _p(rows), B, Cin, H, W, k, stride, pad, Kp, _stream()), "dkd_im2col_nchw_f32")
+    return rows
+
+
+def dwconv3(x, w_tap, stride, dgrad_shape=None):
+    """forward: x [B,H,W,C] -> [B,Ho,Wo,C]; dgrad (dgrad_shape=(H,W)): x is dy [B,Ho,Wo,C] -> dx [B,H,W,C].
+    w_tap None == AvgPool2d(3, stride, 1)."""
+    _chk(x, "x"), _chk(w_tap, "w_tap")
+    B, C = x.shape[0], x.shape[3]
+    if dgrad_shape is None:
+        H, W = x.shape[1:3]
+        Ho, Wo = conv_out_hw(H, W, 3, stride, 1)
+        out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        mode = 0
+    else:
+        H, W = dgrad_shape
+        out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+        mode = 1
+    check(_lib.load().dkd_dwconv3_f32(_p(x), _p(w_tap), _p(out), B, H, W, C, stride, mode, _stream()), "dkd_dwconv3_f32")
+    return out
+
+
+def dwconv3_wgrad(x, dout, stride):
+    _chk(x, "x"), _chk(dout, "dout")
+    B, H, W, C = x.shape
+    Ho = dout.shape[1]
+    part = workspace(B * Ho * 9 * C * 4, x.device, slot=1)
+    check(_lib.load().dkd_dwconv3_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, stride, _stream()), "dkd_dwconv3_wgrad_f32")
+    return colreduce(part[: B * Ho * 9 * C].view(B * Ho, 9 * C)).view(9, C)
+
+
+def copy2d(src, lds, dst, ldd, rows, cols, accumulate=False):
+    check(_lib.load().dkd_copy2d_f32(_p(src), lds, _p(dst), ldd, rows, cols, int(accumulate), _stream()), "dkd_copy2d_f32")
+    return dst

@@ -202,6 +202,27 @@ int dkd_adamw_f32(float* p, const float* g, float* m, float* v, long n, float lr
                   float weight_decay, int step, const float* gnorm2, float max_norm, void* stream);
 int dkd_clip_grad_f32(float* g, long n, const float* gnorm2, float max_norm, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * General (overlapping) convolutions of the STDC / ResNet students: im2col + dkd_gemm_f32, NHWC.
+ * models/backbones/stdc.py:8-24 (ConvX conv k in {1,3}, stride {1,2}, pad k/2, no bias), :113-126 (avd depthwise
+ * 3x3 s2 + AvgPool2d(3,2,1) skip), :153-172 (channel concat).  Adjoints are gather-form (deterministic).
+ * im2col_nhwc: rows[(b,oy,ox)][(ky,kx,c)] (weights permuted to [O][ky][kx][c]); inverse=1 writes dx = col2im(rows)
+ *   into `x` (the adjoint).  im2col_nchw: first layer from the NCHW image, K order (c,ky,kx) zero-padded to Kp % 4 == 0.
+ * dwconv3: depthwise 3x3 pad 1 stride s, tap-major weights [9][C]; w == NULL means every tap = 1/9, i.e.
+ *   AvgPool2d(3, s, 1) with count_include_pad.  mode 0 forward, mode 1 dgrad (in = dy, out = dx; H,W are the
+ *   INPUT extents in both modes).  wgrad writes partials [B*Ho][9][C] to be folded by dkd_colreduce_f32.
+ * copy2d: dst[r*ldd + c] (+)= src[r*lds + c]: channel concat / slice of token-major tensors.
+ */
+int dkd_im2col_nhwc_f32(const float* x, float* rows, int B, int H, int W, int C, int k, int stride, int pad, int inverse,
+                        void* stream);
+int dkd_im2col_nchw_f32(const float* img, float* rows, int B, int Cin, int H, int W, int k, int stride, int pad, int Kp,
+                        void* stream);
+int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int stride, int mode,
+                    void* stream);
+int dkd_dwconv3_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C, int stride,
+                          void* stream);
+int dkd_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

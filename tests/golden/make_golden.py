@@ -8,6 +8,7 @@ What is imported from the reference:
     losses/scalekd.py                  -> ScaleKD, AttentionProjector   (forward + backward)
     train/distillation_module.py       -> DistillationModule.training_step with stand-in teacher/student
     models/backbones/convnext.py       -> D2ConvNextV2
+    models/backbones/stdc.py           -> STDCNet (CatBottleneck path)
 The DINOv2 teacher is NOT imported (external torch.hub dependency, fetch denied): the step fixture uses a
 stand-in teacher whose ``.model.blocks`` are this repo's own oracle ViT blocks with seeded weights.
 
@@ -221,6 +222,42 @@ def gen_convnext():
     _save("convnext_small", **arrays)
 
 
+def gen_stdc():
+    st = _load_file("ref_stdc", "models/backbones/stdc.py")
+    torch.manual_seed(21)
+    base, layers = 16, [2, 2, 2]
+    net = st.STDCNet(base=base, layers=layers)
+    net.init_params()
+    net.train()
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.2 * torch.randn_like(p_))
+    x = torch.randn(2, 3, 64, 64, requires_grad=True)
+    arrays = {"in/x": _np(x), "meta": np.array([base] + layers, dtype=np.int64)}
+    for k, v in net.state_dict().items():
+        if k.startswith("features."):
+            arrays["param/" + k] = _np(v)
+    arrays["meta/n_state_keys"] = np.array(len(net.state_dict()))
+    feats = net(x)
+    loss = 0
+    for k in ("res2", "res3", "res4", "res5"):
+        arrays["out/" + k] = _np(feats[k])
+    for k in ("res4", "res5"):
+        ct = torch.randn_like(feats[k])
+        arrays["in/cotangent_" + k] = _np(ct)
+        loss = loss + (feats[k] * ct).sum()
+    loss.backward()
+    arrays["grad/x"] = _np(x.grad)
+    for k, p_ in net.named_parameters():
+        if k.startswith("features."):
+            arrays["pgrad/" + k] = _np(p_.grad)
+    for k, v in net.state_dict().items():
+        if k.startswith("features.") and "running" in k:
+            arrays["after/" + k] = _np(v)
+    _save("stdc_small", **arrays)
+
+
 def gen_step():
     """DistillationModule.training_step (train/distillation_module.py:247-276) with stand-ins."""
     from oracle import vit_oracle as vit
@@ -309,6 +346,6 @@ def gen_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "step"]
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "step"]
     for w in which:
         globals()["gen_" + w]()

@@ -145,3 +145,27 @@ def test_stage_block_range():
     for n in (12, 24, 40):
         assert list(so.stage_block_range(n, "res2")) == []
         assert list(so.stage_block_range(n, "res3")) == []
+
+
+def test_stdc(golden_dir):
+    from oracle import stdc_oracle as sto
+    g = load(golden_dir, "stdc_small")
+    base, layers = int(g["meta"][0]), [int(v) for v in g["meta"][1:]]
+    p = params_of(g)
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = sto.forward(p, x, layers, base)
+    loss = 0
+    for k in ("res2", "res3", "res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+    for k in ("res4", "res5"):
+        loss = loss + (feats[k] * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x", rtol=5e-4)
+    for k, v in g.items():
+        if k.startswith("pgrad/"):
+            close(p[k[6:]].grad, v, k, rtol=5e-4, atol=1e-5)
+        if k.startswith("after/"):
+            close(p[k[6:]], v, k)
