@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libdkd_hip.so")
 _SCALARS = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "int32_t": ctypes.c_int32,
     "int64_t": ctypes.c_int64, "void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "constfloat*": ctypes.c_void_p,
-    "constvoid*": ctypes.c_void_p,
+    "constvoid*": ctypes.c_void_p, "int*": ctypes.c_void_p, "constint*": ctypes.c_void_p,
 }
 
 

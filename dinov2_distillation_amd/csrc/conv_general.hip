@@ -180,6 +180,67 @@ __global__ void dwconv3_wgrad_kernel(const float4* __restrict__ x, const float4*
     }
 }
 
+// F.max_pool2d(kernel 3, stride 2, pad 1) (resnet.py:543): first maximum in row-major window order, its flat input index
+// kept for the backward pass
+__global__ void maxpool3_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int* __restrict__ arg, int B, int H,
+                                    int W, int C, int s, int Ho, int Wo) {
+    const long total = (long)B * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        long r = i;
+        const int c = (int)(r % C); r /= C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float best = -INFINITY;
+        int bi = -1;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = oy * s + ky - 1;
+            if (y < 0 || y >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = ox * s + kx - 1;
+                if (xx < 0 || xx >= W) continue;
+                const float v = x[(((long)b * H + y) * W + xx) * C + c];
+                if (v > best || bi < 0) { best = v; bi = y * W + xx; }
+            }
+        }
+        out[i] = best;
+        arg[i] = bi;
+    }
+}
+__global__ void maxpool3_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg, float* __restrict__ dx, int B,
+                                    int H, int W, int C, int s, int Ho, int Wo) {
+    const long total = (long)B * H * W * C;
+    GRID_STRIDE(i, total) {
+        long r = i;
+        const int c = (int)(r % C); r /= C;
+        const int xx = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        float acc = 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = y + 1 - ky;
+            if (ty < 0 || ty % s) continue;
+            const int oy = ty / s;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = xx + 1 - kx;
+                if (tx < 0 || tx % s) continue;
+                const int ox = tx / s;
+                if (ox >= Wo) continue;
+                const long o = (((long)b * Ho + oy) * Wo + ox) * C + c;
+                if (arg[o] == y * W + xx) acc += dout[o];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+__global__ void add_relu_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, long nvec) {
+    GRID_STRIDE(i, nvec) {
+        const float4 u = a[i], v = b[i];
+        out[i] = make_float4(fmaxf(u.x + v.x, 0.f), fmaxf(u.y + v.y, 0.f), fmaxf(u.z + v.z, 0.f), fmaxf(u.w + v.w, 0.f));
+    }
+}
+
 // dst[r*ldd + c] (+)= src[r*lds + c], c < cols: channel concat / slice on token-major tensors
 __global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long rows, int cols,
                               int accumulate) {
@@ -270,6 +331,31 @@ extern "C" int dkd_copy2d_f32(const float* src, long lds, float* dst, long ldd, 
     if ((cols & 3) || (lds & 3) || (ldd & 3) || !dkd_aligned16(src) || !dkd_aligned16(dst)) return DKD_ERR_ALIGN;
     hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(rows * (cols / 4))), dim3(256), 0, (hipStream_t)stream, src, lds, dst,
                        ldd, rows, cols, accumulate);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_maxpool3_f32(const float* in, float* out, int* argmax, int B, int H, int W, int C, int stride, int mode,
+                                void* stream) {
+    // mode 0: forward (in = x, out = y, argmax written); mode 1: backward (in = dy, out = dx, argmax read)
+    if (!in || !out || !argmax || B <= 0 || stride <= 0) return DKD_ERR_BAD_ARG;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0)
+        hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(blocks_for((long)B * Ho * Wo * C)), dim3(256), 0, st, in, out, argmax, B,
+                           H, W, C, stride, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(blocks_for((long)B * H * W * C)), dim3(256), 0, st, in, argmax, out, B, H,
+                           W, C, stride, Ho, Wo);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_add_relu_f32(const float* a, const float* b, float* out, long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return DKD_ERR_BAD_ARG;
+    if (n & 3) return DKD_ERR_ALIGN;
+    hipLaunchKernelGGL(add_relu_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, F4(a), F4(b), F4W(out),
+                       n / 4);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

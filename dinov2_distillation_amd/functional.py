@@ -479,3 +479,36 @@ class ConcatChannelsFn(Function):
             outs.append(g)
             off += c
         return tuple(outs)
+
+
+class MaxPool3Fn(Function):
+    """F.max_pool2d(x, kernel_size=3, stride=2, padding=1) on NHWC (models/backbones/resnet.py:543)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y, arg = ops.maxpool3(x, 2)
+        ctx.save_for_backward(arg)
+        ctx.hw = tuple(x.shape[1:3])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        return ops.maxpool3_bwd(_c(dy), arg, *ctx.hw)
+
+
+class AddReluFn(Function):
+    """out = relu(a + b): the residual tail of a ResNet block (resnet.py:395-397, 507-511)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = ops.add_relu(_c(a), _c(b))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (out,) = ctx.saved_tensors
+        g = ops.relu_bwd(_c(dy), out)
+        return g, g

@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .convnext import D2ConvNextV2
+from .resnet import BasicStem, ResNet, make_resnet_stages
 from .stdc import STDCNet
 
 CONVNEXT_CONFIGS = {  # models/wrappers/convnext_wrapper.py:19-49
@@ -68,11 +69,38 @@ class STDCWrapper(nn.Module):
         return {"res2": 64, "res3": 256, "res4": 512, "res5": 1024}  # stdc_wrapper.py:106-111
 
 
+RESNET_CONFIGS = {"resnet_18": (18, "R-18.pkl"), "resnet_34": (34, "R-34.pkl"), "resnet_50": (50, "R-50.pkl"),
+                  "resnet_101": (101, "R-101.pkl")}  # models/wrappers/resnet_wrapper.py:11-16
+
+
+class ResNetWrapper(nn.Module):
+    """models/wrappers/resnet_wrapper.py: BasicStem + make_resnet_stages(depth), norm='BN' (live), freeze_at=0"""
+
+    def __init__(self, model_name="resnet_50", out_features=None):
+        super().__init__()
+        if model_name not in RESNET_CONFIGS:
+            raise NotImplementedError(f"There is not a ResNet config called {model_name}.")
+        depth, ckpt = RESNET_CONFIGS[model_name]
+        out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", ckpt)
+        self.model = ResNet(BasicStem(3, 64), make_resnet_stages(depth), out_features=out_features)
+
+    def get_features(self, x):
+        return self.model(x)
+
+    def get_features_nhwc(self, x):
+        return self.model.forward_features_nhwc(x)
+
+    @property
+    def feature_channels(self):
+        return {k: v for k, v in self.model._out_feature_channels.items() if k != "stem"}
+
+
 class ModelWrapper(nn.Module):
     """models/model_zoo.py:18-145.  Only the student families built on the MI355X kernels are registered; asking for
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
-    MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper}
+    MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

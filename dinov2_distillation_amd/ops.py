@@ -472,3 +472,28 @@ def dwconv3_wgrad(x, dout, stride):
 def copy2d(src, lds, dst, ldd, rows, cols, accumulate=False):
     check(_lib.load().dkd_copy2d_f32(_p(src), lds, _p(dst), ldd, rows, cols, int(accumulate), _stream()), "dkd_copy2d_f32")
     return dst
+
+
+def maxpool3(x, stride=2):
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    Ho, Wo = conv_out_hw(H, W, 3, stride, 1)
+    out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((B, Ho, Wo, C), dtype=torch.int32, device=x.device)
+    check(_lib.load().dkd_maxpool3_f32(_p(x), _p(out), _p(arg), B, H, W, C, stride, 0, _stream()), "dkd_maxpool3_f32")
+    return out, arg
+
+
+def maxpool3_bwd(dy, arg, H, W, stride=2):
+    _chk(dy, "dy")
+    B, _, _, C = dy.shape
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    check(_lib.load().dkd_maxpool3_f32(_p(dy), _p(dx), _p(arg), B, H, W, C, stride, 1, _stream()), "dkd_maxpool3_f32(bwd)")
+    return dx
+
+
+def add_relu(a, b):
+    _chk(a, "a"), _chk(b, "b")
+    out = torch.empty_like(a)
+    check(_lib.load().dkd_add_relu_f32(_p(a), _p(b), _p(out), a.numel(), _stream()), "dkd_add_relu_f32")
+    return out

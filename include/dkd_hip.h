@@ -222,6 +222,12 @@ int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B
 int dkd_dwconv3_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C, int stride,
                           void* stream);
 int dkd_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate, void* stream);
+/* ResNet pieces (models/backbones/resnet.py): F.max_pool2d(3, 2, 1) of the stem (:543) with the arg-max kept for the
+ * backward pass (mode 0 forward, mode 1 backward: in = dy, out = dx; H,W are the input extents in both modes), and the
+ * block tail out = relu(out + shortcut) (:395-397, :507-511); its backward is dkd_relu_bwd_f32 for both addends. */
+int dkd_maxpool3_f32(const float* in, float* out, int* argmax, int B, int H, int W, int C, int stride, int mode,
+                     void* stream);
+int dkd_add_relu_f32(const float* a, const float* b, float* out, long n, void* stream);
 
 #ifdef __cplusplus
 }

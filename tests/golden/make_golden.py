@@ -9,6 +9,7 @@ What is imported from the reference:
     train/distillation_module.py       -> DistillationModule.training_step with stand-in teacher/student
     models/backbones/convnext.py       -> D2ConvNextV2
     models/backbones/stdc.py           -> STDCNet (CatBottleneck path)
+    models/backbones/resnet.py         -> BasicStem, BottleneckBlock, ResNet (fvcore.c2_msra_fill stand-in = its definition)
 The DINOv2 teacher is NOT imported (external torch.hub dependency, fetch denied): the step fixture uses a
 stand-in teacher whose ``.model.blocks`` are this repo's own oracle ViT blocks with seeded weights.
 
@@ -258,6 +259,52 @@ def gen_stdc():
     _save("stdc_small", **arrays)
 
 
+def gen_resnet():
+    fv = types.ModuleType("fvcore"); fvn = types.ModuleType("fvcore.nn"); fvw = types.ModuleType("fvcore.nn.weight_init")
+
+    def c2_msra_fill(m):  # fvcore's definition: kaiming_normal_(fan_out, relu), zero bias
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    fvw.c2_msra_fill = c2_msra_fill
+    fv.nn = fvn; fvn.weight_init = fvw
+    sys.modules.update({"fvcore": fv, "fvcore.nn": fvn, "fvcore.nn.weight_init": fvw})
+    rn = _load_file("ref_resnet", "models/backbones/resnet.py")
+    torch.manual_seed(31)
+    chans, nblk, strides = [8, 16, 32, 64, 128], [2, 1, 2, 1], [1, 2, 2, 2]
+    stem = rn.BasicStem(in_channels=3, out_channels=chans[0], norm="BN")
+    stages = [rn.ResNet.make_stage(rn.BottleneckBlock, n, stride_per_block=[s] + [1] * (n - 1), in_channels=chans[i],
+                                   out_channels=chans[i + 1], bottleneck_channels=chans[i + 1] // 4, norm="BN")
+              for i, (n, s) in enumerate(zip(nblk, strides))]
+    net = rn.ResNet(stem, stages, num_classes=None, out_features=["res2", "res3", "res4", "res5"], freeze_at=0)
+    net.train()
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.2 * torch.randn_like(p_))
+    x = torch.randn(2, 3, 64, 64, requires_grad=True)
+    arrays = {"in/x": _np(x), "meta/nblk": np.array(nblk), "meta/chans": np.array(chans)}
+    for k, v in net.state_dict().items():
+        arrays["param/" + k] = _np(v)
+    feats = net(x)
+    loss = 0
+    for k in ("res2", "res3", "res4", "res5"):
+        arrays["out/" + k] = _np(feats[k])
+    for k in ("res4", "res5"):
+        ct = torch.randn_like(feats[k])
+        arrays["in/cotangent_" + k] = _np(ct)
+        loss = loss + (feats[k] * ct).sum()
+    loss.backward()
+    arrays["grad/x"] = _np(x.grad)
+    for k, p_ in net.named_parameters():
+        arrays["pgrad/" + k] = _np(p_.grad)
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            arrays["after/" + k] = _np(v)
+    _save("resnet_small", **arrays)
+
+
 def gen_step():
     """DistillationModule.training_step (train/distillation_module.py:247-276) with stand-ins."""
     from oracle import vit_oracle as vit
@@ -346,6 +393,6 @@ def gen_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "step"]
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "step"]
     for w in which:
         globals()["gen_" + w]()

@@ -59,7 +59,9 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(ValueError):   # 24 does not divide 1024
         AttentionProjector(8, 1024, (2, 2), 1024, num_heads=24)
     with pytest.raises(NotImplementedError):
-        ModelWrapper("resnet_50", [16, 16])
+        ModelWrapper("swin_tiny", [16, 16])
+    r = ModelWrapper("resnet_50", [16, 16])
+    assert abs(sum(p.numel() for p in r.parameters()) / 1e6 - 23.51) < 0.01 and r.feature_channels["res5"] == 2048
     s = ModelWrapper("stdc_2", [16, 16])
     assert abs(sum(p.numel() for p in s.parameters()) / 1e6 - 9.35) < 0.01 and len(s.state_dict()) == 636
 

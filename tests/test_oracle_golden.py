@@ -169,3 +169,27 @@ def test_stdc(golden_dir):
             close(p[k[6:]].grad, v, k, rtol=5e-4, atol=1e-5)
         if k.startswith("after/"):
             close(p[k[6:]], v, k)
+
+
+def test_resnet(golden_dir):
+    from oracle import resnet_oracle as rno
+    g = load(golden_dir, "resnet_small")
+    nblk = [int(v) for v in g["meta/nblk"]]
+    p = params_of(g)
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = rno.forward(p, x, nblk)
+    loss = 0
+    for k in ("res2", "res3", "res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+    for k in ("res4", "res5"):
+        loss = loss + (feats[k] * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x", rtol=5e-4)
+    for k, v in g.items():
+        if k.startswith("pgrad/"):
+            close(p[k[6:]].grad, v, k, rtol=5e-4, atol=1e-5)
+        if k.startswith("after/"):
+            close(p[k[6:]], v, k)
