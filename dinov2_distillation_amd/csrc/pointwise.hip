@@ -51,6 +51,55 @@ __global__ void sub_group_vec_kernel(const float4* __restrict__ x, const float4*
     }
 }
 
+// SwiGLU (DINOv2 ViT-g FFN): x12 [rows, 2*Hd] -> out[rows, Hd] = silu(x1) * x2
+__global__ void swiglu_fwd_kernel(const float4* __restrict__ x12, float4* __restrict__ out, int hv, long nvec) {
+    EW_LOOP(i, nvec) {
+        const long r = i / hv;
+        const int c = (int)(i % hv);
+        const float4 a = x12[r * 2 * hv + c], b = x12[r * 2 * hv + hv + c];
+        float4 o;
+        o.x = a.x / (1.f + __expf(-a.x)) * b.x; o.y = a.y / (1.f + __expf(-a.y)) * b.y;
+        o.z = a.z / (1.f + __expf(-a.z)) * b.z; o.w = a.w / (1.f + __expf(-a.w)) * b.w;
+        out[i] = o;
+    }
+}
+__device__ __forceinline__ void swiglu_grad(float a, float b, float g, float& da, float& db) {
+    const float sg = 1.f / (1.f + __expf(-a));
+    const float silu = a * sg;
+    da = g * b * (sg + silu * (1.f - sg));
+    db = g * silu;
+}
+__global__ void swiglu_bwd_kernel(const float4* __restrict__ dout, const float4* __restrict__ x12, float4* __restrict__ dx12,
+                                  int hv, long nvec) {
+    EW_LOOP(i, nvec) {
+        const long r = i / hv;
+        const int c = (int)(i % hv);
+        const float4 a = x12[r * 2 * hv + c], b = x12[r * 2 * hv + hv + c], g = dout[i];
+        float4 da, db;
+        swiglu_grad(a.x, b.x, g.x, da.x, db.x); swiglu_grad(a.y, b.y, g.y, da.y, db.y);
+        swiglu_grad(a.z, b.z, g.z, da.z, db.z); swiglu_grad(a.w, b.w, g.w, da.w, db.w);
+        dx12[r * 2 * hv + c] = da;
+        dx12[r * 2 * hv + hv + c] = db;
+    }
+}
+// window partition of a P_h x P_w token grid (losses/scalekd.py:327-335): out[b][(wy,wx,ty,tx)] = in[b][(wy*th+ty, wx*tw+tx)]
+__global__ void window_permute_kernel(const float4* __restrict__ in, float4* __restrict__ out, int B, int Ph, int Pw, int wh,
+                                      int ww, int dv, int inverse, long nvec) {
+    const int th = Ph / wh, tw = Pw / ww;
+    EW_LOOP(i, nvec) {
+        long r = i / dv;
+        const int c = (int)(i % dv);
+        const int t = (int)(r % (Ph * Pw));
+        const long b = r / (Ph * Pw);
+        // t = window-major index -> grid index
+        const int tx = t % tw, ty = (t / tw) % th, wx = (t / (tw * th)) % ww, wy = t / (tw * th * ww);
+        const long grid = (long)(wy * th + ty) * Pw + wx * tw + tx;
+        const long a = (b * Ph * Pw + t) * dv + c, g = (b * Ph * Pw + grid) * dv + c;
+        if (inverse) out[g] = in[a];
+        else out[a] = in[g];
+    }
+}
+
 // ---- BatchNorm (train mode) ------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, int N, float count,
@@ -302,6 +351,31 @@ extern "C" int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float
     const long nvec = (long)B * rows_per_img * (C / 4);
     hipLaunchKernelGGL(grn_gelu_bwd_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(dy), F4(g), F4(h),
                        F4(nx), F4(coef), F4(gamma), F4W(dh), rows_per_img, C / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_swiglu_f32(const float* x12, const float* dout, float* out, long rows, int hidden, int backward, void* stream) {
+    // forward: out[rows, hidden] = silu(x12[:, :hidden]) * x12[:, hidden:];  backward: out = dx12 [rows, 2*hidden]
+    if (!x12 || !out || rows <= 0 || hidden <= 0 || (backward && !dout)) return DKD_ERR_BAD_ARG;
+    if (hidden & 3) return DKD_ERR_ALIGN;
+    const long nvec = rows * (hidden / 4);
+    if (backward)
+        hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(dout), F4(x12),
+                           F4W(out), hidden / 4, nvec);
+    else
+        hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(x12), F4W(out),
+                           hidden / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_window_permute_f32(const float* in, float* out, int B, int Ph, int Pw, int win_h, int win_w, int D,
+                                      int inverse, void* stream) {
+    if (!in || !out || B <= 0 || win_h <= 0 || win_w <= 0 || Ph % win_h || Pw % win_w) return DKD_ERR_BAD_ARG;
+    if (D & 3) return DKD_ERR_ALIGN;
+    const long nvec = (long)B * Ph * Pw * (D / 4);
+    hipLaunchKernelGGL(window_permute_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(in), F4W(out), B, Ph,
+                       Pw, win_h, win_w, D / 4, inverse, nvec);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

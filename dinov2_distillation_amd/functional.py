@@ -188,8 +188,14 @@ def vit_block_forward(x, p, H, save):
     o, lse = ops.attention_forward(qkv, qkv[:, D:], qkv[:, 2 * D:], H, hd, hd ** -0.5, B, N, N, st, st, st)
     x1 = ops.gemm(o.reshape(M, D), p["wproj"], bias=p["bproj"], residual=x2)
     h2, m2, r2 = ops.layernorm_fwd(x1, p["n2w"], p["n2b"], 1e-6, need_stats=save)
-    u = torch.empty((M, p["w1"].shape[0]), dtype=F32, device=x.device) if save else None
-    a = ops.gemm(h2, p["w1"], bias=p["b1"], act=ops.ACT_GELU, preact=u)
+    if p.get("swiglu"):
+        u = ops.gemm(h2, p["w1"], bias=p["b1"])  # [M, 2*hidden] = [x1 | x2]
+        a = ops.swiglu_fwd(u)
+        if not save:
+            u = None
+    else:
+        u = torch.empty((M, p["w1"].shape[0]), dtype=F32, device=x.device) if save else None
+        a = ops.gemm(h2, p["w1"], bias=p["b1"], act=ops.ACT_GELU, preact=u)
     x2o = ops.gemm(a, p["w2"], bias=p["b2"], residual=x1)
     saved = (x2, m1, r1, qkv, o, lse, x1, m2, r2, u) if save else None
     return x2o.reshape(B, N, D), saved
@@ -216,7 +222,7 @@ class ViTBlockFrozenFn(Function):
         M, hd = B * N, D // H
         d2 = _c(dout).reshape(M, D)
         da = ops.gemm(d2, p["w2"], b_layout=1)
-        du = ops.gelu_bwd(da, u)
+        du = ops.swiglu_bwd(da, u) if p.get("swiglu") else ops.gelu_bwd(da, u)
         dh2 = ops.gemm(du, p["w1"], b_layout=1)
         dx1, _, _ = ops.layernorm_bwd(dh2, x1, m2, r2, p["n2w"], affine=False, add=d2)
         do = ops.gemm(dx1, p["wproj"], b_layout=1).reshape(B, N, D)
@@ -230,6 +236,17 @@ class ViTBlockFrozenFn(Function):
 
 
 # =====================================================================================================================
+def _bn_fwd_stats(z, bn_state, training):
+    """train: batch statistics (+ running update); eval: the running statistics (no update)"""
+    running_mean, running_var = bn_state
+    if training:
+        return ops.bn_stats(z, running_mean, running_var, 0.1, 1e-5)
+    rstd = torch.empty_like(running_var)
+    ops.check(ops._lib.load().dkd_bn_finalize_f32(ops._p(running_mean), ops._p(running_var), ops._p(rstd), None, None,
+                                                  running_var.numel(), 2, 0.0, 1e-5, ops._stream()), "dkd_bn_finalize_f32")
+    return running_mean, rstd
+
+
 PROJ_PARAM_NAMES = (
     "pos_embed", "proj_student.0.weight", "proj_student.0.bias", "proj_student.1.weight", "proj_student.1.bias",
     "pos_attention.q.weight", "pos_attention.q.bias", "pos_attention.k.weight", "pos_attention.k.bias",
@@ -245,7 +262,7 @@ class AttentionProjectorFn(Function):
     -> LN.  x is NHWC [B,P,P,Cs]; ext_query is [B,N,D] or None (then self_query [N,D] is used, batch-invariant)."""
 
     @staticmethod
-    def forward(ctx, x, ext_query, self_query, bn_state, num_heads, softmax_scale, training, *params):
+    def forward(ctx, x, ext_query, self_query, bn_state, num_heads, softmax_scale, training, window, *params):
         (pos_embed, wc, bc, bn_w, bn_b, wq, bq, wk, bk, wv, bv, wp, bp, w1, b1, w2, b2, n1w, n1b, n2w, n2b) = params
         x = _c(x)
         B, Ph, Pw, Cs = x.shape
@@ -254,11 +271,7 @@ class AttentionProjectorFn(Function):
         scale = hd ** -0.5 * softmax_scale
         x2 = x.reshape(M, Cs)
         z = ops.gemm(x2, wc.reshape(D, Cs), bias=bc)
-        running_mean, running_var = bn_state
-        if training:
-            mean, rstd = ops.bn_stats(z, running_mean, running_var, 0.1, 1e-5)
-        else:
-            raise NotImplementedError("AttentionProjector eval-mode BatchNorm is not on the training hot path yet")
+        mean, rstd = _bn_fwd_stats(z, bn_state, training)
         pos_t = ops.transpose(pos_embed.reshape(D, N))  # [N, D]
         tok = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, pos_t, relu=True)
         shared = ext_query is None
@@ -266,15 +279,30 @@ class AttentionProjectorFn(Function):
         q = ops.gemm(qin, wq, bias=bq)
         k = ops.gemm(tok, wk, bias=bk)
         v = ops.gemm(tok, wv, bias=bv)
-        st = (N * D, D)
-        o, lse = ops.attention_forward(q, k, v, num_heads, hd, scale, B, N, N, (0 if shared else N * D, D), st, st)
+        wh, ww = window
+        nwin = wh * ww
+        if nwin > 1:  # losses/scalekd.py:303-306: tokens window-major, attention inside each window
+            qw = ops.window_permute((q.reshape(1, N, D).expand(B, N, D).contiguous() if shared else q.reshape(B, N, D)),
+                                    Ph, Pw, wh, ww)
+            kw_, vw = ops.window_permute(k.reshape(B, N, D), Ph, Pw, wh, ww), ops.window_permute(v.reshape(B, N, D), Ph, Pw, wh, ww)
+            T = N // nwin
+            stw = (T * D, D)
+            o, lse = ops.attention_forward(qw, kw_, vw, num_heads, hd, scale, B * nwin, T, T, stw, stw, stw)
+            o = o.reshape(B, N, D)  # :313-314: only VIEWED back - the tokens stay window-major
+            att_saved = (qw, kw_, vw)
+        else:
+            st = (N * D, D)
+            o, lse = ops.attention_forward(q, k, v, num_heads, hd, scale, B, N, N, (0 if shared else N * D, D), st, st)
+            att_saved = (q, k, v)
         y = ops.gemm(o.reshape(M, D), wp, bias=bp, residual=tok)
         zn, m1, r1 = ops.layernorm_fwd(y, n1w, n1b, 1e-5)
         f1 = ops.gemm(zn, w1, bias=b1, act=ops.ACT_RELU)
         f2 = ops.gemm(f1, w2, bias=b2, residual=zn)
         out, m2, r2 = ops.layernorm_fwd(f2, n2w, n2b, 1e-5)
+        q, k, v = att_saved
         ctx.save_for_backward(x2, z, mean, rstd, tok, qin, q, k, v, o, lse, y, m1, r1, zn, f1, f2, m2, r2, *params)
         ctx.meta = (B, N, D, Cs, num_heads, hd, scale, shared, tuple(pos_embed.shape), tuple(wc.shape), tuple(x.shape))
+        ctx.window, ctx.training = (wh, ww), training
         return out.reshape(B, N, D)
 
     @staticmethod
@@ -291,11 +319,24 @@ class AttentionProjectorFn(Function):
         dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w)
         dwp, dbp = ops.linear_wgrad(dy, o.reshape(M, D), True)
         do = ops.gemm(dy, wp, b_layout=1).reshape(B, N, D)
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         dq = torch.empty((B, N, D), dtype=F32, device=dy.device)
-        dk, dv = torch.empty_like(k), torch.empty_like(v)
-        st = (N * D, D)
-        ops.attention_backward(do, q, k, v, o, lse, H, hd, scale, B, N, N, (0 if shared else N * D, D), st, st,
-                               dq, dk, dv, st, st, st)
+        dk, dv = torch.empty((B, N, D), dtype=F32, device=dy.device), torch.empty((B, N, D), dtype=F32, device=dy.device)
+        wh, ww = ctx.window
+        nwin = wh * ww
+        if nwin > 1:
+            Ph, Pw = xshape[1], xshape[2]
+            T = N // nwin
+            stw = (T * D, D)
+            ops.attention_backward(do, q, k, v, o.reshape(B * nwin, T, D), lse, H, hd, scale, B * nwin, T, T, stw, stw, stw,
+                                   dq, dk, dv, stw, stw, stw)
+            dq, dk, dv = (ops.window_permute(t, Ph, Pw, wh, ww, inverse=True) for t in (dq, dk, dv))
+        else:
+            st = (N * D, D)
+            ops.attention_backward(do, q, k, v, o, lse, H, hd, scale, B, N, N, (0 if shared else N * D, D), st, st,
+                                   dq, dk, dv, st, st, st)
+        dk, dv = dk.reshape(M, D), dv.reshape(M, D)
         dwk, dbk = ops.linear_wgrad(dk, tok, True)
         dwv, dbv = ops.linear_wgrad(dv, tok, True)
         dtok = ops.gemm(dk, wk, b_layout=1, residual=dy)  # + attention residual branch
@@ -313,7 +354,7 @@ class AttentionProjectorFn(Function):
         dwc, dbc = ops.linear_wgrad(dz, x2, True)
         dwc = dwc.reshape(wc_shape)
         dx = ops.gemm(dz, wc.reshape(D, Cs), b_layout=1).reshape(xshape) if ctx.needs_input_grad[0] else None
-        return (dx, dext, dself, None, None, None, None,
+        return (dx, dext, dself, None, None, None, None, None,
                 dpos, dwc, dbc, dbn_w, dbn_b, dwq, dbq, dwk, dbk, dwv, dbv, dwp, dbp, dw1, db1, dw2, db2,
                 dn1w, dn1b, dn2w, dn2b)
 
@@ -375,9 +416,8 @@ class ConvBNActFn(Function):
                 w2 = ops.transpose(w.reshape(O, Cin, k * k)).reshape(O, k * k * Cin)  # [O][ky][kx][c]
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
         z = ops.gemm(rows, w2)
-        if not training:
-            raise NotImplementedError("eval-mode BatchNorm is not on the training hot path yet")
-        mean, rstd = ops.bn_stats(z, bn_state[0], bn_state[1], 0.1, 1e-5)
+        mean, rstd = _bn_fwd_stats(z, bn_state, training)
+        ctx.training = training
         y = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, None, relu=relu)
         ctx.save_for_backward(rows, w2, z, mean, rstd, bn_w, bn_b)
         ctx.meta = (k, stride, pad, relu, src_nchw, tuple(x.shape), tuple(w.shape))
@@ -388,6 +428,8 @@ class ConvBNActFn(Function):
         rows, w2, z, mean, rstd, bn_w, bn_b = ctx.saved_tensors
         k, stride, pad, relu, src_nchw, xshape, wshape = ctx.meta
         O = wshape[0]
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         dz, dg, db = ops.bn_bwd(_c(dy).reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu)
         dw2 = ops.linear_wgrad(dz, rows)
         dx = None
@@ -416,10 +458,9 @@ class DepthwiseBNFn(Function):
         C = x.shape[3]
         wt = ops.transpose(w.reshape(C, 9))
         y = ops.dwconv3(x, wt, stride)
-        if not training:
-            raise NotImplementedError("eval-mode BatchNorm is not on the training hot path yet")
         y2 = y.reshape(-1, C)
-        mean, rstd = ops.bn_stats(y2, bn_state[0], bn_state[1], 0.1, 1e-5)
+        mean, rstd = _bn_fwd_stats(y2, bn_state, training)
+        ctx.training = training
         out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=False)
         ctx.save_for_backward(x, wt, y2, mean, rstd, bn_w, bn_b)
         ctx.meta = (stride, tuple(w.shape), tuple(y.shape))
@@ -430,6 +471,8 @@ class DepthwiseBNFn(Function):
         x, wt, y2, mean, rstd, bn_w, bn_b = ctx.saved_tensors
         stride, wshape, yshape = ctx.meta
         C = x.shape[3]
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=False)
         dy = dy.reshape(yshape)
         dx = ops.dwconv3(dy, wt, stride, dgrad_shape=x.shape[1:3]) if ctx.needs_input_grad[0] else None

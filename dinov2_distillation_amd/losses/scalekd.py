@@ -41,8 +41,9 @@ class AttentionProjector(nn.Module):
     def __init__(self, student_dims, teacher_dims, hw_dims, pos_dims, window_shapes=(1, 1), self_query=True,
                  softmax_scale=1.0, num_heads=8):
         super().__init__()
-        if tuple(window_shapes) != (1, 1):
-            raise NotImplementedError("window_shapes != (1,1) has no MI355X kernel yet (config default is [1,1])")
+        self.window_shapes = tuple(int(w) for w in window_shapes)
+        if hw_dims[0] != hw_dims[1] and self.window_shapes != (1, 1):
+            raise ValueError("windowed attention assumes a square token grid (separate_tokens, scalekd.py:329)")
         if teacher_dims % num_heads:
             raise ValueError(f"num_heads={num_heads} must divide teacher_dims={teacher_dims} (scalekd.py:273,299)")
         self.hw_dims, self.student_dims, self.teacher_dims = tuple(hw_dims), student_dims, teacher_dims
@@ -70,7 +71,7 @@ class AttentionProjector(nn.Module):
             bn.num_batches_tracked += 1
         return Fn.AttentionProjectorFn.apply(x_nhwc, query, None if query is not None else self.query.weight,
                                              (bn.running_mean, bn.running_var), self.num_heads, self.softmax_scale,
-                                             self.training, *self._params())
+                                             self.training, self.window_shapes, *self._params())
 
 
 class ScaleKD(nn.Module):

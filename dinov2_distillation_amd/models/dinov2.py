@@ -38,9 +38,9 @@ class _Holder(nn.Module):
 class Block(nn.Module):
     """Parameter names of a DINOv2 block: norm1, attn.{qkv,proj}, ls1.gamma, norm2, mlp.{fc1,fc2}, ls2.gamma."""
 
-    def __init__(self, dim, num_heads, gen):
+    def __init__(self, dim, num_heads, gen, ffn="mlp"):
         super().__init__()
-        self.num_heads = num_heads
+        self.num_heads, self.ffn = num_heads, ffn
         z = lambda n: nn.Parameter(torch.zeros(n), requires_grad=False)
         o = lambda n: nn.Parameter(torch.ones(n), requires_grad=False)
         self.norm1, self.norm2, self.attn, self.mlp, self.ls1, self.ls2 = (_Holder() for _ in range(6))
@@ -50,8 +50,15 @@ class Block(nn.Module):
         self.attn.qkv.weight, self.attn.qkv.bias = _tn(3 * dim, dim, gen=gen), z(3 * dim)
         self.attn.proj.weight, self.attn.proj.bias = _tn(dim, dim, gen=gen), z(dim)
         self.ls1.gamma, self.ls2.gamma = o(dim), o(dim)
-        self.mlp.fc1.weight, self.mlp.fc1.bias = _tn(4 * dim, dim, gen=gen), z(4 * dim)
-        self.mlp.fc2.weight, self.mlp.fc2.bias = _tn(dim, 4 * dim, gen=gen), z(dim)
+        if ffn == "swiglu":  # published SwiGLUFFNFused: hidden = round_up_8(int(4*dim * 2/3)); w12 = [x1 | x2], w3
+            hidden = (int(4 * dim * 2 / 3) + 7) // 8 * 8
+            del self.mlp.fc1, self.mlp.fc2
+            self.mlp.w12, self.mlp.w3 = _Holder(), _Holder()
+            self.mlp.w12.weight, self.mlp.w12.bias = _tn(2 * hidden, dim, gen=gen), z(2 * hidden)
+            self.mlp.w3.weight, self.mlp.w3.bias = _tn(dim, hidden, gen=gen), z(dim)
+        else:
+            self.mlp.fc1.weight, self.mlp.fc1.bias = _tn(4 * dim, dim, gen=gen), z(4 * dim)
+            self.mlp.fc2.weight, self.mlp.fc2.bias = _tn(dim, 4 * dim, gen=gen), z(dim)
         self._prep = None
 
     def prepared(self):
@@ -65,10 +72,11 @@ class Block(nn.Module):
                     "n1w": self.norm1.weight, "n1b": self.norm1.bias, "n2w": self.norm2.weight, "n2b": self.norm2.bias,
                     "wqkv": w, "bqkv": self.attn.qkv.bias,
                     "wproj": (self.attn.proj.weight * ls1[:, None]).contiguous(), "bproj": self.attn.proj.bias * ls1,
-                    "w1": self.mlp.fc1.weight, "b1": self.mlp.fc1.bias,
-                    "w2": (self.mlp.fc2.weight * ls2[:, None]).contiguous(), "b2": self.mlp.fc2.bias * ls2,
-                    "_ver": w._version,
+                    "_ver": w._version, "swiglu": self.ffn == "swiglu",
                 }
+                fin, fout = (self.mlp.w12, self.mlp.w3) if self.ffn == "swiglu" else (self.mlp.fc1, self.mlp.fc2)
+                self._prep.update({"w1": fin.weight, "b1": fin.bias, "w2": (fout.weight * ls2[:, None]).contiguous(),
+                                   "b2": fout.bias * ls2})
         return self._prep
 
     def _apply(self, fn, *a, **k):
@@ -84,8 +92,6 @@ class Block(nn.Module):
 class VisionTransformer(nn.Module):
     def __init__(self, cfg, seed=0):
         super().__init__()
-        if cfg.get("ffn", "mlp") != "mlp":
-            raise NotImplementedError("SwiGLU FFN (dinov2_vitg14) is not built yet")
         gen = torch.Generator().manual_seed(seed)
         D = cfg["embed_dim"]
         self.embed_dim, self.num_heads, self.patch_size = D, cfg["num_heads"], PATCH
@@ -96,7 +102,7 @@ class VisionTransformer(nn.Module):
         self.patch_embed.proj = _Holder()
         self.patch_embed.proj.weight = _tn(D, 3, PATCH, PATCH, gen=gen)
         self.patch_embed.proj.bias = nn.Parameter(torch.zeros(D), requires_grad=False)
-        self.blocks = nn.ModuleList([Block(D, cfg["num_heads"], gen) for _ in range(cfg["depth"])])
+        self.blocks = nn.ModuleList([Block(D, cfg["num_heads"], gen, cfg.get("ffn", "mlp")) for _ in range(cfg["depth"])])
         self.norm = _Holder()
         self.norm.weight = nn.Parameter(torch.ones(D), requires_grad=False)
         self.norm.bias = nn.Parameter(torch.zeros(D), requires_grad=False)

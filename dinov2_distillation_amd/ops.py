@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AttnArgs, GemmArgs, check
+from ._lib import AttnArgs, GemmArgs, check  # noqa: F401
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM = 0, 1, 2, 3, 4
@@ -496,4 +496,31 @@ def add_relu(a, b):
     _chk(a, "a"), _chk(b, "b")
     out = torch.empty_like(a)
     check(_lib.load().dkd_add_relu_f32(_p(a), _p(b), _p(out), a.numel(), _stream()), "dkd_add_relu_f32")
+    return out
+
+
+def swiglu_fwd(x12):
+    _chk(x12, "x12")
+    hidden = x12.shape[-1] // 2
+    rows = x12.numel() // (2 * hidden)
+    out = torch.empty((*x12.shape[:-1], hidden), dtype=torch.float32, device=x12.device)
+    check(_lib.load().dkd_swiglu_f32(_p(x12), None, _p(out), rows, hidden, 0, _stream()), "dkd_swiglu_f32")
+    return out
+
+
+def swiglu_bwd(dout, x12):
+    _chk(dout, "dout"), _chk(x12, "x12")
+    hidden = x12.shape[-1] // 2
+    rows = x12.numel() // (2 * hidden)
+    dx = torch.empty_like(x12)
+    check(_lib.load().dkd_swiglu_f32(_p(x12), _p(dout), _p(dx), rows, hidden, 1, _stream()), "dkd_swiglu_f32(bwd)")
+    return dx
+
+
+def window_permute(x, Ph, Pw, wh, ww, inverse=False):
+    """x [B, Ph*Pw, D] grid order -> window-major order (or back)"""
+    _chk(x, "x")
+    B, N, D = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().dkd_window_permute_f32(_p(x), _p(out), B, Ph, Pw, wh, ww, D, int(inverse), _stream()), "dkd_window_permute_f32")
     return out

@@ -108,6 +108,13 @@ int dkd_gelu_fwd_f32(const float* x, float* y, long n, void* stream);           
 int dkd_gelu_bwd_f32(const float* dy, const float* x, float* dx, long n, void* stream);
 int dkd_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream); /* FFN ReLU losses/scalekd.py:448 */
 int dkd_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, long n, void* stream);
+/* SwiGLU FFN of the ViT-g teacher (external DINOv2 ``SwiGLUFFNFused``): x12 = [x1 | x2] [rows, 2*hidden];
+ * forward out = silu(x1) * x2 [rows, hidden]; backward (dout given) out = d x12 [rows, 2*hidden]. */
+int dkd_swiglu_f32(const float* x12, const float* dout, float* out, long rows, int hidden, int backward, void* stream);
+/* ``separate_tokens`` (losses/scalekd.py:327-335): re-order the tokens of a P_h x P_w grid window-major
+ * (inverse=1: back to grid order).  in/out [B, P_h*P_w, D]. */
+int dkd_window_permute_f32(const float* in, float* out, int B, int Ph, int Pw, int win_h, int win_w, int D, int inverse,
+                           void* stream);
 int dkd_sub_group_vec_f32(const float* x, const float* vec, float* out, long rows_per_group, int groups, int N,
                           void* stream);
 /* train-mode BatchNorm2d of the projector input (losses/scalekd.py:199-201,238): statistics come from

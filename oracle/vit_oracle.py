@@ -85,9 +85,13 @@ def vit_block(p, prefix, x, num_heads, eps=1e-6):
     a = F.linear(ctx, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"])
     x = x + a * p[prefix + "ls1.gamma"]
     y = F.layer_norm(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps)
-    m = F.linear(y, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"])
-    m = F.gelu(m)
-    m = F.linear(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"])
+    if (prefix + "mlp.w12.weight") in p:  # ViT-g: SwiGLUFFNFused, w3(silu(x1) * x2) with [x1 | x2] = w12(y)
+        x1, x2 = F.linear(y, p[prefix + "mlp.w12.weight"], p[prefix + "mlp.w12.bias"]).chunk(2, dim=-1)
+        m = F.linear(F.silu(x1) * x2, p[prefix + "mlp.w3.weight"], p[prefix + "mlp.w3.bias"])
+    else:
+        m = F.linear(y, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"])
+        m = F.gelu(m)
+        m = F.linear(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"])
     return x + m * p[prefix + "ls2.gamma"]
 
 

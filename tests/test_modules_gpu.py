@@ -31,7 +31,7 @@ def nhwc_view(t):
     return t.permute(0, 2, 3, 1).contiguous().cuda().permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("name", ["scalekd_selfq", "scalekd_extq", "scalekd_p6"])
+@pytest.mark.parametrize("name", ["scalekd_selfq", "scalekd_extq", "scalekd_p6", "scalekd_win22"])
 def test_scalekd_against_reference_golden(golden_dir, name):
     from dinov2_distillation_amd.losses import ScaleKD
     g = load(golden_dir, name)
@@ -387,3 +387,77 @@ def test_resnet50_student_runs_full_step():
     l0 = float(st.step(x))
     l1 = float(st.step(x))
     assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
+
+
+def test_swiglu_teacher_block_vs_oracle():
+    """ViT-g style block (SwiGLU FFN, BASELINE configs[4] teacher family) at a reduced width: forward + dgrad"""
+    from dinov2_distillation_amd.models.dinov2 import Block
+    from oracle import vit_oracle as vo
+    gen = torch.Generator().manual_seed(3)
+    D, H = 256, 4
+    blk = Block(D, H, gen, ffn="swiglu")
+    with torch.no_grad():
+        for k, v in blk.state_dict().items():
+            if k.endswith("gamma"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+            elif k.endswith("bias"):
+                v.copy_(0.05 * torch.randn(v.shape, generator=gen))
+            elif v.dim() == 2:
+                v.mul_(4)
+    p = {"blocks.0." + k: v.clone() for k, v in blk.state_dict().items()}
+    assert "blocks.0.mlp.w12.weight" in p and p["blocks.0.mlp.w12.weight"].shape == (2 * 688, 256)
+    x = torch.randn(2, 50, D, generator=gen).requires_grad_(True)
+    ref = vo.vit_block(p, "blocks.0.", x, H)
+    ct = torch.randn(2, 50, D, generator=gen)
+    ref.backward(ct)
+    blk.cuda()
+    xg = x.detach().cuda().requires_grad_(True)
+    out = blk(xg)
+    close(out, ref, "swiglu block fwd")
+    out.backward(ct.cuda())
+    close(xg.grad, x.grad, "swiglu block dgrad")
+    with torch.no_grad():
+        close(blk(x.detach().cuda()), ref, "swiglu block fwd (no-grad path)")
+
+
+def test_validation_step_eval_mode_vs_oracle():
+    """validation_step (train/distillation_module.py:279-309): modules in eval(), BatchNorm uses running statistics"""
+    from dinov2_distillation_amd.config import make_config, set_student_dims
+    from dinov2_distillation_amd.models import DINOv2ViT, ModelWrapper
+    from dinov2_distillation_amd.train import DistillationModule
+    torch.manual_seed(5)
+    cfg = make_config()
+    student = ModelWrapper("convnext_tiny", cfg.teacher.n_patches, cfg.student.student_keys)
+    set_student_dims(cfg, student)
+    teacher = DINOv2ViT("dinov2_vits14", seed=0)
+    mod = DistillationModule(student, teacher, cfg)
+    with torch.no_grad():  # non-trivial running statistics
+        for k, v in mod.losses.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(0.1 * torch.randn_like(v))
+            elif k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand_like(v))
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(7))
+    from oracle import convnext_oracle as cno, step_oracle as so, vit_oracle as vo
+    sp = {k[len("model.model."):]: v.detach().clone() for k, v in mod.student.state_dict().items()}
+    lp = {k: v.detach().clone() for k, v in mod.losses.state_dict().items()}
+    tp = {k: v.detach().clone() for k, v in teacher.model.state_dict().items()}
+    tcfg = vo.VIT_CONFIGS["dinov2_vits14"]
+    with torch.no_grad():
+        ft = vo.teacher_feature_map(tp, x, tcfg)
+        feats = cno.student_features(sp, x, [3, 3, 9, 3], cfg.teacher.n_patches, cfg.student.student_keys)
+        cfgs, w = {}, {}
+        for spec in cfg.loss.losses:
+            kw = spec.kwargs
+            cfgs[kw.name] = dict(alpha=kw.alpha, hw=tuple(kw.pos_hw), num_heads=kw.num_heads, softmax_scale=kw.softmax_scale)
+            w[kw.name] = spec.weight
+        ref = so.compute_losses(lp, cfgs, w, feats, ft, tp, 12, 6, training=False)
+    mod.cuda().eval()
+    before = {k: v.clone() for k, v in mod.losses.state_dict().items() if "running" in k}
+    with torch.no_grad():
+        loss = mod.validation_step(x.cuda(), 0)
+    for k, v in ref.items():
+        close(mod.logged["val_" + k], v, "val_" + k)
+    close(loss, ref["loss"], "val loss")
+    for k, v in before.items():
+        assert torch.equal(v, mod.losses.state_dict()[k]), f"{k} must not change in eval mode"
