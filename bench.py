@@ -124,11 +124,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the distillation step has no CPU path (only cpu_baseline uses the oracle)")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())  # (modulo: lets a 1-GPU box rehearse N ranks with gloo)
+    local = local % torch.cuda.device_count()
     if world > 1:
         from dinov2_distillation_amd.ddp import init_process_group_from_env
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        init_process_group_from_env("nccl")
+        init_process_group_from_env(os.environ.get("DKD_DIST_BACKEND", "nccl"))  # "nccl" == RCCL over xGMI
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 

@@ -149,19 +149,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __re
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rs += As[kk * SA::LDS_LD + tid];
         }
+        // all fragments of the k-tile are read from LDS up front (BK/2 * (TM + TN) registers), then the MFMAs issue
+        // back to back with no LDS wait in between (the per-k-pair read -> wait -> MFMA pattern hipcc otherwise emits
+        // exposes the LDS latency in front of every MFMA group)
+        float a[BK / 2][TM], b[BK / 2][TN];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(2 * s + half) * SA::LDS_LD + (wm * TM + i) * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[s][i] = As[(2 * s + half) * SA::LDS_LD + (wm * TM + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * s + half) * SB::LDS_LD + (wn * TN + j) * 32 + l31];
+            for (int j = 0; j < TN; ++j) b[s][j] = Bs[(2 * s + half) * SB::LDS_LD + (wn * TN + j) * 32 + l31];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep hipcc from sinking the reads back in front of their MFMAs
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
     };
     if (nk > 0) {
         sa.load(A, lda, bm0, M, kbeg, kend, tid);
@@ -243,6 +249,153 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
             rowsum[m] = s * epi.alpha;
         }
     }
+}
+
+
+// =====================================================================================================================
+// bf16x3 split-precision variant (opt-in, dkd_gemm_args.precision = DKD_PREC_BF16X3; NT layout only).
+// Each fp32 operand x is split on the fly into three bf16 terms x = hi + mid + lo (24 mantissa bits in total) while the
+// tile is staged into LDS; the product keeps the six largest cross terms
+//     a*b ~= a_hi*b_hi + a_hi*b_mid + a_mid*b_hi + a_mid*b_mid + a_hi*b_lo + a_lo*b_hi      (dropped terms <= 2^-24 |a||b|)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-level accuracy (measured ~1e-7 relative, tests) at 16/6 = 2.7x
+// the fp32 MFMA rate.  LDS image per plane: [row][32 k] bf16, 80-byte rows (ds_read_b128 fragments are conflict-free: the
+// 16-lane read groups land on 16 distinct 16-byte slots of the 256-byte bank row).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+    h = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    const float4 r = make_float4(v.x - (float)h[0], v.y - (float)h[1], v.z - (float)h[2], v.w - (float)h[3]);
+    m = bf16x4{(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
+    l = bf16x4{(__bf16)(r.x - (float)m[0]), (__bf16)(r.y - (float)m[1]), (__bf16)(r.z - (float)m[2]),
+               (__bf16)(r.w - (float)m[3])};
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float* __restrict__ A, long lda,
+                                                                      const float* __restrict__ B, long ldb, float* C,
+                                                                      long ldc, int M, int N, int K, Epilogue epi) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, NT = WM * WN * 64, RS = 40;  // RS: bf16 per LDS row (80 B)
+    constexpr int NVA = BM * 8 / NT, NVB = BN * 8 / NT;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile must divide over the threads");
+    __shared__ __attribute__((aligned(16))) __bf16 smem[3 * (BM + BN) * RS];
+    __bf16* As = smem;                 // [3][BM][RS]
+    __bf16* Bs = smem + 3 * BM * RS;   // [3][BN][RS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN, half = lane >> 5, l31 = lane & 31;
+    const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Structure: one LDS image; the next tile's fp32 loads are issued before the MFMA block and stay in flight across it;
+    // after the barrier they are split into three bf16 planes and stored (4 waves/SIMD cover the split's VALU time with the
+    // other workgroup's MFMAs).  A register-resident split overlapped with the own wave's MFMAs measured 20-30 % SLOWER
+    // (occupancy loss, gpurun_out/tune_bf16x3_b.log).
+    float4 ra[NVA], rb[NVB];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
+            const int gr = bm0 + r, gk = k0 + 4 * kq;
+            ra[i] = (gr < M && gk < K) ? *reinterpret_cast<const float4*>(A + (long)gr * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
+            const int gr = bn0 + r, gk = k0 + 4 * kq;
+            rb[i] = (gr < N && gk < K) ? *reinterpret_cast<const float4*>(B + (long)gr * ldb + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
+            bf16x4 h, m, l;
+            split3(ra[i], h, m, l);
+            *reinterpret_cast<bf16x4*>(As + (0 * BM + r) * RS + 4 * kq) = h;
+            *reinterpret_cast<bf16x4*>(As + (1 * BM + r) * RS + 4 * kq) = m;
+            *reinterpret_cast<bf16x4*>(As + (2 * BM + r) * RS + 4 * kq) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
+            bf16x4 h, m, l;
+            split3(rb[i], h, m, l);
+            *reinterpret_cast<bf16x4*>(Bs + (0 * BN + r) * RS + 4 * kq) = h;
+            *reinterpret_cast<bf16x4*>(Bs + (1 * BN + r) * RS + 4 * kq) = m;
+            *reinterpret_cast<bf16x4*>(Bs + (2 * BN + r) * RS + 4 * kq) = l;
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    load(0);
+    store();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[i][p] = *reinterpret_cast<const bf16x8*>(As + (p * BM + (wm * TM + i) * 32 + l31) * RS + ks * 16 + half * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * BN + (wn * TN + j) * 32 + l31) * RS + ks * 16 + half * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];  // smallest cross terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) store();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn0 + (wn * TN + j) * 32 + l31;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                epilogue_store(epi, C, ldc, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_bf16x3(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN)), block(WM * WN * 64);
+    hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<WM, WN, TM, TN>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc,
+                       g->M, g->N, g->K, epi);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
 }
 
 template <int WM, int WN, int TM, int TN, int BK, int SCHED>
@@ -332,6 +485,15 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     epi.row_grp_stride = g->row_grp_stride;
     epi.row_off = g->row_off;
     epi.alpha = g->alpha;
+    if (g->precision == DKD_PREC_BF16X3 && g->a_layout == 0 && g->b_layout == 0 && !g->rowsum) {
+        hipStream_t st = (hipStream_t)stream;
+        switch (g->variant) {
+            case 21: return launch_bf16x3<2, 2, 2, 2>(g, epi, st);   // 128 x 128, 4 waves of 64 x 64
+            case 22: return launch_bf16x3<2, 4, 2, 1>(g, epi, st);   // 128 x 128, 8 waves of 64 x 32
+            case 23: return launch_bf16x3<1, 4, 2, 1>(g, epi, st);   // 64 x 128, 4 waves
+            default: return launch_bf16x3<4, 2, 1, 2>(g, epi, st);   // 128 x 128, 8 waves of 32 x 64
+        }
+    }
     const int cfg = pick_cfg(g->M, g->N, g->variant);
     // the workspace was sized for the automatic configuration: never use more slabs than that
     int splits = pick_splits(g->M, g->N, g->K, cfg);

@@ -127,7 +127,7 @@ class PatchConvFn(Function):
             B, H, W, C = xshape
             dw = ops.transpose(dw2.reshape(O, k * k, C)).reshape(wshape)
             if ctx.needs_input_grad[0]:
-                drows = ops.gemm(dy2, w2, b_layout=1)
+                drows = ops.dgrad(dy2, w2)
                 dx = ops.unpatchify_nhwc(drows, B, H, W, C, k)
         return dx, dw, db, None, None
 
@@ -162,11 +162,11 @@ class ConvNeXtBlockFn(Function):
         dout = _c(dout)
         do2 = dout.reshape(M, C)
         dw2, db2 = ops.linear_wgrad(do2, y, True)
-        dy = ops.gemm(do2, w2, b_layout=1)  # [M, 4C]
+        dy = ops.dgrad(do2, w2)  # [M, 4C]
         dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, g, h, (gx, nx, denom), gg, B)
         n2 = n.reshape(M, C)
         dw1, db1 = ops.linear_wgrad(dh, n2, True)
-        dn = ops.gemm(dh, w1, b_layout=1)  # [M, C]
+        dn = ops.dgrad(dh, w1)  # [M, C]
         dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w)
         dd = dd.reshape(B, H, W, C)
         dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
@@ -221,16 +221,16 @@ class ViTBlockFrozenFn(Function):
         B, N, D = ctx.shape
         M, hd = B * N, D // H
         d2 = _c(dout).reshape(M, D)
-        da = ops.gemm(d2, p["w2"], b_layout=1)
+        da = ops.dgrad(d2, p["w2"])
         du = ops.swiglu_bwd(da, u) if p.get("swiglu") else ops.gelu_bwd(da, u)
-        dh2 = ops.gemm(du, p["w1"], b_layout=1)
+        dh2 = ops.dgrad(du, p["w1"])
         dx1, _, _ = ops.layernorm_bwd(dh2, x1, m2, r2, p["n2w"], affine=False, add=d2)
-        do = ops.gemm(dx1, p["wproj"], b_layout=1).reshape(B, N, D)
+        do = ops.dgrad(dx1, p["wproj"]).reshape(B, N, D)
         dqkv = torch.empty_like(qkv)
         st = (N * 3 * D, 3 * D)
         ops.attention_backward(do, qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, H, hd, hd ** -0.5, B, N, N, st, st, st,
                                dqkv, dqkv[:, D:], dqkv[:, 2 * D:], st, st, st)
-        dh1 = ops.gemm(dqkv, p["wqkv"], b_layout=1)
+        dh1 = ops.dgrad(dqkv, p["wqkv"])
         dx, _, _ = ops.layernorm_bwd(dh1, x2, m1, r1, p["n1w"], affine=False, add=dx1)
         return dx.reshape(B, N, D), None
 
@@ -313,12 +313,12 @@ class AttentionProjectorFn(Function):
         M = B * N
         df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w)
         dw2, db2 = ops.linear_wgrad(df2, f1, True)
-        df1 = ops.relu_bwd(ops.gemm(df2, w2, b_layout=1), f1)
+        df1 = ops.relu_bwd(ops.dgrad(df2, w2), f1)
         dw1, db1 = ops.linear_wgrad(df1, zn, True)
-        dzn = ops.gemm(df1, w1, b_layout=1, residual=df2)  # + FFN residual branch
+        dzn = ops.dgrad(df1, w1, residual=df2)  # + FFN residual branch
         dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w)
         dwp, dbp = ops.linear_wgrad(dy, o.reshape(M, D), True)
-        do = ops.gemm(dy, wp, b_layout=1).reshape(B, N, D)
+        do = ops.dgrad(dy, wp).reshape(B, N, D)
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         dq = torch.empty((B, N, D), dtype=F32, device=dy.device)
@@ -339,21 +339,21 @@ class AttentionProjectorFn(Function):
         dk, dv = dk.reshape(M, D), dv.reshape(M, D)
         dwk, dbk = ops.linear_wgrad(dk, tok, True)
         dwv, dbv = ops.linear_wgrad(dv, tok, True)
-        dtok = ops.gemm(dk, wk, b_layout=1, residual=dy)  # + attention residual branch
-        ops.gemm(dv, wv, b_layout=1, out=dtok, residual=dtok)
+        dtok = ops.dgrad(dk, wk, residual=dy)  # + attention residual branch
+        ops.dgrad(dv, wv, out=dtok, residual=dtok)
         if shared:
             dq2 = ops.colreduce(dq.reshape(B, N * D), ops.RED_SUM).reshape(N, D)
         else:
             dq2 = dq.reshape(M, D)
         dwq, dbq = ops.linear_wgrad(dq2, qin, True)
-        dqin = ops.gemm(dq2, wq, b_layout=1)
+        dqin = ops.dgrad(dq2, wq)
         dext = None if shared else dqin.reshape(B, N, D)
         dself = dqin if shared else None
         dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D)).reshape(pos_shape)
         dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True)
         dwc, dbc = ops.linear_wgrad(dz, x2, True)
         dwc = dwc.reshape(wc_shape)
-        dx = ops.gemm(dz, wc.reshape(D, Cs), b_layout=1).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dx = ops.dgrad(dz, wc.reshape(D, Cs)).reshape(xshape) if ctx.needs_input_grad[0] else None
         return (dx, dext, dself, None, None, None, None, None,
                 dpos, dwc, dbc, dbn_w, dbn_b, dwq, dbq, dwk, dbk, dwv, dbv, dwp, dbp, dw1, db1, dw2, db2,
                 dn1w, dn1b, dn2w, dn2b)
@@ -441,11 +441,11 @@ class ConvBNActFn(Function):
             if k == 1 and stride == 1:
                 dw = dw2.reshape(wshape)
                 if ctx.needs_input_grad[0]:
-                    dx = ops.gemm(dz, w2, b_layout=1).reshape(xshape)
+                    dx = ops.dgrad(dz, w2).reshape(xshape)
             else:
                 dw = ops.transpose(dw2.reshape(O, k * k, Cin)).reshape(wshape)
                 if ctx.needs_input_grad[0]:
-                    dx = ops.col2im_nhwc(ops.gemm(dz, w2, b_layout=1), B, H, W, Cin, k, stride, pad)
+                    dx = ops.col2im_nhwc(ops.dgrad(dz, w2), B, H, W, Cin, k, stride, pad)
         return dx, dw, dg, db, None, None, None, None, None, None
 
 

@@ -5,6 +5,7 @@ function validates its tensors (cuda, fp32, layout), allocates outputs, and laun
 `torch.cuda.current_stream()`.  Nothing in this module computes with ATen ops and nothing falls back to the CPU.
 """
 import ctypes
+import os
 
 import torch
 
@@ -15,6 +16,8 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM = 0, 1, 2, 3, 4
 
 _ws = {}
+PREC_F32, PREC_BF16X3 = 0, 1
+GEMM_PRECISION = PREC_BF16X3 if os.environ.get("DKD_GEMM_PRECISION", "f32").lower() == "bf16x3" else PREC_F32
 
 
 def _stream():
@@ -48,7 +51,7 @@ def workspace(nbytes, device, slot=0):
 # ---------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, colscale=None, residual=None, res_mod=0,
          preact=None, alpha=1.0, row_map=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None,
-         variant=0, rowsum=None):
+         variant=0, rowsum=None, precision=None):
     """C = epi(alpha * Aop @ Bop^T).  a/b are 2-D (or flattened-leading-dims) dense tensors:
     a_layout 0: a is [M,K]; 1: a is [K,M].   b_layout 0: b is [N,K]; 1: b is [K,N]."""
     lib = _lib.load()
@@ -76,6 +79,7 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), lda, _p(b2), ldb, _p(out), ldc
     g.bias, g.colscale, g.residual, g.preact, g.workspace = _p(bias), _p(colscale), _p(residual), _p(preact), _p(ws)
     g.rowsum = _p(rowsum)
+    g.precision = GEMM_PRECISION if precision is None else precision
     g.ldr = (N if ldr is None else ldr)
     g.a_layout, g.b_layout, g.M, g.N, g.K = a_layout, b_layout, M, N, K
     g.act, g.res_mod, g.alpha, g.variant = act, res_mod, alpha, variant
@@ -94,8 +98,16 @@ def linear_dgrad(dy, w, accumulate_into=None):
     """dx[..., K] = dy[..., N] @ w[N, K]  (+= accumulate_into)"""
     K = w.shape[1]
     out = None if accumulate_into is None else accumulate_into.reshape(-1, K)
-    dx = gemm(dy, w, b_layout=1, out=out, residual=out)
+    dx = dgrad(dy, w, out=out, residual=out)
     return dx.reshape(*dy.shape[:-1], K)
+
+
+def dgrad(dy, w, **kw):
+    """dx = dy @ w for w stored [N_out, K_in] (the KN operand of dkd_gemm_f32).  In bf16x3 mode the (small) weight is
+    transposed first so the launch becomes NT and takes the split-precision kernel."""
+    if GEMM_PRECISION == PREC_BF16X3 and kw.get("precision") is None:
+        return gemm(dy, transpose(w.reshape(-1, w.shape[-1])), **kw)
+    return gemm(dy, w, b_layout=1, **kw)
 
 
 def linear_wgrad(dy, x, with_bias_grad=False):

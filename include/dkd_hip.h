@@ -42,6 +42,8 @@ int dkd_abi_version(void);
  * Requirements: contiguous extent and leading dimension of A and B multiples of 4 floats, 16-byte aligned bases.
  * `workspace` (dkd_gemm_f32_workspace_bytes) enables split-K for small-output / long-reduction shapes (wgrad).
  */
+#define DKD_PREC_F32 0
+#define DKD_PREC_BF16X3 1
 typedef struct dkd_gemm_args {
     const float* A;
     int64_t lda;
@@ -63,6 +65,8 @@ typedef struct dkd_gemm_args {
     int32_t row_grp, row_grp_stride, row_off;
     float alpha;
     int32_t variant; /* 0 = automatic tile/schedule choice; >0 pins a kernel variant (tuning / A-B tests) */
+    int32_t precision; /* DKD_PREC_F32 (exact fp32 MFMA, default) or DKD_PREC_BF16X3 (3-way bf16 split, fp32 accumulate;
+                          NT layout only, other layouts silently use the exact path) */
 } dkd_gemm_args;
 int dkd_gemm_f32(const dkd_gemm_args* args, void* stream);
 int dkd_gemm_f32_splits(int M, int N, int K);
