@@ -149,25 +149,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __re
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rs += As[kk * SA::LDS_LD + tid];
         }
-        // all fragments of the k-tile are read from LDS up front (BK/2 * (TM + TN) registers), then the MFMAs issue
-        // back to back with no LDS wait in between (the per-k-pair read -> wait -> MFMA pattern hipcc otherwise emits
-        // exposes the LDS latency in front of every MFMA group)
-        float a[BK / 2][TM], b[BK / 2][TN];
+        // (reading every fragment of the k-tile up front behind a sched_barrier, or double-buffering the fragment registers,
+        // measured 0-5 % SLOWER than letting hipcc interleave read -> wait -> MFMA per k-pair: the MFMA pipe, not the LDS
+        // latency, paces the wave; gpurun_out/tune*.log)
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
+            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[s][i] = As[(2 * s + half) * SA::LDS_LD + (wm * TM + i) * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = As[(2 * s + half) * SA::LDS_LD + (wm * TM + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[s][j] = Bs[(2 * s + half) * SB::LDS_LD + (wn * TN + j) * 32 + l31];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep hipcc from sinking the reads back in front of their MFMAs
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s)
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * s + half) * SB::LDS_LD + (wn * TN + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
     };
     if (nk > 0) {
         sa.load(A, lda, bm0, M, kbeg, kend, tid);
@@ -450,11 +447,21 @@ static int pick_splits(int M, int N, int K, int cfg) {
     cfg_tile(cfg, &bm, &bn);
     const long tiles = (long)dkd_cdiv(M, bm) * dkd_cdiv(N, bn);
     if (tiles >= 384 || K < 1024) return 1;
-    long want = (1024 + tiles - 1) / tiles, maxs = K / 512;
+    long maxs = K / 256;  // >= 16 k-tiles per split
     if (maxs < 1) maxs = 1;
-    if (want > maxs) want = maxs;
-    if (want > 128) want = 128;
-    return (int)(want < 1 ? 1 : want);
+    if (maxs > 128) maxs = 128;
+    // among the split counts that give 512..1280 workgroups pick the one whose grid fills whole rounds of the 256 CUs best
+    // (co-resident workgroups share a CU's matrix pipes, so a CU holding one workgroup more than the others finishes last)
+    long best = 1;
+    double best_eff = 0.0;
+    for (long sp = 1; sp <= maxs; ++sp) {
+        const long blocks = tiles * sp;
+        if (blocks < 512 && sp < maxs) continue;
+        if (blocks > 1280 && best_eff > 0.0) break;
+        const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+    }
+    return (int)best;
 }
 
 extern "C" int dkd_gemm_f32_splits(int M, int N, int K) { return pick_splits(M, N, K, pick_cfg(M, N, 0)); }
