@@ -112,14 +112,43 @@ __device__ __forceinline__ void store_T(const f32x16 (&acc)[Cfg<HD>::DCH], float
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K/V tile staging split in two halves so the global loads of tile t+1 fly under the MFMA block of tile t
+// (issue early / write late), with the LDS image double-buffered: one barrier per key tile.
+template <int HD, int NT>
+struct TileRegs {
+    static constexpr int V4 = HD / 4, TOTAL = 32 * V4, NV = (TOTAL + NT - 1) / NT;
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float* __restrict__ base, long rs, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT, r = idx / V4, c4 = idx % V4;
+            v[i] = (idx < TOTAL && row0 + r < nrows) ? *reinterpret_cast<const float4*>(base + (long)(row0 + r) * rs + 4 * c4)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+        constexpr int LDW = Cfg<HD>::LDW;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT, r = idx / V4, c4 = idx % V4;
+            if (idx < TOTAL) {
+                float* d = S + r * LDW + 4 * c4;
+                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            }
+        }
+    }
+};
+
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
     using C = Cfg<HD>;
-    constexpr int NT = NW * 64;
-    __shared__ float Ks[32 * C::LDW], Vs[32 * C::LDW];
+    constexpr int NT = NW * 64, TSZ = 32 * C::LDW;
+    __shared__ float smem[4 * TSZ];  // [buffer][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = (blockIdx.x * NW + wid) * 32 + l31;
+    const int q0 = (blockIdx.x * NW + wid) * 32;
+    const int q = q0 + l31;
+    const bool active = q0 < a.Nq;  // wave-uniform: waves past the last query only help staging
     const float* Qb = a.q + b * a.q_bs + h * HD;
     const float* Kb = a.k + b * a.k_bs + h * HD;
     const float* Vb = a.v + b * a.v_bs + h * HD;
@@ -132,39 +161,56 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     float m = -INFINITY, l = 0.f;
-    zero_pad_cols<HD, NT>(Ks, tid);
-    zero_pad_cols<HD, NT>(Vs, tid);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) zero_pad_cols<HD, NT>(smem + t * TSZ, tid);
 
+    TileRegs<HD, NT> kr, vr;
     const int nkt = (a.Nk + 31) / 32;
+    kr.load(Kb, a.k_rs, 0, a.Nk, tid);
+    vr.load(Vb, a.v_rs, 0, a.Nk, tid);
+    kr.store(smem, tid);
+    vr.store(smem + TSZ, tid);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        stage_tile<HD, NT>(Ks, Kb, a.k_rs, kt * 32, a.Nk, tid);
-        stage_tile<HD, NT>(Vs, Vb, a.v_rs, kt * 32, a.Nk, tid);
-        __syncthreads();
-        f32x16 s = tile_times_frag<HD>(Ks, qf, l31, half);
-        float mt = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (kt * 32 + frag_row(r, half) >= a.Nk) s[r] = -INFINITY;
-            mt = fmaxf(mt, s[r]);
+        const float* Ks = smem + (kt & 1) * 2 * TSZ;
+        const float* Vs = Ks + TSZ;
+        if (kt + 1 < nkt) {
+            kr.load(Kb, a.k_rs, (kt + 1) * 32, a.Nk, tid);
+            vr.load(Vb, a.v_rs, (kt + 1) * 32, a.Nk, tid);
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mn = fmaxf(m, mt);
-        const float alpha = exp2f(m - mn);
-        float ls = 0.f;
+        if (active) {
+            f32x16 s = tile_times_frag<HD>(Ks, qf, l31, half);
+            float mt = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = exp2f(s[r] - mn);
-            ls += s[r];
+            for (int r = 0; r < 16; ++r) {
+                if (kt * 32 + frag_row(r, half) >= a.Nk) s[r] = -INFINITY;
+                mt = fmaxf(mt, s[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mn = fmaxf(m, mt);
+            const float alpha = exp2f(m - mn);
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(s[r] - mn);
+                ls += s[r];
+            }
+            l = l * alpha + ls;
+            m = mn;
+#pragma unroll
+            for (int c = 0; c < C::DCH; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+            tileT_times_regs<HD>(o, Vs, s, l31, half);
         }
-        l = l * alpha + ls;
-        m = mn;
-#pragma unroll
-        for (int c = 0; c < C::DCH; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
-        tileT_times_regs<HD>(o, Vs, s, l31, half);
+        if (kt + 1 < nkt) {
+            float* Kn = smem + ((kt + 1) & 1) * 2 * TSZ;
+            kr.store(Kn, tid);
+            vr.store(Kn + TSZ, tid);
+        }
+        __syncthreads();
     }
+    if (!active) return;
     l += __shfl_xor(l, 32, 64);
     store_T<HD>(o, a.o + b * a.o_bs + h * HD, a.o_rs, q, a.Nq, half, 1.f / l);
     if (a.lse && half == 0 && q < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + q] = m + log2f(l);  // log2 units
@@ -285,6 +331,18 @@ int pick_nw(int n) {  // waves per workgroup (32 rows each): least padded rows, 
     const int w4 = (n + 127) / 128 * 128 - n, w2 = (n + 63) / 64 * 64 - n;
     return w2 < w4 ? 2 : 4;
 }
+// forward: waves past the last query skip the matrix work but still occupy a wave slot for the whole key loop, so pick
+// the workgroup size in {4, 3, 2} waves that wastes the fewest slots (257 teacher tokens = 9 query waves -> 3 x 3;
+// 5-wave workgroups measured 10-60 % slower: one SIMD carries two of the waves)
+int pick_nw_fwd(int n) {
+    const int nwaves = (n + 31) / 32;
+    int best = 4, best_slots = (nwaves + 3) / 4 * 4;
+    for (int nw = 3; nw >= 2; --nw) {
+        const int slots = (nwaves + nw - 1) / nw * nw;
+        if (slots < best_slots) { best = nw; best_slots = slots; }
+    }
+    return best;
+}
 
 bool strides_ok(const dkd_attn_args* a, bool bwd) {
     const int64_t s[] = {a->q_bs, a->q_rs, a->k_bs, a->k_rs, a->v_bs, a->v_rs, a->o_bs, a->o_rs};
@@ -300,10 +358,15 @@ bool strides_ok(const dkd_attn_args* a, bool bwd) {
 
 template <int HD>
 int launch_fwd(const dkd_attn_args* a, hipStream_t st) {
-    const int nw = pick_nw(a->Nq);
+    const int nw = pick_nw_fwd(a->Nq);
     dim3 grid((a->Nq + 32 * nw - 1) / (32 * nw), a->H, a->B);
-    if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(128), 0, st, *a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<HD, 4>), grid, dim3(256), 0, st, *a);
+    switch (nw) {
+        case 1: hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(64), 0, st, *a); break;
+        case 2: hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(128), 0, st, *a); break;
+        case 3: hipLaunchKernelGGL((attn_fwd_kernel<HD, 3>), grid, dim3(192), 0, st, *a); break;
+        case 4: hipLaunchKernelGGL((attn_fwd_kernel<HD, 4>), grid, dim3(256), 0, st, *a); break;
+        default: hipLaunchKernelGGL((attn_fwd_kernel<HD, 5>), grid, dim3(320), 0, st, *a); break;
+    }
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
