@@ -19,6 +19,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 def init_process_group_from_env(backend=None):
     if dist.is_initialized():
@@ -57,6 +59,7 @@ class GradBucketReducer:
         if self.world > 1:
             for p, _, _ in optimizer.layout:
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            ops.add_grad_listener(self._on_grad)  # gradients written from the side stream bypass autograd's accumulation
         self.reset()
 
     def reset(self):
@@ -70,6 +73,8 @@ class GradBucketReducer:
         self.launched[bi] = True
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream())
+            if ops._side_streams:
+                self.side.wait_stream(ops.wgrad_stream())
             with torch.cuda.stream(self.side):
                 buf.div_(self.world)  # SUM of pre-divided grads == AVG (no ReduceOp.AVG on gloo)
                 self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
@@ -78,6 +83,8 @@ class GradBucketReducer:
             self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
 
     def _on_grad(self, p):
+        if id(p) not in self.param_bucket:
+            return
         bi = self.param_bucket[id(p)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and not self.launched[bi]:
@@ -106,6 +113,7 @@ class GradBucketReducer:
         for h in self.hooks:
             h.remove()
         self.hooks = []
+        ops.remove_grad_listener(self._on_grad)
 
 
 def allreduce_metrics(values, process_group=None):

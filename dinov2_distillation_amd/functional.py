@@ -19,6 +19,24 @@ def colsum(x2d):
     return ops.colreduce(x2d, ops.RED_SUM).reshape(-1)
 
 
+def wgrad(dy2, x2, w, b, need_w=True, need_b=True, transform=None, reshape=None):
+    """Weight (+bias) gradient of y = x W^T + b.  Returns (dW, db); in async mode (ops.can_async) the launches go to the side
+    stream straight into w.grad / b.grad and (None, None) is returned."""
+    if need_w and (b is None or need_b) and ops.can_async(w, b):
+        ops.wgrad_into(dy2, x2, w, b, transform)
+        return None, None
+    dw = db = None
+    if need_w and b is not None and need_b:
+        dw, db = ops.linear_wgrad(dy2, x2, True)
+    elif need_w:
+        dw = ops.linear_wgrad(dy2, x2)
+    elif b is not None and need_b:
+        db = colsum(dy2)
+    if dw is not None and reshape is not None:
+        dw = reshape(dw)
+    return dw, db
+
+
 # =====================================================================================================================
 class LinearFn(Function):
     """y = act(x W^T + b) (+ residual).  Replaces nn.Linear / 1x1 conv call sites (include/dkd_hip.h, GEMM)."""
@@ -31,6 +49,7 @@ class LinearFn(Function):
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, w, y if act == ops.ACT_RELU else None)
         ctx.has_bias = b is not None
+        ctx.params = (w, b)
         return y
 
     @staticmethod
@@ -43,13 +62,7 @@ class LinearFn(Function):
             dy = ops.relu_bwd(dy, y)
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
-            dw, db = ops.linear_wgrad(dy2, x2, True)
-        elif ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy2, x2)
-        elif ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2)
+        dw, db = wgrad(dy2, x2, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None, dres
 
 
@@ -111,6 +124,7 @@ class PatchConvFn(Function):
         y = ops.gemm(rows, w2, bias=b)
         ctx.save_for_backward(rows, w2)
         ctx.meta = (k, src_nchw, tuple(x.shape), tuple(w.shape))
+        ctx.params = (w, b)
         return y.reshape(B, H // k, W // k, O)
 
     @staticmethod
@@ -119,13 +133,15 @@ class PatchConvFn(Function):
         k, src_nchw, xshape, wshape = ctx.meta
         O = wshape[0]
         dy2 = _c(dy).reshape(-1, O)
-        dw2, db = ops.linear_wgrad(dy2, rows, True)
+        w, b = ctx.params
         dx = None
         if src_nchw:
-            dw = dw2.reshape(wshape)
+            dw, db = wgrad(dy2, rows, w, b, reshape=lambda t: t.reshape(wshape))
         else:
             B, H, W, C = xshape
-            dw = ops.transpose(dw2.reshape(O, k * k, C)).reshape(wshape)
+            dw, db = wgrad(dy2, rows, w, b,
+                           transform=lambda t: ops.transpose(t.reshape(O, k * k, C), out=w.grad.view(O, C, k * k)),
+                           reshape=lambda t: ops.transpose(t.reshape(O, k * k, C)).reshape(wshape))
             if ctx.needs_input_grad[0]:
                 drows = ops.dgrad(dy2, w2)
                 dx = ops.unpatchify_nhwc(drows, B, H, W, C, k)
@@ -152,6 +168,7 @@ class ConvNeXtBlockFn(Function):
         out = ops.gemm(y, w2, bias=b2, residual=x.reshape(M, C))
         ctx.save_for_backward(x, wt, d, mean, rstd, n, h, g, y, w1, w2, ln_w, gg, *stats)
         ctx.shapes = (B, H, W, C, tuple(dw_w.shape), tuple(grn_g.shape))
+        ctx.params = (w1, b1, w2, b2)
         return out.reshape(B, H, W, C)
 
     @staticmethod
@@ -161,11 +178,12 @@ class ConvNeXtBlockFn(Function):
         M = B * H * W
         dout = _c(dout)
         do2 = dout.reshape(M, C)
-        dw2, db2 = ops.linear_wgrad(do2, y, True)
+        pw1, pb1, pw2, pb2 = ctx.params
+        dw2, db2 = wgrad(do2, y, pw2, pb2)
         dy = ops.dgrad(do2, w2)  # [M, 4C]
         dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, g, h, (gx, nx, denom), gg, B)
         n2 = n.reshape(M, C)
-        dw1, db1 = ops.linear_wgrad(dh, n2, True)
+        dw1, db1 = wgrad(dh, n2, pw1, pb1)
         dn = ops.dgrad(dh, w1)  # [M, C]
         dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w)
         dd = dd.reshape(B, H, W, C)
@@ -303,6 +321,7 @@ class AttentionProjectorFn(Function):
         ctx.save_for_backward(x2, z, mean, rstd, tok, qin, q, k, v, o, lse, y, m1, r1, zn, f1, f2, m2, r2, *params)
         ctx.meta = (B, N, D, Cs, num_heads, hd, scale, shared, tuple(pos_embed.shape), tuple(wc.shape), tuple(x.shape))
         ctx.window, ctx.training = (wh, ww), training
+        ctx.params = params
         return out.reshape(B, N, D)
 
     @staticmethod
@@ -310,14 +329,15 @@ class AttentionProjectorFn(Function):
         (x2, z, mean, rstd, tok, qin, q, k, v, o, lse, y, m1, r1, zn, f1, f2, m2, r2,
          pos_embed, wc, bc, bn_w, bn_b, wq, bq, wk, bk, wv, bv, wp, bp, w1, b1, w2, b2, n1w, n1b, n2w, n2b) = ctx.saved_tensors
         B, N, D, Cs, H, hd, scale, shared, pos_shape, wc_shape, xshape = ctx.meta
+        (_, P_wc, P_bc, _, _, P_wq, P_bq, P_wk, P_bk, P_wv, P_bv, P_wp, P_bp, P_w1, P_b1, P_w2, P_b2, _, _, _, _) = ctx.params
         M = B * N
         df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w)
-        dw2, db2 = ops.linear_wgrad(df2, f1, True)
+        dw2, db2 = wgrad(df2, f1, P_w2, P_b2)
         df1 = ops.relu_bwd(ops.dgrad(df2, w2), f1)
-        dw1, db1 = ops.linear_wgrad(df1, zn, True)
+        dw1, db1 = wgrad(df1, zn, P_w1, P_b1)
         dzn = ops.dgrad(df1, w1, residual=df2)  # + FFN residual branch
         dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w)
-        dwp, dbp = ops.linear_wgrad(dy, o.reshape(M, D), True)
+        dwp, dbp = wgrad(dy, o.reshape(M, D), P_wp, P_bp)
         do = ops.dgrad(dy, wp).reshape(B, N, D)
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
@@ -337,22 +357,21 @@ class AttentionProjectorFn(Function):
             ops.attention_backward(do, q, k, v, o, lse, H, hd, scale, B, N, N, (0 if shared else N * D, D), st, st,
                                    dq, dk, dv, st, st, st)
         dk, dv = dk.reshape(M, D), dv.reshape(M, D)
-        dwk, dbk = ops.linear_wgrad(dk, tok, True)
-        dwv, dbv = ops.linear_wgrad(dv, tok, True)
+        dwk, dbk = wgrad(dk, tok, P_wk, P_bk)
+        dwv, dbv = wgrad(dv, tok, P_wv, P_bv)
         dtok = ops.dgrad(dk, wk, residual=dy)  # + attention residual branch
         ops.dgrad(dv, wv, out=dtok, residual=dtok)
         if shared:
             dq2 = ops.colreduce(dq.reshape(B, N * D), ops.RED_SUM).reshape(N, D)
         else:
             dq2 = dq.reshape(M, D)
-        dwq, dbq = ops.linear_wgrad(dq2, qin, True)
+        dwq, dbq = wgrad(dq2, qin, P_wq, P_bq)
         dqin = ops.dgrad(dq2, wq)
         dext = None if shared else dqin.reshape(B, N, D)
         dself = dqin if shared else None
         dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D)).reshape(pos_shape)
         dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True)
-        dwc, dbc = ops.linear_wgrad(dz, x2, True)
-        dwc = dwc.reshape(wc_shape)
+        dwc, dbc = wgrad(dz, x2, P_wc, P_bc, reshape=lambda t: t.reshape(wc_shape))
         dx = ops.dgrad(dz, wc.reshape(D, Cs)).reshape(xshape) if ctx.needs_input_grad[0] else None
         return (dx, dext, dself, None, None, None, None, None,
                 dpos, dwc, dbc, dbn_w, dbn_b, dwq, dbq, dwk, dbk, dwv, dbv, dwp, dbp, dw1, db1, dw2, db2,

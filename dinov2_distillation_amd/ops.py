@@ -51,7 +51,7 @@ def workspace(nbytes, device, slot=0):
 # ---------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, colscale=None, residual=None, res_mod=0,
          preact=None, alpha=1.0, row_map=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ldr=None,
-         variant=0, rowsum=None, precision=None):
+         variant=0, rowsum=None, precision=None, ws_slot=0):
     """C = epi(alpha * Aop @ Bop^T).  a/b are 2-D (or flattened-leading-dims) dense tensors:
     a_layout 0: a is [M,K]; 1: a is [K,M].   b_layout 0: b is [N,K]; 1: b is [K,N]."""
     lib = _lib.load()
@@ -75,7 +75,7 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     _chk(out, "out")
     ldc = N if ldc is None else ldc
     wsb = lib.dkd_gemm_f32_workspace_bytes(M, N, K, a_layout, b_layout)
-    ws = workspace(wsb, a.device) if wsb else None
+    ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), lda, _p(b2), ldb, _p(out), ldc
     g.bias, g.colscale, g.residual, g.preact, g.workspace = _p(bias), _p(colscale), _p(residual), _p(preact), _p(ws)
     g.rowsum = _p(rowsum)
@@ -116,6 +116,61 @@ def linear_wgrad(dy, x, with_bias_grad=False):
         return gemm(dy, x, a_layout=1, b_layout=1)
     db = torch.empty(dy.shape[-1], dtype=torch.float32, device=dy.device)
     return gemm(dy, x, a_layout=1, b_layout=1, rowsum=db), db
+
+
+# ---- asynchronous weight gradients ----------------------------------------------------------------------------------
+# dW = dy^T x never feeds the rest of the backward pass: it is only needed by the optimiser.  With arena-backed gradients
+# (FusedAdamW) those GEMMs are launched on a side HIP stream straight into the parameter's .grad view, so the MFMA-bound
+# wgrad launches overlap the HBM-bound element-wise kernels (and fill the tail rounds) of the main dgrad chain.
+ASYNC_WGRAD = False      # switched on by optim.FusedAdamW (every parameter owns a persistent .grad view, used once per backward)
+_side_streams = {}
+_grad_listeners = []     # callables(param): told when a parameter's gradient launch has been enqueued on the side stream
+
+
+def wgrad_stream(device=None):
+    idx = torch.cuda.current_device() if device is None else device.index
+    if idx not in _side_streams:
+        _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return _side_streams[idx]
+
+
+def wgrad_join():
+    """make the current stream wait for every weight-gradient launch issued so far"""
+    if _side_streams:
+        torch.cuda.current_stream().wait_stream(wgrad_stream())
+
+
+def add_grad_listener(fn):
+    _grad_listeners.append(fn)
+
+
+def remove_grad_listener(fn):
+    if fn in _grad_listeners:
+        _grad_listeners.remove(fn)
+
+
+def can_async(*params):
+    return ASYNC_WGRAD and all(p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in params)
+
+
+def wgrad_into(dy2, x2, w, b=None, transform=None):
+    """dW = dy2^T x2 (and db = column sums of dy2) written into w.grad / b.grad on the side stream.
+    transform(dw2) -> None may post-process the raw [N, K] result into w.grad (layout changes) on the same stream."""
+    side = wgrad_stream(dy2.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        N, K = dy2.shape[-1], x2.shape[-1]
+        rs = b.grad.view(-1) if b is not None else None
+        if transform is None:
+            gemm(dy2, x2, a_layout=1, b_layout=1, out=w.grad.view(N, K), rowsum=rs, ws_slot=3)
+        else:
+            transform(gemm(dy2, x2, a_layout=1, b_layout=1, rowsum=rs, ws_slot=3))
+    dy2.record_stream(side)
+    x2.record_stream(side)
+    for p_ in (w, b):
+        if p_ is not None:
+            for fn in _grad_listeners:
+                fn(p_)
 
 
 def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):

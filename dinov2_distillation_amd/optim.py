@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .ops import _p, _stream, workspace
 
 ALIGN = 64  # elements: keep every tensor 256-byte aligned inside the arena
@@ -23,6 +23,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._build_arena()
         self._steps = 0
+        ops.ASYNC_WGRAD = self.flat_g.is_cuda  # weight gradients may now be written into the arena from the side stream
 
     def _build_arena(self):
         plist = []
@@ -65,6 +66,7 @@ class FusedAdamW(torch.optim.Optimizer):
         lib = _lib.load()
         if not self.flat_g.is_cuda:
             raise _lib.DkdError("FusedAdamW needs parameters on the GPU (no CPU path)")
+        ops.wgrad_join()
         ws = workspace(lib.dkd_sumsq_f32_workspace_bytes(self.total), self.flat_g.device, slot=2)
         _lib.check(lib.dkd_sumsq_f32(_p(self.flat_g), self.total, _p(self._gnorm), _p(ws), _stream()), "dkd_sumsq_f32")
         return self._gnorm
@@ -76,6 +78,7 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        ops.wgrad_join()  # the side-stream weight gradients must have landed in the arena
         gn = self.grad_norm() if clip_grad_norm is not None else None
         self._steps += 1
         for g in self.param_groups:

@@ -131,6 +131,12 @@ class DistillationModule(_Base):
             self.log(f"val_{k}", v, sync_dist=True)
         return losses["loss"]
 
+    def on_after_backward(self):
+        """Lightning hook: weight gradients are produced on a side stream (ops.wgrad_into); anything that reads .grad on the
+        main stream afterwards (gradient clipping, loggers) must wait for it."""
+        from .. import ops
+        ops.wgrad_join()
+
     # ---- logging ------------------------------------------------------------------------------------------------------
     def log(self, name, value, **kwargs):
         if _Base is not nn.Module:

@@ -461,3 +461,24 @@ def test_validation_step_eval_mode_vs_oracle():
     close(loss, ref["loss"], "val loss")
     for k, v in before.items():
         assert torch.equal(v, mod.losses.state_dict()[k]), f"{k} must not change in eval mode"
+
+
+def test_async_wgrad_matches_sync_path():
+    """weight gradients launched on the side stream straight into the arena == the synchronous autograd path"""
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()
+    grads = []
+    for mode in (True, False):
+        st = DistillationStepper(seed=1)
+        assert ops.ASYNC_WGRAD  # FusedAdamW switched it on
+        ops.ASYNC_WGRAD = mode
+        st.optimizer.zero_grad()
+        loss = st.module.training_step(x, 0)
+        loss.backward()
+        ops.wgrad_join()
+        torch.cuda.synchronize()
+        grads.append(st.optimizer.flat_g.clone())
+    ops.ASYNC_WGRAD = True
+    assert grads[0].abs().max() > 0
+    close(grads[0], grads[1], "arena gradients, async vs sync", rtol=1e-5)
