@@ -139,8 +139,110 @@ struct TileRegs {
     }
 };
 
+// The <= REM_MAX queries left over after the last full 32-query wave (257 teacher tokens: 1 such query per head instead of
+// a 9th MFMA wave): ONE extra workgroup of the forward launch handles them, all its threads cooperating on one row at a
+// time - threads over keys for the logits, (key-group, d) for the output - so it overlaps the MFMA workgroups.
+// scratch: prob[Nk] + red[NT] + part[NT] floats of LDS (host guarantees Nk + 2*NT <= 4*TSZ).
+template <int HD, int NT>
+__device__ void attn_fwd_row(const dkd_attn_args& a, int q, int h, int b, float* __restrict__ scratch, int tid) {
+    float* prob = scratch;
+    float* red = scratch + ((a.Nk + 3) & ~3);
+    const float* qrow = a.q + b * a.q_bs + (long)q * a.q_rs + h * HD;
+    const float* Kb = a.k + b * a.k_bs + h * HD;
+    const float* Vb = a.v + b * a.v_bs + h * HD;
+    float qv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(qrow + d);
+        qv[d] = x.x; qv[d + 1] = x.y; qv[d + 2] = x.z; qv[d + 3] = x.w;
+    }
+    const float sc = a.scale * LOG2E;
+    float mx = -INFINITY;
+    for (int k = tid; k < a.Nk; k += NT) {
+        const float* kr = Kb + (long)k * a.k_rs;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(kr + d);
+            s += (qv[d] * x.x + qv[d + 1] * x.y) + (qv[d + 2] * x.z + qv[d + 3] * x.w);
+        }
+        s *= sc;
+        prob[k] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < NT / 64; ++w) mx = fmaxf(mx, red[w]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int k = tid; k < a.Nk; k += NT) {
+        const float p = exp2f(prob[k] - mx);
+        prob[k] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    sum = red[0];
+    for (int w = 1; w < NT / 64; ++w) sum += red[w];
+    // output: thread = (key group g, d); HD <= 64 uses NT/64 key groups of 64 lanes, wider heads loop over d
+    constexpr int DL = HD < 64 ? HD : 64;           // lanes along d
+    constexpr int NG = NT / DL;                      // key groups
+    float* part = red + NT;
+    for (int d0 = 0; d0 < HD; d0 += DL) {
+        const int d = d0 + tid % DL, g = tid / DL;
+        float acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+        int k = g;
+        for (; k + 15 * NG < a.Nk; k += 16 * NG) {  // 16 independent loads in flight per thread
+            float vv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) vv[u] = Vb[(long)(k + u * NG) * a.v_rs + d];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u] = fmaf(prob[k + u * NG], vv[u], acc[u]);
+        }
+        for (; k < a.Nk; k += NG) acc[0] = fmaf(prob[k], Vb[(long)k * a.v_rs + d], acc[0]);
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { acc0 += acc[u]; acc1 += acc[u + 1]; acc2 += acc[u + 2]; acc3 += acc[u + 3]; }
+        __syncthreads();
+        part[tid] = (acc0 + acc1) + (acc2 + acc3);
+        __syncthreads();
+        if (tid < DL) {
+            float o = 0.f;
+            for (int gg = 0; gg < NG; ++gg) o += part[gg * DL + tid];
+            a.o[b * a.o_bs + (long)q * a.o_rs + h * HD + d0 + tid] = o / sum;
+        }
+    }
+    if (a.lse && tid == 0) a.lse[((long)b * a.H + h) * a.Nq + q] = mx + log2f(sum);
+    __syncthreads();
+}
+
+// One extra key handled on the VALU (online-softmax update with a single logit): used for the <= REM_MAX keys left over
+// after the last full 32-key tile (the CLS token makes the teacher's N = 32 k + 1), instead of a whole padded MFMA tile.
+constexpr int REM_MAX = 4;
+template <int HD>
+__device__ __forceinline__ void attn_one_key(const float* __restrict__ krow, const float* __restrict__ vrow,
+                                             const float (&qf)[HD / 2], f32x16 (&o)[Cfg<HD>::DCH], float& m, float& l, int half) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD / 2; ++d) s = fmaf(krow[half * (HD / 2) + d], qf[d], s);
+    s += __shfl_xor(s, 32, 64);
+    const float mn = fmaxf(m, s);
+    const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+    l = l * alpha + (half == 0 ? p : 0.f);  // the two halves' partial sums are added at the end: count p once
+    m = mn;
+#pragma unroll
+    for (int c = 0; c < Cfg<HD>::DCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = fmaf(p, vrow[32 * c + frag_row(r, half)], o[c][r] * alpha);
+}
+
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int nq_limit) {
     using C = Cfg<HD>;
     constexpr int NT = NW * 64, TSZ = 32 * C::LDW;
     __shared__ float smem[4 * TSZ];  // [buffer][K | V]
@@ -148,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
     const int b = blockIdx.z, h = blockIdx.y;
     const int q0 = (blockIdx.x * NW + wid) * 32;
     const int q = q0 + l31;
-    const bool active = q0 < a.Nq;  // wave-uniform: waves past the last query only help staging
+    const bool active = q0 < nq_limit;  // wave-uniform: waves past the last query only help staging
     const float* Qb = a.q + b * a.q_bs + h * HD;
     const float* Kb = a.k + b * a.k_bs + h * HD;
     const float* Vb = a.v + b * a.v_bs + h * HD;
@@ -166,6 +268,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
 
     TileRegs<HD, NT> kr, vr;
     const int nkt = (a.Nk + 31) / 32;
+    const int rem = a.Nk & 31;
+    const bool valu_tail = rem > 0 && rem <= REM_MAX && nkt > 1;
     kr.load(Kb, a.k_rs, 0, a.Nk, tid);
     vr.load(Vb, a.v_rs, 0, a.Nk, tid);
     kr.store(smem, tid);
@@ -178,7 +282,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
             kr.load(Kb, a.k_rs, (kt + 1) * 32, a.Nk, tid);
             vr.load(Vb, a.v_rs, (kt + 1) * 32, a.Nk, tid);
         }
-        if (active) {
+        if (active && valu_tail && kt == nkt - 1) {
+            for (int j = 0; j < rem; ++j) attn_one_key<HD>(Ks + j * C::LDW, Vs + j * C::LDW, qf, o, m, l, half);
+        } else if (active) {
             f32x16 s = tile_times_frag<HD>(Ks, qf, l31, half);
             float mt = -INFINITY;
 #pragma unroll
@@ -210,10 +316,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a) {
         }
         __syncthreads();
     }
-    if (!active) return;
-    l += __shfl_xor(l, 32, 64);
-    store_T<HD>(o, a.o + b * a.o_bs + h * HD, a.o_rs, q, a.Nq, half, 1.f / l);
-    if (a.lse && half == 0 && q < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + q] = m + log2f(l);  // log2 units
+    if (active) {
+        l += __shfl_xor(l, 32, 64);
+        store_T<HD>(o, a.o + b * a.o_bs + h * HD, a.o_rs, q, nq_limit, half, 1.f / l);
+        if (a.lse && half == 0 && q < nq_limit) a.lse[((long)b * a.H + h) * a.Nq + q] = m + log2f(l);  // log2 units
+    }
+    // leftover queries (nq_limit < Nq): the LAST workgroup of each (head, image) appends them after its own tiles.  A
+    // separate workgroup for them measured +25 % on the teacher shape: it perturbs the even 3-per-CU placement of the MFMA
+    // workgroups (gpurun_out notes in DESIGN.md).
+    if (nq_limit < a.Nq && blockIdx.x == gridDim.x - 1)
+        for (int qq = nq_limit; qq < a.Nq; ++qq) attn_fwd_row<HD, NT>(a, qq, h, b, smem, tid);
 }
 
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]
@@ -358,15 +470,19 @@ bool strides_ok(const dkd_attn_args* a, bool bwd) {
 
 template <int HD>
 int launch_fwd(const dkd_attn_args* a, hipStream_t st) {
-    const int nw = pick_nw_fwd(a->Nq);
-    dim3 grid((a->Nq + 32 * nw - 1) / (32 * nw), a->H, a->B);
+    // queries left over after the last full wave go to the row kernel when there are only a few of them
+    const int qrem = a->Nq & 31;
+    const bool row_tail = qrem > 0 && qrem <= REM_MAX && a->Nq > 32 && a->Nk + 2 * 256 + 4 <= 4 * 32 * Cfg<HD>::LDW;
+    const int nq_main = row_tail ? a->Nq - qrem : a->Nq;
+    const int nw = pick_nw_fwd(nq_main);
+    dim3 grid((nq_main + 32 * nw - 1) / (32 * nw), a->H, a->B);
     switch (nw) {
-        case 1: hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(64), 0, st, *a); break;
-        case 2: hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(128), 0, st, *a); break;
-        case 3: hipLaunchKernelGGL((attn_fwd_kernel<HD, 3>), grid, dim3(192), 0, st, *a); break;
-        case 4: hipLaunchKernelGGL((attn_fwd_kernel<HD, 4>), grid, dim3(256), 0, st, *a); break;
-        default: hipLaunchKernelGGL((attn_fwd_kernel<HD, 5>), grid, dim3(320), 0, st, *a); break;
+        case 1: hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(64), 0, st, *a, nq_main); break;
+        case 2: hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(128), 0, st, *a, nq_main); break;
+        case 3: hipLaunchKernelGGL((attn_fwd_kernel<HD, 3>), grid, dim3(192), 0, st, *a, nq_main); break;
+        default: hipLaunchKernelGGL((attn_fwd_kernel<HD, 4>), grid, dim3(256), 0, st, *a, nq_main); break;
     }
+
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -8,6 +8,7 @@ straight into the arena, (ii) the DDP all-reduce works on contiguous bucket slic
 (iii) the whole optimiser is 2 + n_groups kernel launches.
 """
 import ctypes
+import os
 
 import torch
 
@@ -23,7 +24,8 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._build_arena()
         self._steps = 0
-        ops.ASYNC_WGRAD = self.flat_g.is_cuda  # weight gradients may now be written into the arena from the side stream
+        # weight gradients may now be written into the arena from the side stream (DKD_ASYNC_WGRAD=0 keeps one stream)
+        ops.ASYNC_WGRAD = self.flat_g.is_cuda and os.environ.get("DKD_ASYNC_WGRAD", "1") != "0"
 
     def _build_arena(self):
         plist = []
