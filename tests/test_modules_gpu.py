@@ -481,3 +481,38 @@ def test_async_wgrad_matches_sync_path():
     ops.ASYNC_WGRAD = True
     assert grads[0].abs().max() > 0
     close(grads[0], grads[1], "arena gradients, async vs sync", rtol=1e-5)
+
+
+def test_fused_clip_adamw_vs_oracle():
+    """A14: gradient_clip_val=1.0 ("norm") + AdamW (lr 1e-3, betas .9/.999, wd .01) over the flat arena vs the oracle's
+    restatement of torch.optim.AdamW / clip_grad_norm_ (which is itself checked against torch here), 3 steps."""
+    import torch.nn as nn
+    from dinov2_distillation_amd.optim import FusedAdamW
+    from oracle import step_oracle as so
+    g = torch.Generator().manual_seed(0)
+    shapes = [(96, 3, 4, 4), (96,), (384, 96), (1, 1, 1, 384), (37,), (1536, 384)]
+    ps = [nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    ref_p = [p.detach().clone() for p in ps]
+    tp = [nn.Parameter(p.detach().clone()) for p in ps]
+    topt = torch.optim.AdamW(tp, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    m_ = [torch.zeros_like(p) for p in ref_p]
+    v_ = [torch.zeros_like(p) for p in ref_p]
+    dev = [nn.Parameter(p.detach().clone().cuda()) for p in ps]
+    opt = FusedAdamW([{"params": dev[:3]}, {"params": dev[3:]}], lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    for step in range(1, 4):
+        grads = [torch.randn(*s, generator=g) * (3.0 if step == 1 else 0.01) for s in shapes]  # step 1 clips, later ones do not
+        opt.zero_grad()
+        for p, gr in zip(dev, grads):
+            p.grad.copy_(gr.cuda())
+        opt.step(clip_grad_norm=1.0)
+        gref = [gr.clone() for gr in grads]
+        total = so.clip_grad_norm_(gref, 1.0)
+        so.adamw_step_(ref_p, gref, m_, v_, step)
+        for p, gr in zip(tp, grads):
+            p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(tp, 1.0)
+        topt.step()
+        close(opt._gnorm[1], total, f"grad norm step {step}", rtol=1e-5)
+        for a, b, c in zip(dev, ref_p, tp):
+            close(a, b, f"param after step {step} (vs oracle)", rtol=2e-6)
+            close(b, c.detach(), f"oracle vs torch.optim.AdamW step {step}", rtol=2e-6)
