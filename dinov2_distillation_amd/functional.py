@@ -19,6 +19,21 @@ def colsum(x2d):
     return ops.colreduce(x2d, ops.RED_SUM).reshape(-1)
 
 
+def direct(*params):
+    """gradient destinations for small (used-once) parameters: their arena views when every one of them can be written in
+    place, else Nones (-> the gradients are returned to autograd)"""
+    outs = [ops.grad_out(p) for p in params]
+    return outs if all(o is not None for o in outs) else [None] * len(params)
+
+
+def ret(out, value, param):
+    """what backward returns for `param`: None once the gradient sits in its arena view (DDP reducer notified)"""
+    if out is None:
+        return value
+    ops.grad_done(param)
+    return None
+
+
 def wgrad(dy2, x2, w, b, need_w=True, need_b=True, transform=None, reshape=None):
     """Weight (+bias) gradient of y = x W^T + b.  Returns (dW, db); in async mode (ops.can_async) the launches go to the side
     stream straight into w.grad / b.grad and (None, None) is returned."""
@@ -76,14 +91,16 @@ class LayerNormFn(Function):
         x = _c(x)
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
         ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, gamma = ctx.saved_tensors
         affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        dx, dg, db = ops.layernorm_bwd(_c(dy), x, mean, rstd, gamma, affine=affine)
-        return dx, dg, db, None
+        og, ob = direct(*ctx.params) if affine else (None, None)
+        dx, dg, db = ops.layernorm_bwd(_c(dy), x, mean, rstd, gamma, affine=affine, dg_out=og, db_out=ob)
+        return dx, ret(og, dg, ctx.params[0]), ret(ob, db, ctx.params[1]), None
 
 
 def layer_norm(x, gamma, beta, eps):
@@ -169,6 +186,7 @@ class ConvNeXtBlockFn(Function):
         ctx.save_for_backward(x, wt, d, mean, rstd, n, h, g, y, w1, w2, ln_w, gg, *stats)
         ctx.shapes = (B, H, W, C, tuple(dw_w.shape), tuple(grn_g.shape))
         ctx.params = (w1, b1, w2, b2)
+        ctx.small = (dw_w, dw_b, ln_w, ln_b, grn_g, grn_b)
         return out.reshape(B, H, W, C)
 
     @staticmethod
@@ -181,16 +199,20 @@ class ConvNeXtBlockFn(Function):
         pw1, pb1, pw2, pb2 = ctx.params
         dw2, db2 = wgrad(do2, y, pw2, pb2)
         dy = ops.dgrad(do2, w2)  # [M, 4C]
-        dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, g, h, (gx, nx, denom), gg, B)
+        p_dww, p_dwb, p_lnw, p_lnb, p_gg, p_gb = ctx.small
+        o_dww, o_dwb, o_lnw, o_lnb, o_gg, o_gb = direct(*ctx.small)
+        dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, g, h, (gx, nx, denom), gg, B,
+                                              None if o_gg is None else o_gg.view(-1), None if o_gb is None else o_gb.view(-1))
         n2 = n.reshape(M, C)
         dw1, db1 = wgrad(dh, n2, pw1, pb1)
         dn = ops.dgrad(dh, w1)  # [M, C]
-        dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w)
+        dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w, dg_out=o_lnw, db_out=o_lnb)
         dd = dd.reshape(B, H, W, C)
         dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
-        ddw = ops.transpose(ops.dwconv7_wgrad(x, dd)).reshape(dw_shape)
-        ddb = colsum(dd.reshape(M, C))
-        return (dx, ddw, ddb, dln_w, dln_b, dw1, db1, dgrn_g.reshape(grn_shape), dgrn_b.reshape(grn_shape), dw2, db2)
+        ddw = ops.transpose(ops.dwconv7_wgrad(x, dd), out=None if o_dww is None else o_dww.view(C, 49)).reshape(dw_shape)
+        ddb = ops.colreduce(dd.reshape(M, C), ops.RED_SUM, out=None if o_dwb is None else o_dwb.view(1, C)).reshape(-1)
+        return (dx, ret(o_dww, ddw, p_dww), ret(o_dwb, ddb, p_dwb), ret(o_lnw, dln_w, p_lnw), ret(o_lnb, dln_b, p_lnb),
+                dw1, db1, ret(o_gg, dgrn_g.reshape(grn_shape), p_gg), ret(o_gb, dgrn_b.reshape(grn_shape), p_gb), dw2, db2)
 
 
 # =====================================================================================================================
@@ -329,14 +351,16 @@ class AttentionProjectorFn(Function):
         (x2, z, mean, rstd, tok, qin, q, k, v, o, lse, y, m1, r1, zn, f1, f2, m2, r2,
          pos_embed, wc, bc, bn_w, bn_b, wq, bq, wk, bk, wv, bv, wp, bp, w1, b1, w2, b2, n1w, n1b, n2w, n2b) = ctx.saved_tensors
         B, N, D, Cs, H, hd, scale, shared, pos_shape, wc_shape, xshape = ctx.meta
-        (_, P_wc, P_bc, _, _, P_wq, P_bq, P_wk, P_bk, P_wv, P_bv, P_wp, P_bp, P_w1, P_b1, P_w2, P_b2, _, _, _, _) = ctx.params
+        (P_pos, P_wc, P_bc, P_bnw, P_bnb, P_wq, P_bq, P_wk, P_bk, P_wv, P_bv, P_wp, P_bp, P_w1, P_b1, P_w2, P_b2,
+         P_n1w, P_n1b, P_n2w, P_n2b) = ctx.params
+        o_pos, o_bnw, o_bnb, o_n1w, o_n1b, o_n2w, o_n2b = direct(P_pos, P_bnw, P_bnb, P_n1w, P_n1b, P_n2w, P_n2b)
         M = B * N
-        df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w)
+        df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w, dg_out=o_n2w, db_out=o_n2b)
         dw2, db2 = wgrad(df2, f1, P_w2, P_b2)
         df1 = ops.relu_bwd(ops.dgrad(df2, w2), f1)
         dw1, db1 = wgrad(df1, zn, P_w1, P_b1)
         dzn = ops.dgrad(df1, w1, residual=df2)  # + FFN residual branch
-        dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w)
+        dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w, dg_out=o_n1w, db_out=o_n1b)
         dwp, dbp = wgrad(dy, o.reshape(M, D), P_wp, P_bp)
         do = ops.dgrad(dy, wp).reshape(B, N, D)
         if not ctx.training:
@@ -369,13 +393,15 @@ class AttentionProjectorFn(Function):
         dqin = ops.dgrad(dq2, wq)
         dext = None if shared else dqin.reshape(B, N, D)
         dself = dqin if shared else None
-        dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D)).reshape(pos_shape)
-        dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True)
+        dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D),
+                             out=None if o_pos is None else o_pos.view(D, N)).reshape(pos_shape)
+        dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True, dgamma_out=o_bnw, dbeta_out=o_bnb)
         dwc, dbc = wgrad(dz, x2, P_wc, P_bc, reshape=lambda t: t.reshape(wc_shape))
         dx = ops.dgrad(dz, wc.reshape(D, Cs)).reshape(xshape) if ctx.needs_input_grad[0] else None
         return (dx, dext, dself, None, None, None, None, None,
-                dpos, dwc, dbc, dbn_w, dbn_b, dwq, dbq, dwk, dbk, dwv, dbv, dwp, dbp, dw1, db1, dw2, db2,
-                dn1w, dn1b, dn2w, dn2b)
+                ret(o_pos, dpos, P_pos), dwc, dbc, ret(o_bnw, dbn_w, P_bnw), ret(o_bnb, dbn_b, P_bnb), dwq, dbq, dwk, dbk,
+                dwv, dbv, dwp, dbp, dw1, db1, dw2, db2, ret(o_n1w, dn1w, P_n1w), ret(o_n1b, dn1b, P_n1b),
+                ret(o_n2w, dn2w, P_n2w), ret(o_n2b, dn2b, P_n2b))
 
 
 # =====================================================================================================================

@@ -173,6 +173,19 @@ def wgrad_into(dy2, x2, w, b=None, transform=None):
                 fn(p_)
 
 
+def grad_out(p):
+    """the parameter's arena gradient view to write a (used-once) gradient into directly, or None (-> return it to autograd)"""
+    return p.grad if can_async(p) else None
+
+
+def grad_done(*params):
+    """tell the DDP reducer that these parameters' gradients have been enqueued (they bypass autograd's accumulation)"""
+    for p_ in params:
+        if p_ is not None:
+            for fn in _grad_listeners:
+                fn(p_)
+
+
 def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):
     """x viewed as [groups, rows_per_group, N] -> out[groups, N]."""
     lib = _lib.load()
@@ -222,7 +235,7 @@ def layernorm_fwd(x, gamma, beta, eps, need_stats=True, in_rows=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True, add=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True, add=None, dg_out=None, db_out=None):
     lib = _lib.load()
     _chk(dy, "dy"), _chk(x, "x")
     C = x.shape[-1]
@@ -230,8 +243,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True, add=None):
     dx = torch.empty_like(x)
     dg = db = ws = None
     if affine:
-        dg = torch.empty(C, dtype=torch.float32, device=x.device)
-        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device) if dg_out is None else dg_out
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if db_out is None else db_out
         ws = workspace(lib.dkd_layernorm_bwd_f32_workspace_bytes(rows, C), x.device)
     check(lib.dkd_layernorm_bwd_f32(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(add), _p(dx), _p(dg), _p(db), _p(ws),
                                     rows, C, _stream()), "dkd_layernorm_bwd_f32")
@@ -362,7 +375,7 @@ def bn_act_pos_fwd(z, mean, rstd, gamma, beta, pos=None, relu=True):
     return out
 
 
-def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True):
+def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True, dgamma_out=None, dbeta_out=None):
     """-> dz, dgamma, dbeta for out = relu(bn(z)) (+ pos)."""
     lib = _lib.load()
     N = z.shape[-1]
@@ -371,8 +384,8 @@ def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True):
     xhat = torch.empty_like(z)
     check(lib.dkd_bn_bwd_prep_f32(_p(dt), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dbn), _p(xhat), rows, N,
                                   int(relu), _stream()), "dkd_bn_bwd_prep_f32")
-    dbeta = colreduce(dbn, RED_SUM).reshape(N)
-    dgamma = colreduce(dbn, RED_DOT, y=xhat).reshape(N)
+    dbeta = colreduce(dbn, RED_SUM, out=None if dbeta_out is None else dbeta_out.view(1, N)).reshape(N)
+    dgamma = colreduce(dbn, RED_DOT, y=xhat, out=None if dgamma_out is None else dgamma_out.view(1, N)).reshape(N)
     dz = torch.empty_like(z)
     check(lib.dkd_bn_bwd_apply_f32(_p(dbn), _p(xhat), _p(dbeta), _p(dgamma), _p(gamma), _p(rstd), _p(dz), rows, N,
                                    _stream()), "dkd_bn_bwd_apply_f32")
@@ -459,7 +472,7 @@ def grn_fwd(g, gamma, beta, B):
     return y, (gx, nx, denom)
 
 
-def grn_gelu_bwd(dy, g, h, stats, gamma, B):
+def grn_gelu_bwd(dy, g, h, stats, gamma, B, dgamma_out=None, dbeta_out=None):
     """-> dh (through GRN and GELU), dgamma, dbeta"""
     lib = _lib.load()
     gx, nx, denom = stats
@@ -467,11 +480,11 @@ def grn_gelu_bwd(dy, g, h, stats, gamma, B):
     rpi = g.numel() // C // B
     both = colreduce(dy, RED_DOT_SUM, y=g, groups=B)  # one pass: [0] = sum_hw dy*g, [1] = sum_hw dy, per image
     A = both[0]
-    dbeta = colreduce(both[1], RED_SUM).reshape(C)
+    dbeta = colreduce(both[1], RED_SUM, out=None if dbeta_out is None else dbeta_out.view(1, C)).reshape(C)
     coef, dgp = torch.empty_like(A), torch.empty_like(A)
     check(lib.dkd_grn_bwd_stats_f32(_p(A), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgp), B, C, _stream()),
           "dkd_grn_bwd_stats_f32")
-    dgamma = colreduce(dgp, RED_SUM).reshape(C)
+    dgamma = colreduce(dgp, RED_SUM, out=None if dgamma_out is None else dgamma_out.view(1, C)).reshape(C)
     dh = torch.empty_like(g)
     check(lib.dkd_grn_gelu_bwd_f32(_p(dy), _p(g), _p(h), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
           "dkd_grn_gelu_bwd_f32")
