@@ -66,6 +66,7 @@ class GradBucketReducer:
         self.pending = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.handles = []
+        self.seen = set()
 
     def _launch(self, bi):
         start, end, _ = self.buckets[bi]
@@ -83,8 +84,12 @@ class GradBucketReducer:
             self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
 
     def _on_grad(self, p):
-        if id(p) not in self.param_bucket:
+        # A parameter whose gradient was written straight into the arena is announced by the ops listener (after its
+        # kernel has been enqueued); autograd then STILL runs the post-accumulate hook for the None that backward returned.
+        # Count each parameter once per step, or buckets launch before their last gradients have been enqueued.
+        if id(p) not in self.param_bucket or id(p) in self.seen:
             return
+        self.seen.add(id(p))
         bi = self.param_bucket[id(p)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and not self.launched[bi]:

@@ -105,6 +105,31 @@ def _ddp_worker(rank, world, port, q):
     assert "NCCL_P2P_DISABLE" not in os.environ
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 70), torch.nn.Linear(70, 5))
+    from dinov2_distillation_amd import ops
+
+    class DirectLinear(torch.autograd.Function):
+        """the product's "direct" gradient path in miniature: backward writes dW/db into the arena views itself, announces
+        them through ops.grad_done and returns None (autograd still runs the post-accumulate hook for such a None)."""
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x)
+            ctx.params = (w, b)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            (x,) = ctx.saved_tensors
+            w, b = ctx.params
+            dx = dy @ w
+            w.grad.copy_(dy.t() @ x)
+            b.grad.copy_(dy.sum(0))
+            ops.grad_done(w, b)
+            return dx, None, None
+
+    def forward_direct(x):
+        h = torch.relu(net[0](x))
+        h = DirectLinear.apply(h, net[2].weight, net[2].bias)
+        return net[3](h)
 
     class FlatOpt:  # the arena layout FusedAdamW builds, on CPU tensors
         def __init__(self, params):
@@ -125,13 +150,13 @@ def _ddp_worker(rank, world, port, q):
     if rank == 1:
         with torch.no_grad():
             opt.flat_p.add_(1.0)  # diverge on purpose: broadcast must restore rank 0's weights
-    red = GradBucketReducer(opt, bucket_bytes=4096 * 4)
-    assert len(red.buckets) >= 3
+    red = GradBucketReducer(opt, bucket_bytes=33600 * 4)  # -> [w0 b0 w2 b2] [w3 b3]: the direct-written pair shares a bucket
+    assert [b[2] for b in red.buckets] == [4, 2]
     red.broadcast_parameters(0)
     x = torch.randn(8, 40, generator=torch.Generator().manual_seed(100 + rank))
-    for _ in range(2):  # two steps: hooks re-arm
+    for it in range(3):  # several steps: hooks re-arm; the last one mixes autograd-accumulated and directly written gradients
         opt.flat_g.zero_()
-        net(x).pow(2).sum().backward()
+        (forward_direct(x) if it == 2 else net(x)).pow(2).sum().backward()
         assert any(red.launched), "buckets must be launched from the grad hooks during backward"
         red.finish()
     # reference: average of the per-rank gradients computed in one process
