@@ -9,6 +9,7 @@ What is imported from the reference:
     train/distillation_module.py       -> DistillationModule.training_step with stand-in teacher/student
     models/backbones/convnext.py       -> D2ConvNextV2
     models/backbones/stdc.py           -> STDCNet (CatBottleneck path)
+    models/backbones/swin.py           -> SwinTransformer (drop rate 0)
     models/backbones/resnet.py         -> BasicStem, BottleneckBlock, ResNet (fvcore.c2_msra_fill stand-in = its definition)
 The DINOv2 teacher is NOT imported (external torch.hub dependency, fetch denied): the step fixture uses a
 stand-in teacher whose ``.model.blocks`` are this repo's own oracle ViT blocks with seeded weights.
@@ -305,6 +306,47 @@ def gen_resnet():
     _save("resnet_small", **arrays)
 
 
+def gen_swin():
+    """SwinTransformer (models/backbones/swin.py) at drop rate 0: odd grids, window padding, shifted masks, patch merging."""
+    sw = _load_file("ref_swin", "models/backbones/swin.py")
+    torch.manual_seed(41)
+    dim, depths, heads, ws = 16, [2, 2, 2, 2], [1, 1, 2, 4], 7
+    net = sw.SwinTransformer(pretrain_img_size=224, patch_size=4, in_chans=3, embed_dim=dim, depths=depths, num_heads=heads,
+                             window_size=ws, mlp_ratio=[4, 4, 4, 4], qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                             attn_drop_rate=0.0, drop_path_rate=0.0)
+    net.train()
+    with torch.no_grad():  # default init leaves LN at (1,0) and the bias table at 0.02: perturb so they matter
+        for n_, p_ in net.named_parameters():
+            if not p_.requires_grad:
+                continue
+            if "relative_position_bias_table" in n_:
+                p_.mul_(25.0)
+            elif p_.dim() == 1:
+                p_.add_(0.2 * torch.randn_like(p_))
+    x = torch.randn(2, 3, 86, 90, requires_grad=True)  # 86,90 -> padded 88,92 -> grids 22x23, 11x12, 6x6, 3x3
+    arrays = {"in/x": _np(x), "meta/depths": np.array(depths), "meta/heads": np.array(heads), "meta/dim": np.array(dim),
+              "meta/window": np.array(ws)}
+    for k, v in net.state_dict().items():
+        arrays["param/" + k] = _np(v)
+    feats = net(x)
+    loss = 0
+    for k in ("res2", "res3", "res4", "res5"):
+        arrays["out/" + k] = _np(feats[k])
+    P = (5, 5)  # ModelWrapper resize (models/model_zoo.py:123-128)
+    for k in ("res4", "res5"):
+        r = torch.nn.functional.interpolate(feats[k], size=P, mode="bilinear", align_corners=False)
+        ct = torch.randn_like(r)
+        arrays["out/resized_" + k] = _np(r)
+        arrays["in/cotangent_" + k] = _np(ct)
+        loss = loss + (r * ct).sum()
+    loss.backward()
+    arrays["grad/x"] = _np(x.grad)
+    for k, p_ in net.named_parameters():
+        if p_.requires_grad and p_.grad is not None:
+            arrays["pgrad/" + k] = _np(p_.grad)
+    _save("swin_small", **arrays)
+
+
 def gen_step():
     """DistillationModule.training_step (train/distillation_module.py:247-276) with stand-ins."""
     from oracle import vit_oracle as vit
@@ -393,6 +435,6 @@ def gen_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "step"]
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "swin", "step"]
     for w in which:
         globals()["gen_" + w]()

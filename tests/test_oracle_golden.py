@@ -108,6 +108,42 @@ def test_convnext(golden_dir):
             close(p[k[6:]].grad, v, k, rtol=5e-4)
 
 
+def test_swin(golden_dir):
+    from oracle import swin_oracle as swo
+    g = load(golden_dir, "swin_small")
+    cfg = dict(embed_dim=int(g["meta/dim"]), depths=[int(v) for v in g["meta/depths"]],
+               num_heads=[int(v) for v in g["meta/heads"]], window=int(g["meta/window"]))
+    p = params_of(g)
+    assert torch.equal(p["layers.0.blocks.0.attn.relative_position_index"], swo.relative_position_index(cfg["window"]))
+    for v in p.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = swo.forward_features(p, x, cfg)
+    for k in ("res2", "res3", "res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+    loss = 0
+    for k in ("res4", "res5"):
+        r = torch.nn.functional.interpolate(feats[k], size=(5, 5), mode="bilinear", align_corners=False)
+        close(r, g["out/resized_" + k], "resized " + k)
+        loss = loss + (r * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x")
+    n = 0
+    for k, v in g.items():
+        if k.startswith("pgrad/"):
+            close(p[k[6:]].grad, v, k, rtol=5e-4)
+            n += 1
+    assert n > 100
+    no_grad = [k for k, v in p.items() if v.dtype.is_floating_point and "pgrad/" + k not in g]
+    assert sorted(no_grad) == ["norm0.bias", "norm0.weight", "norm1.bias", "norm1.weight"]  # feed res2 / res3 only
+    for k in no_grad:
+        assert p[k].grad is None or float(p[k].grad.abs().max()) == 0.0, k
+    # synthetic-init shapes follow the reference state dict
+    q = swo.init_swin_params(cfg, seed=1)
+    assert set(q) == set(p) and all(q[k].shape == p[k].shape for k in p)
+
+
 def test_step_compute_losses(golden_dir):
     g = load(golden_dir, "step_res45")
     D, heads, depth, P, c4, c5, B = [int(v) for v in g["meta"]]
