@@ -22,6 +22,7 @@ _SCALARS = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "int32_t": ctypes.c_int32,
     "int64_t": ctypes.c_int64, "void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "constfloat*": ctypes.c_void_p,
     "constvoid*": ctypes.c_void_p, "int*": ctypes.c_void_p, "constint*": ctypes.c_void_p,
+    "constint32_t*": ctypes.c_void_p, "int32_t*": ctypes.c_void_p,
 }
 
 
@@ -77,6 +78,7 @@ def _make_struct(name, fields):
 STRUCTS = {n: _make_struct(n, f) for n, f in _STRUCT_DEFS.items()}
 GemmArgs = STRUCTS["dkd_gemm_args"]
 AttnArgs = STRUCTS["dkd_attn_args"]
+WinAttnArgs = STRUCTS["dkd_winattn_args"]
 
 _lib = None
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restr
 template <int V>
 __global__ void patchify_nchw_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Cin, int H, int W,
                                      int k) {
-    const int ph = H / k, pw = W / k, kv = k / V, K = Cin * k * k;
+    const int ph = (H + k - 1) / k, pw = (W + k - 1) / k, kv = k / V, K = Cin * k * k;
     const long total = (long)B * ph * pw * Cin * k * kv;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long r = idx;
@@ -126,9 +126,10 @@ __global__ void patchify_nchw_kernel(const float* __restrict__ img, float* __res
         const int b = (int)(r / ph);
         const float* src = img + (((long)b * Cin + c) * H + py * k + ky) * W + px * k + kx;
         float* dst = out + ((long)(b * ph + py) * pw + px) * K + (c * k + ky) * k + kx;
-        if (V == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
-        else if (V == 2) *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(src);
-        else *dst = *src;
+        const bool in = py * k + ky < H && px * k + kx < W;  // W % V == 0: a vector is wholly inside or wholly in the zero pad
+        if (V == 4) *reinterpret_cast<float4*>(dst) = in ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (V == 2) *reinterpret_cast<float2*>(dst) = in ? *reinterpret_cast<const float2*>(src) : make_float2(0.f, 0.f);
+        else *dst = in ? *src : 0.f;
     }
 }
 
@@ -266,9 +267,9 @@ extern "C" int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* 
 }
 
 extern "C" int dkd_patchify_nchw_f32(const float* img, float* out, int B, int Cin, int H, int W, int k, void* stream) {
-    if (!img || !out || B <= 0 || k <= 0 || H % k || W % k) return DKD_ERR_BAD_ARG;
+    if (!img || !out || B <= 0 || k <= 0 || H <= 0 || W <= 0) return DKD_ERR_BAD_ARG;
     const int V = (k % 4 == 0 && W % 4 == 0) ? 4 : ((k % 2 == 0 && W % 2 == 0) ? 2 : 1);
-    const long total = (long)B * Cin * H * W / V;
+    const long total = (long)B * Cin * ((H + k - 1) / k * k) * ((W + k - 1) / k * k) / V;
     dim3 grid(blocks_for(total)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (V == 4) hipLaunchKernelGGL(patchify_nchw_kernel<4>, grid, block, 0, st, img, out, B, Cin, H, W, k);

@@ -1,0 +1,479 @@
+// Swin-Transformer student kernels (models/backbones/swin.py of the reference), gfx950.
+//
+//  * gather_rows      : every token re-ordering of the backbone is ONE row gather with a precomputed int32 map
+//                       (zero-pad + cyclic roll + window partition, :283-306; window merge + un-roll + crop, :313-328;
+//                       PatchMerging's 2x2 concat with odd-grid padding, :359-371) and so is each of their adjoints
+//                       (the maps are injective away from the pad rows).  HBM-bound: reads C floats, writes C floats per row.
+//  * winattn fwd/bwd  : window attention with relative-position bias and shift mask (:151-199).  A window is N = 49
+//                       tokens x head_dim 32: far too small for an MFMA tiling to pay (49 -> 64 padding, 58 % useful),
+//                       and the whole backbone spends ~1 % of the step here, so it is a VALU kernel: one wave per
+//                       (window, head), lane = query row (forward, backward phase 1) or key row (backward phase 2), the
+//                       other operand broadcast from LDS; the N x N logits never leave registers.
+//  * dropout          : counter-based (stateless) Bernoulli mask, regenerated in backward from (seed, offset).
+//  * index_add_rows   : deterministic fold of the [N*N, H] bias gradient into the (2w-1)^2-row table.
+#include "common.h"
+#include "dkd_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---- row gather ---------------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ in, const int* __restrict__ idx, const float* __restrict__ res,
+                                   float* __restrict__ out, long rows, int cq) {
+    const long total = rows * cq;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long r = t / cq;
+        const int c = (int)(t - r * cq);
+        const int s = idx[r];
+        float4 v = s >= 0 ? reinterpret_cast<const float4*>(in)[(long)s * cq + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) {
+            const float4 a = reinterpret_cast<const float4*>(res)[t];
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        reinterpret_cast<float4*>(out)[t] = v;
+    }
+}
+
+// narrow rows (C not a multiple of 4: the [T, heads] relative-position table)
+__global__ void gather_rows_scalar_kernel(const float* __restrict__ in, const int* __restrict__ idx, const float* __restrict__ res,
+                                          float* __restrict__ out, long rows, int C) {
+    const long total = rows * C;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long r = t / C;
+        const int s = idx[r];
+        float v = s >= 0 ? in[(long)s * C + (t - r * C)] : 0.f;
+        if (res) v += res[t];
+        out[t] = v;
+    }
+}
+
+// out[t, :] = sum over rows r with idx[r] == t of src[r, :]   (T and C tiny: (2w-1)^2 x heads)
+__global__ void index_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ out,
+                                      int rows, int C) {
+    const int t = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r)
+            if (idx[r] == t) acc += src[(long)r * C + c];
+        out[(long)t * C + c] = acc;
+    }
+}
+
+// dbias[(ij)*H + h] = sum over parts of part[p][h][ij]
+__global__ void winattn_dbias_kernel(const float* __restrict__ part, float* __restrict__ out, int parts, int H, int NN) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= H * NN) return;
+    const int h = e / NN, ij = e - h * NN;
+    float acc = 0.f;
+    for (int p = 0; p < parts; ++p) acc += part[((long)p * H + h) * NN + ij];
+    out[(long)ij * H + h] = acc;
+}
+
+// ---- dropout ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, uint32_t thresh, float inv_keep,
+                               uint64_t seed, uint64_t offset) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) {
+        const uint64_t h = mix64(seed ^ ((offset + (uint64_t)t) * 0x9E3779B97F4A7C15ull));
+        float4 v = reinterpret_cast<const float4*>(x)[t];
+        v.x = ((uint32_t)(h & 0xFFFF) >= thresh) ? v.x * inv_keep : 0.f;          // 16 random bits per element
+        v.y = ((uint32_t)((h >> 16) & 0xFFFF) >= thresh) ? v.y * inv_keep : 0.f;
+        v.z = ((uint32_t)((h >> 32) & 0xFFFF) >= thresh) ? v.z * inv_keep : 0.f;
+        v.w = ((uint32_t)(h >> 48) >= thresh) ? v.w * inv_keep : 0.f;
+        reinterpret_cast<float4*>(y)[t] = v;
+    }
+}
+
+// ---- window attention ---------------------------------------------------------------------------------------------
+constexpr int WA_WAVES = 4;
+
+template <int N, int HD>
+struct WinCfg {
+    static constexpr int NP = N | 1;      // odd row pitch of the [N][N] bias tile: lane-per-row and lane-per-column reads are conflict-free
+    static constexpr int HP = HD + 4;     // row pitch of the [N][HD] operand tiles (b128 reads by row-owner lanes spread over banks)
+    static constexpr int TILE = N * HP;
+};
+
+// stage rows [N][HD] of one (window, head) from global (row stride rs floats) into an LDS tile with pitch HP; one wave
+template <int N, int HD>
+__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, long rs, int lane) {
+    constexpr int Q = HD / 4, HP = WinCfg<N, HD>::HP;
+    for (int e = lane; e < N * Q; e += 64) {
+        const int r = e / Q, c = (e - r * Q) * 4;
+        st4(dst + r * HP + c, ld4(src + (long)r * rs + c));
+    }
+}
+
+template <int N, int HD>
+__global__ __launch_bounds__(WA_WAVES * 64) void winattn_fwd_kernel(dkd_winattn_args a) {
+    using Cfg = WinCfg<N, HD>;
+    extern __shared__ float smem[];
+    float* sBias = smem;                              // [N][NP]
+    float* sTiles = smem + N * Cfg::NP;               // per wave: K tile, V tile
+    int* sLab = reinterpret_cast<int*>(sTiles + WA_WAVES * 2 * Cfg::TILE);  // per wave: 64 labels
+    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) sBias[(e / N) * Cfg::NP + (e % N)] = a.bias[(long)e * a.H + h];
+    float* sK = sTiles + wave * 2 * Cfg::TILE;
+    float* sV = sK + Cfg::TILE;
+    int* lab = sLab + wave * 64;
+    const bool active = lane < N;
+    for (int base = blockIdx.x * WA_WAVES; base < a.Bw; base += gridDim.x * WA_WAVES) {
+        const int w = base + wave;
+        const bool live = w < a.Bw;
+        __syncthreads();  // bias staged (first trip) / previous trip's tiles no longer read
+        if (live) {
+            const long row0 = (long)w * N;
+            stage_tile<N, HD>(sK, a.k + row0 * a.k_rs + h * HD, a.k_rs, lane);
+            stage_tile<N, HD>(sV, a.v + row0 * a.v_rs + h * HD, a.v_rs, lane);
+            if (a.labels) lab[lane] = active ? a.labels[(long)(w % a.nW) * N + lane] : -1;
+        }
+        __syncthreads();
+        if (!live || !active) continue;
+        const long row = (long)w * N + lane;
+        float q[HD];
+        {
+            const float* qp = a.q + row * a.q_rs + h * HD;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 t = ld4(qp + d);
+                q[d] = t.x * a.scale; q[d + 1] = t.y * a.scale; q[d + 2] = t.z * a.scale; q[d + 3] = t.w * a.scale;
+            }
+        }
+        const int my_lab = a.labels ? lab[lane] : 0;
+        float s[N];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float acc = sBias[lane * Cfg::NP + j];
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 kk = ld4(sK + j * Cfg::HP + d);
+                acc = fmaf(q[d], kk.x, acc); acc = fmaf(q[d + 1], kk.y, acc);
+                acc = fmaf(q[d + 2], kk.z, acc); acc = fmaf(q[d + 3], kk.w, acc);
+            }
+            if (a.labels && lab[j] != my_lab) acc -= 100.0f;
+            s[j] = acc;
+            m = fmaxf(m, acc);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            s[j] = __expf(s[j] - m);
+            l += s[j];
+        }
+        float o[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 vv = ld4(sV + j * Cfg::HP + d);
+                o[d] = fmaf(s[j], vv.x, o[d]); o[d + 1] = fmaf(s[j], vv.y, o[d + 1]);
+                o[d + 2] = fmaf(s[j], vv.z, o[d + 2]); o[d + 3] = fmaf(s[j], vv.w, o[d + 3]);
+            }
+        }
+        const float inv = 1.0f / l;
+        float* op = a.o + row * a.o_rs + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) st4(op + d, make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv));
+    }
+}
+
+// Backward.  Phase 1 (lane = query i): recompute the softmax row, delta_i = dO_i . O_i, dQ_i; row statistics go to LDS.
+// Phase 2 (lane = key j): with Q and dO of the window now in the LDS tiles, recompute column j of P and accumulate
+// dK_j, dV_j in registers and dS into the workgroup's [N][N] bias-gradient tile (LDS atomics, one address per lane).
+template <int N, int HD>
+__global__ __launch_bounds__(WA_WAVES * 64) void winattn_bwd_kernel(dkd_winattn_args a) {
+    using Cfg = WinCfg<N, HD>;
+    extern __shared__ float smem[];
+    float* sBias = smem;                                   // [N][NP]
+    float* sDb = sBias + N * Cfg::NP;                      // [N][NP]
+    float* sTiles = sDb + N * Cfg::NP;                     // per wave: tile A (K, then Q*scale), tile B (V, then dO)
+    float* sStat = sTiles + WA_WAVES * 2 * Cfg::TILE;      // per wave: m[64], 1/l[64], delta[64]
+    int* sLab = reinterpret_cast<int*>(sStat + WA_WAVES * 3 * 64);
+    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+        sBias[(e / N) * Cfg::NP + (e % N)] = a.bias[(long)e * a.H + h];
+        sDb[(e / N) * Cfg::NP + (e % N)] = 0.f;
+    }
+    float* sA = sTiles + wave * 2 * Cfg::TILE;
+    float* sB = sA + Cfg::TILE;
+    float* sM = sStat + wave * 3 * 64;
+    float* sL = sM + 64;
+    float* sD = sL + 64;
+    int* lab = sLab + wave * 64;
+    const bool active = lane < N;
+    for (int base = blockIdx.x * WA_WAVES; base < a.Bw; base += gridDim.x * WA_WAVES) {
+        const int w = base + wave;
+        const bool live = w < a.Bw;
+        const bool work = live && active;
+        const long row = (long)w * N + lane;
+        __syncthreads();
+        if (live) {
+            const long row0 = (long)w * N;
+            stage_tile<N, HD>(sA, a.k + row0 * a.k_rs + h * HD, a.k_rs, lane);
+            stage_tile<N, HD>(sB, a.v + row0 * a.v_rs + h * HD, a.v_rs, lane);
+            if (a.labels) lab[lane] = active ? a.labels[(long)(w % a.nW) * N + lane] : -1;
+        }
+        __syncthreads();
+        const int my_lab = (a.labels && live) ? lab[lane] : 0;
+        float q[HD], g[HD];  // phase 1: scaled q_i and dO_i of this lane's row
+        if (work) {
+            const float* qp = a.q + row * a.q_rs + h * HD;
+            const float* gp = a.d_o + row * a.do_rs + h * HD;
+            const float* op = a.o + row * a.o_rs + h * HD;
+            float delta = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 t = ld4(qp + d), u = ld4(gp + d), v = ld4(op + d);
+                q[d] = t.x * a.scale; q[d + 1] = t.y * a.scale; q[d + 2] = t.z * a.scale; q[d + 3] = t.w * a.scale;
+                g[d] = u.x; g[d + 1] = u.y; g[d + 2] = u.z; g[d + 3] = u.w;
+                delta += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+            }
+            float p[N];
+            float m = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float acc = sBias[lane * Cfg::NP + j];
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 kk = ld4(sA + j * Cfg::HP + d);
+                    acc = fmaf(q[d], kk.x, acc); acc = fmaf(q[d + 1], kk.y, acc);
+                    acc = fmaf(q[d + 2], kk.z, acc); acc = fmaf(q[d + 3], kk.w, acc);
+                }
+                if (a.labels && lab[j] != my_lab) acc -= 100.0f;
+                p[j] = acc;
+                m = fmaxf(m, acc);
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                p[j] = __expf(p[j] - m);
+                l += p[j];
+            }
+            const float inv = 1.0f / l;
+            float dq[HD];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 vv = ld4(sB + j * Cfg::HP + d);
+                    dp = fmaf(g[d], vv.x, dp); dp = fmaf(g[d + 1], vv.y, dp);
+                    dp = fmaf(g[d + 2], vv.z, dp); dp = fmaf(g[d + 3], vv.w, dp);
+                }
+                const float ds = p[j] * inv * (dp - delta);
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 kk = ld4(sA + j * Cfg::HP + d);
+                    dq[d] = fmaf(ds, kk.x, dq[d]); dq[d + 1] = fmaf(ds, kk.y, dq[d + 1]);
+                    dq[d + 2] = fmaf(ds, kk.z, dq[d + 2]); dq[d + 3] = fmaf(ds, kk.w, dq[d + 3]);
+                }
+            }
+            float* dqp = a.dq + row * a.dq_rs + h * HD;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4)
+                st4(dqp + d, make_float4(dq[d] * a.scale, dq[d + 1] * a.scale, dq[d + 2] * a.scale, dq[d + 3] * a.scale));
+            sM[lane] = m;
+            sL[lane] = inv;
+            sD[lane] = delta;
+        }
+        // own K / V rows out of the tiles before they are overwritten with Q / dO
+        float kr[HD], vr[HD];
+        if (work) {
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 t = ld4(sA + lane * Cfg::HP + d), u = ld4(sB + lane * Cfg::HP + d);
+                kr[d] = t.x; kr[d + 1] = t.y; kr[d + 2] = t.z; kr[d + 3] = t.w;
+                vr[d] = u.x; vr[d + 1] = u.y; vr[d + 2] = u.z; vr[d + 3] = u.w;
+            }
+        }
+        __syncthreads();
+        if (work) {
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                st4(sA + lane * Cfg::HP + d, make_float4(q[d], q[d + 1], q[d + 2], q[d + 3]));
+                st4(sB + lane * Cfg::HP + d, make_float4(g[d], g[d + 1], g[d + 2], g[d + 3]));
+            }
+        }
+        __syncthreads();
+        if (work) {  // phase 2: lane = key j
+            float dk[HD], dv[HD];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dk[d] = dv[d] = 0.f;
+#pragma unroll 1
+            for (int i = 0; i < N; ++i) {
+                float qq[HD], gg[HD];  // row i of (scaled) Q and of dO, broadcast reads
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 t = ld4(sA + i * Cfg::HP + d), u = ld4(sB + i * Cfg::HP + d);
+                    qq[d] = t.x; qq[d + 1] = t.y; qq[d + 2] = t.z; qq[d + 3] = t.w;
+                    gg[d] = u.x; gg[d + 1] = u.y; gg[d + 2] = u.z; gg[d + 3] = u.w;
+                }
+                float s = sBias[i * Cfg::NP + lane], dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    s = fmaf(kr[d], qq[d], s);
+                    dp = fmaf(vr[d], gg[d], dp);
+                }
+                if (a.labels && lab[i] != my_lab) s -= 100.0f;
+                const float p = __expf(s - sM[i]) * sL[i];
+                const float ds = p * (dp - sD[i]);
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    dk[d] = fmaf(ds, qq[d], dk[d]);
+                    dv[d] = fmaf(p, gg[d], dv[d]);
+                }
+                atomicAdd(&sDb[i * Cfg::NP + lane], ds);
+            }
+            float* dkp = a.dk + row * a.dk_rs + h * HD;
+            float* dvp = a.dv + row * a.dv_rs + h * HD;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                st4(dkp + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]));  // q in the tile is pre-scaled: dk carries `scale`
+                st4(dvp + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
+            }
+        }
+    }
+    __syncthreads();
+    float* part = a.dbias_part + ((long)blockIdx.x * a.H + h) * N * N;
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) part[e] = sDb[(e / N) * Cfg::NP + (e % N)];
+}
+
+template <int N, int HD>
+size_t fwd_smem() {
+    using Cfg = WinCfg<N, HD>;
+    return (size_t)(N * Cfg::NP + WA_WAVES * 2 * Cfg::TILE) * 4 + WA_WAVES * 64 * 4;
+}
+template <int N, int HD>
+size_t bwd_smem() {
+    using Cfg = WinCfg<N, HD>;
+    return (size_t)(2 * N * Cfg::NP + WA_WAVES * 2 * Cfg::TILE + WA_WAVES * 3 * 64) * 4 + WA_WAVES * 64 * 4;
+}
+
+int check_args(const dkd_winattn_args* a, bool bwd) {
+    if (!a || !a->q || !a->k || !a->v || !a->o || !a->bias || a->Bw <= 0 || a->H <= 0 || a->nW <= 0) return DKD_ERR_BAD_ARG;
+    if (a->labels && a->Bw % a->nW) return DKD_ERR_BAD_ARG;
+    if (bwd && (!a->d_o || !a->dq || !a->dk || !a->dv || !a->dbias_part)) return DKD_ERR_BAD_ARG;
+    const int64_t rs[] = {a->q_rs, a->k_rs, a->v_rs, a->o_rs};
+    for (int64_t s : rs)
+        if (s < (int64_t)a->H * a->hd || (s & 3)) return DKD_ERR_ALIGN;
+    if (bwd) {
+        const int64_t rb[] = {a->do_rs, a->dq_rs, a->dk_rs, a->dv_rs};
+        for (int64_t s : rb)
+            if (s < (int64_t)a->H * a->hd || (s & 3)) return DKD_ERR_ALIGN;
+        if (!dkd_aligned16(a->d_o) || !dkd_aligned16(a->dq) || !dkd_aligned16(a->dk) || !dkd_aligned16(a->dv)) return DKD_ERR_ALIGN;
+    }
+    if (!dkd_aligned16(a->q) || !dkd_aligned16(a->k) || !dkd_aligned16(a->v) || !dkd_aligned16(a->o)) return DKD_ERR_ALIGN;
+    return DKD_OK;
+}
+
+template <int N, int HD>
+int launch_fwd(const dkd_winattn_args* a, hipStream_t st) {
+    static bool attr = false;
+    const size_t sm = fwd_smem<N, HD>();
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)winattn_fwd_kernel<N, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    dim3 grid(dkd_winattn_parts(a->Bw, a->H), a->H);
+    hipLaunchKernelGGL((winattn_fwd_kernel<N, HD>), grid, dim3(WA_WAVES * 64), sm, st, *a);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+template <int N, int HD>
+int launch_bwd(const dkd_winattn_args* a, hipStream_t st) {
+    static bool attr = false;
+    const size_t sm = bwd_smem<N, HD>();
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)winattn_bwd_kernel<N, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    dim3 grid(dkd_winattn_parts(a->Bw, a->H), a->H);
+    hipLaunchKernelGGL((winattn_bwd_kernel<N, HD>), grid, dim3(WA_WAVES * 64), sm, st, *a);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+}  // namespace
+
+extern "C" int dkd_winattn_parts(int Bw, int H) {
+    if (Bw <= 0 || H <= 0) return 0;
+    const int want = (768 + H - 1) / H;  // ~3 workgroups per CU over (parts x heads)
+    const int need = (Bw + WA_WAVES - 1) / WA_WAVES;
+    return need < want ? need : want;
+}
+
+extern "C" int dkd_winattn_fwd_f32(const dkd_winattn_args* a, void* stream) {
+    const int rc = check_args(a, false);
+    if (rc) return rc;
+    if (a->N == 49 && a->hd == 32) return launch_fwd<49, 32>(a, (hipStream_t)stream);
+    if (a->N == 49 && a->hd == 16) return launch_fwd<49, 16>(a, (hipStream_t)stream);
+    return DKD_ERR_UNSUPPORTED;
+}
+
+extern "C" int dkd_winattn_bwd_f32(const dkd_winattn_args* a, void* stream) {
+    const int rc = check_args(a, true);
+    if (rc) return rc;
+    if (a->parts != dkd_winattn_parts(a->Bw, a->H)) return DKD_ERR_BAD_ARG;
+    if (a->N == 49 && a->hd == 32) return launch_bwd<49, 32>(a, (hipStream_t)stream);
+    if (a->N == 49 && a->hd == 16) return launch_bwd<49, 16>(a, (hipStream_t)stream);
+    return DKD_ERR_UNSUPPORTED;
+}
+
+extern "C" int dkd_winattn_dbias_f32(const float* part, float* dbias, int parts, int H, int N, void* stream) {
+    if (!part || !dbias || parts <= 0 || H <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
+    const int total = H * N * N;
+    hipLaunchKernelGGL(winattn_dbias_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, dbias, parts, H,
+                       N * N);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_gather_rows_f32(const float* in, const int* idx, const float* res, float* out, long rows, int C, void* stream) {
+    if (!in || !idx || !out || rows <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    if ((C & 3) || !dkd_aligned16(in) || !dkd_aligned16(out) || (res && !dkd_aligned16(res))) {
+        const long total = rows * C, blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                           (hipStream_t)stream, in, idx, res, out, rows, C);
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
+    const long total = rows * (C / 4);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, in,
+                       idx, res, out, rows, C / 4);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_index_add_rows_f32(const float* src, const int* idx, float* out, int rows, int T, int C, void* stream) {
+    if (!src || !idx || !out || rows <= 0 || T <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(index_add_rows_kernel, dim3(T), dim3(64), 0, (hipStream_t)stream, src, idx, out, rows, C);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_dropout_f32(const float* x, float* y, long n, float p, int64_t seed, int64_t offset, void* stream) {
+    if (!x || !y || n <= 0 || !(p >= 0.f && p < 1.f)) return DKD_ERR_BAD_ARG;
+    if ((n & 3) || !dkd_aligned16(x) || !dkd_aligned16(y)) return DKD_ERR_ALIGN;
+    const uint32_t thresh = (uint32_t)(p * 65536.0f + 0.5f);
+    const long n4 = n / 4;
+    const long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       n4, thresh, 1.0f / (1.0f - p), (uint64_t)seed, (uint64_t)offset);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}

@@ -142,7 +142,7 @@ class PatchConvFn(Function):
         ctx.save_for_backward(rows, w2)
         ctx.meta = (k, src_nchw, tuple(x.shape), tuple(w.shape))
         ctx.params = (w, b)
-        return y.reshape(B, H // k, W // k, O)
+        return y.reshape(B, -(-H // k), -(-W // k), O)  # ceil: a ragged image edge is zero-padded (Swin patch-embed)
 
     @staticmethod
     def backward(ctx, dy):
@@ -600,3 +600,134 @@ class AddReluFn(Function):
         (out,) = ctx.saved_tensors
         g = ops.relu_bwd(_c(dy), out)
         return g, g
+
+
+# =====================================================================================================================
+# Swin-Transformer student (models/backbones/swin.py)
+_DROP_CALLS = [0]
+
+
+def _drop_seed():
+    """a fresh (seed, call number) for one block's dropout masks; the masks are regenerated from it in backward"""
+    _DROP_CALLS[0] += 1
+    return torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, _DROP_CALLS[0]
+
+
+def _drop(x, p, seed, slot):
+    s, call = seed
+    return ops.dropout(x, p, s, ((call * 4 + slot) << 40))
+
+
+class SwinBlockFn(Function):
+    """SwinTransformerBlock.forward (swin.py:268-334) on tokens [B, H*W, C]:
+    LN -> (zero-pad, roll, window partition: ONE row gather) -> qkv -> window attention (+ relative-position bias, shift mask)
+    -> proj -> dropout -> (window merge, un-roll, crop: one row gather, fused with the residual add) -> LN -> fc1+GELU ->
+    dropout -> fc2 -> dropout -> + residual.  geom: models.swin.BlockGeometry (index maps, labels)."""
+
+    @staticmethod
+    def forward(ctx, x, geom, num_heads, p_drop, n1w, n1b, table, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+        x = _c(x)
+        B, L, C = x.shape
+        M, hd, N = B * L, C // num_heads, geom.N
+        x2 = x.reshape(M, C)
+        drop = p_drop > 0.0
+        seed = _drop_seed() if drop else None
+        y, m1, r1 = ops.layernorm_fwd(x2, n1w, n1b, 1e-5)
+        yw = ops.gather_rows(y, geom.to_win)
+        qkv = ops.gemm(yw, qkv_w, bias=qkv_b)
+        bias = ops.gather_rows(table, geom.rel_index)  # [N*N, heads]
+        Bw = geom.to_win.numel() // N
+        o = ops.winattn_forward(qkv, bias, geom.labels, Bw, geom.nW, num_heads, N, hd, hd ** -0.5)
+        a = ops.gemm(o, proj_w, bias=proj_b)
+        if drop:
+            a = _drop(a, p_drop, seed, 0)
+        x1 = ops.gather_rows(a, geom.from_win, res=x2)
+        z, m2, r2 = ops.layernorm_fwd(x1, n2w, n2b, 1e-5)
+        u = torch.empty((M, fc1_w.shape[0]), dtype=F32, device=x.device)
+        g = ops.gemm(z, fc1_w, bias=fc1_b, act=ops.ACT_GELU, preact=u)
+        if drop:
+            g = _drop(g, p_drop, seed, 1)
+            out = ops.axpby(x1, _drop(ops.gemm(g, fc2_w, bias=fc2_b), p_drop, seed, 2))
+        else:
+            out = ops.gemm(g, fc2_w, bias=fc2_b, residual=x1)
+        ctx.save_for_backward(x2, m1, r1, yw, qkv, o, bias, x1, m2, r2, z, u, g, n1w, n2w, qkv_w, proj_w, fc1_w, fc2_w)
+        ctx.meta = (B, L, C, num_heads, p_drop, seed, geom)
+        ctx.lin = (qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b)
+        ctx.small = (n1w, n1b, table, n2w, n2b)
+        return out.reshape(B, L, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, m1, r1, yw, qkv, o, bias, x1, m2, r2, z, u, g, n1w, n2w, qkv_w, proj_w, fc1_w, fc2_w = ctx.saved_tensors
+        B, L, C, nH, p_drop, seed, geom = ctx.meta
+        M, hd, N = B * L, C // nH, geom.N
+        drop = p_drop > 0.0
+        pqkv_w, pqkv_b, pproj_w, pproj_b, pfc1_w, pfc1_b, pfc2_w, pfc2_b = ctx.lin
+        p_n1w, p_n1b, p_tab, p_n2w, p_n2b = ctx.small
+        o_n1w, o_n1b, o_tab, o_n2w, o_n2b = direct(*ctx.small)
+        d2 = _c(dout).reshape(M, C)
+        dmo = _drop(d2, p_drop, seed, 2) if drop else d2
+        dfc2_w, dfc2_b = wgrad(dmo, g, pfc2_w, pfc2_b)
+        dg = ops.dgrad(dmo, fc2_w)
+        if drop:
+            dg = _drop(dg, p_drop, seed, 1)
+        du = ops.gelu_bwd(dg, u)
+        dfc1_w, dfc1_b = wgrad(du, z, pfc1_w, pfc1_b)
+        dz = ops.dgrad(du, fc1_w)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(dz, x1, m2, r2, n2w, add=d2, dg_out=o_n2w, db_out=o_n2b)
+        da = ops.gather_rows(dx1, geom.to_win)  # adjoint of the window merge (pad slots receive nothing)
+        if drop:
+            da = _drop(da, p_drop, seed, 0)
+        dproj_w, dproj_b = wgrad(da, o, pproj_w, pproj_b)
+        do = ops.dgrad(da, proj_w)
+        Bw = geom.to_win.numel() // N
+        dqkv, dbias = ops.winattn_backward(do, qkv, o, bias, geom.labels, Bw, geom.nW, nH, N, hd, hd ** -0.5)
+        dtab = ops.index_add_rows(dbias, geom.rel_index, p_tab.shape[0], out=o_tab)
+        dqkv_w, dqkv_b = wgrad(dqkv, yw, pqkv_w, pqkv_b)
+        dyw = ops.dgrad(dqkv, qkv_w)
+        dy = ops.gather_rows(dyw, geom.from_win)  # adjoint of pad + roll + partition
+        dx, dn1w, dn1b = ops.layernorm_bwd(dy, x2, m1, r1, n1w, add=dx1, dg_out=o_n1w, db_out=o_n1b)
+        return (dx.reshape(B, L, C), None, None, None, ret(o_n1w, dn1w, p_n1w), ret(o_n1b, dn1b, p_n1b), ret(o_tab, dtab, p_tab),
+                dqkv_w, dqkv_b, dproj_w, dproj_b, ret(o_n2w, dn2w, p_n2w), ret(o_n2b, dn2b, p_n2b), dfc1_w, dfc1_b, dfc2_w, dfc2_b)
+
+
+class PatchMergeFn(Function):
+    """PatchMerging.forward (swin.py:350-376): zero-padded 2x2 concat (one row gather) -> LN(4C) -> Linear(4C -> 2C, no bias)."""
+
+    @staticmethod
+    def forward(ctx, x, geom, nw, nb, red_w):
+        x = _c(x)
+        B, L, C = x.shape
+        xm = ops.gather_rows(x.reshape(B * L, C), geom.merge).reshape(-1, 4 * C)
+        y, m, r = ops.layernorm_fwd(xm, nw, nb, 1e-5)
+        out = ops.gemm(y, red_w)
+        ctx.save_for_backward(xm, m, r, y, nw, red_w)
+        ctx.meta = (B, L, C, geom)
+        ctx.params = (nw, nb, red_w)
+        return out.reshape(B, -1, red_w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        xm, m, r, y, nw, red_w = ctx.saved_tensors
+        B, L, C, geom = ctx.meta
+        p_nw, p_nb, p_red = ctx.params
+        o_nw, o_nb = direct(p_nw, p_nb)
+        d2 = _c(dout).reshape(-1, red_w.shape[0])
+        dred, _ = wgrad(d2, y, p_red, None)
+        dy = ops.dgrad(d2, red_w)
+        dxm, dnw, dnb = ops.layernorm_bwd(dy, xm, m, r, nw, dg_out=o_nw, db_out=o_nb)
+        dx = ops.gather_rows(dxm.reshape(-1, C), geom.unmerge)
+        return dx.reshape(B, L, C), None, ret(o_nw, dnw, p_nw), ret(o_nb, dnb, p_nb), dred
+
+
+class DropoutFn(Function):
+    """nn.Dropout on its own (pos_drop, swin.py:625,709)"""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p, ctx.seed = p, _drop_seed()
+        return _drop(_c(x), p, ctx.seed, 3)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _drop(_c(dy), ctx.p, ctx.seed, 3), None

@@ -8,6 +8,7 @@ from .. import functional as Fn
 from .convnext import D2ConvNextV2
 from .resnet import BasicStem, ResNet, make_resnet_stages
 from .stdc import STDCNet
+from .swin import D2SwinTransformer
 
 CONVNEXT_CONFIGS = {  # models/wrappers/convnext_wrapper.py:19-49
     "convnext_atto": ([2, 2, 6, 2], [40, 80, 160, 320], "convnextv2_atto_1k_224_ema.pkl"),
@@ -96,11 +97,45 @@ class ResNetWrapper(nn.Module):
         return {k: v for k, v in self.model._out_feature_channels.items() if k != "stem"}
 
 
+SWIN_CONFIGS = {  # models/wrappers/swin_wrapper.py:11-28
+    "swin_tiny": dict(embed_dims=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7,
+                      ckpt="swin_tiny_patch4_window7_224.pkl"),
+    "swin_small": dict(embed_dims=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=7,
+                       ckpt="swin_small_patch4_window7_224.pkl"),
+}
+
+
+class D2SwinTransformerWrapper(nn.Module):
+    """models/wrappers/swin_wrapper.py: drop_rate 0.3 (live in train mode), attention dropout / drop-path 0"""
+
+    def __init__(self, model_name="swin_tiny", out_features=None):
+        super().__init__()
+        if model_name not in SWIN_CONFIGS:
+            raise NotImplementedError(f"There is not a Swin config called {model_name}.")
+        c = SWIN_CONFIGS[model_name]
+        self._out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", c["ckpt"])
+        self.model = D2SwinTransformer(embed_dims=c["embed_dims"], depths=c["depths"], num_heads=c["num_heads"],
+                                       window_size=c["window_size"], drop_rate=0.3, out_features=self._out_features)
+        self._out_feature_channels = self.model._out_feature_channels
+
+    def get_features(self, x):
+        return self.model(x)
+
+    def get_features_nhwc(self, x):
+        feats = self.model.forward_features_nhwc(x)
+        return {k: v for k, v in feats.items() if k in self._out_features}
+
+    @property
+    def feature_channels(self):
+        return self._out_feature_channels
+
+
 class ModelWrapper(nn.Module):
     """models/model_zoo.py:18-145.  Only the student families built on the MI355X kernels are registered; asking for
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
-    MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper}
+    MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper, "swin": D2SwinTransformerWrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

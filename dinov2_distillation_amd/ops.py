@@ -415,9 +415,10 @@ def dwconv7_wgrad(x, dout):
 
 
 def patchify_nchw(img, k):
+    """rows [(b,py,px)][(c,ky,kx)]; a ragged right/bottom edge (H or W not a multiple of k) reads as zero padding"""
     _chk(img, "img")
     B, Cin, H, W = img.shape
-    out = torch.empty((B * (H // k) * (W // k), Cin * k * k), dtype=torch.float32, device=img.device)
+    out = torch.empty((B * (-(-H // k)) * (-(-W // k)), Cin * k * k), dtype=torch.float32, device=img.device)
     check(_lib.load().dkd_patchify_nchw_f32(_p(img), _p(out), B, Cin, H, W, k, _stream()), "dkd_patchify_nchw_f32")
     return out
 
@@ -604,3 +605,90 @@ def window_permute(x, Ph, Pw, wh, ww, inverse=False):
     out = torch.empty_like(x)
     check(_lib.load().dkd_window_permute_f32(_p(x), _p(out), B, Ph, Pw, wh, ww, D, int(inverse), _stream()), "dkd_window_permute_f32")
     return out
+
+
+# ---- Swin student (models/backbones/swin.py) ---------------------------------------------------------------------------
+def _chk_idx(idx, name, device):
+    if idx.dtype != torch.int32 or not idx.is_cuda or not idx.is_contiguous() or idx.device != device:
+        raise _lib.DkdError(f"{name}: expected a contiguous CUDA(HIP) int32 tensor on {device}")
+
+
+def gather_rows(x, idx, res=None, out=None):
+    """out[r] = x[idx[r]] (zero row where idx[r] < 0) (+ res[r]).  x [rows_in, C], idx int32 [rows_out]."""
+    _chk(x, "x"), _chk(res, "res"), _chk(out, "out")
+    _chk_idx(idx, "idx", x.device)
+    C = x.shape[-1]
+    rows = idx.numel()
+    if out is None:
+        out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    if out.numel() != rows * C or (res is not None and res.numel() != rows * C):
+        raise _lib.DkdError("gather_rows: out / res must hold idx.numel() rows of x's width")
+    check(_lib.load().dkd_gather_rows_f32(_p(x), _p(idx), _p(res), _p(out), rows, C, _stream()), "dkd_gather_rows_f32")
+    return out
+
+
+def index_add_rows(src, idx, T, out=None):
+    """out[t] = sum of the rows r of src with idx[r] == t (deterministic)"""
+    _chk(src, "src"), _chk(out, "out")
+    _chk_idx(idx, "idx", src.device)
+    rows, C = src.shape
+    if out is None:
+        out = torch.empty((T, C), dtype=torch.float32, device=src.device)
+    check(_lib.load().dkd_index_add_rows_f32(_p(src), _p(idx), _p(out), rows, T, C, _stream()), "dkd_index_add_rows_f32")
+    return out
+
+
+def dropout(x, p, seed, offset, out=None):
+    """y = x * mask / (1 - p), mask ~ Bernoulli(1 - p) regenerated from (seed, offset): call again on dy for the backward"""
+    _chk(x, "x"), _chk(out, "out")
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().dkd_dropout_f32(_p(x), _p(out), x.numel(), float(p), int(seed), int(offset), _stream()), "dkd_dropout_f32")
+    return out
+
+
+def _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
+    a = _lib.WinAttnArgs()
+    C = H * hd
+    _chk(qkv, "qkv"), _chk(o, "o"), _chk(bias, "bias")
+    if labels is not None:
+        _chk_idx(labels, "labels", qkv.device)
+        if labels.numel() != nW * N:
+            raise _lib.DkdError("winattn: labels must be [nW, N]")
+    if qkv.shape != (Bw * N, 3 * C) or bias.shape != (N * N, H):
+        raise _lib.DkdError(f"winattn: qkv {tuple(qkv.shape)} / bias {tuple(bias.shape)} do not match Bw={Bw} N={N} H={H} hd={hd}")
+    esz = qkv.element_size()
+    a.q, a.k, a.v = qkv.data_ptr(), qkv.data_ptr() + C * esz, qkv.data_ptr() + 2 * C * esz
+    a.o, a.bias, a.labels = o.data_ptr(), bias.data_ptr(), None if labels is None else labels.data_ptr()
+    a.q_rs = a.k_rs = a.v_rs = 3 * C
+    a.o_rs = C
+    a.Bw, a.nW, a.H, a.N, a.hd, a.scale = Bw, nW, H, N, hd, scale
+    return a
+
+
+def winattn_forward(qkv, bias, labels, Bw, nW, H, N, hd, scale):
+    """qkv [Bw*N, 3*H*hd] packed (3, H, hd) per row -> context [Bw*N, H*hd]"""
+    o = torch.empty((Bw * N, H * hd), dtype=torch.float32, device=qkv.device)
+    a = _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale)
+    check(_lib.load().dkd_winattn_fwd_f32(ctypes.byref(a), _stream()), f"dkd_winattn_fwd_f32[N={N},hd={hd}]")
+    return o
+
+
+def winattn_backward(do, qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
+    """-> (dqkv [Bw*N, 3C], dbias [N*N, H])"""
+    lib = _lib.load()
+    _chk(do, "do")
+    C = H * hd
+    dqkv = torch.empty_like(qkv)
+    parts = lib.dkd_winattn_parts(Bw, H)
+    part = torch.empty((parts, H * N * N), dtype=torch.float32, device=qkv.device)
+    a = _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale)
+    esz = qkv.element_size()
+    a.d_o, a.do_rs = do.data_ptr(), C
+    a.dq, a.dk, a.dv = dqkv.data_ptr(), dqkv.data_ptr() + C * esz, dqkv.data_ptr() + 2 * C * esz
+    a.dq_rs = a.dk_rs = a.dv_rs = 3 * C
+    a.dbias_part, a.parts = part.data_ptr(), parts
+    check(lib.dkd_winattn_bwd_f32(ctypes.byref(a), _stream()), f"dkd_winattn_bwd_f32[N={N},hd={hd}]")
+    dbias = torch.empty((N * N, H), dtype=torch.float32, device=qkv.device)
+    check(lib.dkd_winattn_dbias_f32(_p(part), _p(dbias), parts, H, N, _stream()), "dkd_winattn_dbias_f32")
+    return dqkv, dbias

@@ -189,7 +189,8 @@ int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, const float* 
 int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* partials, int B, int H, int W, int C, void* stream);
 long dkd_dwconv7_wgrad_f32_parts(int B, int H);
 /* Non-overlapping k x k stride-k convs as GEMMs: stem 4x4 s4 (:117), downsample 2x2 s2 (:124), DINOv2 patch-embed
- * 14x14 s14.  nchw: image [B,Cin,H,W] -> rows [(b,py,px)][(c,ky,kx)].  nhwc: feature [B,H,W,C] <-> rows
+ * 14x14 s14, Swin patch-embed 4x4 s4 (swin.py:514-531).  nchw: image [B,Cin,H,W] -> rows [(b,py,px)][(c,ky,kx)] with
+ * py < ceil(H/k), px < ceil(W/k): a ragged right/bottom edge reads as zeros (the F.pad of swin.py:526-529).  nhwc: feature [B,H,W,C] <-> rows
  * [(b,py,px)][(ky,kx,c)] (inverse=1 scatters rows back = the conv's dgrad layout step). */
 int dkd_patchify_nchw_f32(const float* img, float* out, int B, int Cin, int H, int W, int k, void* stream);
 int dkd_patchify_nhwc_f32(const float* src, float* dst, int B, int H, int W, int C, int k, int inverse, void* stream);
@@ -239,6 +240,44 @@ int dkd_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, 
 int dkd_maxpool3_f32(const float* in, float* out, int* argmax, int B, int H, int W, int C, int stride, int mode,
                      void* stream);
 int dkd_add_relu_f32(const float* a, const float* b, float* out, long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Swin-Transformer student (models/backbones/swin.py).
+ * gather_rows: out[r, :] = (idx[r] >= 0 ? in[idx[r], :] : 0) (+ res[r, :]).  With a precomputed map this is the zero-pad +
+ *   cyclic roll + window partition of SwinTransformerBlock.forward (:283-306), its inverse (:313-328, fused with the
+ *   residual add :331), PatchMerging's padded 2x2 concat (:359-371) and every adjoint of those (float4 path when C % 4 == 0 and the
+ *   buffers are 16-byte aligned, scalar otherwise - the [T, heads] bias table).
+ * winattn: WindowAttention.forward (:151-199) core, softmax(scale q k^T + bias + mask) v per (window, head), N = window^2
+ *   tokens.  Element (window w, token n, head h, d) of x lives at x[(w*N + n)*x_rs + h*hd + d].  bias: the gathered
+ *   relative-position table, bias[(i*N + j)*H + h] (:172-181).  labels: [nW, N] region id of every window slot of the
+ *   cyclic shift (:457-478) - the mask is (label_i != label_j ? -100 : 0) - or NULL for un-shifted blocks.  Backward
+ *   recomputes the probabilities, writes dq/dk/dv and per-workgroup partial sums of d(bias) as
+ *   dbias_part[parts][H][N*N], parts = dkd_winattn_parts(Bw, H); dkd_winattn_dbias_f32 folds them into
+ *   dbias[(i*N + j)*H + h], which dkd_index_add_rows_f32 then scatters into the table gradient.
+ *   Supported: N = 49 (window 7), hd in {16, 32}.
+ * index_add_rows: out[t, :] = sum_{r: idx[r] == t} src[r, :], deterministic (table gradient, rows = N*N, T = (2w-1)^2).
+ * dropout: nn.Dropout(p) of Mlp / proj_drop / pos_drop (:78-85, :146, :625): y = keep ? x / (1-p) : 0 with a stateless
+ *   counter-based mask of (seed, offset + element index); the backward pass calls it again on dy with the same pair.
+ */
+typedef struct dkd_winattn_args {
+    const float *q, *k, *v;
+    float* o;
+    const float* bias;
+    const int32_t* labels;
+    const float* d_o;
+    float *dq, *dk, *dv;
+    float* dbias_part;
+    int64_t q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;
+    int32_t Bw, nW, H, N, hd, parts;
+    float scale;
+} dkd_winattn_args;
+int dkd_winattn_fwd_f32(const dkd_winattn_args* args, void* stream);
+int dkd_winattn_bwd_f32(const dkd_winattn_args* args, void* stream);
+int dkd_winattn_parts(int Bw, int H);
+int dkd_winattn_dbias_f32(const float* part, float* dbias, int parts, int H, int N, void* stream);
+int dkd_gather_rows_f32(const float* in, const int* idx, const float* res, float* out, long rows, int C, void* stream);
+int dkd_index_add_rows_f32(const float* src, const int* idx, float* out, int rows, int T, int C, void* stream);
+int dkd_dropout_f32(const float* x, float* y, long n, float p, int64_t seed, int64_t offset, void* stream);
 
 #ifdef __cplusplus
 }

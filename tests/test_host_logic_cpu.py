@@ -59,7 +59,14 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(ValueError):   # 24 does not divide 1024
         AttentionProjector(8, 1024, (2, 2), 1024, num_heads=24)
     with pytest.raises(NotImplementedError):
-        ModelWrapper("swin_tiny", [16, 16])
+        ModelWrapper("mit_b0", [16, 16])      # a family without an MI355X backbone fails loudly
+    with pytest.raises(NotImplementedError, match="Swin config"):   # models/wrappers/swin_wrapper.py:39-41
+        ModelWrapper("swin_huge", [16, 16])
+    w = ModelWrapper("swin_tiny", [37, 37])
+    assert sum(p.numel() for p in w.parameters() if p.requires_grad) == 27_520_698 and w.feature_channels["res4"] == 384
+    sd = w.state_dict()
+    assert sd["model.model.layers.2.blocks.5.attn.relative_position_index"].dtype == torch.int64  # swin.py:139-141
+    assert "model.model.layers.0.downsample.reduction.weight" in sd and "model.model.norm3.bias" in sd
     r = ModelWrapper("resnet_50", [16, 16])
     assert abs(sum(p.numel() for p in r.parameters()) / 1e6 - 23.51) < 0.01 and r.feature_channels["res5"] == 2048
     s = ModelWrapper("stdc_2", [16, 16])

@@ -302,3 +302,88 @@ def test_wgrad_with_fused_bias_grad(ops, M, N, K):
     dw, db = ops.linear_wgrad(dev(dy), dev(x), True)
     close(dw, dy.double().t() @ x.double(), "wgrad", rtol=3e-4)
     close(db, dy.double().sum(0), "fused bias grad", rtol=3e-4)
+
+
+# ---- Swin student kernels ------------------------------------------------------------------------------------------
+def test_gather_rows_and_index_add(ops):
+    g = torch.Generator().manual_seed(5)
+    for C in (96, 3):  # float4 path / scalar path (the [T, heads] bias table)
+        x = torch.randn(500, C, generator=g)
+        idx = torch.randint(-1, 500, (777,), generator=g)
+        res = torch.randn(777, C, generator=g)
+        ref = torch.where(idx[:, None] >= 0, x[idx.clamp(min=0)], torch.zeros(1))
+        out = ops.gather_rows(dev(x), dev(idx.to(torch.int32)))
+        assert torch.equal(out.cpu(), ref), C
+        out = ops.gather_rows(dev(x), dev(idx.to(torch.int32)), res=dev(res))
+        assert torch.equal(out.cpu(), ref + res), C
+    src = torch.randn(2401, 6, generator=g)
+    idx = torch.randint(0, 169, (2401,), generator=g)
+    ref = torch.zeros(169, 6, dtype=torch.float64).index_add_(0, idx, src.double())
+    close(ops.index_add_rows(dev(src), dev(idx.to(torch.int32)), 169), ref.float(), "index_add_rows", rtol=1e-6)
+
+
+def test_dropout_mask_statistics_and_replay(ops):
+    n, p = 1 << 20, 0.3
+    x = torch.ones(n, device="cuda")
+    y = ops.dropout(x, p, 1234, 0)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 3e-3, kept                      # Bernoulli(1-p): sigma ~ 4.5e-4 at n = 2^20
+    assert torch.allclose(y[y != 0], torch.full((1,), 1 / (1 - p), device="cuda"))
+    assert torch.equal(y, ops.dropout(x, p, 1234, 0))            # replay (backward) reproduces the mask
+    y2 = ops.dropout(x, p, 1234, 1 << 40)
+    agree = ((y != 0) == (y2 != 0)).float().mean().item()
+    assert abs(agree - (p * p + (1 - p) ** 2)) < 5e-3, agree      # another offset: an independent mask
+    dy = torch.randn(n, device="cuda")
+    assert torch.equal(ops.dropout(dy, p, 1234, 0), dy * y)      # d/dx = the same scaled mask
+    assert torch.equal(ops.dropout(dy, 0.0, 7, 0), dy)
+
+
+def _winattn_ref(qkv, bias, labels, Bw, nW, H, N, hd, scale):
+    C = H * hd
+    t = qkv.double().reshape(Bw, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0] * scale, t[1], t[2]
+    s = q @ k.transpose(-1, -2) + bias.double().reshape(N, N, H).permute(2, 0, 1)[None]
+    if labels is not None:
+        lab = labels.reshape(nW, N)
+        mask = torch.where(lab[:, :, None] != lab[:, None, :], -100.0, 0.0).double()  # [nW, N, N]
+        s = (s.reshape(Bw // nW, nW, H, N, N) + mask[None, :, None]).reshape(Bw, H, N, N)
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(Bw * N, C)
+
+
+@pytest.mark.parametrize("H,hd,B,nW,shifted", [(3, 32, 3, 4, True), (2, 32, 2, 9, False), (1, 16, 1, 1, True), (4, 16, 5, 2, True)])
+def test_window_attention(ops, H, hd, B, nW, shifted):
+    """swin.py:151-199 core (relative-position bias + shift mask), forward and all four gradients, vs fp64 torch"""
+    g = torch.Generator().manual_seed(11)
+    N, C, Bw = 49, H * hd, B * nW
+    qkv = torch.randn(Bw * N, 3 * C, generator=g)
+    bias = torch.randn(N * N, H, generator=g)
+    labels = torch.randint(0, 3, (nW, N), generator=g) if shifted else None
+    do = torch.randn(Bw * N, C, generator=g)
+    qkv_r, bias_r = qkv.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = _winattn_ref(qkv_r, bias_r, labels, Bw, nW, H, N, hd, hd ** -0.5)
+    (ref * do.double()).sum().backward()
+    lab_d = None if labels is None else dev(labels.to(torch.int32))
+    o = ops.winattn_forward(dev(qkv), dev(bias), lab_d, Bw, nW, H, N, hd, hd ** -0.5)
+    close(o, ref.float(), "window attention out", rtol=2e-5)
+    dqkv, dbias = ops.winattn_backward(dev(do), dev(qkv), o, dev(bias), lab_d, Bw, nW, H, N, hd, hd ** -0.5)
+    close(dqkv[:, :C], qkv_r.grad[:, :C], "dq", rtol=5e-5)
+    close(dqkv[:, C:2 * C], qkv_r.grad[:, C:2 * C], "dk", rtol=5e-5)
+    close(dqkv[:, 2 * C:], qkv_r.grad[:, 2 * C:], "dv", rtol=5e-5)
+    close(dbias, bias_r.grad, "dbias", rtol=5e-5)
+
+
+def test_window_attention_rejects_unsupported_shapes(ops):
+    from dinov2_distillation_amd._lib import DkdError
+    qkv = torch.randn(64, 3 * 32, device="cuda")
+    with pytest.raises(DkdError, match="UNSUPPORTED"):
+        ops.winattn_forward(qkv, torch.zeros(64 * 64, 1, device="cuda"), None, 1, 1, 1, 64, 32, 1.0)
+
+
+def test_patchify_ragged_edge_is_zero_padded(ops):
+    """Swin patch-embed (swin.py:524-531): F.pad to a multiple of 4, then the 4x4 s4 conv"""
+    x = torch.randn(2, 3, 86, 90, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(8, 3, 4, 4, generator=torch.Generator().manual_seed(3))
+    ref = F.conv2d(F.pad(x, (0, 2, 0, 2)), w, stride=4).permute(0, 2, 3, 1).reshape(-1, 8)
+    rows = ops.patchify_nchw(dev(x), 4)
+    assert rows.shape == (2 * 22 * 23, 48)
+    close(ops.gemm(rows, dev(w.reshape(8, 48))), ref, "ragged patch-embed", rtol=2e-5)

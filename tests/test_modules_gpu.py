@@ -186,7 +186,8 @@ def test_teacher_forward_vs_oracle():
 def _oracle_step(mod, cfg, x):
     """the oracle run of the whole step with the module's weights"""
     from oracle import convnext_oracle as cno, step_oracle as so, vit_oracle as vo
-    sp = {k[len("model.model."):]: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.student.state_dict().items()}
+    sp = {k[len("model.model."):]: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point)
+          for k, v in mod.student.state_dict().items()}
     lp = {k: v.detach().cpu().clone() for k, v in mod.losses.state_dict().items()}
     for k, v in lp.items():
         if v.dtype.is_floating_point and "running" not in k:
@@ -195,8 +196,12 @@ def _oracle_step(mod, cfg, x):
     tcfg = vo.VIT_CONFIGS[cfg.teacher.model_name]
     with torch.no_grad():
         feat_t = vo.teacher_feature_map(tp, x, tcfg)
-    depths = mod.student.model.model.depths
-    feats = cno.student_features(sp, x, depths, cfg.teacher.n_patches, cfg.student.student_keys)
+    if cfg.student.model_name.startswith("swin"):
+        from oracle import swin_oracle as swo
+        feats = swo.student_features(sp, x, swo.SWIN_CONFIGS[cfg.student.model_name], cfg.teacher.n_patches, cfg.student.student_keys)
+    else:
+        depths = mod.student.model.model.depths
+        feats = cno.student_features(sp, x, depths, cfg.teacher.n_patches, cfg.student.student_keys)
     cfgs, w = {}, {}
     for spec in cfg.loss.losses:
         kw = spec.kwargs
@@ -576,3 +581,102 @@ def test_ddp_two_ranks_on_gpu_average_matches_manual():
     for rank, err, launched, nb in res:
         assert err < 1e-5, (rank, err)
         assert launched >= nb - 2, (launched, nb)
+
+
+def test_swin_against_reference_golden(golden_dir):
+    """models/backbones/swin.py (drop rate 0): odd grids, window padding, shifted masks, patch merging - every stage output,
+    the ModelWrapper resize and every parameter gradient against the fixture generated from the reference."""
+    from dinov2_distillation_amd import functional as Fn
+    from dinov2_distillation_amd.models.swin import SwinTransformer
+    g = load(golden_dir, "swin_small")
+    net = SwinTransformer(int(g["meta/dim"]), [int(v) for v in g["meta/depths"]], [int(v) for v in g["meta/heads"]],
+                          int(g["meta/window"]), 4, 0.0)
+    sd = {k[6:]: v for k, v in g.items() if k.startswith("param/")}
+    assert set(sd) == set(net.state_dict()), set(sd) ^ set(net.state_dict())
+    net.load_state_dict(sd)
+    net.cuda().train()
+    feats = net(g["in/x"].cuda())
+    for k in ("res2", "res3", "res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+    loss = 0
+    for k in ("res4", "res5"):
+        r = Fn.ResizeFn.apply(feats[k].permute(0, 2, 3, 1), 5, 5).permute(0, 3, 1, 2)
+        close(r, g["out/resized_" + k], "resized " + k)
+        loss = loss + (r * g["in/cotangent_" + k].cuda()).sum()
+    loss.backward()
+    params = dict(net.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith("pgrad/"):
+            close(params[k[6:]].grad, v, k, rtol=5e-4)
+            n += 1
+    assert n > 100
+    for k in ("norm0.weight", "norm0.bias", "norm1.weight", "norm1.bias"):  # feed res2 / res3 only
+        assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0
+
+
+def test_swin_tiny_student_step_vs_oracle_and_dropout():
+    """dinov2_vits14 -> swin_tiny (the student family of BASELINE configs[3]) at 224x224, B=2.  With dropout off: loss, every
+    logged scalar and the student / projector gradients against the CPU oracle (kink-robust statistics, see the config-2
+    test).  With the wrapper's drop_rate 0.3 (swin_wrapper.py:89) the step runs, differs, and replays its masks in backward."""
+    from dinov2_distillation_amd.config import make_config, set_student_dims
+    from dinov2_distillation_amd.models import DINOv2ViT, ModelWrapper
+    from dinov2_distillation_amd.train import DistillationModule
+    torch.manual_seed(3)
+    cfg = make_config(student="swin_tiny")
+    student = ModelWrapper("swin_tiny", cfg.teacher.n_patches, cfg.student.student_keys)
+    set_student_dims(cfg, student)
+    assert student.feature_channels == {"res2": 96, "res3": 192, "res4": 384, "res5": 768}
+    assert sum(p.numel() for p in student.parameters() if p.requires_grad) == 27_520_698  # swin_tiny, as the reference builds it
+    swin = student.model.model
+
+    def set_drop(p):
+        swin.drop_rate = p
+        for m in swin.modules():
+            if hasattr(m, "drop"):
+                m.drop = p
+
+    with torch.no_grad():
+        for n_, p_ in student.named_parameters():
+            if "relative_position_bias_table" in n_:
+                p_.mul_(25.0)
+    mod = DistillationModule(student, DINOv2ViT("dinov2_vits14", seed=0), cfg)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(9))
+    ref, sp, lp = _oracle_step(mod, cfg, x)
+    mod.cuda().train()
+    set_drop(0.0)
+    loss = mod.training_step(x.cuda(), 0)
+    for k, v in ref.items():
+        close(mod.logged["train_" + k], v, k)
+    loss.backward()
+    num = den = 0.0
+    per = []
+    gmax = max(v.grad.abs().max().item() for v in sp.values() if v.grad is not None)
+    for k, p in mod.student.named_parameters():
+        r = sp[k[len("model.model."):]].grad
+        if not p.requires_grad:
+            continue
+        # mathematically zero gradients: norm0 / norm1 (res2 / res3 are not distilled) and the biases of norm2 / norm3
+        # (a per-channel shift of the feature is removed by the projector's train-mode BatchNorm) - rounding noise only
+        if r is None or r.abs().max() < 1e-6 * gmax:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-5 * gmax, k
+            continue
+        gd, rd = p.grad.detach().cpu().double(), r.double()
+        num += ((gd - rd) ** 2).sum().item()
+        den += (rd ** 2).sum().item()
+        per.append((((gd - rd).norm() / rd.norm()).item(), k))
+    rel = (num / den) ** 0.5
+    print(f"swin_tiny step: student grad relL2 {rel:.2e}; worst tensor {max(per)}")
+    assert rel <= 3e-3 and max(per)[0] <= 2e-2, (rel, max(per))
+    l0 = float(loss)
+    assert abs(float(mod.training_step(x.cuda(), 0)) - l0) < 1e-6 * abs(l0)  # p = 0: deterministic
+    set_drop(0.3)
+    l1 = mod.training_step(x.cuda(), 0)
+    l1.backward()
+    assert torch.isfinite(l1) and abs(float(l1) - l0) > 1e-6 * abs(l0)
+    assert all(torch.isfinite(p.grad).all() for p in mod.student.parameters() if p.grad is not None)
+    mod.eval()
+    with torch.no_grad():
+        a = mod.student(x.cuda())["res5"].clone()
+        b = mod.student(x.cuda())["res5"]
+    assert torch.equal(a, b)  # eval: dropout is the identity
