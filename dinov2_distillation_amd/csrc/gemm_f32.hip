@@ -231,6 +231,205 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const float* __re
         }
 }
 
+// =====================================================================================================================
+// "v2" family: v_mfma_f32_16x16x4_f32 with K-contiguous LDS rows for K-contiguous operands.
+//   * A K-contiguous operand tile lives in LDS as [row][BK + 4]: the global float4 (4 consecutive k) is stored as ONE
+//     ds_write_b128 (no transposition) and a fragment is ONE ds_read_b128 per 16 rows x 16 k: lane (g = lane/16, i = lane%16)
+//     reads k = 4g..4g+3 of row i and feeds element s of that vector to MFMA step s.  The four steps of a 16-k block then
+//     cover k = {4g + s}: a permutation of the reduction index, applied identically to both operands, so the sum is the same.
+//     Row pitch BK+4 floats: the 8 lanes served per LDS cycle of a b128 access start 4 banks apart (conflict-free).
+//   * An M- (or N-) contiguous operand keeps the k-major tile [k][EXT + 4] (float4 row stores) and is read with four
+//     ds_read_b32 per fragment (k = 4g + s); EXT + 4 == 4 (mod 8) puts the two 16-lane groups of a half wave 16 banks apart.
+//   * The MFMA is issued as D^T: first operand = the Bop fragment (rows of D index n), second = the Aop fragment, so each
+//     lane ends up with FOUR CONSECUTIVE n of one output row m -> float4 bias / residual loads and float4 stores.
+//   * 16 (64x64 per wave) or 8 independent accumulators per wave: long runs of independent MFMAs between fragment reads.
+template <int EXT, int BK, bool KC, int NT>
+struct Stager2 {
+    static constexpr int TOTAL = EXT * BK / 4;
+    static constexpr int NV = (TOTAL + NT - 1) / NT;
+    static constexpr int LDS_LD = KC ? BK + 4 : EXT + 4;
+    static constexpr int SIZE = KC ? EXT * (BK + 4) : BK * (EXT + 4);
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int rows, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TOTAL % NT != 0 && idx >= TOTAL) {
+            } else if (KC) {
+                const int r = idx / (BK / 4), kq = idx % (BK / 4);
+                const int gr = row0 + r, gk = k0 + 4 * kq;
+                if (gr < rows && gk < kend) x = *reinterpret_cast<const float4*>(P + (long)gr * ld + gk);
+            } else {
+                const int k = idx / (EXT / 4), mq = idx % (EXT / 4);
+                const int gk = k0 + k, gr = row0 + 4 * mq;
+                if (gk < kend && gr < rows) x = *reinterpret_cast<const float4*>(P + (long)gk * ld + gr);
+            }
+            v[i] = x;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT;
+            if (TOTAL % NT != 0 && idx >= TOTAL) continue;
+            if (KC) {
+                const int r = idx / (BK / 4), kq = idx % (BK / 4);
+                *reinterpret_cast<float4*>(S + r * LDS_LD + 4 * kq) = v[i];
+            } else {
+                const int k = idx / (EXT / 4), mq = idx % (EXT / 4);
+                *reinterpret_cast<float4*>(S + k * LDS_LD + 4 * mq) = v[i];
+            }
+        }
+    }
+    // fragment of 16 rows starting at r0 for the 16-k block kb: element s = Aop[r0 + lane%16][16*kb + 4*(lane/16) + s]
+    static __device__ __forceinline__ float4 frag(const float* __restrict__ S, int r0, int kb, int g, int i16) {
+        if (KC) return *reinterpret_cast<const float4*>(S + (r0 + i16) * LDS_LD + 16 * kb + 4 * g);
+        const float* p = S + (16 * kb + 4 * g) * LDS_LD + r0 + i16;
+        return make_float4(p[0], p[LDS_LD], p[2 * LDS_LD], p[3 * LDS_LD]);
+    }
+};
+
+__device__ __forceinline__ void epilogue_store4(const Epilogue& e, float* C, long ldc, int m, int n, int N, f32x4 acc, bool vec) {
+    if (!vec) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) epilogue_store(e, C, ldc, m, n + r, acc[r]);
+        return;
+    }
+    float4 v = make_float4(acc[0] * e.alpha, acc[1] * e.alpha, acc[2] * e.alpha, acc[3] * e.alpha);
+    if (e.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    long orow = m;
+    if (e.row_grp > 0) orow = (long)(m / e.row_grp) * e.row_grp_stride + (m % e.row_grp) + e.row_off;
+    if (e.preact) *reinterpret_cast<float4*>(e.preact + orow * ldc + n) = v;
+    v.x = apply_act(v.x, e.act); v.y = apply_act(v.y, e.act); v.z = apply_act(v.z, e.act); v.w = apply_act(v.w, e.act);
+    if (e.colscale) {
+        const float4 c = *reinterpret_cast<const float4*>(e.colscale + n);
+        v.x *= c.x; v.y *= c.y; v.z *= c.z; v.w *= c.w;
+    }
+    if (e.residual) {
+        const long rr = e.res_mod > 0 ? (long)(m % e.res_mod) : orow;
+        const float4 r = *reinterpret_cast<const float4*>(e.residual + rr * e.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4*>(C + orow * ldc + n) = v;
+}
+
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* __restrict__ A, long lda,
+                                                                   const float* __restrict__ B, long ldb, float* C, long ldc,
+                                                                   int M, int N, int K, int kchunk, Epilogue epi,
+                                                                   float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
+    using SA = Stager2<BM, BK, A_KC, NT>;
+    using SB = Stager2<BN, BK, B_KC, NT>;
+    constexpr int A_SZ = SA::SIZE, B_SZ = SB::SIZE;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    const int g = lane >> 4, i16 = lane & 15;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    SA sa;
+    SB sb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const bool do_rowsum = !A_KC && rowsum != nullptr && bn0 == 0 && tid < BM;
+    float rs = 0.f;
+    auto compute = [&](const float* As, const float* Bs) {
+        if (do_rowsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += As[kk * SA::LDS_LD + tid];
+        }
+#pragma unroll
+        for (int kb = 0; kb < BK / 16; ++kb) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = SA::frag(As, (wm * TM + i) * 16, kb, g, i16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = SB::frag(Bs, (wn * TN + j) * 16, kb, g, i16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].x, a[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].y, a[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    if (nk > 0) {
+        sa.load(A, lda, bm0, M, kbeg, kend, tid);
+        sb.load(B, ldb, bn0, N, kbeg, kend, tid);
+        sa.store(smem, tid);
+        sb.store(smem + A_SZ, tid);
+        if (nk > 1) {
+            sa.load(A, lda, bm0, M, kbeg + BK, kend, tid);
+            sb.load(B, ldb, bn0, N, kbeg + BK, kend, tid);
+        }
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        float* As = smem + cur * (A_SZ + B_SZ);
+        float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
+        if (kt + 1 < nk) {
+            sa.store(An, tid);
+            sb.store(An + A_SZ, tid);
+        }
+        if (kt + 2 < nk) {
+            sa.load(A, lda, bm0, M, kbeg + (kt + 2) * BK, kend, tid);
+            sb.load(B, ldb, bn0, N, kbeg + (kt + 2) * BK, kend, tid);
+        }
+        compute(As, As + A_SZ);
+        __syncthreads();
+    }
+
+    // D^T map of the 16x16 MFMA: row (= n here) = 4*(lane/16) + r, col (= m here) = lane%16
+    const bool partial = ws != nullptr;
+    if (do_rowsum && bm0 + tid < M) {
+        if (partial) ws[(long)gridDim.y * M * N + (long)blockIdx.y * M + bm0 + tid] = rs;
+        else rowsum[bm0 + tid] = rs * epi.alpha;
+    }
+    float* out = partial ? ws + (long)blockIdx.y * M * N : C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = bm0 + (wm * TM + i) * 16 + i16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn0 + (wn * TN + j) * 16 + 4 * g;
+            if (n >= N) continue;
+            if (partial) {
+                if ((N & 3) == 0) {
+                    *reinterpret_cast<float4*>(out + (long)m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < N) out[(long)m * N + n + r] = acc[i][j][r];
+                }
+            } else {
+                epilogue_store4(epi, C, ldc, m, n, N, acc[i][j], vec_ok != 0);
+            }
+        }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* C,
                                      long ldc, Epilogue epi, float* __restrict__ rowsum) {
     const long total = (long)M * N;
@@ -419,57 +618,101 @@ int launch_cfg(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     return DKD_OK;
 }
 
+template <int WM, int WN, int TM, int TN, int BK>
+int launch_v2(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
+    float* ws = splits > 1 ? g->workspace : nullptr;
+    // float4 epilogue: every pointer it touches 16-byte aligned, leading dimensions and N multiples of 4
+    int vec = (g->N % 4 == 0) && (g->ldc % 4 == 0) && dkd_aligned16(g->C);
+    if (g->bias && !dkd_aligned16(g->bias)) vec = 0;
+    if (g->colscale && !dkd_aligned16(g->colscale)) vec = 0;
+    if (g->preact && !dkd_aligned16(g->preact)) vec = 0;
+    if (g->residual && (!dkd_aligned16(g->residual) || (g->ldr % 4))) vec = 0;
+#define DKD_GEMM_LAUNCH2(AKC, BKC)                                                                                      \
+    hipLaunchKernelGGL((gemm_f32_v2_kernel<WM, WN, TM, TN, BK, AKC, BKC>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, \
+                       g->C, g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
+    if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH2(true, true);
+    else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH2(true, false);
+    else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH2(false, true);
+    else DKD_GEMM_LAUNCH2(false, false);
+#undef DKD_GEMM_LAUNCH2
+    DKD_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long total = (long)g->M * g->N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g->workspace, splits, g->M, g->N,
+                           g->C, g->ldc, epi, g->rowsum);
+        DKD_LAUNCH_CHECK();
+    }
+    return DKD_OK;
+}
+
 }  // namespace
 
 // ---- automatic configuration --------------------------------------------------------------------------------------
-// Measured on MI355X (gpurun_out/tune*.log, fp32, random operands): the 32x64 / 64x32 per-wave tiles (2 accumulators,
-// ~90 registers, 5 waves/SIMD) beat 64x64 per wave everywhere; 128x128 blocks of 8 such waves win once the grid has
-// >= 4 tiles per CU, 64x128 blocks of 4 waves win on the 300-600-tile grids (N = 384 projections), 128x96 on N = 96/192.
-enum { CFG_128x128_8W = 2, CFG_64x128_4W = 3, CFG_128x96_4W = 4 };
+// Measured on MI355X (scripts/tune_v2.py over every GEMM shape of the config-[1] step, gpurun_out/tune_v2_*.log): the v2
+// family (16x16x4 MFMA, K-contiguous LDS rows, float4 epilogue) beats the 32x32x2 family on every shape, and within it SMALL
+// workgroup tiles win - 64x64 (4 waves of 32x32, 4 accumulators each, 20 KB of LDS: 8 workgroups per CU) - because many
+// small workgroups in different phases keep a CU's matrix pipes fed across each other's barriers and fill the last round of
+// the 256 CUs more evenly.  Exceptions: N = 96 likes a single 64x96 column tile (BK = 32 for the weight-gradient layout),
+// and grids under 3 tiles per CU like 32x64.
+// The 32x32x2 kernels stay reachable through `variant` (1..5) for A/B measurements.
+enum { CFG_128x128_8W = 2, CFG_64x128_4W = 3, CFG_128x96_4W = 4, V2_64x64 = 44, V2_64x96 = 43, V2_64x96_BK32 = 55, V2_32x64 = 52 };
 
-static int pick_cfg(int M, int N, int variant) {
+static int pick_cfg(int M, int N, int a_layout, int b_layout, int variant) {
     if (variant > 0) return variant;
-    if (N <= 96 || N == 192) return CFG_128x96_4W;
-    const long t128 = (long)dkd_cdiv(M, 128) * dkd_cdiv(N, 128);
-    return t128 >= 1024 ? CFG_128x128_8W : CFG_64x128_4W;
+    if (N == 96) return a_layout == 1 && b_layout == 1 ? V2_64x96_BK32 : V2_64x96;
+    const long t64 = (long)dkd_cdiv(M, 64) * dkd_cdiv(N, 64);
+    return t64 < 768 && !(a_layout == 1 && b_layout == 1) ? V2_32x64 : V2_64x64;
 }
 static void cfg_tile(int cfg, int* bm, int* bn) {
     switch (cfg) {
-        case 1: case CFG_128x128_8W: *bm = 128; *bn = 128; break;
-        case CFG_128x96_4W: *bm = 128; *bn = 96; break;
+        case 1: case CFG_128x128_8W: case 31: case 32: case 35: case 38: case 39: *bm = 128; *bn = 128; break;
+        case 40: *bm = 128; *bn = 64; break;
+        case CFG_128x96_4W: case 42: *bm = 128; *bn = 96; break;
+        case 43: *bm = 64; *bn = 96; break;
+        case 44: case 47: case 48: case 49: case 50: case 51: case 56: case 57: *bm = 64; *bn = 64; break;
+        case 52: *bm = 32; *bn = 64; break;
+        case 53: *bm = 64; *bn = 32; break;
+        case 54: *bm = 96; *bn = 64; break;
+        case 55: *bm = 64; *bn = 96; break;
+        case 46: *bm = 64; *bn = 192; break;
         default: *bm = 64; *bn = 128; break;
     }
 }
 // Split the reduction only when the output grid alone cannot fill the chip (weight gradients: small M x N, reduction
-// over all B*H*W rows).  Aim at ~1024 workgroups, >= 32 k-tiles per split, <= 128 slabs.
+// over all B*H*W rows).  Aim at 4..10 (small) workgroups per CU, >= 256 k per split, <= 128 slabs.
 static int pick_splits(int M, int N, int K, int cfg) {
     int bm, bn;
     cfg_tile(cfg, &bm, &bn);
     const long tiles = (long)dkd_cdiv(M, bm) * dkd_cdiv(N, bn);
-    if (tiles >= 384 || K < 1024) return 1;
+    if (tiles >= 1024 || K < 1024) return 1;
     long maxs = K / 256;  // >= 16 k-tiles per split
     if (maxs < 1) maxs = 1;
     if (maxs > 128) maxs = 128;
-    // among the split counts that give 512..1280 workgroups pick the one whose grid fills whole rounds of the 256 CUs best
+    // among the split counts that give 1024..2560 workgroups pick the one whose grid fills whole rounds of the 256 CUs best
     // (co-resident workgroups share a CU's matrix pipes, so a CU holding one workgroup more than the others finishes last)
     long best = 1;
     double best_eff = 0.0;
     for (long sp = 1; sp <= maxs; ++sp) {
         const long blocks = tiles * sp;
-        if (blocks < 512 && sp < maxs) continue;
-        if (blocks > 1280 && best_eff > 0.0) break;
+        if (blocks < 1024 && sp < maxs) continue;
+        if (blocks > 2560 && best_eff > 0.0) break;
         const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
     }
     return (int)best;
 }
 
-extern "C" int dkd_gemm_f32_splits(int M, int N, int K) { return pick_splits(M, N, K, pick_cfg(M, N, 0)); }
+static int auto_splits(int M, int N, int K, int a_layout, int b_layout) {
+    return pick_splits(M, N, K, pick_cfg(M, N, a_layout, b_layout, 0));
+}
+
+extern "C" int dkd_gemm_f32_splits(int M, int N, int K) { return auto_splits(M, N, K, 1, 1); }  // the wgrad (split-K) layout
 
 extern "C" long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout) {
-    (void)a_layout;
-    (void)b_layout;
-    const int splits = dkd_gemm_f32_splits(M, N, K);
+    const int splits = auto_splits(M, N, K, a_layout, b_layout);
     return splits > 1 ? (long)splits * ((long)M * N + M) * sizeof(float) : 0;
 }
 
@@ -501,11 +744,11 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
             default: return launch_bf16x3<4, 2, 1, 2>(g, epi, st);   // 128 x 128, 8 waves of 32 x 64
         }
     }
-    const int cfg = pick_cfg(g->M, g->N, g->variant);
+    const int cfg = pick_cfg(g->M, g->N, g->a_layout, g->b_layout, g->variant);
     // the workspace was sized for the automatic configuration: never use more slabs than that
     int splits = pick_splits(g->M, g->N, g->K, cfg);
-    const int auto_splits = dkd_gemm_f32_splits(g->M, g->N, g->K);
-    if (splits > auto_splits) splits = auto_splits;
+    const int auto_sp = auto_splits(g->M, g->N, g->K, g->a_layout, g->b_layout);
+    if (splits > auto_sp) splits = auto_sp;
     if (splits > 1 && !g->workspace) splits = 1;
     int kchunk = g->K;
     if (splits > 1) {
@@ -519,6 +762,33 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case CFG_64x128_4W: return launch_cfg<1, 4, 2, 1, 16, 1>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 64 x 32
         case CFG_128x96_4W: return launch_cfg<4, 1, 1, 3, 16, 1>(g, epi, splits, kchunk, st);   // 128 x 96, 4 waves of 32 x 96
         case 5: return launch_cfg<2, 2, 1, 2, 16, 1>(g, epi, splits, kchunk, st);               // 64 x 128, 4 waves of 32 x 64
+        // v2 family (16x16x4 MFMA, K-contiguous LDS rows): tuning variants 31..
+        case 31: return launch_v2<2, 2, 4, 4, 16>(g, epi, splits, kchunk, st);   // 128 x 128, 4 waves of 64 x 64, BK 16
+        case 32: return launch_v2<2, 2, 4, 4, 32>(g, epi, splits, kchunk, st);   // 128 x 128, 4 waves of 64 x 64, BK 32
+        case 33: return launch_v2<2, 2, 2, 4, 32>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 32 x 64, BK 32
+        case 34: return launch_v2<2, 2, 2, 4, 16>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 32 x 64, BK 16
+        case 35: return launch_v2<2, 4, 4, 2, 32>(g, epi, splits, kchunk, st);   // 128 x 128, 8 waves of 64 x 32, BK 32
+        case 36: return launch_v2<2, 2, 4, 8, 16>(g, epi, splits, kchunk, st);   // 128 x 256, 4 waves of 64 x 128, BK 16
+        case 38: return launch_v2<4, 2, 2, 4, 16>(g, epi, splits, kchunk, st);   // 128 x 128, 8 waves of 32 x 64
+        case 39: return launch_v2<2, 4, 4, 2, 16>(g, epi, splits, kchunk, st);   // 128 x 128, 8 waves of 64 x 32
+        case 40: return launch_v2<2, 2, 4, 2, 16>(g, epi, splits, kchunk, st);   // 128 x 64, 4 waves of 64 x 32
+        case 41: return launch_v2<1, 4, 4, 2, 16>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 64 x 32
+        case 42: return launch_v2<4, 1, 2, 6, 16>(g, epi, splits, kchunk, st);   // 128 x 96, 4 waves of 32 x 96
+        case 43: return launch_v2<2, 2, 2, 3, 16>(g, epi, splits, kchunk, st);   // 64 x 96, 4 waves of 32 x 48
+        case 44: return launch_v2<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 4 waves of 32 x 32
+        case 45: return launch_v2<4, 1, 1, 8, 16>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 16 x 128
+        case 46: return launch_v2<2, 2, 2, 6, 16>(g, epi, splits, kchunk, st);   // 64 x 192, 4 waves of 32 x 96
+        case 47: return launch_v2<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);   // 64 x 64, 4 waves of 32 x 32, BK 32
+        case 48: return launch_v2<1, 4, 4, 1, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 4 waves of 64 x 16
+        case 49: return launch_v2<4, 1, 1, 4, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 4 waves of 16 x 64
+        case 50: return launch_v2<2, 1, 2, 4, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 2 waves of 32 x 64
+        case 51: return launch_v2<1, 2, 4, 2, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 2 waves of 64 x 32
+        case 52: return launch_v2<2, 2, 1, 2, 16>(g, epi, splits, kchunk, st);   // 32 x 64, 4 waves of 16 x 32
+        case 53: return launch_v2<2, 2, 2, 1, 16>(g, epi, splits, kchunk, st);   // 64 x 32, 4 waves of 32 x 16
+        case 54: return launch_v2<2, 2, 3, 2, 16>(g, epi, splits, kchunk, st);   // 96 x 64, 4 waves of 48 x 32
+        case 55: return launch_v2<2, 2, 2, 3, 32>(g, epi, splits, kchunk, st);   // 64 x 96, BK 32
+        case 56: return launch_v2<4, 2, 1, 2, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 8 waves of 16 x 32
+        case 57: return launch_v2<1, 1, 4, 4, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 1 wave of 64 x 64
         default: return DKD_ERR_BAD_ARG;
     }
 }

@@ -34,9 +34,19 @@ for (M, N, K, al, bl), cnt in shapes.items():
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     fl = 2.0 * M * N * K
-    rows.append((cnt * us, cnt, M, N, K, al, bl, us, fl / us / 1e6))
+    # vendor library (rocBLAS / hipBLASLt through torch.matmul, strict fp32) on the same operands: a yardstick only
+    torch.backends.cuda.matmul.allow_tf32 = False
+    am = a if al == 0 else a.t()
+    bm = b.t() if bl == 0 else b
+    for _ in range(2): torch.matmul(am, bm, out=out)
+    e0.record()
+    for _ in range(reps): torch.matmul(am, bm, out=out)
+    e1.record(); torch.cuda.synchronize()
+    us_lib = e0.elapsed_time(e1) * 1e3 / reps
+    rows.append((cnt * us, cnt, M, N, K, al, bl, us, fl / us / 1e6, us_lib, fl / us_lib / 1e6))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("total gemm time per step: %.2f ms over %d launches" % (tot / 1e3, sum(r[1] for r in rows)))
 for r in rows[:40]:
-    print("%7.1f us total  x%3d  M=%6d N=%5d K=%6d a%d b%d  %8.1f us  %6.1f TF/s" % r)
+    print("%7.1f us total  x%3d  M=%6d N=%5d K=%6d a%d b%d  %8.1f us  %6.1f TF/s | torch.matmul %8.1f us %6.1f TF/s" % r)
+print("vendor-library total for the same launches: %.2f ms" % (sum(r[1] * r[9] for r in rows) / 1e3))
