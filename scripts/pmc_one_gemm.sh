@@ -1,0 +1,24 @@
+#!/bin/bash
+# SQ counter passes over scripts/one_gemm.py (one counter group per run); prints per-kernel averages.
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/pmc_v2
+i=0
+for C in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1)); D=$R/gpurun_out/pmc_v2/g$i
+  LIB=1 timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python3 $R/scripts/one_gemm.py "$@" > $D.log 2>&1 || { tail -5 $D.log; echo "group $i failed: $C"; }
+done
+cd $R && python3 - <<'PY'
+import csv,glob,collections
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+dur=collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmc_v2/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"]
+        if "gemm" not in k and "Cijk" not in k: continue
+        k=("v2" if "v2_kernel" in k else ("lib "+k[k.find("MT"):k.find("MT")+14] if "Cijk" in k else "v1"))
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,d in agg.items():
+    print(k, {c: round(sum(v)/len(v)) for c,v in sorted(d.items())})
+PY

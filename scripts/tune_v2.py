@@ -28,7 +28,7 @@ for M, N, K, al, bl, cnt in shapes:
     res = torch.randn(M, N, generator=g).cuda()
     ref = None
     line = "M=%6d N=%5d K=%6d a%d b%d x%2d |" % (M, N, K, al, bl, cnt)
-    times = {}
+    times, outs, kws = {}, {}, {}
     for v in variants:
         out = torch.empty(M, N, device="cuda")
         kw = dict(a_layout=al, b_layout=bl, out=out, variant=v)
@@ -39,16 +39,23 @@ for M, N, K, al, bl, cnt in shapes:
         except Exception as e:
             line += " v%d: %s |" % (v, str(e)[-24:])
             continue
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5): ops.gemm(a, b, **kw)
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 5
+        kws[v], outs[v] = kw, out
+    torch.cuda.synchronize()
+    samples = {v: [] for v in kws}
+    for rnd in range(7):  # interleaved rounds: clock / thermal drift hits every variant alike; report the median
+        for v in (list(kws) if rnd % 2 == 0 else list(kws)[::-1]):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3): ops.gemm(a, b, **kws[v])
+            e1.record(); torch.cuda.synchronize()
+            samples[v].append(e0.elapsed_time(e1) * 1e3 / 3)
+    for v in kws:
+        us = sorted(samples[v])[len(samples[v]) // 2]
         if ref is None:
-            ref = out.clone()
+            ref = outs[v].clone()
             err = 0.0
         else:
-            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            err = ((outs[v] - ref).abs().max() / ref.abs().max()).item()
         times[v] = us
         tot[v] += cnt * us
         line += " v%d %6.1fus %5.1fTF%s |" % (v, us, 2.0 * M * N * K / us / 1e6, "" if err < 1e-5 else " ERR %.1e" % err)
