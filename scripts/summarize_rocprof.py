@@ -11,11 +11,11 @@ os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 shutil.copy(stats, os.path.join(root, "profiles", name + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-with open(os.path.join(root, "profiles", name + ".md"), "w") as f:
-    f.write(f"# {name}: rocprofv3 --kernel-trace --stats\n\n{note}\n\n")
+with open(os.path.join(root, "profiles", name + "_kernel_stats.md"), "w") as f:
+    f.write(f"# {name}_kernel_stats: rocprofv3 --kernel-trace --stats\n\n{note}\n\n")
     f.write(f"Total kernel time {tot/1e6:.2f} ms over the whole run" + (f" = {tot/1e6/steps:.2f} ms per step ({steps} steps incl. warm-up)" if steps else "") + ".\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:40]:
         f.write("| `%s` | %s | %.2f | %.1f | %.1f |\n" % (r["Name"][:110].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                    float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
-print(open(os.path.join(root, "profiles", name + ".md")).read()[:3000])
+print(open(os.path.join(root, "profiles", name + "_kernel_stats.md")).read()[:3000])
