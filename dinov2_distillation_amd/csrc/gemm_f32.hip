@@ -498,16 +498,18 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& h, bf16x4& m, bf1
                (__bf16)(r.w - (float)m[3])};
 }
 
-template <int WM, int WN, int TM, int TN>
+// P = 3: the split-precision product above.  P = 1: plain bf16 operands (round-to-nearest of the fp32 values while staging),
+// fp32 accumulation - the frozen teacher's opt-in "bf16 on MFMA" mode (BASELINE configs[4]); activations stay fp32 in HBM.
+template <int WM, int WN, int TM, int TN, int P>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float* __restrict__ A, long lda,
                                                                       const float* __restrict__ B, long ldb, float* C,
                                                                       long ldc, int M, int N, int K, Epilogue epi) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, NT = WM * WN * 64, RS = 40;  // RS: bf16 per LDS row (80 B)
     constexpr int NVA = BM * 8 / NT, NVB = BN * 8 / NT;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile must divide over the threads");
-    __shared__ __attribute__((aligned(16))) __bf16 smem[3 * (BM + BN) * RS];
-    __bf16* As = smem;                 // [3][BM][RS]
-    __bf16* Bs = smem + 3 * BM * RS;   // [3][BN][RS]
+    __shared__ __attribute__((aligned(16))) __bf16 smem[P * (BM + BN) * RS];
+    __bf16* As = smem;                 // [P][BM][RS]
+    __bf16* Bs = smem + P * BM * RS;   // [P][BN][RS]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN, half = lane >> 5, l31 = lane & 31;
@@ -549,8 +551,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
             bf16x4 h, m, l;
             split3(ra[i], h, m, l);
             *reinterpret_cast<bf16x4*>(As + (0 * BM + r) * RS + 4 * kq) = h;
-            *reinterpret_cast<bf16x4*>(As + (1 * BM + r) * RS + 4 * kq) = m;
-            *reinterpret_cast<bf16x4*>(As + (2 * BM + r) * RS + 4 * kq) = l;
+            if (P == 3) {
+                *reinterpret_cast<bf16x4*>(As + (1 * BM + r) * RS + 4 * kq) = m;
+                *reinterpret_cast<bf16x4*>(As + (2 * BM + r) * RS + 4 * kq) = l;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
@@ -558,8 +562,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
             bf16x4 h, m, l;
             split3(rb[i], h, m, l);
             *reinterpret_cast<bf16x4*>(Bs + (0 * BN + r) * RS + 4 * kq) = h;
-            *reinterpret_cast<bf16x4*>(Bs + (1 * BN + r) * RS + 4 * kq) = m;
-            *reinterpret_cast<bf16x4*>(Bs + (2 * BN + r) * RS + 4 * kq) = l;
+            if (P == 3) {
+                *reinterpret_cast<bf16x4*>(Bs + (1 * BN + r) * RS + 4 * kq) = m;
+                *reinterpret_cast<bf16x4*>(Bs + (2 * BN + r) * RS + 4 * kq) = l;
+            }
         }
     };
 
@@ -571,27 +577,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
         if (kt + 1 < nk) load((kt + 1) * BK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[TM][3], b[TN][3];
+            bf16x8 a[TM][P], b[TN][P];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < P; ++p)
                     a[i][p] = *reinterpret_cast<const bf16x8*>(As + (p * BM + (wm * TM + i) * 32 + l31) * RS + ks * 16 + half * 8);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < P; ++p)
                     b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * BN + (wn * TN + j) * 32 + l31) * RS + ks * 16 + half * 8);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];  // smallest cross terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    if (P == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P - 1], b[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][P - 1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P / 2], b[j][P / 2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P / 2], b[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][P / 2], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
                     acc[i][j] = c;
                 }
@@ -615,11 +623,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
         }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int P = 3>
 int launch_bf16x3(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN)), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<WM, WN, TM, TN>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc,
+    hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<WM, WN, TM, TN, P>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc,
                        g->M, g->N, g->K, epi);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
@@ -762,6 +770,12 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     epi.row_grp_stride = g->row_grp_stride;
     epi.row_off = g->row_off;
     epi.alpha = g->alpha;
+    if (g->precision == DKD_PREC_BF16 && g->a_layout == 0 && g->b_layout == 0 && !g->rowsum) {
+        hipStream_t st = (hipStream_t)stream;
+        const long t128 = (long)dkd_cdiv(g->M, 128) * dkd_cdiv(g->N, 128);
+        if (g->variant == 23 || (g->variant == 0 && t128 < 512)) return launch_bf16x3<1, 4, 2, 1, 1>(g, epi, st);  // 64 x 128
+        return launch_bf16x3<4, 2, 1, 2, 1>(g, epi, st);                                                            // 128 x 128
+    }
     if (g->precision == DKD_PREC_BF16X3 && g->a_layout == 0 && g->b_layout == 0 && !g->rowsum) {
         hipStream_t st = (hipStream_t)stream;
         switch (g->variant) {

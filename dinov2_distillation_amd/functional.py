@@ -216,27 +216,28 @@ class ConvNeXtBlockFn(Function):
 
 
 # =====================================================================================================================
-def vit_block_forward(x, p, H, save):
+def vit_block_forward(x, p, H, save, prec=None):
     """DINOv2 pre-norm block with LayerScale folded into the (frozen) projection weights.
-    x [B,N,D]; p: dict of prepared tensors.  Returns (out, saved-tuple or None)."""
+    x [B,N,D]; p: dict of prepared tensors; prec: GEMM precision of this (frozen) block (None = the global default).
+    Returns (out, saved-tuple or None)."""
     B, N, D = x.shape
     M, hd = B * N, D // H
     x2 = x.reshape(M, D)
     h1, m1, r1 = ops.layernorm_fwd(x2, p["n1w"], p["n1b"], 1e-6, need_stats=save)
-    qkv = ops.gemm(h1, p["wqkv"], bias=p["bqkv"])  # [M, 3D] packed (3, H, hd)
+    qkv = ops.gemm(h1, p["wqkv"], bias=p["bqkv"], precision=prec)  # [M, 3D] packed (3, H, hd)
     st = (N * 3 * D, 3 * D)
     o, lse = ops.attention_forward(qkv, qkv[:, D:], qkv[:, 2 * D:], H, hd, hd ** -0.5, B, N, N, st, st, st)
-    x1 = ops.gemm(o.reshape(M, D), p["wproj"], bias=p["bproj"], residual=x2)
+    x1 = ops.gemm(o.reshape(M, D), p["wproj"], bias=p["bproj"], residual=x2, precision=prec)
     h2, m2, r2 = ops.layernorm_fwd(x1, p["n2w"], p["n2b"], 1e-6, need_stats=save)
     if p.get("swiglu"):
-        u = ops.gemm(h2, p["w1"], bias=p["b1"])  # [M, 2*hidden] = [x1 | x2]
+        u = ops.gemm(h2, p["w1"], bias=p["b1"], precision=prec)  # [M, 2*hidden] = [x1 | x2]
         a = ops.swiglu_fwd(u)
         if not save:
             u = None
     else:
         u = torch.empty((M, p["w1"].shape[0]), dtype=F32, device=x.device) if save else None
-        a = ops.gemm(h2, p["w1"], bias=p["b1"], act=ops.ACT_GELU, preact=u)
-    x2o = ops.gemm(a, p["w2"], bias=p["b2"], residual=x1)
+        a = ops.gemm(h2, p["w1"], bias=p["b1"], act=ops.ACT_GELU, preact=u, precision=prec)
+    x2o = ops.gemm(a, p["w2"], bias=p["b2"], residual=x1, precision=prec)
     saved = (x2, m1, r1, qkv, o, lse, x1, m2, r2, u) if save else None
     return x2o.reshape(B, N, D), saved
 
@@ -248,7 +249,7 @@ class ViTBlockFrozenFn(Function):
     @staticmethod
     def forward(ctx, x, blk):
         x = _c(x)
-        out, saved = vit_block_forward(x, blk.prepared(), blk.num_heads, save=True)
+        out, saved = vit_block_forward(x, blk.prepared(), blk.num_heads, save=True, prec=blk.precision)
         ctx.blk = blk
         ctx.save_for_backward(*saved)
         ctx.shape = tuple(x.shape)
@@ -261,16 +262,21 @@ class ViTBlockFrozenFn(Function):
         B, N, D = ctx.shape
         M, hd = B * N, D // H
         d2 = _c(dout).reshape(M, D)
-        da = ops.dgrad(d2, p["w2"])
+        prec = ctx.blk.precision
+
+        def dg(dy, name):  # dgrad through a frozen weight; the bf16 modes use its cached transpose
+            return ops.dgrad(dy, p[name], precision=prec, w_t=ctx.blk.transposed(name))
+
+        da = dg(d2, "w2")
         du = ops.swiglu_bwd(da, u) if p.get("swiglu") else ops.gelu_bwd(da, u)
-        dh2 = ops.dgrad(du, p["w1"])
+        dh2 = dg(du, "w1")
         dx1, _, _ = ops.layernorm_bwd(dh2, x1, m2, r2, p["n2w"], affine=False, add=d2)
-        do = ops.dgrad(dx1, p["wproj"]).reshape(B, N, D)
+        do = dg(dx1, "wproj").reshape(B, N, D)
         dqkv = torch.empty_like(qkv)
         st = (N * 3 * D, 3 * D)
         ops.attention_backward(do, qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, H, hd, hd ** -0.5, B, N, N, st, st, st,
                                dqkv, dqkv[:, D:], dqkv[:, 2 * D:], st, st, st)
-        dh1 = ops.dgrad(dqkv, p["wqkv"])
+        dh1 = dg(dqkv, "wqkv")
         dx, _, _ = ops.layernorm_bwd(dh1, x2, m1, r1, p["n1w"], affine=False, add=dx1)
         return dx.reshape(B, N, D), None
 

@@ -60,6 +60,18 @@ class Block(nn.Module):
             self.mlp.fc1.weight, self.mlp.fc1.bias = _tn(4 * dim, dim, gen=gen), z(4 * dim)
             self.mlp.fc2.weight, self.mlp.fc2.bias = _tn(dim, 4 * dim, gen=gen), z(dim)
         self._prep = None
+        self.precision = None  # GEMM precision of this frozen block: None (global default) / ops.PREC_F32 / PREC_BF16X3 / PREC_BF16
+
+    def transposed(self, name):
+        """cached [K, N] copy of a prepared weight for the NT-only bf16 kernels' dgrad; None in the exact mode"""
+        prec = ops.GEMM_PRECISION if self.precision is None else self.precision
+        if prec == ops.PREC_F32:
+            return None
+        p = self.prepared()
+        if "t_" + name not in p:
+            with torch.no_grad():
+                p["t_" + name] = ops.transpose(p[name])
+        return p["t_" + name]
 
     def prepared(self):
         """Kernel-ready frozen weights; LayerScale is folded into the projections once (the teacher never trains):
@@ -86,7 +98,7 @@ class Block(nn.Module):
     def forward(self, x):
         if torch.is_grad_enabled() and x.requires_grad:
             return Fn.ViTBlockFrozenFn.apply(x, self)
-        return Fn.vit_block_forward(x.contiguous(), self.prepared(), self.num_heads, save=False)[0]
+        return Fn.vit_block_forward(x.contiguous(), self.prepared(), self.num_heads, save=False, prec=self.precision)[0]
 
 
 class VisionTransformer(nn.Module):
@@ -107,6 +119,15 @@ class VisionTransformer(nn.Module):
         self.norm.weight = nn.Parameter(torch.ones(D), requires_grad=False)
         self.norm.bias = nn.Parameter(torch.zeros(D), requires_grad=False)
         self._pos_cache = {}
+        self.precision = None
+
+    def set_precision(self, precision):
+        """GEMM arithmetic of the frozen teacher: None / "f32" (exact fp32 MFMA), "bf16x3" (split precision) or "bf16"
+        (operands rounded to bf16, fp32 accumulate - BASELINE configs[4]'s "bf16 teacher on MFMA")."""
+        self.precision = ops.PRECISIONS[precision] if (precision is None or isinstance(precision, str)) else precision
+        for blk in self.blocks:
+            blk.precision = self.precision
+        return self
 
     def _apply(self, fn, *a, **k):
         self._pos_cache = {}
@@ -140,7 +161,7 @@ class VisionTransformer(nn.Module):
         rows = ops.patchify_nchw(x.contiguous(), PATCH)
         tok = torch.empty((B * (n + 1), D), dtype=torch.float32, device=x.device)
         ops.gemm(rows, self.patch_embed.proj.weight.reshape(D, -1), bias=self.patch_embed.proj.bias, out=tok,
-                 residual=table[1:], res_mod=n, row_map=(n, n + 1, 1, B * (n + 1)))
+                 residual=table[1:], res_mod=n, row_map=(n, n + 1, 1, B * (n + 1)), precision=self.precision)
         ops.set_rows(tok, table[0], B, (n + 1) * D)
         t = tok.view(B, n + 1, D)
         for blk in self.blocks:
@@ -151,9 +172,9 @@ class VisionTransformer(nn.Module):
 
 
 class DINOv2ViT(nn.Module):
-    def __init__(self, model_name="dinov2_vitg14", seed=0):
+    def __init__(self, model_name="dinov2_vitg14", seed=0, precision=None):
         super().__init__()
-        self.model = VisionTransformer(VIT_CONFIGS[model_name], seed=seed)
+        self.model = VisionTransformer(VIT_CONFIGS[model_name], seed=seed).set_precision(precision)
         self.model.eval()
         for p in self.model.parameters():
             p.requires_grad = False

@@ -16,7 +16,8 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM = 0, 1, 2, 3, 4
 
 _ws = {}
-PREC_F32, PREC_BF16X3 = 0, 1
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PRECISIONS = {None: None, "f32": PREC_F32, "fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 GEMM_PRECISION = PREC_BF16X3 if os.environ.get("DKD_GEMM_PRECISION", "f32").lower() == "bf16x3" else PREC_F32
 
 
@@ -39,8 +40,8 @@ def _chk(t, name, contiguous=True):
 
 
 def workspace(nbytes, device, slot=0):
-    """Stream-ordered scratch: one growing buffer per (device, slot)."""
-    key = (device.index, slot)
+    """Stream-ordered scratch: one growing buffer per (device, stream, slot) - kernels on different streams never share one."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, slot)
     w = _ws.get(key)
     if w is None or w.numel() * 4 < nbytes:
         w = torch.empty(max(int(nbytes) // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
@@ -103,10 +104,13 @@ def linear_dgrad(dy, w, accumulate_into=None):
 
 
 def dgrad(dy, w, **kw):
-    """dx = dy @ w for w stored [N_out, K_in] (the KN operand of dkd_gemm_f32).  In bf16x3 mode the (small) weight is
-    transposed first so the launch becomes NT and takes the split-precision kernel."""
-    if GEMM_PRECISION == PREC_BF16X3 and kw.get("precision") is None:
-        return gemm(dy, transpose(w.reshape(-1, w.shape[-1])), **kw)
+    """dx = dy @ w for w stored [N_out, K_in] (the KN operand of dkd_gemm_f32).  In the bf16 modes the (small) weight is
+    transposed first (or its cached transpose ``w_t`` is used) so the launch becomes NT and takes the bf16 MFMA kernel."""
+    prec = GEMM_PRECISION if kw.get("precision") is None else kw["precision"]
+    if prec in (PREC_BF16X3, PREC_BF16):
+        wt = kw.pop("w_t", None)
+        return gemm(dy, transpose(w.reshape(-1, w.shape[-1])) if wt is None else wt, **kw)
+    kw.pop("w_t", None)
     return gemm(dy, w, b_layout=1, **kw)
 
 

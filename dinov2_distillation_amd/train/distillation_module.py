@@ -30,6 +30,16 @@ def _get(cfg, key, default=None):
     return getattr(cfg, key, default)
 
 
+TEACHER_ON_SIDE_STREAM = os.environ.get("DKD_TEACHER_STREAM", "1") != "0"
+_TEACHER_STREAMS = {}
+
+
+def _teacher_stream(device):
+    if device.index not in _TEACHER_STREAMS:
+        _TEACHER_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return _TEACHER_STREAMS[device.index]
+
+
 class DistillationModule(_Base):
     def __init__(self, student, teacher, cfg):
         super().__init__()
@@ -116,9 +126,23 @@ class DistillationModule(_Base):
         return loss_dict
 
     def _extract_features(self, batch):
-        with torch.no_grad():
-            teacher_features = self.teacher(batch)[_get(self.cfg["teacher"], "teacher_key", "feature_map")]
-        return {"student": self.student(batch), "teacher": teacher_features}
+        """train/distillation_module.py:311-337.  The frozen teacher's forward depends on nothing but the batch, so it is
+        issued on a side HIP stream and overlaps the student's forward (whose HBM-bound depthwise / LayerNorm / GRN kernels
+        leave the matrix pipes idle); the main stream joins before the losses read the teacher feature."""
+        key = _get(self.cfg["teacher"], "teacher_key", "feature_map")
+        if not (batch.is_cuda and TEACHER_ON_SIDE_STREAM):
+            with torch.no_grad():
+                teacher_features = self.teacher(batch)[key]
+            return {"student": self.student(batch), "teacher": teacher_features}
+        main = torch.cuda.current_stream(batch.device)
+        side = _teacher_stream(batch.device)
+        side.wait_stream(main)  # the batch, and every consumer of the previous step's teacher buffers, are done
+        with torch.cuda.stream(side), torch.no_grad():
+            teacher_features = self.teacher(batch)[key]
+        student_features = self.student(batch)
+        main.wait_stream(side)
+        teacher_features.record_stream(main)
+        return {"student": student_features, "teacher": teacher_features}
 
     def training_step(self, batch, batch_idx):
         losses = self._compute_losses(self._extract_features(batch))

@@ -11,12 +11,12 @@ from .train import DistillationModule
 
 class DistillationStepper:
     def __init__(self, teacher="dinov2_vits14", student="convnext_tiny", crop=224, device="cuda", heads=(16, 24),
-                 clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20):
+                 clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None):
         self.cfg = make_config(teacher, student, crop, heads=heads, lr=lr)
         torch.manual_seed(seed)  # student seed 1, ScaleKD follows; identical on every rank
         self.student = ModelWrapper(student, self.cfg.teacher.n_patches, self.cfg.student.student_keys)
         set_student_dims(self.cfg, self.student)
-        self.teacher = DINOv2ViT(teacher, seed=0)
+        self.teacher = DINOv2ViT(teacher, seed=0, precision=teacher_precision)
         self.module = DistillationModule(self.student, self.teacher, self.cfg).to(device).train()
         self.optimizer = self.module.configure_optimizers()
         if isinstance(self.optimizer, dict):

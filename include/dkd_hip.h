@@ -44,6 +44,7 @@ int dkd_abi_version(void);
  */
 #define DKD_PREC_F32 0
 #define DKD_PREC_BF16X3 1
+#define DKD_PREC_BF16 2
 typedef struct dkd_gemm_args {
     const float* A;
     int64_t lda;
@@ -65,8 +66,10 @@ typedef struct dkd_gemm_args {
     int32_t row_grp, row_grp_stride, row_off;
     float alpha;
     int32_t variant; /* 0 = automatic tile/schedule choice; >0 pins a kernel variant (tuning / A-B tests) */
-    int32_t precision; /* DKD_PREC_F32 (exact fp32 MFMA, default) or DKD_PREC_BF16X3 (3-way bf16 split, fp32 accumulate;
-                          NT layout only, other layouts silently use the exact path) */
+    int32_t precision; /* DKD_PREC_F32 (exact fp32 MFMA, default), DKD_PREC_BF16X3 (3-way bf16 split of each fp32 operand,
+                          6 MFMA products, fp32 accumulate: fp32-level accuracy) or DKD_PREC_BF16 (operands rounded to bf16
+                          while staged, fp32 accumulate: the frozen teacher's opt-in mode).  Both bf16 modes exist for the NT
+                          layout only; other layouts silently use the exact path */
 } dkd_gemm_args;
 int dkd_gemm_f32(const dkd_gemm_args* args, void* stream);
 int dkd_gemm_f32_splits(int M, int N, int K);

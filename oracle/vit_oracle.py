@@ -68,13 +68,40 @@ def init_vit_params(cfg, seed=0, depth=None, dtype=torch.float32):
     return p
 
 
-def vit_block(p, prefix, x, num_heads, eps=1e-6):
+class _Bf16Linear(torch.autograd.Function):
+    """y = round_bf16(x) round_bf16(w)^T + b with fp32 accumulation; dx = round_bf16(dy) round_bf16(w) (the frozen weight
+    gets no gradient): the arithmetic of a bf16-operand MFMA in both directions."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        wr = w.bfloat16().float()
+        ctx.save_for_backward(wr)
+        return F.linear(x.bfloat16().float(), wr, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (wr,) = ctx.saved_tensors
+        return dy.bfloat16().float() @ wr, None, None
+
+
+def _linear(x, w, b, bf16, scale=None):
+    """F.linear; bf16=True restates the opt-in "bf16 teacher on MFMA" arithmetic (BASELINE configs[4]): both operands rounded
+    to bfloat16 (round-to-nearest-even), products and sums in fp32.  ``scale`` (LayerScale) is folded into the weight BEFORE
+    the rounding, as the product folds it into the frozen projection weights."""
+    if scale is not None:
+        w, b = w * scale[:, None], b * scale
+    if bf16:
+        return _Bf16Linear.apply(x, w, b)
+    return F.linear(x, w, b)
+
+
+def vit_block(p, prefix, x, num_heads, eps=1e-6, bf16=False):
     """One pre-norm block: x += ls1*proj(MHSA(LN(x))); x += ls2*MLP(LN(x)).
     Call site in the reference: train/distillation_module.py:177 (``blocks[i](feat)``)."""
     B, N, D = x.shape
     hd = D // num_heads
     y = F.layer_norm(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps)
-    qkv = F.linear(y, p[prefix + "attn.qkv.weight"], p[prefix + "attn.qkv.bias"])
+    qkv = _linear(y, p[prefix + "attn.qkv.weight"], p[prefix + "attn.qkv.bias"], bf16)
     qkv = qkv.view(B, N, 3, num_heads, hd)
     q = qkv[:, :, 0].transpose(1, 2)  # [B,h,N,hd]
     k = qkv[:, :, 1].transpose(1, 2)
@@ -82,17 +109,16 @@ def vit_block(p, prefix, x, num_heads, eps=1e-6):
     logits = (q * hd ** -0.5) @ k.transpose(-1, -2)
     ctx = torch.softmax(logits, dim=-1) @ v
     ctx = ctx.transpose(1, 2).reshape(B, N, D)
-    a = F.linear(ctx, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"])
-    x = x + a * p[prefix + "ls1.gamma"]
+    x = x + _linear(ctx, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"], bf16, scale=p[prefix + "ls1.gamma"])
     y = F.layer_norm(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps)
     if (prefix + "mlp.w12.weight") in p:  # ViT-g: SwiGLUFFNFused, w3(silu(x1) * x2) with [x1 | x2] = w12(y)
-        x1, x2 = F.linear(y, p[prefix + "mlp.w12.weight"], p[prefix + "mlp.w12.bias"]).chunk(2, dim=-1)
-        m = F.linear(F.silu(x1) * x2, p[prefix + "mlp.w3.weight"], p[prefix + "mlp.w3.bias"])
+        x1, x2 = _linear(y, p[prefix + "mlp.w12.weight"], p[prefix + "mlp.w12.bias"], bf16).chunk(2, dim=-1)
+        m = _linear(F.silu(x1) * x2, p[prefix + "mlp.w3.weight"], p[prefix + "mlp.w3.bias"], bf16, scale=p[prefix + "ls2.gamma"])
     else:
-        m = F.linear(y, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"])
+        m = _linear(y, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"], bf16)
         m = F.gelu(m)
-        m = F.linear(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"])
-    return x + m * p[prefix + "ls2.gamma"]
+        m = _linear(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"], bf16, scale=p[prefix + "ls2.gamma"])
+    return x + m
 
 
 def resize_pos_table(pos_embed, ph, pw, offset=0.1):
@@ -111,25 +137,28 @@ def resize_pos_table(pos_embed, ph, pw, offset=0.1):
     return torch.cat([cls_pos, patch_pos], dim=1)
 
 
-def vit_tokens(p, x, cfg, depth=None):
+def vit_tokens(p, x, cfg, depth=None, bf16=False):
     """Patch-embed + CLS + position + all blocks + final LN; returns [B, 1+P*P, D]."""
     B, _, H, W = x.shape
     ph, pw = H // PATCH, W // PATCH
     depth = cfg["depth"] if depth is None else depth
-    t = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=PATCH)
+    if bf16:
+        t = F.conv2d(x.bfloat16().float(), p["patch_embed.proj.weight"].bfloat16().float(), p["patch_embed.proj.bias"], stride=PATCH)
+    else:
+        t = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=PATCH)
     t = t.flatten(2).transpose(1, 2)  # [B, P*P, D]
     t = torch.cat([p["cls_token"].expand(B, -1, -1), t], dim=1)
     t = t + resize_pos_table(p["pos_embed"], ph, pw)
     for i in range(depth):
-        t = vit_block(p, f"blocks.{i}.", t, cfg["num_heads"])
+        t = vit_block(p, f"blocks.{i}.", t, cfg["num_heads"], bf16=bf16)
     return F.layer_norm(t, (t.shape[-1],), p["norm.weight"], p["norm.bias"], 1e-6)
 
 
-def teacher_feature_map(p, x, cfg, depth=None):
+def teacher_feature_map(p, x, cfg, depth=None, bf16=False):
     """``DINOv2ViT.forward`` contract (models/backbones/dinov2.py:32-40): tokens of the last layer
     (``get_intermediate_layers(n=1, return_class_token=True)`` applies the final norm and strips CLS),
     reshaped [B,P,P,D] and permuted to [B,D,P,P] without copying."""
     B, _, H, W = x.shape
     ph, pw = H // PATCH, W // PATCH
-    tok = vit_tokens(p, x, cfg, depth)[:, 1:]
+    tok = vit_tokens(p, x, cfg, depth, bf16)[:, 1:]
     return tok.reshape(B, ph, pw, tok.shape[-1]).permute(0, 3, 1, 2)
