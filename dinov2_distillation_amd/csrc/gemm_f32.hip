@@ -462,20 +462,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* C,
-                                     long ldc, Epilogue epi, float* __restrict__ rowsum) {
+                                     long ldc, Epilogue epi, float* __restrict__ rowsum, int vec_ok) {
     const long total = (long)M * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total + (rowsum ? M : 0);
-         i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        if (i < total) {
+    if (vec_ok) {  // N % 4 == 0 and an aligned epilogue: four columns per thread, slab loads four deep in flight
+        const long tq = total >> 2;
+        for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < tq; q += (long)gridDim.x * blockDim.x) {
+            const float4* p = reinterpret_cast<const float4*>(ws) + q;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int z = 0;
+            for (; z + 4 <= splits; z += 4) {
+                const float4 a = p[(long)z * tq], b = p[(long)(z + 1) * tq], c = p[(long)(z + 2) * tq], d = p[(long)(z + 3) * tq];
+                s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+                s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+            }
+            for (; z < splits; ++z) {
+                const float4 a = p[(long)z * tq];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            const long i = q << 2;
+            epilogue_store4(epi, C, ldc, (int)(i / N), (int)(i % N), N, f32x4{s.x, s.y, s.z, s.w}, true);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            float s = 0.f;
             for (int z = 0; z < splits; ++z) s += ws[(long)z * total + i];
             epilogue_store(epi, C, ldc, (int)(i / N), (int)(i % N), s);
-        } else {
-            const long m = i - total;
+        }
+    }
+    if (rowsum)
+        for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+            float s = 0.f;
             for (int z = 0; z < splits; ++z) s += ws[(long)splits * total + (long)z * M + m];
             rowsum[m] = s * epi.alpha;
         }
-    }
 }
 
 
@@ -623,6 +642,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
         }
 }
 
+// float4 epilogue: every pointer it touches 16-byte aligned, leading dimensions and N multiples of 4
+static int epilogue_vec_ok(const dkd_gemm_args* g) {
+    int vec = (g->N % 4 == 0) && (g->ldc % 4 == 0) && dkd_aligned16(g->C);
+    if (g->bias && !dkd_aligned16(g->bias)) vec = 0;
+    if (g->colscale && !dkd_aligned16(g->colscale)) vec = 0;
+    if (g->preact && !dkd_aligned16(g->preact)) vec = 0;
+    if (g->residual && (!dkd_aligned16(g->residual) || (g->ldr % 4))) vec = 0;
+    return vec;
+}
+
+static int launch_splitk_reduce(const dkd_gemm_args* g, const Epilogue& epi, int splits, hipStream_t st) {
+    const int vec = epilogue_vec_ok(g) && dkd_aligned16(g->workspace);
+    const long work = (long)g->M * g->N / (vec ? 4 : 1);
+    const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g->workspace, splits, g->M, g->N, g->C, g->ldc, epi,
+                       g->rowsum, vec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
 template <int WM, int WN, int TM, int TN, int P = 3>
 int launch_bf16x3(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -647,13 +686,7 @@ int launch_cfg(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     else DKD_GEMM_LAUNCH(false, false);
 #undef DKD_GEMM_LAUNCH
     DKD_LAUNCH_CHECK();
-    if (splits > 1) {
-        const long total = (long)g->M * g->N;
-        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g->workspace, splits, g->M, g->N,
-                           g->C, g->ldc, epi, g->rowsum);
-        DKD_LAUNCH_CHECK();
-    }
+    if (splits > 1) return launch_splitk_reduce(g, epi, splits, st);
     return DKD_OK;
 }
 
@@ -662,12 +695,7 @@ int launch_v2(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchun
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
     float* ws = splits > 1 ? g->workspace : nullptr;
-    // float4 epilogue: every pointer it touches 16-byte aligned, leading dimensions and N multiples of 4
-    int vec = (g->N % 4 == 0) && (g->ldc % 4 == 0) && dkd_aligned16(g->C);
-    if (g->bias && !dkd_aligned16(g->bias)) vec = 0;
-    if (g->colscale && !dkd_aligned16(g->colscale)) vec = 0;
-    if (g->preact && !dkd_aligned16(g->preact)) vec = 0;
-    if (g->residual && (!dkd_aligned16(g->residual) || (g->ldr % 4))) vec = 0;
+    const int vec = epilogue_vec_ok(g);
 #define DKD_GEMM_LAUNCH2(AKC, BKC)                                                                                      \
     hipLaunchKernelGGL((gemm_f32_v2_kernel<WM, WN, TM, TN, BK, AKC, BKC, PF>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, \
                        g->C, g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
@@ -677,13 +705,7 @@ int launch_v2(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchun
     else DKD_GEMM_LAUNCH2(false, false);
 #undef DKD_GEMM_LAUNCH2
     DKD_LAUNCH_CHECK();
-    if (splits > 1) {
-        const long total = (long)g->M * g->N;
-        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g->workspace, splits, g->M, g->N,
-                           g->C, g->ldc, epi, g->rowsum);
-        DKD_LAUNCH_CHECK();
-    }
+    if (splits > 1) return launch_splitk_reduce(g, epi, splits, st);
     return DKD_OK;
 }
 

@@ -8,53 +8,68 @@ namespace {
 
 constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048
 
-template <bool WRITE_STATS>
+// Rows narrower than a wave share it: LPR lanes per row (16 / 32 / 64), 64/LPR rows per wave, VPL float4 per lane
+// (C <= 4 * LPR * VPL).  ConvNeXt's C = 96 rows (24 float4) used to occupy 24 of 64 lanes; now two rows ride one wave.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int LPR, int VPL, bool WRITE_STATS>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             long rows, int C, float eps, int in_grp, int in_grp_stride,
                                                             int in_off) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane / LPR, lir = lane % LPR;
     const int nv = C >> 2;
     const float invC = 1.f / (float)C;
-    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
+    float4 gm[VPL], bt[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lir + i * LPR;
+        gm[i] = c < nv ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[i] = c < nv ? reinterpret_cast<const float4*>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long row = ((long)blockIdx.x * 4 + wid) * RPW + sub; row < rows; row += (long)gridDim.x * 4 * RPW) {
         const long irow = in_grp > 0 ? (row / in_grp) * in_grp_stride + row % in_grp + in_off : row;
         const float4* xr = reinterpret_cast<const float4*>(x + irow * C);
-        float4 v[LN_MAXV];
+        float4 v[VPL];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + i * 64;
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lir + i * LPR;
             v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
-        const float mu = wave_sum(s) * invC;
+        const float mu = group_sum<LPR>(s) * invC;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + i * 64;
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lir + i * LPR;
             if (c < nv) {
                 const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
                 q += (a * a + b * b) + (cc * cc + d * d);
             }
         }
-        const float rs = rsqrtf(wave_sum(q) * invC + eps);
+        const float rs = rsqrtf(group_sum<LPR>(q) * invC + eps);
         float4* yr = reinterpret_cast<float4*>(y + row * C);
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + i * 64;
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lir + i * LPR;
             if (c < nv) {
-                const float4 g = reinterpret_cast<const float4*>(gamma)[c];
-                const float4 b = reinterpret_cast<const float4*>(beta)[c];
                 float4 o;
-                o.x = (v[i].x - mu) * rs * g.x + b.x;
-                o.y = (v[i].y - mu) * rs * g.y + b.y;
-                o.z = (v[i].z - mu) * rs * g.z + b.z;
-                o.w = (v[i].w - mu) * rs * g.w + b.w;
+                o.x = (v[i].x - mu) * rs * gm[i].x + bt[i].x;
+                o.y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
+                o.z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
+                o.w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
                 yr[c] = o;
             }
         }
-        if (WRITE_STATS && lane == 0) {
+        if (WRITE_STATS && lir == 0) {
             mean[row] = mu;
             rstd[row] = rs;
         }
@@ -63,33 +78,38 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Per-block partial sums of
 // dgamma = sum dy*xhat and dbeta = sum dy go to ws[block][2][C] (AFFINE) and are folded by reduce_partials.
-template <bool AFFINE>
+template <int LPR, int VPL, bool AFFINE>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ add, float* __restrict__ dx,
                                                             float* __restrict__ ws, long rows, int C) {
-    __shared__ float red[AFFINE ? 4 * LN_MAXV * 256 : 4];  // [wave][C <= 2048]
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR, SLOTS = 4 * RPW, CMAX = 4 * LPR * VPL;
+    __shared__ float red[AFFINE ? SLOTS * CMAX : 4];  // [wave x sub-row][C]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane / LPR, lir = lane % LPR;
     const int nv = C >> 2;
     const float invC = 1.f / (float)C;
-    float4 ag[LN_MAXV], ab[LN_MAXV];
+    float4 ag[VPL], ab[VPL], gm[VPL];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lir + i * LPR;
+        ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gm[i] = c < nv ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long row = ((long)blockIdx.x * 4 + wid) * RPW + sub; row < rows; row += (long)gridDim.x * 4 * RPW) {
         const float4* xr = reinterpret_cast<const float4*>(x + row * C);
         const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
         const float mu = mean[row], rs = rstd[row];
-        float4 xh[LN_MAXV], g[LN_MAXV];
+        float4 xh[VPL], g[VPL];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + i * 64;
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lir + i * LPR;
             if (c < nv) {
-                const float4 xv = xr[c], dv = dr[c], gm = reinterpret_cast<const float4*>(gamma)[c];
+                const float4 xv = xr[c], dv = dr[c];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+                g[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
                 s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
                 s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
                 if (AFFINE) {
@@ -100,12 +120,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        s1 = wave_sum(s1) * invC;
-        s2 = wave_sum(s2) * invC;
+        s1 = group_sum<LPR>(s1) * invC;
+        s2 = group_sum<LPR>(s2) * invC;
         float4* oxr = reinterpret_cast<float4*>(dx + row * C);
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + i * 64;
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lir + i * LPR;
             if (c < nv) {
                 float4 o;
                 o.x = rs * (g[i].x - s1 - xh[i].x * s2);
@@ -121,18 +141,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
     }
     if (AFFINE) {
-        // fold the 4 waves of the block through LDS, then one partial row per block
-        float* r = red;  // dgamma and dbeta are folded one after the other through the same 32 KiB
-        for (int part = 0; part < 2; ++part) {
+        // fold the (4 waves x RPW sub-rows) accumulators of the block through LDS, then one partial row per block
+        const int slot = wid * RPW + sub;
+        for (int part = 0; part < 2; ++part) {  // dgamma and dbeta one after the other through the same buffer
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
-                const int c = lane + i * 64;
-                if (c < nv) reinterpret_cast<float4*>(r + wid * (LN_MAXV * 256))[c] = part == 0 ? ag[i] : ab[i];
+            for (int i = 0; i < VPL; ++i) {
+                const int c = lir + i * LPR;
+                if (c < nv) reinterpret_cast<float4*>(red + slot * CMAX)[c] = part == 0 ? ag[i] : ab[i];
             }
             __syncthreads();
             for (int c = threadIdx.x; c < C; c += 256) {
-                const float s = (r[c] + r[LN_MAXV * 256 + c]) + (r[2 * LN_MAXV * 256 + c] + r[3 * LN_MAXV * 256 + c]);
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < SLOTS; ++k) s += red[k * CMAX + c];
                 ws[((long)blockIdx.x * 2 + part) * C + c] = s;
             }
         }
@@ -258,26 +280,51 @@ void colreduce_plan(long rows_per_group, int groups, int N, int* CL, int* nsplit
 
 }  // namespace
 
+// (LPR, VPL) for a row of nv float4: the narrowest lane group that holds it
+#define DKD_LN_DISPATCH(nv, CALL)                          \
+    do {                                                   \
+        if ((nv) <= 16) { CALL(16, 1); }                   \
+        else if ((nv) <= 32) { CALL(32, 1); }              \
+        else if ((nv) <= 64) { CALL(64, 1); }              \
+        else if ((nv) <= 128) { CALL(64, 2); }             \
+        else if ((nv) <= 192) { CALL(64, 3); }             \
+        else if ((nv) <= 256) { CALL(64, 4); }             \
+        else if ((nv) <= 384) { CALL(64, 6); }             \
+        else { CALL(64, 8); }                              \
+    } while (0)
+
+static int ln_rows_per_block(int nv) { return 4 * (nv <= 16 ? 4 : (nv <= 32 ? 2 : 1)); }
+
 extern "C" int dkd_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                      float* rstd, long rows, int C, float eps, int in_row_grp, int in_row_grp_stride,
                                      int in_row_off, void* stream) {
     if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
     if ((C & 3) || C > LN_MAXV * 256) return DKD_ERR_UNSUPPORTED;
-    const int blocks = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
-    if (mean && rstd)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, rows, C, eps, in_row_grp, in_row_grp_stride, in_row_off);
-    else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                           y, mean, rstd, rows, C, eps, in_row_grp, in_row_grp_stride, in_row_off);
+    const int nv = C / 4, rpb = ln_rows_per_block(nv);
+    const int blocks = (int)((rows + rpb - 1) / rpb < 4096 ? (rows + rpb - 1) / rpb : 4096);
+    hipStream_t st = (hipStream_t)stream;
+#define DKD_LN_FWD(L, V)                                                                                                   \
+    if (mean && rstd)                                                                                                      \
+        hipLaunchKernelGGL((layernorm_fwd_kernel<L, V, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y, mean,    \
+                           rstd, rows, C, eps, in_row_grp, in_row_grp_stride, in_row_off);                                 \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((layernorm_fwd_kernel<L, V, false>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y, mean,   \
+                           rstd, rows, C, eps, in_row_grp, in_row_grp_stride, in_row_off)
+    DKD_LN_DISPATCH(nv, DKD_LN_FWD);
+#undef DKD_LN_FWD
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 
-static int ln_bwd_blocks(long rows) { return (int)((rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256); }
+// 4 workgroups per CU: enough waves in flight to cover the HBM latency of the two row reads; partials stay tiny
+static int ln_bwd_blocks(long rows, int C) {
+    const int rpb = ln_rows_per_block(C / 4);
+    const long b = (rows + rpb - 1) / rpb;
+    return (int)(b < 1024 ? b : 1024);
+}
 
 extern "C" long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C) {
-    return (long)ln_bwd_blocks(rows) * 2 * C * sizeof(float);
+    return (long)ln_bwd_blocks(rows, C) * 2 * C * sizeof(float);
 }
 
 extern "C" int dkd_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
@@ -285,18 +332,22 @@ extern "C" int dkd_layernorm_bwd_f32(const float* dy, const float* x, const floa
                                      float* ws, long rows, int C, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || rows <= 0) return DKD_ERR_BAD_ARG;
     if ((C & 3) || C > LN_MAXV * 256) return DKD_ERR_UNSUPPORTED;
-    const int blocks = ln_bwd_blocks(rows);
+    const int blocks = ln_bwd_blocks(rows, C), nv = C / 4;
     hipStream_t st = (hipStream_t)stream;
     if (dgamma && dbeta) {
         if (!ws) return DKD_ERR_BAD_ARG;
-        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx,
-                           ws, rows, C);
+#define DKD_LN_BWD(L, V) \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<L, V, true>), dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx, ws, rows, C)
+        DKD_LN_DISPATCH(nv, DKD_LN_BWD);
+#undef DKD_LN_BWD
         DKD_LAUNCH_CHECK();
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, ws, blocks, 2 * C, dgamma,
                            dbeta, C, 1.0f);
     } else {
-        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx,
-                           ws, rows, C);
+#define DKD_LN_BWD(L, V) \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<L, V, false>), dim3(blocks), dim3(256), 0, st, dy, x, mean, rstd, gamma, add, dx, ws, rows, C)
+        DKD_LN_DISPATCH(nv, DKD_LN_BWD);
+#undef DKD_LN_BWD
     }
     DKD_LAUNCH_CHECK();
     return DKD_OK;

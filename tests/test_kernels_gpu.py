@@ -79,7 +79,7 @@ def test_gemm_epilogues(ops):
     close(outb, ref.reshape(-1, N), "row remap + periodic residual")
 
 
-@pytest.mark.parametrize("C", [96, 384, 768, 1536])
+@pytest.mark.parametrize("C", [16, 48, 64, 96, 128, 192, 384, 768, 1024, 1280, 1536, 2048])  # every (lanes-per-row, float4-per-lane) variant
 def test_layernorm(ops, C):
     g = torch.Generator().manual_seed(C)
     rows = 531
