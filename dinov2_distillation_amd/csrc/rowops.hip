@@ -164,19 +164,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nparts, int n,
                                                               float* __restrict__ out0, float* __restrict__ out1, int split,
                                                               float scale) {
-    // out[j] = scale * sum_p ws[p][j]; columns [0,split) go to out0, [split,n) to out1.  64 columns x 4 part-lanes.
-    __shared__ float red[256];
-    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (j < n)
-        for (int p = pl; p < nparts; p += 4) s += ws[(long)p * n + j];
+    // out[j] = scale * sum_p ws[p][j]; columns [0,split) go to out0, [split,n) to out1 (n, split % 4 == 0).
+    // 16 float4 column lanes x 16 part lanes per block; each thread keeps four partial rows in flight.
+    __shared__ float4 red[256];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int j4 = blockIdx.x * 16 + cl, n4 = n >> 2;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j4 < n4) {
+        const float4* w = reinterpret_cast<const float4*>(ws) + j4;
+        int p = pl;
+        for (; p + 48 < nparts; p += 64) {
+            const float4 a = w[(long)p * n4], b = w[(long)(p + 16) * n4], c = w[(long)(p + 32) * n4], d = w[(long)(p + 48) * n4];
+            s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+            s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; p < nparts; p += 16) {
+            const float4 a = w[(long)p * n4];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
     red[threadIdx.x] = s;
     __syncthreads();
-    if (pl == 0 && j < n) {
-        s = ((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c])) * scale;
-        if (j < split) out0[j] = s;
-        else out1[j - split] = s;
+    if (pl == 0 && j4 < n4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float4 a = red[k * 16 + cl];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+        const int j = j4 << 2;
+        if (j < split) *reinterpret_cast<float4*>(out0 + j) = s;
+        else *reinterpret_cast<float4*>(out1 + (j - split)) = s;
     }
 }
 
@@ -341,7 +359,7 @@ extern "C" int dkd_layernorm_bwd_f32(const float* dy, const float* x, const floa
         DKD_LN_DISPATCH(nv, DKD_LN_BWD);
 #undef DKD_LN_BWD
         DKD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, ws, blocks, 2 * C, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C / 4 + 15) / 16), dim3(256), 0, st, ws, blocks, 2 * C, dgamma,
                            dbeta, C, 1.0f);
     } else {
 #define DKD_LN_BWD(L, V) \
