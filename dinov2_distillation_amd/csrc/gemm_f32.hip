@@ -387,7 +387,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
     };
     // Pipeline: tile t is computed from LDS buffer t&1 while tile t+1 is written to the other buffer from registers and the
     // global loads of tile t+2 (PF == 2) or t+3 (PF == 3, a second register set: two tiles in flight) are issued; one barrier
-    // per tile.
+    // per tile.  Measured and rejected (scripts/tune_v2.py, gpurun_out/tune_v2_[g-i].log): PF == 3 (+-0 %), reading the next
+    // tile's fragments into a second register set before the current tile's MFMAs (3 % slower), BK = 32 / 64 with the
+    // matching swizzles (4-40 % slower), per-wave tiles above 32 x 32 (3-25 % slower): with 6-8 waves per SIMD the hardware's
+    // wave interleaving already covers what those transformations try to cover in software.
     SA sa2;
     SB sb2;
     if (nk > 0) {
