@@ -79,3 +79,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_integration_doc_struct_matches_header():
+    """the ctypes binding shown to maintainers in INTEGRATION.md must list exactly the fields of dkd_gemm_args"""
+    import re
+    from dinov2_distillation_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = re.findall(r'\("(\w+)", ctypes', open(os.path.join(root, "INTEGRATION.md")).read())
+    assert doc == [f for f, _ in _lib._STRUCT_DEFS["dkd_gemm_args"]]
