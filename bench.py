@@ -191,27 +191,33 @@ def main():
         ms_s = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
         fl_s = sum(f for _, _, f, _ in recs)
         serial = round(fl_s / (ms_s * 1e-3) / 1e12, 2) if ms_s > 0 else None
-    # Extra, clearly separated measurement: the same step with the opt-in bf16x3 split-precision GEMMs (fp32-level accuracy,
-    # see DESIGN.md).  It never feeds `value`.
-    alt = None
+    # Extra, clearly separated measurements: the same step with the opt-in GEMM arithmetic modes.  They never
+    # feed `value`.
+    alts = {}
     if not args.no_alt and ops.GEMM_PRECISION == ops.PREC_F32:
-        ops.GEMM_PRECISION = ops.PREC_BF16X3
-        for _ in range(2):
-            stepper.step(batch)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            stepper.step(batch)
-        sync()
-        dta = time.perf_counter() - t1
-        ops.GEMM_PRECISION = ops.PREC_F32
-        if world > 1:
-            t = torch.tensor([dta], device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dta = t.item()
-        alt = {"gemm_precision": "bf16x3 split (3 x bf16 terms per fp32 operand, 6 MFMA products, fp32 accumulate) on forward + "
-                                 "dgrad GEMMs, exact fp32 MFMA on wgrad", "value": round(args.batch * world * args.steps / dta, 2),
-               "unit": "images/s", "ms_per_step": round(dta / args.steps * 1e3, 3)}
+        for key, prec, desc in (
+                ("alt_bf16x3", ops.PREC_BF16X3, "bf16x3 split (3 x bf16 terms per fp32 operand, 6 MFMA products, fp32 accumulate: "
+                                               "fp32-level accuracy) on forward + dgrad GEMMs, exact fp32 MFMA on wgrad"),
+                ("alt_bf16_operands", ops.PREC_BF16, "operands rounded to bf16 while staged (activations and master weights stay fp32 "
+                                                     "in HBM), fp32 accumulate, on forward + dgrad GEMMs incl. the teacher; exact "
+                                                     "fp32 MFMA on wgrad - the arithmetic class of the reference's default "
+                                                     "precision=16 autocast")):
+            ops.GEMM_PRECISION = prec
+            for _ in range(2):
+                stepper.step(batch)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                stepper.step(batch)
+            sync()
+            dta = time.perf_counter() - t1
+            ops.GEMM_PRECISION = ops.PREC_F32
+            if world > 1:
+                t = torch.tensor([dta], device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dta = t.item()
+            alts[key] = {"gemm_precision": desc, "value": round(args.batch * world * args.steps / dta, 2), "unit": "images/s",
+                         "ms_per_step": round(dta / args.steps * 1e3, 3)}
     note(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank != 0:
         if world > 1:
@@ -226,10 +232,10 @@ def main():
         "config": {"workload": "dinov2_vits14 -> convnext_tiny, ScaleKD res4+res5, 224x224, bs=%d/GPU (BASELINE configs[1]); "
                                "full step incl. grad all-reduce, clip 1.0, AdamW" % args.batch,
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-        "loss": round(lossv, 5), "gemm_precision": "f32 (exact fp32 MFMA)" if ops.GEMM_PRECISION == ops.PREC_F32 else "bf16x3 split",
+        "loss": round(lossv, 5), "gemm_precision": {ops.PREC_F32: "f32 (exact fp32 MFMA)", ops.PREC_BF16X3: "bf16x3 split (DKD_GEMM_PRECISION)",
+                                                          ops.PREC_BF16: "bf16 operands, fp32 accumulate (DKD_GEMM_PRECISION)"}[ops.GEMM_PRECISION],
     }
-    if alt is not None:
-        res["alt_bf16x3"] = alt
+    res.update(alts)
     if not args.no_roofline:
         n, gemm_ms, gemm_fl = prof.summary()
         ach_timed = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0

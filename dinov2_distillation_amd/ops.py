@@ -18,7 +18,7 @@ RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM = 0, 1, 2, 3, 4
 _ws = {}
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {None: None, "f32": PREC_F32, "fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
-GEMM_PRECISION = PREC_BF16X3 if os.environ.get("DKD_GEMM_PRECISION", "f32").lower() == "bf16x3" else PREC_F32
+GEMM_PRECISION = PRECISIONS.get(os.environ.get("DKD_GEMM_PRECISION", "f32").lower(), PREC_F32)  # process-wide default
 
 
 def _stream():

@@ -725,3 +725,33 @@ def test_swin_tiny_student_step_vs_oracle_and_dropout():
         a = mod.student(x.cuda())["res5"].clone()
         b = mod.student(x.cuda())["res5"]
     assert torch.equal(a, b)  # eval: dropout is the identity
+
+
+def test_bf16_operand_mode_step_close_to_fp32():
+    """The opt-in bf16-operand GEMM mode (DKD_GEMM_PRECISION=bf16: forward + dgrad GEMMs with operands rounded to bf16, fp32
+    accumulate and fp32 activations; weight gradients exact) is the arithmetic class of the reference's default
+    precision=16 autocast.  It must stay a small perturbation of the fp32 step: loss within 1e-2, gradients within a few %."""
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(device="cuda:0")
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(77)).cuda()
+
+    def run(prec):
+        ops.GEMM_PRECISION = prec
+        try:
+            st.optimizer.zero_grad()
+            loss = st.module.training_step(x, 0)
+            loss.backward()
+            ops.wgrad_join()
+            torch.cuda.synchronize()
+            return float(loss), st.optimizer.flat_g.clone()
+        finally:
+            ops.GEMM_PRECISION = ops.PREC_F32
+
+    l32, g32 = run(ops.PREC_F32)
+    l16, g16 = run(ops.PREC_BF16)
+    l3, g3 = run(ops.PREC_BF16X3)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    print(f"loss fp32 {l32:.5f} bf16 {l16:.5f} bf16x3 {l3:.5f}; grad relL2 bf16 {rel(g16, g32):.2e} bf16x3 {rel(g3, g32):.2e}")
+    assert abs(l16 - l32) <= 1e-2 * abs(l32) and 1e-4 < rel(g16, g32) <= 1e-1
+    assert abs(l3 - l32) <= 1e-5 * abs(l32) and rel(g3, g32) <= 3e-3
