@@ -197,3 +197,50 @@ def test_bucketed_gradient_allreduce_gloo_world2():
     for rank, err, a, b in res:
         assert err < 1e-5, (rank, err)
         assert abs(a - 0.5) < 1e-6 and abs(b - 2.0) < 1e-6
+
+
+def test_student_checkpoint_warm_start_and_export_keys(tmp_path):
+    """train/distillation_module.py:381-438 (per-family key remap of .pkl / .pth student checkpoints, numpy -> tensor,
+    strict=False) and the key surface scripts/convert_to_anyma.py:22-31 exports from a trained module's state dict."""
+    import pickle
+    import numpy as np
+    from dinov2_distillation_amd.config import make_config, set_student_dims
+    from dinov2_distillation_amd.models import DINOv2ViT, ModelWrapper
+    from dinov2_distillation_amd.train import DistillationModule
+
+    def module(student_name, ckpt):
+        cfg = make_config(student=student_name)
+        cfg.student.checkpoint_path = str(ckpt) if ckpt else None
+        student = ModelWrapper(student_name, cfg.teacher.n_patches, cfg.student.student_keys)
+        set_student_dims(cfg, student)
+        teacher = DINOv2ViT("dinov2_vits14", seed=0)
+        teacher.model.blocks = teacher.model.blocks[:1]  # construction only: keep the CPU test light
+        return DistillationModule(student, teacher, cfg)
+
+    # STDC: detectron-style .pkl, numpy arrays, keys prefixed 'cp.backbone.' (distillation_module.py:413-415)
+    ref = ModelWrapper("stdc_1", [16, 16])
+    sd = {k[len("model.model."):]: v for k, v in ref.state_dict().items()}
+    k0 = "features.0.conv.weight"
+    w0 = np.full(tuple(sd[k0].shape), 0.25, dtype=np.float32)
+    pkl = tmp_path / "STDCNet1.pkl"
+    with open(pkl, "wb") as f:
+        pickle.dump({"model": {"cp.backbone." + k0: w0, "cp.backbone.not_a_key": np.zeros(3, dtype=np.float32)}}, f)
+    m = module("stdc_1", pkl)
+    assert torch.equal(m.student.state_dict()["model.model." + k0], torch.from_numpy(w0))
+    # ConvNeXt: .pth of tensors, keys un-prefixed (the final else branch, :422-424)
+    cref = ModelWrapper("convnext_atto", [16, 16])
+    ck = "downsample_layers.0.0.bias"
+    pth = tmp_path / "convnext.pth"
+    torch.save({ck: torch.full_like(cref.state_dict()["model.model." + ck], 3.0)}, pth)
+    m2 = module("convnext_atto", pth)
+    assert float(m2.student.state_dict()["model.model." + ck].min()) == 3.0
+    with pytest.raises(ValueError, match="Unsupported checkpoint format"):
+        bad = tmp_path / "weights.bin"
+        bad.write_bytes(b"x")
+        module("convnext_atto", bad)
+    # export surface (convert_to_anyma.py:23-29): student backbone keys, projector / loss keys filtered out
+    w_student = {k: v for k, v in m2.state_dict().items() if "student" in k and "scalekd" not in k and "feature_matchers" not in k}
+    exported = {k.replace("student.model.model.", "backbone."): v for k, v in w_student.items()}
+    assert exported and all(k.startswith("backbone.") for k in exported)
+    assert "backbone.stages.3.1.pwconv2.weight" in exported and not any("projector" in k for k in exported)
+    assert any(k.startswith("losses.scalekd_res4.projector_0") for k in m2.state_dict())
