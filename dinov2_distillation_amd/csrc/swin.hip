@@ -92,73 +92,70 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // ---- window attention ---------------------------------------------------------------------------------------------
+// One wave per (window, head); a workgroup of 4 waves shares only the head's [N][N] bias tile (LDS, odd pitch: lane-per-row
+// and lane-per-column reads are conflict-free).  Lane = query row (forward, backward phase 1) or key row (backward phase 2);
+// the OTHER operand's rows are wave-uniform and are read straight from global memory with wave-uniform addresses (one 16-byte
+// request per wave-instruction, L1-resident: a window-head's K and V are 12.5 KB).  First version staged them in LDS and read
+// them back with same-address ds_read_b128: on gfx950 that "broadcast" costs ~45 LDS cycles per instruction
+// (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, scripts/pmc_winattn.sh) and the kernel ran at 5 % of the VALU peak; this form is 2x
+// faster and still delivery-bound (a lane-per-row VALU formulation has to broadcast one operand somehow).  The structural fix
+// is the MFMA formulation (S^T = K Q^T tiles whose accumulators are the B operand of O^T = V^T P^T, as in attention.hip) with
+// the 49 -> 64 padding: ~8k MFMA cycles per window-head against ~130k cycles here; noted in DESIGN.md as next.
 constexpr int WA_WAVES = 4;
 
-template <int N, int HD>
+template <int N>
 struct WinCfg {
-    static constexpr int NP = N | 1;      // odd row pitch of the [N][N] bias tile: lane-per-row and lane-per-column reads are conflict-free
-    static constexpr int HP = HD + 4;     // row pitch of the [N][HD] operand tiles (b128 reads by row-owner lanes spread over banks)
-    static constexpr int TILE = N * HP;
+    static constexpr int NP = N | 1;
 };
 
-// stage rows [N][HD] of one (window, head) from global (row stride rs floats) into an LDS tile with pitch HP; one wave
-template <int N, int HD>
-__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, long rs, int lane) {
-    constexpr int Q = HD / 4, HP = WinCfg<N, HD>::HP;
-    for (int e = lane; e < N * Q; e += 64) {
-        const int r = e / Q, c = (e - r * Q) * 4;
-        st4(dst + r * HP + c, ld4(src + (long)r * rs + c));
-    }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Wave-uniform rows are read with ordinary vector loads (all 64 lanes, one address).  Routing them through the constant address
+// space instead (hipcc then emits s_load_dwordx8 into SGPRs) measured 1.5x SLOWER: ~400 scalar loads per window-head, issued in
+// SGPR-sized batches behind s_waitcnt lgkmcnt(0), are latency-bound at 1-2 waves per SIMD.
+__device__ __forceinline__ float4 ldu4(const float* p) { return ld4(p); }
+__device__ __forceinline__ float lane_value(float v, int lane) {  // lane: wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
 template <int N, int HD>
 __global__ __launch_bounds__(WA_WAVES * 64) void winattn_fwd_kernel(dkd_winattn_args a) {
-    using Cfg = WinCfg<N, HD>;
-    extern __shared__ float smem[];
-    float* sBias = smem;                              // [N][NP]
-    float* sTiles = smem + N * Cfg::NP;               // per wave: K tile, V tile
-    int* sLab = reinterpret_cast<int*>(sTiles + WA_WAVES * 2 * Cfg::TILE);  // per wave: 64 labels
-    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < N * N; e += blockDim.x) sBias[(e / N) * Cfg::NP + (e % N)] = a.bias[(long)e * a.H + h];
-    float* sK = sTiles + wave * 2 * Cfg::TILE;
-    float* sV = sK + Cfg::TILE;
-    int* lab = sLab + wave * 64;
+    constexpr int NP = WinCfg<N>::NP;
+    __shared__ float sBias[N * NP];
+    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) sBias[(e / N) * NP + (e % N)] = a.bias[(long)e * a.H + h];
+    __syncthreads();
     const bool active = lane < N;
-    for (int base = blockIdx.x * WA_WAVES; base < a.Bw; base += gridDim.x * WA_WAVES) {
-        const int w = base + wave;
-        const bool live = w < a.Bw;
-        __syncthreads();  // bias staged (first trip) / previous trip's tiles no longer read
-        if (live) {
-            const long row0 = (long)w * N;
-            stage_tile<N, HD>(sK, a.k + row0 * a.k_rs + h * HD, a.k_rs, lane);
-            stage_tile<N, HD>(sV, a.v + row0 * a.v_rs + h * HD, a.v_rs, lane);
-            if (a.labels) lab[lane] = active ? a.labels[(long)(w % a.nW) * N + lane] : -1;
-        }
-        __syncthreads();
-        if (!live || !active) continue;
-        const long row = (long)w * N + lane;
+    const int li = active ? lane : N - 1;  // idle lanes shadow the last row (loads stay in bounds, nothing is stored)
+    for (int w = blockIdx.x * WA_WAVES + wave; w < a.Bw; w += gridDim.x * WA_WAVES) {
+        const long row0 = (long)w * N;
+        const float* kp = a.k + row0 * a.k_rs + h * HD;  // wave-uniform
+        const float* vp = a.v + row0 * a.v_rs + h * HD;
+        const int* labp = a.labels ? a.labels + (long)(w % a.nW) * N : nullptr;
+        const int my_lab = labp ? labp[li] : 0;
         float q[HD];
         {
-            const float* qp = a.q + row * a.q_rs + h * HD;
+            const float* qp = a.q + (row0 + li) * a.q_rs + h * HD;
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
                 const float4 t = ld4(qp + d);
                 q[d] = t.x * a.scale; q[d + 1] = t.y * a.scale; q[d + 2] = t.z * a.scale; q[d + 3] = t.w * a.scale;
             }
         }
-        const int my_lab = a.labels ? lab[lane] : 0;
         float s[N];
         float m = -3.0e38f;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            float acc = sBias[lane * Cfg::NP + j];
+            float acc0 = sBias[li * NP + j], acc1 = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; d += 4) {
-                const float4 kk = ld4(sK + j * Cfg::HP + d);
-                acc = fmaf(q[d], kk.x, acc); acc = fmaf(q[d + 1], kk.y, acc);
-                acc = fmaf(q[d + 2], kk.z, acc); acc = fmaf(q[d + 3], kk.w, acc);
+            for (int d = 0; d < HD; d += 8) {
+                const float4 k0 = ldu4(kp + (long)j * a.k_rs + d), k1 = ldu4(kp + (long)j * a.k_rs + d + 4);
+                acc0 = fmaf(q[d], k0.x, acc0); acc1 = fmaf(q[d + 4], k1.x, acc1);
+                acc0 = fmaf(q[d + 1], k0.y, acc0); acc1 = fmaf(q[d + 5], k1.y, acc1);
+                acc0 = fmaf(q[d + 2], k0.z, acc0); acc1 = fmaf(q[d + 6], k1.z, acc1);
+                acc0 = fmaf(q[d + 3], k0.w, acc0); acc1 = fmaf(q[d + 7], k1.w, acc1);
             }
-            if (a.labels && lab[j] != my_lab) acc -= 100.0f;
+            float acc = acc0 + acc1;
+            if (labp && __builtin_amdgcn_readlane(my_lab, j) != my_lab) acc -= 100.0f;
             s[j] = acc;
             m = fmaxf(m, acc);
         }
@@ -175,62 +172,51 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_fwd_kernel(dkd_winattn_
         for (int j = 0; j < N; ++j) {
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
-                const float4 vv = ld4(sV + j * Cfg::HP + d);
+                const float4 vv = ldu4(vp + (long)j * a.v_rs + d);
                 o[d] = fmaf(s[j], vv.x, o[d]); o[d + 1] = fmaf(s[j], vv.y, o[d + 1]);
                 o[d + 2] = fmaf(s[j], vv.z, o[d + 2]); o[d + 3] = fmaf(s[j], vv.w, o[d + 3]);
             }
         }
-        const float inv = 1.0f / l;
-        float* op = a.o + row * a.o_rs + h * HD;
+        if (active) {
+            const float inv = 1.0f / l;
+            float* op = a.o + (row0 + lane) * a.o_rs + h * HD;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) st4(op + d, make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv));
+            for (int d = 0; d < HD; d += 4) st4(op + d, make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv));
+        }
     }
 }
 
-// Backward.  Phase 1 (lane = query i): recompute the softmax row, delta_i = dO_i . O_i, dQ_i; row statistics go to LDS.
-// Phase 2 (lane = key j): with Q and dO of the window now in the LDS tiles, recompute column j of P and accumulate
-// dK_j, dV_j in registers and dS into the workgroup's [N][N] bias-gradient tile (LDS atomics, one address per lane).
+// Backward.  Phase 1 (lane = query i): recompute the softmax row, delta_i = dO_i . O_i, dQ_i.  Phase 2 (lane = key j): walk the
+// queries (their Q / dO rows wave-uniform, their row statistics fetched from lane i with v_readlane), recompute column j of P and
+// accumulate dK_j, dV_j in registers and dS into the workgroup's [N][N] bias-gradient tile (LDS atomics, one address per lane).
 template <int N, int HD>
 __global__ __launch_bounds__(WA_WAVES * 64) void winattn_bwd_kernel(dkd_winattn_args a) {
-    using Cfg = WinCfg<N, HD>;
-    extern __shared__ float smem[];
-    float* sBias = smem;                                   // [N][NP]
-    float* sDb = sBias + N * Cfg::NP;                      // [N][NP]
-    float* sTiles = sDb + N * Cfg::NP;                     // per wave: tile A (K, then Q*scale), tile B (V, then dO)
-    float* sStat = sTiles + WA_WAVES * 2 * Cfg::TILE;      // per wave: m[64], 1/l[64], delta[64]
-    int* sLab = reinterpret_cast<int*>(sStat + WA_WAVES * 3 * 64);
-    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NP = WinCfg<N>::NP;
+    __shared__ float sBias[N * NP];
+    __shared__ float sDb[N * NP];
+    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
     for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
-        sBias[(e / N) * Cfg::NP + (e % N)] = a.bias[(long)e * a.H + h];
-        sDb[(e / N) * Cfg::NP + (e % N)] = 0.f;
+        sBias[(e / N) * NP + (e % N)] = a.bias[(long)e * a.H + h];
+        sDb[(e / N) * NP + (e % N)] = 0.f;
     }
-    float* sA = sTiles + wave * 2 * Cfg::TILE;
-    float* sB = sA + Cfg::TILE;
-    float* sM = sStat + wave * 3 * 64;
-    float* sL = sM + 64;
-    float* sD = sL + 64;
-    int* lab = sLab + wave * 64;
+    __syncthreads();
     const bool active = lane < N;
-    for (int base = blockIdx.x * WA_WAVES; base < a.Bw; base += gridDim.x * WA_WAVES) {
-        const int w = base + wave;
-        const bool live = w < a.Bw;
-        const bool work = live && active;
-        const long row = (long)w * N + lane;
-        __syncthreads();
-        if (live) {
-            const long row0 = (long)w * N;
-            stage_tile<N, HD>(sA, a.k + row0 * a.k_rs + h * HD, a.k_rs, lane);
-            stage_tile<N, HD>(sB, a.v + row0 * a.v_rs + h * HD, a.v_rs, lane);
-            if (a.labels) lab[lane] = active ? a.labels[(long)(w % a.nW) * N + lane] : -1;
-        }
-        __syncthreads();
-        const int my_lab = (a.labels && live) ? lab[lane] : 0;
-        float q[HD], g[HD];  // phase 1: scaled q_i and dO_i of this lane's row
-        if (work) {
-            const float* qp = a.q + row * a.q_rs + h * HD;
-            const float* gp = a.d_o + row * a.do_rs + h * HD;
-            const float* op = a.o + row * a.o_rs + h * HD;
-            float delta = 0.f;
+    const int li = active ? lane : N - 1;
+    for (int w = blockIdx.x * WA_WAVES + wave; w < a.Bw; w += gridDim.x * WA_WAVES) {
+        const long row0 = (long)w * N;
+        const float* qb = a.q + row0 * a.q_rs + h * HD;    // wave-uniform bases
+        const float* kb = a.k + row0 * a.k_rs + h * HD;
+        const float* vb = a.v + row0 * a.v_rs + h * HD;
+        const float* gb = a.d_o + row0 * a.do_rs + h * HD;
+        const int* labp = a.labels ? a.labels + (long)(w % a.nW) * N : nullptr;
+        const int my_lab = labp ? labp[li] : 0;
+        float m, inv, delta;
+        {   // ---- phase 1 ----
+            float q[HD], g[HD];
+            const float* qp = qb + (long)li * a.q_rs;
+            const float* gp = gb + (long)li * a.do_rs;
+            const float* op = a.o + (row0 + li) * a.o_rs + h * HD;
+            delta = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
                 const float4 t = ld4(qp + d), u = ld4(gp + d), v = ld4(op + d);
@@ -239,17 +225,20 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_bwd_kernel(dkd_winattn_
                 delta += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
             }
             float p[N];
-            float m = -3.0e38f;
+            m = -3.0e38f;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                float acc = sBias[lane * Cfg::NP + j];
+                float acc0 = sBias[li * NP + j], acc1 = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; d += 4) {
-                    const float4 kk = ld4(sA + j * Cfg::HP + d);
-                    acc = fmaf(q[d], kk.x, acc); acc = fmaf(q[d + 1], kk.y, acc);
-                    acc = fmaf(q[d + 2], kk.z, acc); acc = fmaf(q[d + 3], kk.w, acc);
+                for (int d = 0; d < HD; d += 8) {
+                    const float4 k0 = ldu4(kb + (long)j * a.k_rs + d), k1 = ldu4(kb + (long)j * a.k_rs + d + 4);
+                    acc0 = fmaf(q[d], k0.x, acc0); acc1 = fmaf(q[d + 4], k1.x, acc1);
+                    acc0 = fmaf(q[d + 1], k0.y, acc0); acc1 = fmaf(q[d + 5], k1.y, acc1);
+                    acc0 = fmaf(q[d + 2], k0.z, acc0); acc1 = fmaf(q[d + 6], k1.z, acc1);
+                    acc0 = fmaf(q[d + 3], k0.w, acc0); acc1 = fmaf(q[d + 7], k1.w, acc1);
                 }
-                if (a.labels && lab[j] != my_lab) acc -= 100.0f;
+                float acc = acc0 + acc1;
+                if (labp && __builtin_amdgcn_readlane(my_lab, j) != my_lab) acc -= 100.0f;
                 p[j] = acc;
                 m = fmaxf(m, acc);
             }
@@ -259,106 +248,88 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_bwd_kernel(dkd_winattn_
                 p[j] = __expf(p[j] - m);
                 l += p[j];
             }
-            const float inv = 1.0f / l;
+            inv = 1.0f / l;
             float dq[HD];
 #pragma unroll
             for (int d = 0; d < HD; ++d) dq[d] = 0.f;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                float dp = 0.f;
+                float dp0 = 0.f, dp1 = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; d += 4) {
-                    const float4 vv = ld4(sB + j * Cfg::HP + d);
-                    dp = fmaf(g[d], vv.x, dp); dp = fmaf(g[d + 1], vv.y, dp);
-                    dp = fmaf(g[d + 2], vv.z, dp); dp = fmaf(g[d + 3], vv.w, dp);
+                for (int d = 0; d < HD; d += 8) {
+                    const float4 v0 = ldu4(vb + (long)j * a.v_rs + d), v1 = ldu4(vb + (long)j * a.v_rs + d + 4);
+                    dp0 = fmaf(g[d], v0.x, dp0); dp1 = fmaf(g[d + 4], v1.x, dp1);
+                    dp0 = fmaf(g[d + 1], v0.y, dp0); dp1 = fmaf(g[d + 5], v1.y, dp1);
+                    dp0 = fmaf(g[d + 2], v0.z, dp0); dp1 = fmaf(g[d + 6], v1.z, dp1);
+                    dp0 = fmaf(g[d + 3], v0.w, dp0); dp1 = fmaf(g[d + 7], v1.w, dp1);
                 }
-                const float ds = p[j] * inv * (dp - delta);
+                const float ds = p[j] * inv * ((dp0 + dp1) - delta);
 #pragma unroll
                 for (int d = 0; d < HD; d += 4) {
-                    const float4 kk = ld4(sA + j * Cfg::HP + d);
+                    const float4 kk = ldu4(kb + (long)j * a.k_rs + d);
                     dq[d] = fmaf(ds, kk.x, dq[d]); dq[d + 1] = fmaf(ds, kk.y, dq[d + 1]);
                     dq[d + 2] = fmaf(ds, kk.z, dq[d + 2]); dq[d + 3] = fmaf(ds, kk.w, dq[d + 3]);
                 }
             }
-            float* dqp = a.dq + row * a.dq_rs + h * HD;
+            if (active) {
+                float* dqp = a.dq + (row0 + lane) * a.dq_rs + h * HD;
 #pragma unroll
-            for (int d = 0; d < HD; d += 4)
-                st4(dqp + d, make_float4(dq[d] * a.scale, dq[d + 1] * a.scale, dq[d + 2] * a.scale, dq[d + 3] * a.scale));
-            sM[lane] = m;
-            sL[lane] = inv;
-            sD[lane] = delta;
+                for (int d = 0; d < HD; d += 4)
+                    st4(dqp + d, make_float4(dq[d] * a.scale, dq[d + 1] * a.scale, dq[d + 2] * a.scale, dq[d + 3] * a.scale));
+            }
         }
-        // own K / V rows out of the tiles before they are overwritten with Q / dO
-        float kr[HD], vr[HD];
-        if (work) {
+        {   // ---- phase 2 ----
+            float kr[HD], vr[HD], dk[HD], dv[HD];
+            const float* kp = kb + (long)li * a.k_rs;
+            const float* vp = vb + (long)li * a.v_rs;
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
-                const float4 t = ld4(sA + lane * Cfg::HP + d), u = ld4(sB + lane * Cfg::HP + d);
+                const float4 t = ld4(kp + d), u = ld4(vp + d);
                 kr[d] = t.x; kr[d + 1] = t.y; kr[d + 2] = t.z; kr[d + 3] = t.w;
                 vr[d] = u.x; vr[d + 1] = u.y; vr[d + 2] = u.z; vr[d + 3] = u.w;
+                dk[d] = dk[d + 1] = dk[d + 2] = dk[d + 3] = 0.f;
+                dv[d] = dv[d + 1] = dv[d + 2] = dv[d + 3] = 0.f;
             }
-        }
-        __syncthreads();
-        if (work) {
-#pragma unroll
-            for (int d = 0; d < HD; d += 4) {
-                st4(sA + lane * Cfg::HP + d, make_float4(q[d], q[d + 1], q[d + 2], q[d + 3]));
-                st4(sB + lane * Cfg::HP + d, make_float4(g[d], g[d + 1], g[d + 2], g[d + 3]));
-            }
-        }
-        __syncthreads();
-        if (work) {  // phase 2: lane = key j
-            float dk[HD], dv[HD];
-#pragma unroll
-            for (int d = 0; d < HD; ++d) dk[d] = dv[d] = 0.f;
 #pragma unroll 1
             for (int i = 0; i < N; ++i) {
-                float qq[HD], gg[HD];  // row i of (scaled) Q and of dO, broadcast reads
+                float s0 = 0.f, s1 = 0.f, dp0 = 0.f, dp1 = 0.f;
+                float qq[HD], gg[HD];  // row i of Q and of dO: wave-uniform loads
 #pragma unroll
                 for (int d = 0; d < HD; d += 4) {
-                    const float4 t = ld4(sA + i * Cfg::HP + d), u = ld4(sB + i * Cfg::HP + d);
+                    const float4 t = ldu4(qb + (long)i * a.q_rs + d), u = ldu4(gb + (long)i * a.do_rs + d);
                     qq[d] = t.x; qq[d + 1] = t.y; qq[d + 2] = t.z; qq[d + 3] = t.w;
                     gg[d] = u.x; gg[d + 1] = u.y; gg[d + 2] = u.z; gg[d + 3] = u.w;
                 }
-                float s = sBias[i * Cfg::NP + lane], dp = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) {
-                    s = fmaf(kr[d], qq[d], s);
-                    dp = fmaf(vr[d], gg[d], dp);
+                for (int d = 0; d < HD; d += 2) {
+                    s0 = fmaf(kr[d], qq[d], s0); s1 = fmaf(kr[d + 1], qq[d + 1], s1);
+                    dp0 = fmaf(vr[d], gg[d], dp0); dp1 = fmaf(vr[d + 1], gg[d + 1], dp1);
                 }
-                if (a.labels && lab[i] != my_lab) s -= 100.0f;
-                const float p = __expf(s - sM[i]) * sL[i];
-                const float ds = p * (dp - sD[i]);
+                float sc = fmaf(s0 + s1, a.scale, sBias[i * NP + li]);
+                if (labp && __builtin_amdgcn_readlane(my_lab, i) != my_lab) sc -= 100.0f;
+                const float p = __expf(sc - lane_value(m, i)) * lane_value(inv, i);
+                const float ds = p * ((dp0 + dp1) - lane_value(delta, i));
 #pragma unroll
                 for (int d = 0; d < HD; ++d) {
                     dk[d] = fmaf(ds, qq[d], dk[d]);
                     dv[d] = fmaf(p, gg[d], dv[d]);
                 }
-                atomicAdd(&sDb[i * Cfg::NP + lane], ds);
+                if (active) atomicAdd(&sDb[i * NP + lane], ds);
             }
-            float* dkp = a.dk + row * a.dk_rs + h * HD;
-            float* dvp = a.dv + row * a.dv_rs + h * HD;
+            if (active) {
+                float* dkp = a.dk + (row0 + lane) * a.dk_rs + h * HD;
+                float* dvp = a.dv + (row0 + lane) * a.dv_rs + h * HD;
 #pragma unroll
-            for (int d = 0; d < HD; d += 4) {
-                st4(dkp + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]));  // q in the tile is pre-scaled: dk carries `scale`
-                st4(dvp + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
+                for (int d = 0; d < HD; d += 4) {
+                    st4(dkp + d, make_float4(dk[d] * a.scale, dk[d + 1] * a.scale, dk[d + 2] * a.scale, dk[d + 3] * a.scale));
+                    st4(dvp + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
+                }
             }
         }
     }
     __syncthreads();
     float* part = a.dbias_part + ((long)blockIdx.x * a.H + h) * N * N;
-    for (int e = threadIdx.x; e < N * N; e += blockDim.x) part[e] = sDb[(e / N) * Cfg::NP + (e % N)];
-}
-
-template <int N, int HD>
-size_t fwd_smem() {
-    using Cfg = WinCfg<N, HD>;
-    return (size_t)(N * Cfg::NP + WA_WAVES * 2 * Cfg::TILE) * 4 + WA_WAVES * 64 * 4;
-}
-template <int N, int HD>
-size_t bwd_smem() {
-    using Cfg = WinCfg<N, HD>;
-    return (size_t)(2 * N * Cfg::NP + WA_WAVES * 2 * Cfg::TILE + WA_WAVES * 3 * 64) * 4 + WA_WAVES * 64 * 4;
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) part[e] = sDb[(e / N) * NP + (e % N)];
 }
 
 int check_args(const dkd_winattn_args* a, bool bwd) {
@@ -380,29 +351,15 @@ int check_args(const dkd_winattn_args* a, bool bwd) {
 
 template <int N, int HD>
 int launch_fwd(const dkd_winattn_args* a, hipStream_t st) {
-    static bool attr = false;
-    const size_t sm = fwd_smem<N, HD>();
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)winattn_fwd_kernel<N, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
     dim3 grid(dkd_winattn_parts(a->Bw, a->H), a->H);
-    hipLaunchKernelGGL((winattn_fwd_kernel<N, HD>), grid, dim3(WA_WAVES * 64), sm, st, *a);
+    hipLaunchKernelGGL((winattn_fwd_kernel<N, HD>), grid, dim3(WA_WAVES * 64), 0, st, *a);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 template <int N, int HD>
 int launch_bwd(const dkd_winattn_args* a, hipStream_t st) {
-    static bool attr = false;
-    const size_t sm = bwd_smem<N, HD>();
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)winattn_bwd_kernel<N, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
     dim3 grid(dkd_winattn_parts(a->Bw, a->H), a->H);
-    hipLaunchKernelGGL((winattn_bwd_kernel<N, HD>), grid, dim3(WA_WAVES * 64), sm, st, *a);
+    hipLaunchKernelGGL((winattn_bwd_kernel<N, HD>), grid, dim3(WA_WAVES * 64), 0, st, *a);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
