@@ -255,14 +255,30 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
-__global__ void colreduce_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int groups, int nsplit,
-                                       int N, float scale) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)groups * N) return;
-    const int g = (int)(i / N), n = (int)(i % N);
-    float s = 0.f;
-    for (int p = 0; p < nsplit; ++p) s += ws[((long)g * nsplit + p) * N + n];
-    out[i] = s * scale;
+// out[g][n] = scale * sum_p ws[g][p][n]: 32 column lanes x 8 split lanes per block (grid: column chunks x groups)
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int groups,
+                                                              int nsplit, int N, float scale) {
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cl, g = blockIdx.y;
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        const float* w = ws + (long)g * nsplit * N + n;
+        int p = pl;
+        for (; p + 8 < nsplit; p += 16) {
+            s0 += w[(long)p * N];
+            s1 += w[(long)(p + 8) * N];
+        }
+        if (p < nsplit) s0 += w[(long)p * N];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (pl == 0 && n < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k * 32 + cl];
+        out[(long)g * N + n] = s * scale;
+    }
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
@@ -290,7 +306,7 @@ void colreduce_plan(long rows_per_group, int groups, int N, int* CL, int* nsplit
     long maxs = rows_per_group / ((long)RL * 8);  // >= 8 rows per thread
     if (maxs < 1) maxs = 1;
     long ns = want < maxs ? want : maxs;
-    if (ns > 64) ns = 64;  // the second pass walks the partials serially per column: keep it short
+    if (ns > 512) ns = 512;  // (the fold pass spreads the partials of a column over 8 lanes)
     long rps = (rows_per_group + ns - 1) / ns;
     ns = (rows_per_group + rps - 1) / rps;
     *CL = cl; *nsplit = (int)ns; *rows_per_split = (int)rps; *colblocks = cb;
@@ -404,12 +420,12 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
     DKD_LAUNCH_CHECK();
     if (ns > 1) {
         const long total = (long)groups * N;
-        hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, ws, out, groups, ns,
-                           N, scale);
+        const dim3 fgrid((N + 31) / 32, groups);
+        hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale);
         DKD_LAUNCH_CHECK();
         if (op == DKD_RED_DOT_SUM) {
-            hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st,
-                               ws + (long)groups * ns * N, out + total, groups, ns, N, scale);
+            hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws + (long)groups * ns * N, out + total, groups, ns,
+                               N, scale);
             DKD_LAUNCH_CHECK();
         }
     }
