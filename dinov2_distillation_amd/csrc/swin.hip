@@ -11,6 +11,8 @@
 //                       other operand broadcast from LDS; the N x N logits never leave registers.
 //  * dropout          : counter-based (stateless) Bernoulli mask, regenerated in backward from (seed, offset).
 //  * index_add_rows   : deterministic fold of the [N*N, H] bias gradient into the (2w-1)^2-row table.
+#include <stdlib.h>
+
 #include "common.h"
 #include "dkd_hip.h"
 
@@ -366,6 +368,14 @@ int launch_bwd(const dkd_winattn_args* a, hipStream_t st) {
 
 }  // namespace
 
+// matrix-core kernels (swin_mfma.hip): the default; DKD_WINATTN_VALU=1 selects the lane-per-row kernels above for A/B runs
+int dkd_winattn_mfma_fwd(const dkd_winattn_args* a, hipStream_t st);
+int dkd_winattn_mfma_bwd(const dkd_winattn_args* a, hipStream_t st);
+static bool winattn_use_valu() {
+    static const bool v = getenv("DKD_WINATTN_VALU") != nullptr && getenv("DKD_WINATTN_VALU")[0] == '1';
+    return v;
+}
+
 extern "C" int dkd_winattn_parts(int Bw, int H) {
     if (Bw <= 0 || H <= 0) return 0;
     const int want = (768 + H - 1) / H;  // ~3 workgroups per CU over (parts x heads)
@@ -376,6 +386,7 @@ extern "C" int dkd_winattn_parts(int Bw, int H) {
 extern "C" int dkd_winattn_fwd_f32(const dkd_winattn_args* a, void* stream) {
     const int rc = check_args(a, false);
     if (rc) return rc;
+    if (a->N == 49 && (a->hd == 32 || a->hd == 16) && !winattn_use_valu()) return dkd_winattn_mfma_fwd(a, (hipStream_t)stream);
     if (a->N == 49 && a->hd == 32) return launch_fwd<49, 32>(a, (hipStream_t)stream);
     if (a->N == 49 && a->hd == 16) return launch_fwd<49, 16>(a, (hipStream_t)stream);
     return DKD_ERR_UNSUPPORTED;
@@ -385,6 +396,7 @@ extern "C" int dkd_winattn_bwd_f32(const dkd_winattn_args* a, void* stream) {
     const int rc = check_args(a, true);
     if (rc) return rc;
     if (a->parts != dkd_winattn_parts(a->Bw, a->H)) return DKD_ERR_BAD_ARG;
+    if (a->N == 49 && (a->hd == 32 || a->hd == 16) && !winattn_use_valu()) return dkd_winattn_mfma_bwd(a, (hipStream_t)stream);
     if (a->N == 49 && a->hd == 32) return launch_bwd<49, 32>(a, (hipStream_t)stream);
     if (a->N == 49 && a->hd == 16) return launch_bwd<49, 16>(a, (hipStream_t)stream);
     return DKD_ERR_UNSUPPORTED;
