@@ -197,10 +197,10 @@ def main():
     if not args.no_alt and ops.GEMM_PRECISION == ops.PREC_F32:
         for key, prec, desc in (
                 ("alt_bf16x3", ops.PREC_BF16X3, "bf16x3 split (3 x bf16 terms per fp32 operand, 6 MFMA products, fp32 accumulate: "
-                                               "fp32-level accuracy) on forward + dgrad GEMMs, exact fp32 MFMA on wgrad"),
+                                               "fp32-level accuracy) on every GEMM of the step (forward, dgrad, weight gradients)"),
                 ("alt_bf16_operands", ops.PREC_BF16, "operands rounded to bf16 while staged (activations and master weights stay fp32 "
-                                                     "in HBM), fp32 accumulate, on forward + dgrad GEMMs incl. the teacher; exact "
-                                                     "fp32 MFMA on wgrad - the arithmetic class of the reference's default "
+                                                     "in HBM), fp32 accumulate, on every GEMM of the step incl. the teacher and the "
+                                                     "weight gradients - the arithmetic class of the reference's default "
                                                      "precision=16 autocast")):
             ops.GEMM_PRECISION = prec
             for _ in range(2):

@@ -522,13 +522,20 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& h, bf16x4& m, bf1
 
 // P = 3: the split-precision product above.  P = 1: plain bf16 operands (round-to-nearest of the fp32 values while staging),
 // fp32 accumulation - the frozen teacher's opt-in "bf16 on MFMA" mode (BASELINE configs[4]); activations stay fp32 in HBM.
-template <int WM, int WN, int TM, int TN, int P>
+// KC = true: both operands K-contiguous (forward; dgrad through a transposed weight).  KC = false: both operands contiguous
+// along m / n with the reduction index as the slow one (weight gradients dW = dy^T x): a thread then loads a 4 (k) x 4 (m) patch
+// (four float4 rows), converts and writes FOUR k-contiguous bf16 quadruples (ds_write_b64) into the same [row][32 k] LDS image,
+// so the MFMA loop is unchanged; lanes run along k first (8 k-quads x 8 m-quads per wave) which keeps those stores conflict-free
+// (rows 4 apart sit 320 B = 16 banks apart) and the global loads in 128-byte runs.  Split-K over blockIdx.y for that layout.
+template <int WM, int WN, int TM, int TN, int P, bool KC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float* __restrict__ A, long lda,
                                                                       const float* __restrict__ B, long ldb, float* C,
-                                                                      long ldc, int M, int N, int K, Epilogue epi) {
+                                                                      long ldc, int M, int N, int K, int kchunk, Epilogue epi,
+                                                                      float* __restrict__ ws) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, NT = WM * WN * 64, RS = 40;  // RS: bf16 per LDS row (80 B)
     constexpr int NVA = BM * 8 / NT, NVB = BN * 8 / NT;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile must divide over the threads");
+    static_assert(KC || (NVA % 4 == 0 && NVB % 4 == 0), "the transposing staging moves 4 x 4 patches");
     __shared__ __attribute__((aligned(16))) __bf16 smem[P * (BM + BN) * RS];
     __bf16* As = smem;                 // [P][BM][RS]
     __bf16* Bs = smem + P * BM * RS;   // [P][BN][RS]
@@ -538,6 +545,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
     const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
     const int tile = xcd_remap(blockIdx.x, nbm * nbn);
     const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = min(K, kbeg + kchunk);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -548,55 +557,82 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // Structure: one LDS image; the next tile's fp32 loads are issued before the MFMA block and stay in flight across it;
-    // after the barrier they are split into three bf16 planes and stored (4 waves/SIMD cover the split's VALU time with the
+    // after the barrier they are split into bf16 planes and stored (4 waves/SIMD cover the split's VALU time with the
     // other workgroup's MFMAs).  A register-resident split overlapped with the own wave's MFMAs measured 20-30 % SLOWER
     // (occupancy loss, gpurun_out/tune_bf16x3_b.log).
     float4 ra[NVA], rb[NVB];
+    auto load_one = [&](float4* r, int nv, const float* __restrict__ X, long ld, int x0, int xmax, int k0) {
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < nv; ++i) {
+                const int idx = tid + i * NT, rr = idx >> 3, kq = idx & 7;
+                const int gr = x0 + rr, gk = k0 + 4 * kq;
+                r[i] = (gr < xmax && gk < kend) ? *reinterpret_cast<const float4*>(X + (long)gr * ld + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < nv / 4; ++p) {
+                const int idx = tid + p * NT, kq = idx & 7, mq = idx >> 3;  // patch: k = 4kq..4kq+3, rows 4mq..4mq+3
+                const int gr = x0 + 4 * mq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gk = k0 + 4 * kq + i;
+                    r[4 * p + i] = (gr < xmax && gk < kend) ? *reinterpret_cast<const float4*>(X + (long)gk * ld + gr) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+    auto store_one = [&](const float4* r, int nv, __bf16* S, int EXT) {
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < nv; ++i) {
+                const int idx = tid + i * NT, rr = idx >> 3, kq = idx & 7;
+                bf16x4 h, m, l;
+                split3(r[i], h, m, l);
+                *reinterpret_cast<bf16x4*>(S + (0 * EXT + rr) * RS + 4 * kq) = h;
+                if (P == 3) {
+                    *reinterpret_cast<bf16x4*>(S + (1 * EXT + rr) * RS + 4 * kq) = m;
+                    *reinterpret_cast<bf16x4*>(S + (2 * EXT + rr) * RS + 4 * kq) = l;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < nv / 4; ++p) {
+                const int idx = tid + p * NT, kq = idx & 7, mq = idx >> 3;
+                const float4 k0v = r[4 * p], k1v = r[4 * p + 1], k2v = r[4 * p + 2], k3v = r[4 * p + 3];
+                const float4 cols[4] = {make_float4(k0v.x, k1v.x, k2v.x, k3v.x), make_float4(k0v.y, k1v.y, k2v.y, k3v.y),
+                                        make_float4(k0v.z, k1v.z, k2v.z, k3v.z), make_float4(k0v.w, k1v.w, k2v.w, k3v.w)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // row 4mq+i of the tile, k = 4kq..4kq+3
+                    bf16x4 h, m, l;
+                    split3(cols[i], h, m, l);
+                    const int rr = 4 * mq + i;
+                    *reinterpret_cast<bf16x4*>(S + (0 * EXT + rr) * RS + 4 * kq) = h;
+                    if (P == 3) {
+                        *reinterpret_cast<bf16x4*>(S + (1 * EXT + rr) * RS + 4 * kq) = m;
+                        *reinterpret_cast<bf16x4*>(S + (2 * EXT + rr) * RS + 4 * kq) = l;
+                    }
+                }
+            }
+        }
+    };
     auto load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
-            const int gr = bm0 + r, gk = k0 + 4 * kq;
-            ra[i] = (gr < M && gk < K) ? *reinterpret_cast<const float4*>(A + (long)gr * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
-            const int gr = bn0 + r, gk = k0 + 4 * kq;
-            rb[i] = (gr < N && gk < K) ? *reinterpret_cast<const float4*>(B + (long)gr * ldb + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        load_one(ra, NVA, A, lda, bm0, M, k0);
+        load_one(rb, NVB, B, ldb, bn0, N, k0);
     };
     auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
-            bf16x4 h, m, l;
-            split3(ra[i], h, m, l);
-            *reinterpret_cast<bf16x4*>(As + (0 * BM + r) * RS + 4 * kq) = h;
-            if (P == 3) {
-                *reinterpret_cast<bf16x4*>(As + (1 * BM + r) * RS + 4 * kq) = m;
-                *reinterpret_cast<bf16x4*>(As + (2 * BM + r) * RS + 4 * kq) = l;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int idx = tid + i * NT, r = idx >> 3, kq = idx & 7;
-            bf16x4 h, m, l;
-            split3(rb[i], h, m, l);
-            *reinterpret_cast<bf16x4*>(Bs + (0 * BN + r) * RS + 4 * kq) = h;
-            if (P == 3) {
-                *reinterpret_cast<bf16x4*>(Bs + (1 * BN + r) * RS + 4 * kq) = m;
-                *reinterpret_cast<bf16x4*>(Bs + (2 * BN + r) * RS + 4 * kq) = l;
-            }
-        }
+        store_one(ra, NVA, As, BM);
+        store_one(rb, NVB, Bs, BN);
     };
 
-    const int nk = (K + BK - 1) / BK;
-    load(0);
-    store();
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load(kbeg);
+        store();
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load((kt + 1) * BK);
+        if (kt + 1 < nk) load(kbeg + (kt + 1) * BK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[TM][P], b[TN][P];
@@ -630,6 +666,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
         if (kt + 1 < nk) store();
         __syncthreads();
     }
+    const bool partial = ws != nullptr;
+    float* out = partial ? ws + (long)blockIdx.y * M * N : C;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -640,7 +678,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_nt_kernel(const float
             for (int r = 0; r < 16; ++r) {
                 const int m = bm0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
-                epilogue_store(epi, C, ldc, m, n, acc[i][j][r]);
+                if (partial) out[(long)m * N + n] = acc[i][j][r];
+                else epilogue_store(epi, C, ldc, m, n, acc[i][j][r]);
             }
         }
 }
@@ -669,9 +708,38 @@ template <int WM, int WN, int TM, int TN, int P = 3>
 int launch_bf16x3(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN)), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<WM, WN, TM, TN, P>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc,
-                       g->M, g->N, g->K, epi);
+    hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<WM, WN, TM, TN, P, true>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C,
+                       g->ldc, g->M, g->N, g->K, g->K, epi, (float*)nullptr);
     DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+// weight-gradient layout (a_layout == b_layout == 1): 128 x 128 tiles of 4 waves, split-K slabs folded by splitk_reduce_kernel
+template <int P>
+int launch_bf16_tn(const dkd_gemm_args* g, const Epilogue& epi, int max_splits, hipStream_t st) {
+    const long tiles = (long)dkd_cdiv(g->M, 128) * dkd_cdiv(g->N, 128);
+    int splits = 1;
+    if (g->workspace && max_splits > 1 && tiles < 512) {
+        long want = (768 + tiles - 1) / tiles, maxk = g->K / 256;
+        if (maxk < 1) maxk = 1;
+        splits = (int)(want < maxk ? want : maxk);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    int kchunk = g->K;
+    if (splits > 1) {
+        kchunk = ((g->K + splits - 1) / splits + 31) / 32 * 32;
+        splits = (g->K + kchunk - 1) / kchunk;
+    }
+    dim3 grid((unsigned)tiles, splits), block(256);
+    hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<2, 2, 2, 2, P, false>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc,
+                       g->M, g->N, g->K, kchunk, epi, splits > 1 ? g->workspace : (float*)nullptr);
+    DKD_LAUNCH_CHECK();
+    if (splits > 1) {
+        dkd_gemm_args g2 = *g;
+        g2.rowsum = nullptr;
+        return launch_splitk_reduce(&g2, epi, splits, st);
+    }
     return DKD_OK;
 }
 
@@ -795,6 +863,12 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     epi.row_grp_stride = g->row_grp_stride;
     epi.row_off = g->row_off;
     epi.alpha = g->alpha;
+    if ((g->precision == DKD_PREC_BF16 || g->precision == DKD_PREC_BF16X3) && g->a_layout == 1 && g->b_layout == 1 && !g->rowsum &&
+        g->variant == 0) {
+        const int max_sp = auto_splits(g->M, g->N, g->K, 1, 1);  // the workspace was sized for this many slabs
+        return g->precision == DKD_PREC_BF16 ? launch_bf16_tn<1>(g, epi, max_sp, (hipStream_t)stream)
+                                             : launch_bf16_tn<3>(g, epi, max_sp, (hipStream_t)stream);
+    }
     if (g->precision == DKD_PREC_BF16 && g->a_layout == 0 && g->b_layout == 0 && !g->rowsum) {
         hipStream_t st = (hipStream_t)stream;
         const long t128 = (long)dkd_cdiv(g->M, 128) * dkd_cdiv(g->N, 128);

@@ -119,6 +119,9 @@ def linear_wgrad(dy, x, with_bias_grad=False):
     if not with_bias_grad:
         return gemm(dy, x, a_layout=1, b_layout=1)
     db = torch.empty(dy.shape[-1], dtype=torch.float32, device=dy.device)
+    if GEMM_PRECISION != PREC_F32:  # the bf16 weight-gradient kernels have no fused row sum
+        colreduce(dy.reshape(-1, dy.shape[-1]), RED_SUM, out=db.view(1, -1))
+        return gemm(dy, x, a_layout=1, b_layout=1), db
     return gemm(dy, x, a_layout=1, b_layout=1, rowsum=db), db
 
 
@@ -165,6 +168,9 @@ def wgrad_into(dy2, x2, w, b=None, transform=None):
     with torch.cuda.stream(side):
         N, K = dy2.shape[-1], x2.shape[-1]
         rs = b.grad.view(-1) if b is not None else None
+        if rs is not None and GEMM_PRECISION != PREC_F32:  # the bf16 weight-gradient kernels have no fused row sum
+            colreduce(dy2, RED_SUM, out=rs.view(1, -1))
+            rs = None
         if transform is None:
             gemm(dy2, x2, a_layout=1, b_layout=1, out=w.grad.view(N, K), rowsum=rs, ws_slot=3)
         else:
