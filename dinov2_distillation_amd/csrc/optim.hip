@@ -58,6 +58,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, cons
     }
 }
 
+// Same update with every scalar read from DEVICE memory, hyper = {lr, beta1, beta2, eps, weight_decay, step}: nothing about
+// the optimiser state is baked into the launch arguments, so a captured hipGraph of the training step stays valid while the
+// step counter advances and a scheduler changes the learning rate (both live in `hyper`).
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                        float4* __restrict__ m, float4* __restrict__ v, long nvec,
+                                                        const float* __restrict__ hyper, const float* __restrict__ gnorm,
+                                                        float max_norm) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], t = hyper[5];
+    const float inv_bc1 = 1.f / (1.f - powf(b1, t)), inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, t));
+    float clip = 1.f;
+    if (gnorm) clip = fminf(1.f, max_norm / (gnorm[1] + 1e-6f));
+    const float decay = 1.f - lr * wd, step = lr * inv_bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+#define DKD_ADAMW_LANE(c)                                          \
+    {                                                              \
+        const float gr = gg.c * clip;                              \
+        mm.c = b1 * mm.c + (1.f - b1) * gr;                        \
+        vv.c = b2 * vv.c + (1.f - b2) * gr * gr;                   \
+        const float den = sqrtf(vv.c) * inv_sqrt_bc2 + eps;        \
+        pp.c = pp.c * decay - step * (mm.c / den);                 \
+    }
+        DKD_ADAMW_LANE(x) DKD_ADAMW_LANE(y) DKD_ADAMW_LANE(z) DKD_ADAMW_LANE(w)
+#undef DKD_ADAMW_LANE
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
 __global__ void scale_by_clip_kernel(float4* __restrict__ g, long nvec, const float* __restrict__ gnorm, float max_norm) {
     const float clip = fminf(1.f, max_norm / (gnorm[1] + 1e-6f));
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
@@ -95,6 +123,19 @@ extern "C" int dkd_adamw_f32(float* p, const float* g, float* m, float* v, long 
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(p),
                        reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), nvec,
                        lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), gnorm2, max_norm);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_adamw_dev_f32(float* p, const float* g, float* m, float* v, long n, const float* hyper6, const float* gnorm2,
+                                 float max_norm, void* stream) {
+    if (!p || !g || !m || !v || !hyper6 || n <= 0) return DKD_ERR_BAD_ARG;
+    if ((n & 3) || !dkd_aligned16(p) || !dkd_aligned16(g) || !dkd_aligned16(m) || !dkd_aligned16(v)) return DKD_ERR_ALIGN;
+    const long nvec = n / 4;
+    long b = (nvec + 255) / 256;
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((int)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m),
+                       reinterpret_cast<float4*>(v), nvec, hyper6, gnorm2, max_norm);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

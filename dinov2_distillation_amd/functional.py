@@ -322,6 +322,7 @@ class AttentionProjectorFn(Function):
         tok = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, pos_t, relu=True)
         shared = ext_query is None
         qin = _c(self_query) if shared else _c(ext_query).reshape(M, D)
+        ctx.sq = self_query if shared else None
         q = ops.gemm(qin, wq, bias=bq)
         k = ops.gemm(tok, wk, bias=bk)
         v = ops.gemm(tok, wv, bias=bv)
@@ -396,9 +397,10 @@ class AttentionProjectorFn(Function):
         else:
             dq2 = dq.reshape(M, D)
         dwq, dbq = wgrad(dq2, qin, P_wq, P_bq)
-        dqin = ops.dgrad(dq2, wq)
+        o_sq = ops.grad_out(ctx.sq) if shared else None  # the self-query embedding's gradient goes straight into the arena
+        dqin = ops.dgrad(dq2, wq, out=None if o_sq is None else o_sq.view(N, D))
         dext = None if shared else dqin.reshape(B, N, D)
-        dself = dqin if shared else None
+        dself = ret(o_sq, dqin, ctx.sq) if shared else None
         dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D),
                              out=None if o_pos is None else o_pos.view(D, N)).reshape(pos_shape)
         dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True, dgamma_out=o_bnw, dbeta_out=o_bnb)
@@ -472,6 +474,7 @@ class ConvBNActFn(Function):
         y = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, None, relu=relu)
         ctx.save_for_backward(rows, w2, z, mean, rstd, bn_w, bn_b)
         ctx.meta = (k, stride, pad, relu, src_nchw, tuple(x.shape), tuple(w.shape))
+        ctx.params = (w, bn_w, bn_b)
         return y.reshape(B, Ho, Wo, O)
 
     @staticmethod
@@ -481,23 +484,28 @@ class ConvBNActFn(Function):
         O = wshape[0]
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
-        dz, dg, db = ops.bn_bwd(_c(dy).reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu)
-        dw2 = ops.linear_wgrad(dz, rows)
+        p_w, p_g, p_b = ctx.params
+        o_g, o_b = direct(p_g, p_b)
+        dz, dg, db = ops.bn_bwd(_c(dy).reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu, dgamma_out=o_g, dbeta_out=o_b)
         dx = None
         if src_nchw:
             Cin = xshape[1]
-            dw = dw2[:, : Cin * k * k].reshape(wshape)
+            kk = Cin * k * k  # the im2col rows are padded to a multiple of 4 columns: keep the real ones
+            dw, _ = wgrad(dz, rows, p_w, None, transform=lambda t: p_w.grad.view(O, kk).copy_(t[:, :kk]),  # < 10 K floats
+                          reshape=lambda t: t[:, :kk].reshape(wshape))
         else:
             B, H, W, Cin = xshape
             if k == 1 and stride == 1:
-                dw = dw2.reshape(wshape)
+                dw, _ = wgrad(dz, rows, p_w, None, reshape=lambda t: t.reshape(wshape))
                 if ctx.needs_input_grad[0]:
                     dx = ops.dgrad(dz, w2).reshape(xshape)
             else:
-                dw = ops.transpose(dw2.reshape(O, k * k, Cin)).reshape(wshape)
+                dw, _ = wgrad(dz, rows, p_w, None,
+                              transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
+                              reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
                 if ctx.needs_input_grad[0]:
                     dx = ops.col2im_nhwc(ops.dgrad(dz, w2), B, H, W, Cin, k, stride, pad)
-        return dx, dw, dg, db, None, None, None, None, None, None
+        return dx, dw, ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None, None
 
 
 class DepthwiseBNFn(Function):
@@ -515,6 +523,7 @@ class DepthwiseBNFn(Function):
         out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=False)
         ctx.save_for_backward(x, wt, y2, mean, rstd, bn_w, bn_b)
         ctx.meta = (stride, tuple(w.shape), tuple(y.shape))
+        ctx.params = (w, bn_w, bn_b)
         return out.reshape(y.shape)
 
     @staticmethod
@@ -524,11 +533,13 @@ class DepthwiseBNFn(Function):
         C = x.shape[3]
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
-        dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=False)
+        p_w, p_g, p_b = ctx.params
+        o_w, o_g, o_b = direct(p_w, p_g, p_b)
+        dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=False, dgamma_out=o_g, dbeta_out=o_b)
         dy = dy.reshape(yshape)
         dx = ops.dwconv3(dy, wt, stride, dgrad_shape=x.shape[1:3]) if ctx.needs_input_grad[0] else None
-        dw = ops.transpose(ops.dwconv3_wgrad(x, dy, stride)).reshape(wshape)
-        return dx, dw, dg, db, None, None, None
+        dw = ops.transpose(ops.dwconv3_wgrad(x, dy, stride), out=None if o_w is None else o_w.view(C, 9)).reshape(wshape)
+        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None
 
 
 class AvgPool3Fn(Function):

@@ -175,7 +175,7 @@ def wgrad_into(dy2, x2, w, b=None, transform=None):
             gemm(dy2, x2, a_layout=1, b_layout=1, out=w.grad.view(N, K), rowsum=rs, ws_slot=3)
         else:
             transform(gemm(dy2, x2, a_layout=1, b_layout=1, rowsum=rs, ws_slot=3))
-    dy2.record_stream(side)
+    dy2.record_stream(side)  # (also during graph capture: the private pool recycles freed blocks inside one capture)
     x2.record_stream(side)
     for p_ in (w, b):
         if p_ is not None:

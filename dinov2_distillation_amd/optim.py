@@ -24,6 +24,8 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._build_arena()
         self._steps = 0
+        self.graph_safe = False  # True: every optimiser scalar lives in device memory (hipGraph capture of the step)
+        self._hyper = None
         # weight gradients may now be written into the arena from the side stream (DKD_ASYNC_WGRAD=0 keeps one stream)
         ops.ASYNC_WGRAD = self.flat_g.is_cuda and os.environ.get("DKD_ASYNC_WGRAD", "1") != "0"
 
@@ -57,6 +59,17 @@ class FusedAdamW(torch.optim.Optimizer):
         self.total = total
         self._gnorm = torch.zeros(2, dtype=torch.float32, device=dev)
 
+    def sync_hyper(self):
+        """(graph-safe mode) push lr / betas / eps / weight_decay of every param group to the device; the step counter is kept.
+        Call after a scheduler changed ``group['lr']`` - it is a small H2D copy outside the captured graph."""
+        rows = [[g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], 0.0] for g in self.param_groups]
+        host = torch.tensor(rows, dtype=torch.float32)
+        if self._hyper is None:
+            host[:, 5] = float(self._steps)  # completed steps so far; step() increments it on the device before use
+            self._hyper = host.to(self.flat_p.device)
+        else:
+            self._hyper[:, :5].copy_(host[:, :5], non_blocking=True)
+
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
         for p, off, n in self.layout:  # re-attach if something replaced .grad
@@ -82,7 +95,21 @@ class FusedAdamW(torch.optim.Optimizer):
         lib = _lib.load()
         ops.wgrad_join()  # the side-stream weight gradients must have landed in the arena
         gn = self.grad_norm() if clip_grad_norm is not None else None
+        if self.graph_safe and self._hyper is None:
+            self.sync_hyper()
         self._steps += 1
+        if self.graph_safe:
+            self._hyper[:, 5] += 1.0  # the step counter advances on the device (captured with the graph)
+            for i, g in enumerate(self.param_groups):
+                a, b = g["_range"]
+                if b > a:
+                    _lib.check(lib.dkd_adamw_dev_f32(ctypes.c_void_p(self.flat_p.data_ptr() + 4 * a),
+                                                     ctypes.c_void_p(self.flat_g.data_ptr() + 4 * a),
+                                                     ctypes.c_void_p(self.flat_m.data_ptr() + 4 * a),
+                                                     ctypes.c_void_p(self.flat_v.data_ptr() + 4 * a), b - a,
+                                                     ctypes.c_void_p(self._hyper.data_ptr() + 24 * i), _p(gn),
+                                                     float(clip_grad_norm or 0.0), _stream()), "dkd_adamw_dev_f32")
+            return loss
         for g in self.param_groups:
             a, b = g["_range"]
             if b <= a:

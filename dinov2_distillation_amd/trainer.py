@@ -27,6 +27,45 @@ class DistillationStepper:
         self.clip = clip
         self.step_idx = 0
 
+    # ---- hipGraph replay of the whole step -----------------------------------------------------------------------------
+    # Every launch of the step is capture-safe (no allocation or synchronisation inside the library, side streams fork from and
+    # re-join the capturing stream, optimiser scalars live in device memory), so the ~1600 launches of one step can be replayed
+    # as ONE graph.  At bs 64 the GPU is the bottleneck and this buys nothing; at small batches (BASELINE configs[0], bs 2)
+    # the step is bound by the 17 ms of host enqueue and the graph removes it.
+    def capture(self, batch):
+        if self.reducer is not None:
+            raise NotImplementedError("graph capture of the multi-rank step is not wired up (RCCL capture untested)")
+        if getattr(self.student.model.model, "drop_rate", 0.0) > 0.0 and self.module.training:
+            raise NotImplementedError("dropout seeds are host-side: capture would replay one mask")
+        self.optimizer.graph_safe = True
+        self.optimizer.sync_hyper()
+        self.static_batch = batch.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm every lazily created buffer / stream on a non-default stream first
+            for _ in range(2):
+                self._step_body(self.static_batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._step_body(self.static_batch)
+        return self
+
+    def step_graph(self, batch):
+        if batch.data_ptr() != self.static_batch.data_ptr():
+            self.static_batch.copy_(batch, non_blocking=True)
+        self.graph.replay()
+        self.step_idx += 1
+        return self.static_loss
+
+    def _step_body(self, batch):
+        self.optimizer.zero_grad()
+        loss = self.module.training_step(batch, 0)
+        loss.backward()
+        self.optimizer.step(clip_grad_norm=self.clip)
+        return loss.detach()
+
     def step(self, batch):
         self.optimizer.zero_grad()
         loss = self.module.training_step(batch, self.step_idx)

@@ -215,6 +215,10 @@ int dkd_sumsq_f32(const float* x, long n, float* out2, float* ws, void* stream);
 long dkd_sumsq_f32_workspace_bytes(long n);
 int dkd_adamw_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, const float* gnorm2, float max_norm, void* stream);
+/* the same update with {lr, beta1, beta2, eps, weight_decay, step} read from a 6-float DEVICE vector: no optimiser scalar is a
+ * launch argument, so a captured hipGraph of the whole step stays valid across steps and learning-rate changes */
+int dkd_adamw_dev_f32(float* p, const float* g, float* m, float* v, long n, const float* hyper6, const float* gnorm2,
+                      float max_norm, void* stream);
 int dkd_clip_grad_f32(float* g, long n, const float* gnorm2, float max_norm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
