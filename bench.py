@@ -177,15 +177,16 @@ def main():
     if not args.no_roofline:
         n0 = len(prof.records)
         from dinov2_distillation_amd.train import distillation_module as dm
-        async_was, side_was = ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM
+        async_was, side_was, chain_was = ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS
         ops.ASYNC_WGRAD = False            # every kernel of these two steps on ONE stream: weight gradients ...
-        dm.TEACHER_ON_SIDE_STREAM = False  # ... and the teacher forward are not co-scheduled with anything
+        dm.TEACHER_ON_SIDE_STREAM = False  # ... the teacher forward ...
+        dm.TWO_CHAIN_STREAMS = False       # ... and the frequency loss chain are not co-scheduled with anything
         prof.enabled = True
         for _ in range(2):
             stepper.step(batch)
         sync()
         prof.enabled = False
-        ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM = async_was, side_was
+        ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS = async_was, side_was, chain_was
         recs = prof.records[n0:]
         prof.records = prof.records[:n0]
         ms_s = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)

@@ -74,8 +74,8 @@ class GradBucketReducer:
         self.launched[bi] = True
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream())
-            if ops._side_streams:
-                self.side.wait_stream(ops.wgrad_stream())
+            for s in ops.producer_streams():  # weight-gradient stream, frequency-chain stream
+                self.side.wait_stream(s)
             with torch.cuda.stream(self.side):
                 buf.div_(self.world)  # SUM of pre-divided grads == AVG (no ReduceOp.AVG on gloo)
                 self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))

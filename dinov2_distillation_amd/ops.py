@@ -141,10 +141,26 @@ def wgrad_stream(device=None):
     return _side_streams[idx]
 
 
+_producer_streams = {}   # device index -> extra streams on which backward kernels write parameter gradients
+
+
+def register_producer_stream(stream):
+    lst = _producer_streams.setdefault(stream.device.index, [])
+    if stream not in lst:
+        lst.append(stream)
+
+
+def producer_streams(device=None):
+    idx = torch.cuda.current_device() if device is None else device.index
+    return list(_producer_streams.get(idx, [])) + ([_side_streams[idx]] if idx in _side_streams else [])
+
+
 def wgrad_join():
-    """make the current stream wait for every weight-gradient launch issued so far"""
-    if _side_streams:
-        torch.cuda.current_stream().wait_stream(wgrad_stream())
+    """make the current stream wait for every gradient-producing side stream (weight-gradient stream, loss-chain stream)"""
+    cur = torch.cuda.current_stream()
+    for s in producer_streams():
+        if s != cur:
+            cur.wait_stream(s)
 
 
 def add_grad_listener(fn):
