@@ -35,10 +35,26 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact (erf) GELU and its derivative, as nn.GELU() / F.gelu default
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact (erf) GELU and its derivative, as nn.GELU() / F.gelu default.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7
+// absolute, i.e. at the level of one fp32 rounding of the result) instead of the ~2x costlier ocml erff: one v_rcp, one v_exp
+// and a degree-5 Horner; the Gaussian e = exp(-x^2/2) it needs is shared with the derivative's density term.
+__device__ __forceinline__ float erf_as(float z, float& e_out) {  // erf(z), e_out = exp(-z*z)
+    const float az = fabsf(z);
+    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
+    const float e = __expf(-az * az);
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    e_out = e;
+    return copysignf(fmaf(-p * t, e, 1.0f), z);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float e;
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float e;  // exp(-x^2/2)
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
