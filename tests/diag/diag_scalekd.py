@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): ScaleKD at real sizes vs fp64 oracle, per-parameter errors; also pieces."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dinov2_distillation_amd.losses import ScaleKD
 from dinov2_distillation_amd import ops

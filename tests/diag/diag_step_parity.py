@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): config-2 step at B=2 - ours vs fp32 CPU oracle vs fp64 CPU oracle, per-parameter errors."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dinov2_distillation_amd.config import make_config, set_student_dims
 from dinov2_distillation_amd.models import DINOv2ViT, ModelWrapper
