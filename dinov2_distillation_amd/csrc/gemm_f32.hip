@@ -390,7 +390,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
     // per tile.  Measured and rejected (scripts/tune_v2.py, gpurun_out/tune_v2_[g-i].log): PF == 3 (+-0 %), reading the next
     // tile's fragments into a second register set before the current tile's MFMAs (3 % slower), BK = 32 / 64 with the
     // matching swizzles (4-40 % slower), per-wave tiles above 32 x 32 (3-25 % slower): with 6-8 waves per SIMD the hardware's
-    // wave interleaving already covers what those transformations try to cover in software.
+    // wave interleaving already covers what those transformations try to cover in software.  A persistent variant (fixed grid
+    // walking the tiles, (tile, k-tile) pairs as one pipelined sequence so the next tile's loads fly under the epilogue) was
+    // 15-20 % slower on every shape, single-tile workgroups included: the epilogue inside the loop costs the occupancy.
     SA sa2;
     SB sb2;
     if (nk > 0) {
