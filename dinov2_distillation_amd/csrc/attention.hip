@@ -19,6 +19,11 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
+// raw v_exp_f32: the arguments here are logit - running max <= 0 and the results are probabilities, so the library
+// exp2f's denormal-range scaffolding (compare, two selects, add, ldexp per call: 5 extra VALU ops next to every MFMA)
+// buys nothing; results below 2^-126 flush to 0
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 template <int HD>
@@ -232,7 +237,7 @@ __device__ __forceinline__ void attn_one_key(const float* __restrict__ krow, con
     for (int d = 0; d < HD / 2; ++d) s = fmaf(krow[half * (HD / 2) + d], qf[d], s);
     s += __shfl_xor(s, 32, 64);
     const float mn = fmaxf(m, s);
-    const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+    const float alpha = exp2_raw(m - mn), p = exp2_raw(s - mn);
     l = l * alpha + (half == 0 ? p : 0.f);  // the two halves' partial sums are added at the end: count p once
     m = mn;
 #pragma unroll
@@ -266,6 +271,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int 
 #pragma unroll
     for (int t = 0; t < 4; ++t) zero_pad_cols<HD, NT>(smem + t * TSZ, tid);
 
+    // ONE leftover query (the CLS token: N = 32 k + 1) rides along in the key loop of the last workgroup of its (head,
+    // image) on the VALU, off the K/V tiles already in LDS: each of the 4 waves takes 8 keys of the tile - lane (j, c) the
+    // dims chunk c of key j for the logit, lane d for the output - and keeps its own online-softmax partial; the four
+    // partials are merged after the loop.  (Appending the row after the loop re-read K and V from global: a 20 us serial
+    // tail on the teacher shape.)
+    constexpr bool XLOOP = NW == 4 && HD <= 64;
+    constexpr int DPL = HD / 8;
+    const bool xrow = XLOOP && a.Nq - nq_limit == 1 && blockIdx.x == gridDim.x - 1;
+    float xq[DPL], xm = -INFINITY, xl = 0.f, xo = 0.f;
+    if (xrow) {
+        const float* qx = Qb + (long)nq_limit * a.q_rs + (lane & 7) * DPL;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) xq[i] = qx[i] * (a.scale * LOG2E);
+    }
+
     TileRegs<HD, NT> kr, vr;
     const int nkt = (a.Nk + 31) / 32;
     const int rem = a.Nk & 31;
@@ -282,23 +302,51 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int 
             kr.load(Kb, a.k_rs, (kt + 1) * 32, a.Nk, tid);
             vr.load(Vb, a.v_rs, (kt + 1) * 32, a.Nk, tid);
         }
+        if (xrow) {
+            const int j = wid * 8 + (lane >> 3);
+            const float* kp = Ks + j * C::LDW + (lane & 7) * DPL;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) s = fmaf(kp[i], xq[i], s);
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            if (kt * 32 + j >= a.Nk) s = -INFINITY;
+            float mt = fmaxf(s, __shfl_xor(s, 8, 64));
+            mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mn = fmaxf(xm, mt);
+            if (mn > -INFINITY) {  // wave-uniform
+                const float alpha = exp2_raw(xm - mn), p = exp2_raw(s - mn);
+                xl = xl * alpha + p;
+                xm = mn;
+                const float* vp = Vs + wid * 8 * C::LDW + (lane < C::HDP ? lane : C::HDP - 1);
+                float acc = xo * alpha;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 8 * jj)), vp[jj * C::LDW], acc);
+                xo = acc;
+            }
+        }
         if (active && valu_tail && kt == nkt - 1) {
             for (int j = 0; j < rem; ++j) attn_one_key<HD>(Ks + j * C::LDW, Vs + j * C::LDW, qf, o, m, l, half);
         } else if (active) {
             f32x16 s = tile_times_frag<HD>(Ks, qf, l31, half);
+            if (kt == nkt - 1 && rem != 0) {  // only the last key tile can hold padded keys
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + frag_row(r, half) >= a.Nk) s[r] = -INFINITY;
+            }
             float mt = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (kt * 32 + frag_row(r, half) >= a.Nk) s[r] = -INFINITY;
-                mt = fmaxf(mt, s[r]);
-            }
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float mn = fmaxf(m, mt);
-            const float alpha = exp2f(m - mn);
+            const float alpha = exp2_raw(m - mn);
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(s[r] - mn);
+                s[r] = exp2_raw(s[r] - mn);
                 ls += s[r];
             }
             l = l * alpha + ls;
@@ -324,8 +372,29 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int 
     // leftover queries (nq_limit < Nq): the LAST workgroup of each (head, image) appends them after its own tiles.  A
     // separate workgroup for them measured +25 % on the teacher shape: it perturbs the even 3-per-CU placement of the MFMA
     // workgroups (gpurun_out notes in DESIGN.md).
-    if (nq_limit < a.Nq && blockIdx.x == gridDim.x - 1)
+    if (xrow) {
+        float lw = wave_sum((lane & 7) == 0 ? xl : 0.f);  // every lane of a key's group carries the same p
+        float* sc = smem + wid * 66;
+        if (lane < HD) sc[lane] = xo;
+        if (lane == 0) { sc[64] = xm; sc[65] = lw; }
+        __syncthreads();
+        if (wid == 0) {
+            float M = smem[64];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, smem[w * 66 + 64]);
+            float L = 0.f, O = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float f = exp2f(smem[w * 66 + 64] - M);
+                L = fmaf(f, smem[w * 66 + 65], L);
+                if (lane < HD) O = fmaf(f, smem[w * 66 + lane], O);
+            }
+            if (lane < HD) a.o[b * a.o_bs + (long)nq_limit * a.o_rs + h * HD + lane] = O / L;
+            if (a.lse && lane == 0) a.lse[((long)b * a.H + h) * a.Nq + nq_limit] = M + log2f(L);
+        }
+    } else if (nq_limit < a.Nq && blockIdx.x == gridDim.x - 1) {
         for (int qq = nq_limit; qq < a.Nq; ++qq) attn_fwd_row<HD, NT>(a, qq, h, b, smem, tid);
+    }
 }
 
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]
@@ -379,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(dkd_attn_args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool valid = kt * 32 + frag_row(r, half) < a.Nk;
-            const float p = valid ? exp2f(s[r] - lse) : 0.f;
+            const float p = valid ? exp2_raw(s[r] - lse) : 0.f;
             s[r] = p * (dp[r] - dl) * a.scale;  // dS^T
         }
         tileT_times_regs<HD>(dq, Ks, s, l31, half);
@@ -428,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(dkd_attn_args a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = frag_row(r, half);
-            const float p = exp2f(s[r] * sc2 - lse_s[qr]);
+            const float p = exp2_raw(s[r] * sc2 - lse_s[qr]);
             s[r] = p;
             ds[r] = p * (dp[r] - dl_s[qr]) * a.scale;
         }
