@@ -122,13 +122,19 @@ __device__ __forceinline__ void store_T(const f32x16 (&acc)[Cfg<HD>::DCH], float
 template <int HD, int NT>
 struct TileRegs {
     static constexpr int V4 = HD / 4, TOTAL = 32 * V4, NV = (TOTAL + NT - 1) / NT;
+    static constexpr bool FULL = TOTAL % NT == 0;  // every thread owns NV float4 of the tile: no predicate
     float4 v[NV];
+    // Rows past the last key are read from the last key instead of zero-filled (their logits are masked / their
+    // probabilities are 0, any finite value does): the loads need no predicate and address tile base (wave-uniform)
+    // + a 32-bit per-thread offset.
     __device__ __forceinline__ void load(const float* __restrict__ base, long rs, int row0, int nrows, int tid) {
+        const float* tb = base + (long)row0 * rs;
+        const int lim = nrows - 1 - row0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * NT, r = idx / V4, c4 = idx % V4;
-            v[i] = (idx < TOTAL && row0 + r < nrows) ? *reinterpret_cast<const float4*>(base + (long)(row0 + r) * rs + 4 * c4)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL || idx < TOTAL)
+                v[i] = *reinterpret_cast<const float4*>(tb + (unsigned)(min(r, lim) * (int)rs + 4 * c4));
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
@@ -136,7 +142,7 @@ struct TileRegs {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * NT, r = idx / V4, c4 = idx % V4;
-            if (idx < TOTAL) {
+            if (FULL || idx < TOTAL) {
                 float* d = S + r * LDW + 4 * c4;
                 d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
             }
