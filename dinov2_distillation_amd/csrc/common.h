@@ -53,6 +53,12 @@ __device__ __forceinline__ float gelu_f(float x) {
     float e;
     return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, e));
 }
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {  // gelu(x) and gelu'(x) from one erf
+    float e;
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+    g = x * cdf;
+    dg = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float e;  // exp(-x^2/2)
     const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));

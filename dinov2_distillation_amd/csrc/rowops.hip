@@ -205,6 +205,10 @@ __device__ __forceinline__ float4 colop(const float4 x, const float4 y, const fl
     if (OP == DKD_RED_SUM) return x;
     if (OP == DKD_RED_DOT) return make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
     if (OP == DKD_RED_SUMSQ) return make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w);
+    if (OP == DKD_RED_GELUSQ) {
+        const float4 g = make_float4(gelu_f(x.x), gelu_f(x.y), gelu_f(x.z), gelu_f(x.w));
+        return make_float4(g.x * g.x, g.y * g.y, g.z * g.z, g.w * g.w);
+    }
     // DKD_RED_SQDIFF: (x - aux)^2
     const float4 d = make_float4(x.x - a.x, x.y - a.y, x.z - a.z, x.w - a.w);
     return make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     const long r0 = (long)sp * rows_per_split;
     const long r1 = min(rows_per_group, r0 + rows_per_split);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
-    constexpr bool TWO = OP == DKD_RED_DOT_SUM;
+    constexpr bool TWO = OP == DKD_RED_DOT_SUM || OP == DKD_RED_DOTGELU_SUM;
     if (4 * c4 < N) {
         const float4 a = OP == DKD_RED_SQDIFF ? reinterpret_cast<const float4*>(aux)[c4] : acc;
         const long base = (long)g * rows_per_group;
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
             const float4 x = *reinterpret_cast<const float4*>(X + (base + r) * ldx + 4 * c4);
             float4 y = x;
             if (OP == DKD_RED_DOT || TWO) y = *reinterpret_cast<const float4*>(Y + (base + r) * ldx + 4 * c4);
+            if (OP == DKD_RED_DOTGELU_SUM) y = make_float4(gelu_f(y.x), gelu_f(y.y), gelu_f(y.z), gelu_f(y.w));
             const float4 v = colop<TWO ? DKD_RED_DOT : OP>(x, y, a);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             if (TWO) { acc2.x += x.x; acc2.y += x.y; acc2.z += x.z; acc2.w += x.w; }
@@ -397,7 +402,8 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
                                  long rows_per_group, int groups, int N, long ldx, int op, float scale, void* stream) {
     if (!X || !out || rows_per_group <= 0 || groups <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
     if ((N & 3) || (ldx & 3)) return DKD_ERR_ALIGN;
-    if ((op == DKD_RED_DOT || op == DKD_RED_DOT_SUM) && !Y) return DKD_ERR_BAD_ARG;
+    const bool two = op == DKD_RED_DOT_SUM || op == DKD_RED_DOTGELU_SUM;
+    if ((op == DKD_RED_DOT || two) && !Y) return DKD_ERR_BAD_ARG;
     if (op == DKD_RED_SQDIFF && !aux) return DKD_ERR_BAD_ARG;
     int cl, ns, rps, cb;
     colreduce_plan(rows_per_group, groups, N, &cl, &ns, &rps, &cb);
@@ -414,6 +420,8 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
         case DKD_RED_SUMSQ: DKD_CR(DKD_RED_SUMSQ); break;
         case DKD_RED_SQDIFF: DKD_CR(DKD_RED_SQDIFF); break;
         case DKD_RED_DOT_SUM: DKD_CR(DKD_RED_DOT_SUM); break;
+        case DKD_RED_GELUSQ: DKD_CR(DKD_RED_GELUSQ); break;
+        case DKD_RED_DOTGELU_SUM: DKD_CR(DKD_RED_DOTGELU_SUM); break;
         default: return DKD_ERR_BAD_ARG;
     }
 #undef DKD_CR
@@ -423,7 +431,7 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
         const dim3 fgrid((N + 31) / 32, groups);
         hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale);
         DKD_LAUNCH_CHECK();
-        if (op == DKD_RED_DOT_SUM) {
+        if (two) {
             hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws + (long)groups * ns * N, out + total, groups, ns,
                                N, scale);
             DKD_LAUNCH_CHECK();

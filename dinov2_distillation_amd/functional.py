@@ -166,6 +166,9 @@ class PatchConvFn(Function):
 
 
 # =====================================================================================================================
+CONVNEXT_KEEP_GELU_OUT = False
+
+
 class ConvNeXtBlockFn(Function):
     """ConvNeXt-V2 block on NHWC (models/backbones/convnext.py:75-87):
     dw7x7 -> LN(1e-6) -> Linear(4C) -> GELU -> GRN -> Linear(C) -> + input."""
@@ -178,12 +181,19 @@ class ConvNeXtBlockFn(Function):
         wt = ops.transpose(dw_w.reshape(C, 49))  # tap-major [49, C]
         d = ops.dwconv7(x, wt, dw_b)
         n, mean, rstd = ops.layernorm_fwd(d, ln_w, ln_b, 1e-6)
-        h = torch.empty((M, 4 * C), dtype=F32, device=x.device)
-        g = ops.gemm(n.reshape(M, C), w1, bias=b1, act=ops.ACT_GELU, preact=h)
+        # only the pre-activation h is kept: GRN (energies, apply) and the backward recompute gelu(h) in flight, which
+        # saves one [M,4C] store in this GEMM's epilogue and one [M,4C] read in the backward
         gg, gb = grn_g.reshape(-1), grn_b.reshape(-1)
-        y, stats = ops.grn_fwd(g, gg, gb, B)
+        if CONVNEXT_KEEP_GELU_OUT:  # A/B switch (scripts/ab_step.py): also store g = gelu(h), as the first version did
+            h = torch.empty((M, 4 * C), dtype=F32, device=x.device)
+            g = ops.gemm(n.reshape(M, C), w1, bias=b1, act=ops.ACT_GELU, preact=h)
+            y, stats = ops.grn_fwd(g, gg, gb, B)
+        else:
+            h, g = ops.gemm(n.reshape(M, C), w1, bias=b1), None
+            y, stats = ops.grn_fwd(h, gg, gb, B, preact=True)
         out = ops.gemm(y, w2, bias=b2, residual=x.reshape(M, C))
-        ctx.save_for_backward(x, wt, d, mean, rstd, n, h, g, y, w1, w2, ln_w, gg, *stats)
+        ctx.g = g
+        ctx.save_for_backward(x, wt, d, mean, rstd, n, h, y, w1, w2, ln_w, gg, *stats)
         ctx.shapes = (B, H, W, C, tuple(dw_w.shape), tuple(grn_g.shape))
         ctx.params = (w1, b1, w2, b2)
         ctx.small = (dw_w, dw_b, ln_w, ln_b, grn_g, grn_b)
@@ -191,7 +201,7 @@ class ConvNeXtBlockFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, wt, d, mean, rstd, n, h, g, y, w1, w2, ln_w, gg, gx, nx, denom = ctx.saved_tensors
+        x, wt, d, mean, rstd, n, h, y, w1, w2, ln_w, gg, gx, nx, denom = ctx.saved_tensors
         B, H, W, C, dw_shape, grn_shape = ctx.shapes
         M = B * H * W
         dout = _c(dout)
@@ -201,7 +211,7 @@ class ConvNeXtBlockFn(Function):
         dy = ops.dgrad(do2, w2)  # [M, 4C]
         p_dww, p_dwb, p_lnw, p_lnb, p_gg, p_gb = ctx.small
         o_dww, o_dwb, o_lnw, o_lnb, o_gg, o_gb = direct(*ctx.small)
-        dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, g, h, (gx, nx, denom), gg, B,
+        dh, dgrn_g, dgrn_b = ops.grn_gelu_bwd(dy, ctx.g, h, (gx, nx, denom), gg, B,
                                               None if o_gg is None else o_gg.view(-1), None if o_gb is None else o_gb.view(-1))
         n2 = n.reshape(M, C)
         dw1, db1 = wgrad(dh, n2, pw1, pb1)

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import AttnArgs, GemmArgs, check  # noqa: F401
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM = 0, 1, 2, 3, 4
+RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM, RED_GELUSQ, RED_DOTGELU_SUM = 0, 1, 2, 3, 4, 5, 6
 
 _ws = {}
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
@@ -220,7 +220,7 @@ def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):
     rows = x.numel() // N
     rpg = rows // groups
     if out is None:
-        out = torch.empty((2, groups, N) if op == RED_DOT_SUM else (groups, N), dtype=torch.float32, device=x.device)
+        out = torch.empty((2, groups, N) if op in (RED_DOT_SUM, RED_DOTGELU_SUM) else (groups, N), dtype=torch.float32, device=x.device)
     wsb = lib.dkd_colreduce_f32_workspace_bytes(rpg, groups, N)
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.dkd_colreduce_f32(_p(x), _p(y), _p(aux), _p(out), _p(ws), rpg, groups, N, N, op, scale, _stream()),
@@ -485,34 +485,36 @@ def set_rows(out, vec, B, row_stride):
     return out
 
 
-def grn_fwd(g, gamma, beta, B):
-    """g [B*HW, C] (post-GELU) -> y, (gx, nx, denom)"""
+def grn_fwd(g, gamma, beta, B, preact=False):
+    """g [B*HW, C] post-GELU (preact=True: the pre-activation h, gelu recomputed on the fly) -> y, (gx, nx, denom)"""
     lib = _lib.load()
     C = g.shape[-1]
     rpi = g.numel() // C // B
-    sumsq = colreduce(g, RED_SUMSQ, groups=B)
+    sumsq = colreduce(g, RED_GELUSQ if preact else RED_SUMSQ, groups=B)
     gx, nx = torch.empty_like(sumsq), torch.empty_like(sumsq)
     denom = torch.empty(B, dtype=torch.float32, device=g.device)
     check(lib.dkd_grn_stats_f32(_p(sumsq), _p(gx), _p(nx), _p(denom), B, C, _stream()), "dkd_grn_stats_f32")
     y = torch.empty_like(g)
-    check(lib.dkd_grn_apply_f32(_p(g), _p(nx), _p(gamma), _p(beta), _p(y), B, rpi, C, _stream()), "dkd_grn_apply_f32")
+    check(lib.dkd_grn_apply_f32(_p(g), _p(nx), _p(gamma), _p(beta), _p(y), B, rpi, C, int(preact), _stream()),
+          "dkd_grn_apply_f32")
     return y, (gx, nx, denom)
 
 
 def grn_gelu_bwd(dy, g, h, stats, gamma, B, dgamma_out=None, dbeta_out=None):
-    """-> dh (through GRN and GELU), dgamma, dbeta"""
+    """-> dh (through GRN and GELU), dgamma, dbeta.  g=None: only the pre-activation h was kept, g = gelu(h) is recomputed"""
     lib = _lib.load()
     gx, nx, denom = stats
-    C = g.shape[-1]
-    rpi = g.numel() // C // B
-    both = colreduce(dy, RED_DOT_SUM, y=g, groups=B)  # one pass: [0] = sum_hw dy*g, [1] = sum_hw dy, per image
+    C = h.shape[-1]
+    rpi = h.numel() // C // B
+    # one pass: [0] = sum_hw dy*g, [1] = sum_hw dy, per image
+    both = colreduce(dy, RED_DOT_SUM, y=g, groups=B) if g is not None else colreduce(dy, RED_DOTGELU_SUM, y=h, groups=B)
     A = both[0]
     dbeta = colreduce(both[1], RED_SUM, out=None if dbeta_out is None else dbeta_out.view(1, C)).reshape(C)
     coef, dgp = torch.empty_like(A), torch.empty_like(A)
     check(lib.dkd_grn_bwd_stats_f32(_p(A), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgp), B, C, _stream()),
           "dkd_grn_bwd_stats_f32")
     dgamma = colreduce(dgp, RED_SUM, out=None if dgamma_out is None else dgamma_out.view(1, C)).reshape(C)
-    dh = torch.empty_like(g)
+    dh = torch.empty_like(h)
     check(lib.dkd_grn_gelu_bwd_f32(_p(dy), _p(g), _p(h), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
           "dkd_grn_gelu_bwd_f32")
     return dh, dgamma, dbeta

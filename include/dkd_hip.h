@@ -102,6 +102,8 @@ long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C);
 #define DKD_RED_SUMSQ 2  /* x * x        */
 #define DKD_RED_SQDIFF 3 /* (x - aux[n])^2 */
 #define DKD_RED_DOT_SUM 4 /* two planes: out[0:G*N] = sum x*y, out[G*N:2*G*N] = sum x (one pass over x) */
+#define DKD_RED_GELUSQ 5  /* gelu(x)^2 : GRN energies straight from the pre-activation */
+#define DKD_RED_DOTGELU_SUM 6 /* DKD_RED_DOT_SUM with y := gelu(y) */
 int dkd_colreduce_f32(const float* X, const float* Y, const float* aux, float* out, float* ws, long rows_per_group,
                       int groups, int N, long ldx, int op, float scale, void* stream);
 long dkd_colreduce_f32_workspace_bytes(long rows_per_group, int groups, int N);
@@ -135,10 +137,12 @@ int dkd_bn_bwd_prep_f32(const float* dt, const float* z, const float* mean, cons
                         const float* beta, float* dbn, float* xhat, long rows, int N, int relu, void* stream);
 int dkd_bn_bwd_apply_f32(const float* dbn, const float* xhat, const float* sum_dbn, const float* sum_dbn_xhat,
                          const float* gamma, const float* rstd, float* dz, long rows, int N, void* stream);
-/* ConvNeXt-V2 GRN on NHWC rows (models/backbones/convnext.py:39-50): sumsq[b][c] from dkd_colreduce_f32 */
+/* ConvNeXt-V2 GRN on NHWC rows (models/backbones/convnext.py:39-50): sumsq[b][c] from dkd_colreduce_f32.
+ * The block (convnext.py:75-87) keeps only the pre-activation h of its GELU: input_is_preact != 0 makes dkd_grn_apply_f32
+ * read h and recompute g = gelu(h) (energies: DKD_RED_GELUSQ), and dkd_grn_gelu_bwd_f32 with g == NULL does the same. */
 int dkd_grn_stats_f32(const float* sumsq, float* gx, float* nx, float* denom, int B, int C, void* stream);
 int dkd_grn_apply_f32(const float* g, const float* nx, const float* gamma, const float* beta, float* y, int B,
-                      long rows_per_img, int C, void* stream);
+                      long rows_per_img, int C, int input_is_preact, void* stream);
 int dkd_grn_bwd_stats_f32(const float* A, const float* gx, const float* nx, const float* denom, const float* gamma,
                           float* coef, float* dgamma_part, int B, int C, void* stream);
 int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const float* nx, const float* coef,

@@ -293,6 +293,13 @@ def test_grn(ops):
     close(dh.reshape(B, 7, 7, C), h.grad, "grn+gelu dh", rtol=2e-4)
     close(dga, ga.grad.reshape(C), "grn dgamma", rtol=2e-4)
     close(dbe, be.grad.reshape(C), "grn dbeta", rtol=2e-4)
+    # the block's own route: only the pre-activation is kept, gelu(h) is recomputed inside the kernels
+    yd, stats = ops.grn_fwd(hd, dev(ga.detach().reshape(C)), dev(be.detach().reshape(C)), B, preact=True)
+    close(yd.reshape(B, 7, 7, C), y, "grn fwd from preact")
+    dh, dga, dbe = ops.grn_gelu_bwd(dev(dy.reshape(B * HW, C)), None, hd, stats, dev(ga.detach().reshape(C)), B)
+    close(dh.reshape(B, 7, 7, C), h.grad, "grn+gelu dh from preact", rtol=2e-4)
+    close(dga, ga.grad.reshape(C), "grn dgamma from preact", rtol=2e-4)
+    close(dbe, be.grad.reshape(C), "grn dbeta from preact", rtol=2e-4)
 
 
 @pytest.mark.parametrize("M,N,K", [(20000, 96, 384), (3000, 384, 1536), (512, 768, 192), (200704, 96, 384)])
