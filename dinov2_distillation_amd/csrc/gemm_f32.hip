@@ -392,7 +392,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
     // matching swizzles (4-40 % slower), per-wave tiles above 32 x 32 (3-25 % slower): with 6-8 waves per SIMD the hardware's
     // wave interleaving already covers what those transformations try to cover in software.  A persistent variant (fixed grid
     // walking the tiles, (tile, k-tile) pairs as one pipelined sequence so the next tile's loads fly under the epilogue) was
-    // 15-20 % slower on every shape, single-tile workgroups included: the epilogue inside the loop costs the occupancy.
+    // 15-20 % slower on every shape, single-tile workgroups included: the epilogue inside the loop costs the occupancy.  An
+    // LDS-free variant (every lane reads the float4 of its fragment row straight from global/L1, register double buffer, no
+    // barrier; 64x64 .. single-wave 64x64 tiles) was 30-50 % slower (gpurun_out/tune_v2_l.log): 4 x 1 KB vector loads per 16
+    // MFMAs saturate the CU's texture path long before the matrix pipes.
     SA sa2;
     SB sb2;
     if (nk > 0) {
