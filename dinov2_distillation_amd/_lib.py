@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "dkd_hip.h")
-LIB_PATH = os.path.join(_PKG, "lib", "libdkd_hip.so")
+LIB_PATH = os.environ.get("DKD_HIP_LIB") or os.path.join(_PKG, "lib", "libdkd_hip.so")  # override: A/B of two builds
 
 _SCALARS = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "int32_t": ctypes.c_int32,

@@ -5,6 +5,7 @@
 //   * bilinear resize, align_corners=False, forward and (gather-form, deterministic) backward
 //                                                                                  (models/model_zoo.py:123-128)
 // Channel is the fastest index, so consecutive lanes read consecutive channels: every access is a dense 16 B/lane run.
+#include <cstdlib>
 #include "common.h"
 #include "dkd_hip.h"
 
@@ -15,53 +16,150 @@ __device__ __forceinline__ void fma4(float4& a, const float4 w, const float4 x) 
 }
 
 // thread = (channel quad, 7 consecutive x, one y, one image).  wt is tap-major [49][C].
+// The kernel is VALU-bound (98 packed FMAs per input row), so everything around the FMAs is kept off the vector ALU:
+// addresses are 32-bit float4 indices off the wave-uniform tensor base (one add per load instead of a 64-bit multiply-add
+// chain; the launcher checks the tensor has < 2^32 float4), out-of-range columns are loaded from the clamped column and
+// zeroed afterwards only in the threads of the first / last strip of a row.
 template <bool FLIP>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                       const float* __restrict__ bias, const float* __restrict__ add,
                                                       float* __restrict__ out, int B, int H, int W, int C) {
-    const int cq = C >> 2, xt = (W + 6) / 7;
-    const long total = (long)B * H * xt * cq;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % cq);
-        long r = idx / cq;
+    const unsigned cq = C >> 2, xt = (W + 6) / 7;
+    const unsigned total = (unsigned)B * H * xt * cq;  // < 2^32 (launcher): the index split below stays in 32-bit division
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    const float4* w4 = reinterpret_cast<const float4*>(wt);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned c4 = idx % cq;
+        unsigned r = idx / cq;
         const int x0 = (int)(r % xt) * 7;
         r /= xt;
-        const int y = (int)(r % H), b = (int)(r / H);
+        const int y = (int)(r % (unsigned)H), b = (int)(r / (unsigned)H);
         float4 acc[7];
         const float4 bv = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[k] = bv;
-        const float4* inb = reinterpret_cast<const float4*>(in) + (long)b * H * W * cq + c4;
-        const float4* w4 = reinterpret_cast<const float4*>(wt) + c4;
+        const bool edge = x0 < 3 || x0 + 9 >= W;
+        unsigned xo[13];  // float4 offset of column x0 + k - 3 (clamped) within a row
+#pragma unroll
+        for (int k = 0; k < 13; ++k) xo[k] = (unsigned)min(max(x0 + k - 3, 0), W - 1) * (unsigned)cq + c4;
 #pragma unroll 1
         for (int i = 0; i < 7; ++i) {
             const int yy = y + i - 3;
             if (yy < 0 || yy >= H) continue;
+            const unsigned rowb = (unsigned)((b * H + yy) * W) * (unsigned)cq;
             float4 v[13];
 #pragma unroll
-            for (int k = 0; k < 13; ++k) {
-                const int xx = x0 + k - 3;
-                v[k] = (xx >= 0 && xx < W) ? inb[((long)yy * W + xx) * cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 13; ++k) v[k] = in4[rowb + xo[k]];
+            if (edge) {
+#pragma unroll
+                for (int k = 0; k < 13; ++k)
+                    if (x0 + k - 3 < 0 || x0 + k - 3 >= W) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            const unsigned wb = (unsigned)(FLIP ? 48 - i * 7 : i * 7) * (unsigned)cq + c4;
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const int tap = FLIP ? 48 - (i * 7 + j) : i * 7 + j;
-                const float4 wv = w4[(long)tap * cq];
+                const float4 wv = FLIP ? w4[wb - (unsigned)j * cq] : w4[wb + (unsigned)j * cq];
 #pragma unroll
                 for (int k = 0; k < 7; ++k) fma4(acc[k], wv, v[k + j]);
             }
         }
-        float4* ob = reinterpret_cast<float4*>(out) + ((long)(b * H + y) * W + x0) * cq + c4;
-        const float4* ab = add ? reinterpret_cast<const float4*>(add) + ((long)(b * H + y) * W + x0) * cq + c4 : nullptr;
+        const unsigned ob = (unsigned)((b * H + y) * W + x0) * (unsigned)cq + c4;
+        float4* o4 = reinterpret_cast<float4*>(out);
+        const float4* a4 = reinterpret_cast<const float4*>(add);
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             if (x0 + k >= W) break;
             float4 o = acc[k];
-            if (ab) {
-                const float4 a = ab[(long)k * cq];
+            if (add) {
+                const float4 a = a4[ob + (unsigned)k * cq];
                 o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
             }
-            ob[(long)k * cq] = o;
+            o4[ob + (unsigned)k * cq] = o;
+        }
+    }
+}
+
+// Second form of the same convolution, for when the weights of a workgroup's channel range fit in LDS (always, for the
+// ConvNeXt widths): the first form is bound by the CU's vector-memory path (13 input + 7 weight float4 loads per 98 packed
+// FMAs: 20 x 1 KB per wave against 64 B/clk), not by HBM and not by the VALU.  Here
+//   * the 49 x CB weight float4 of the block's CB channel quads are staged once in LDS (ds_read_b128 has its own 128 B/clk),
+//   * a thread produces RY output rows x 7 columns: an input row is loaded once and feeds up to RY tap rows (vertical
+//     reuse: (RY + 6) / RY input rows per output row instead of 7).
+// block = CB channel quads x SP spatial tiles (CB * SP <= 256), grid.y = channel chunks, grid.x strides over the tiles.
+template <bool FLIP, int RY, int XW>
+__global__ __launch_bounds__(256) void dwconv7_lds_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                          const float* __restrict__ bias, const float* __restrict__ add,
+                                                          float* __restrict__ out, int B, int H, int W, int C, int CB, int SP) {
+    extern __shared__ float4 wl[];  // [49][CB], already flipped for the dgrad form
+    const unsigned cq = C >> 2, xt = (W + XW - 1) / XW, nyb = (H + RY - 1) / RY;
+    const unsigned c40 = blockIdx.y * CB;
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    const float4* w4 = reinterpret_cast<const float4*>(wt);
+    for (unsigned t = threadIdx.x; t < 49u * CB; t += 256) {
+        const unsigned tap = t / CB, cc = t % CB;
+        wl[t] = w4[(FLIP ? 48 - tap : tap) * cq + c40 + cc];
+    }
+    __syncthreads();
+    const unsigned cc = threadIdx.x % CB, sp = threadIdx.x / CB;
+    if (sp >= (unsigned)SP) return;
+    const unsigned c4 = c40 + cc;
+    const unsigned total = (unsigned)B * nyb * xt;
+    const float4 bv = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned st = blockIdx.x * SP + sp; st < total; st += gridDim.x * SP) {
+        const int x0 = (int)(st % xt) * XW;
+        unsigned r = st / xt;
+        const int y0 = (int)(r % nyb) * RY, b = (int)(r / nyb);
+        float4 acc[RY][XW];
+#pragma unroll
+        for (int ro = 0; ro < RY; ++ro)
+#pragma unroll
+            for (int k = 0; k < XW; ++k) acc[ro][k] = bv;
+        const bool edge = x0 < 3 || x0 + XW + 2 >= W;
+        unsigned xo[XW + 6];
+#pragma unroll
+        for (int k = 0; k < XW + 6; ++k) xo[k] = (unsigned)min(max(x0 + k - 3, 0), W - 1) * cq + c4;
+#pragma unroll
+        for (int t = 0; t < RY + 6; ++t) {  // fully unrolled: the (input row, output row) -> tap row map is static
+            const int yy = y0 - 3 + t;
+            if (yy < 0 || yy >= H) continue;
+            const unsigned rowb = (unsigned)((b * H + yy) * W) * cq;
+            float4 v[XW + 6];
+#pragma unroll
+            for (int k = 0; k < XW + 6; ++k) v[k] = in4[rowb + xo[k]];
+            if (edge) {
+#pragma unroll
+                for (int k = 0; k < XW + 6; ++k)
+                    if (x0 + k - 3 < 0 || x0 + k - 3 >= W) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int ro = 0; ro < RY; ++ro) {
+                const int i = t - ro;  // tap row of this input row for output row y0 + ro
+                if (i < 0 || i > 6) continue;
+                const float4* wr = wl + (unsigned)(i * 7) * CB + cc;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float4 wv = wr[(unsigned)j * CB];
+#pragma unroll
+                    for (int k = 0; k < XW; ++k) fma4(acc[ro][k], wv, v[k + j]);
+                }
+            }
+        }
+        float4* o4 = reinterpret_cast<float4*>(out);
+        const float4* a4 = reinterpret_cast<const float4*>(add);
+#pragma unroll
+        for (int ro = 0; ro < RY; ++ro) {
+            if (y0 + ro >= H) break;
+            const unsigned ob = (unsigned)((b * H + y0 + ro) * W + x0) * cq + c4;
+#pragma unroll
+            for (int k = 0; k < XW; ++k) {
+                if (x0 + k >= W) break;
+                float4 o = acc[ro][k];
+                if (add) {
+                    const float4 a = a4[ob + (unsigned)k * cq];
+                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                }
+                o4[ob + (unsigned)k * cq] = o;
+            }
         }
     }
 }
@@ -241,6 +339,36 @@ extern "C" int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, co
     if (!in || !w_tap_major || !out || B <= 0 || H <= 0 || W <= 0) return DKD_ERR_BAD_ARG;
     if (C & 3) return DKD_ERR_UNSUPPORTED;
     const long total = (long)B * H * ((W + 6) / 7) * (C / 4);
+    // 32-bit float4 / thread indexing inside the kernel
+    if ((long)B * H * W * (C / 4) >= (1L << 32) || total >= (1L << 31)) return DKD_ERR_UNSUPPORTED;
+    static const int force = getenv("DKD_DWCONV_RY") ? atoi(getenv("DKD_DWCONV_RY")) : -1;  // A/B: 0 = first form
+    const int cq = C / 4;
+    int CB = 0;  // largest divisor of cq that is <= 64: the block's channel-quad range
+    for (int d = 1; d <= 64 && d <= cq; ++d)
+        if (cq % d == 0) CB = d;
+    // measured (scripts/bench_dwconv.py, bs 64): RY = 3 wins at 56 x 56 and 28 x 28 (fwd 77 -> 53 us, 42 -> 30 us) and for the
+    // forward at 14 x 14; at 7 x 7 (and the dgrad at 14 x 14) there are too few tiles for the bigger per-thread footprint.
+    // 4-wide strips (more threads, less reuse) and RY = 4 (one wave per SIMD) were slower.
+    const int ry = force >= 0 ? force : (H >= 28 || (H >= 14 && !flip) ? 3 : 0), xw = 7;
+    if (ry >= 2 && CB >= 16) {
+        const int SP = 256 / CB, chunks = cq / CB;
+        const int nyb = (H + ry - 1) / ry;
+        const long tiles = (long)B * nyb * ((W + xw - 1) / xw);
+        long gx = (tiles + SP - 1) / SP;
+        const long cap = 3072 / chunks > 1 ? 3072 / chunks : 1;  // ~12 blocks per CU in flight over all chunks, then stride
+        if (gx > cap) gx = cap;
+        const dim3 grid((unsigned)gx, chunks), block(256);
+        const size_t lds = (size_t)49 * CB * sizeof(float4);
+        hipStream_t st = (hipStream_t)stream;
+#define DKD_DW(FL, R, X) hipLaunchKernelGGL((dwconv7_lds_kernel<FL, R, X>), grid, block, lds, st, in, w_tap_major, bias, add, out, B, H, W, C, CB, SP)
+#define DKD_DW2(FL, R) DKD_DW(FL, R, 7)
+        if (flip) { if (ry >= 4) { DKD_DW2(true, 4); } else if (ry == 3) { DKD_DW2(true, 3); } else { DKD_DW2(true, 2); } }
+        else { if (ry >= 4) { DKD_DW2(false, 4); } else if (ry == 3) { DKD_DW2(false, 3); } else { DKD_DW2(false, 2); } }
+#undef DKD_DW2
+#undef DKD_DW
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
     if (flip)
         hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, w_tap_major,
                            bias, add, out, B, H, W, C);

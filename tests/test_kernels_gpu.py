@@ -228,7 +228,7 @@ def test_batchnorm_relu_pos(ops):
     close(db, be.grad, "bn dbeta", rtol=2e-4)
 
 
-@pytest.mark.parametrize("B,H,C", [(2, 56, 96), (3, 14, 384), (2, 7, 768), (1, 28, 192)])
+@pytest.mark.parametrize("B,H,C", [(2, 56, 96), (3, 14, 384), (2, 7, 768), (1, 28, 192), (1, 15, 96), (2, 30, 64), (1, 29, 32)])
 def test_dwconv7(ops, B, H, C):
     g = torch.Generator().manual_seed(H)
     x = torch.randn(B, C, H, H, generator=g).requires_grad_(True)
