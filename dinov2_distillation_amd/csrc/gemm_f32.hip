@@ -477,39 +477,61 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <int EXT, int BK, int NT>
+template <int EXT, int BK, bool KC, int NT>
 struct DmaStager {
-    static constexpr int SPR = BK / 4, SLOTS = EXT * SPR, NP = (SLOTS + NT - 1) / NT;  // 16-byte slots of a [EXT][BK] tile
+    // KC: [EXT][BK] image, SPR = BK/4 slots per row.  !KC (operand contiguous along M / N): k-major [BK][EXT] image, EXT/4
+    // slots per k-row, slot index XOR 4*((k/4)%4): the four lane groups of a ds_read_b32 fragment read (k = 4g + s) then hit
+    // four different 16-bank groups (conflict-free without padding, which an LDS-DMA image cannot have).
+    static constexpr int SPR = KC ? BK / 4 : EXT / 4, SLOTS = EXT * BK / 4, NP = (SLOTS + NT - 1) / NT;
     static_assert(SLOTS % 64 == 0, "a wave's 1 KiB must not straddle the tile end");
+    static_assert(KC || EXT % 64 == 0, "k-major image: the XOR needs 16 slots per row");
     const float* src[NP];
+    long step;
     __device__ __forceinline__ void init(const float* __restrict__ P, long ld, int row0, int rows, int k0, int tid) {
+        step = KC ? BK : (long)BK * ld;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int q = tid + p * NT, r = q / SPR, c = q % SPR;
-            const int kq = Stager2<EXT, BK, true, NT>::swz(r, c);
-            src[p] = P + (long)min(row0 + r, rows - 1) * ld + k0 + 4 * kq;
+            if (KC) {
+                const int kq = Stager2<EXT, BK, true, NT>::swz(r, c);
+                src[p] = P + (long)min(row0 + r, rows - 1) * ld + k0 + 4 * kq;
+            } else {  // r = k within the tile, c = slot within the k-row
+                const int mq = c ^ (((r >> 2) & 3) << 2);
+                src[p] = P + (long)(k0 + r) * ld + min(row0 + 4 * mq, rows - 4);
+            }
         }
     }
-    // tile kt of this operand -> LDS image at S (wave-uniform destination: S + 16 B * first slot of this wave's piece)
-    __device__ __forceinline__ void issue(float* __restrict__ S, int kt, int tid) const {
+    // the next tile of this operand -> LDS image at S (wave-uniform destination: S + 16 B * first slot of this wave's piece)
+    __device__ __forceinline__ void issue(float* __restrict__ S, int tid) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int q0 = (tid & ~63) + p * NT;
             if (SLOTS % NT == 0 || q0 < SLOTS)
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[p] + BK * kt), (lds_void_t*)(S + 4 * q0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src[p], (lds_void_t*)(S + 4 * q0), 16, 0, 0);
+            src[p] += step;
         }
+    }
+    // fragment of 16 rows starting at r0 for the 16-k block kb: element s = op[r0 + lane%16][16*kb + 4*(lane/16) + s]
+    static __device__ __forceinline__ float4 frag(const float* __restrict__ S, int r0, int kb, int g, int i16) {
+        if (KC) return Stager2<EXT, BK, true, NT>::frag(S, r0, kb, g, i16);
+        const float* p = S + (16 * kb + 4 * g) * EXT + 4 * (((r0 + i16) >> 2) ^ (g << 2)) + (i16 & 3);
+        return make_float4(p[0], p[EXT], p[2 * EXT], p[3 * EXT]);
+    }
+    // element (k, m) of the k-major image (bias-gradient row sums)
+    static __device__ __forceinline__ float at(const float* __restrict__ S, int k, int m) {
+        return S[k * EXT + 4 * ((m >> 2) ^ (((k >> 2) & 3) << 2)) + (m & 3)];
     }
 };
 
-template <int WM, int WN, int TM, int TN, int BK>
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda,
                                                                     const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                     int M, int N, int K, int kchunk, Epilogue epi,
-                                                                    float* __restrict__ ws, int vec_ok) {
+                                                                    float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
-    using SA = Stager2<BM, BK, true, NT>;
-    using SB = Stager2<BN, BK, true, NT>;
-    constexpr int A_SZ = SA::SIZE, B_SZ = SB::SIZE;
+    using DA = DmaStager<BM, BK, A_KC, NT>;
+    using DB = DmaStager<BN, BK, B_KC, NT>;
+    constexpr int A_SZ = BM * BK, B_SZ = BN * BK;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -526,13 +548,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    DmaStager<BM, BK, NT> da;
-    DmaStager<BN, BK, NT> db;
+    DA da;
+    DB db;
     da.init(A, lda, bm0, M, kbeg, tid);
     db.init(B, ldb, bn0, N, kbeg, tid);
+    const bool do_rowsum = !A_KC && rowsum != nullptr && bn0 == 0 && tid < BM;
+    float rs = 0.f;
     if (nk > 0) {
-        da.issue(smem, 0, tid);
-        db.issue(smem + A_SZ, 0, tid);
+        da.issue(smem, tid);
+        db.issue(smem + A_SZ, tid);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -541,16 +565,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
         const float* As = smem + cur * (A_SZ + B_SZ);
         float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
         if (kt + 1 < nk) {  // every wave passed the barrier: nobody reads the other buffer any more
-            da.issue(An, kt + 1, tid);
-            db.issue(An + A_SZ, kt + 1, tid);
+            da.issue(An, tid);
+            db.issue(An + A_SZ, tid);
+        }
+        if (do_rowsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += DA::at(As, kk, tid);
         }
 #pragma unroll
         for (int kb = 0; kb < BK / 16; ++kb) {
             float4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = SA::frag(As, (wm * TM + i) * 16, kb, g, i16);
+            for (int i = 0; i < TM; ++i) a[i] = DA::frag(As, (wm * TM + i) * 16, kb, g, i16);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = SB::frag(As + A_SZ, (wn * TN + j) * 16, kb, g, i16);
+            for (int j = 0; j < TN; ++j) b[j] = DB::frag(As + A_SZ, (wn * TN + j) * 16, kb, g, i16);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -566,6 +594,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
     }
 
     const bool partial = ws != nullptr;
+    if (do_rowsum && bm0 + tid < M) {
+        if (partial) ws[(long)gridDim.y * M * N + (long)blockIdx.y * M + bm0 + tid] = rs;
+        else rowsum[bm0 + tid] = rs * epi.alpha;
+    }
     float* out = partial ? ws + (long)blockIdx.y * M * N : C;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -906,15 +938,31 @@ int launch_v2(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchun
     return DKD_OK;
 }
 
+// can the LDS-DMA kernel run this problem?  (whole BK-deep tiles, 16-byte aligned rows, whole float4 at the M / N edge of an
+// operand that is contiguous along M / N)
+template <int BK>
+static bool dma_ok(const dkd_gemm_args* g, int kchunk) {
+    if ((g->K % BK) || (kchunk % BK) || (g->lda & 3) || (g->ldb & 3)) return false;
+    if (g->a_layout == 1 && (g->M & 3)) return false;
+    if (g->b_layout == 1 && (g->N & 3)) return false;
+    if (g->rowsum && g->a_layout == 0) return false;
+    return true;
+}
 template <int WM, int WN, int TM, int TN, int BK>
 int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
-    if (g->a_layout != 0 || g->b_layout != 0 || g->rowsum || (g->K % BK) || (kchunk % BK) || (g->lda & 3) || (g->ldb & 3))
-        return DKD_ERR_UNSUPPORTED;
+    if (!dma_ok<BK>(g, kchunk)) return DKD_ERR_UNSUPPORTED;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
     float* ws = splits > 1 ? g->workspace : nullptr;
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc, g->M,
-                       g->N, g->K, kchunk, epi, ws, epilogue_vec_ok(g));
+    const int vec = epilogue_vec_ok(g);
+#define DKD_GEMM_LAUNCH3(AKC, BKC)                                                                                          \
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
+                       g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
+    if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH3(true, true);
+    else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH3(true, false);
+    else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH3(false, true);
+    else DKD_GEMM_LAUNCH3(false, false);
+#undef DKD_GEMM_LAUNCH3
     DKD_LAUNCH_CHECK();
     if (splits > 1) return launch_splitk_reduce(g, epi, splits, st);
     return DKD_OK;
@@ -933,10 +981,10 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
 enum { CFG_128x128_8W = 2, CFG_64x128_4W = 3, CFG_128x96_4W = 4, V2_64x64 = 44, V2_64x96 = 43, V2_64x96_BK32 = 55, V2_32x64 = 52,
        DMA_64x64_BK32 = 101 };
 
-// LDS-DMA staging (NT layout only): measured +1..14 % over the register-staged 64x64 kernel once the reduction is long
-// enough to amortise its one-tile-deep prologue (gpurun_out/tune_v2_n.log); short reductions stay on register staging.
+// LDS-DMA staging: measured +1..14 % over the register-staged 64x64 kernel in every layout once the reduction is long
+// enough to amortise its one-tile-deep prologue (gpurun_out/tune_v2_[n-p].log); short reductions stay on register staging.
 static bool dma_shape(int N, int K, int a_layout, int b_layout) {
-    return a_layout == 0 && b_layout == 0 && N != 96 && (K >= 768 || (K >= 384 && N >= 1152));
+    return N != 96 && (K >= 768 || (a_layout == 0 && b_layout == 0 && K >= 384 && N >= 1152));
 }
 static int pick_cfg(int M, int N, int K, int a_layout, int b_layout, int variant) {
     if (variant > 0) return variant;
@@ -1039,11 +1087,11 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     if (splits > 1 && !g->workspace) splits = 1;
     int kchunk = g->K;
     if (splits > 1) {
-        kchunk = ((g->K + splits - 1) / splits + 15) / 16 * 16;
+        const int kq = cfg >= 100 ? 32 : 16;
+        kchunk = ((g->K + splits - 1) / splits + kq - 1) / kq * kq;
         splits = (g->K + kchunk - 1) / kchunk;
     }
-    if (g->variant == 0 && cfg == DMA_64x64_BK32 &&
-        (g->rowsum || (g->K % 32) || (kchunk % 32) || (g->lda & 3) || (g->ldb & 3)))
+    if (g->variant == 0 && cfg == DMA_64x64_BK32 && !dma_ok<32>(g, kchunk))
         cfg = V2_64x64;  // same tile, register staging: handles the ragged cases
     hipStream_t st = (hipStream_t)stream;
     switch (cfg) {
