@@ -999,7 +999,8 @@ static void cfg_tile(int cfg, int* bm, int* bn) {
         case 40: *bm = 128; *bn = 64; break;
         case CFG_128x96_4W: *bm = 128; *bn = 96; break;
         case 43: case 55: *bm = 64; *bn = 96; break;
-        case 44: case 64: case 100: case 101: case 102: *bm = 64; *bn = 64; break;
+        case 44: case 64: case 100: case 101: case 102: case 104: case 105: *bm = 64; *bn = 64; break;
+        case 106: case 107: *bm = 128; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
         default: *bm = 64; *bn = 128; break;  // 3, 5, 34, 45, 65
     }
@@ -1110,6 +1111,10 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 101: return launch_dma<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, BK 32
         case 102: return launch_dma<2, 2, 2, 2, 64>(g, epi, splits, kchunk, st);     // 64 x 64, BK 64
         case 103: return launch_dma<2, 2, 2, 4, 32>(g, epi, splits, kchunk, st);     // 64 x 128, BK 32
+        case 104: return launch_dma<1, 2, 4, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, 2 waves of 64 x 32, BK 16
+        case 105: return launch_dma<1, 2, 4, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, 2 waves of 64 x 32, BK 32
+        case 106: return launch_dma<2, 2, 4, 2, 16>(g, epi, splits, kchunk, st);     // 128 x 64, 4 waves of 64 x 32, BK 16
+        case 107: return launch_dma<2, 2, 4, 2, 32>(g, epi, splits, kchunk, st);     // 128 x 64, BK 32
         case 45: return launch_v2<4, 1, 1, 8, 16>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 16 x 128
         case 52: return launch_v2<2, 2, 1, 2, 16>(g, epi, splits, kchunk, st);   // 32 x 64, 4 waves of 16 x 32
         case 55: return launch_v2<2, 2, 2, 3, 32>(g, epi, splits, kchunk, st);   // 64 x 96, BK 32

@@ -167,6 +167,7 @@ class PatchConvFn(Function):
 
 # =====================================================================================================================
 CONVNEXT_KEEP_GELU_OUT = False
+DWCONV_WGRAD_ON_SIDE_STREAM = True
 
 
 class ConvNeXtBlockFn(Function):
@@ -218,9 +219,22 @@ class ConvNeXtBlockFn(Function):
         dn = ops.dgrad(dh, w1)  # [M, C]
         dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w, dg_out=o_lnw, db_out=o_lnb)
         dd = dd.reshape(B, H, W, C)
-        dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
-        ddw = ops.transpose(ops.dwconv7_wgrad(x, dd), out=None if o_dww is None else o_dww.view(C, 49)).reshape(dw_shape)
-        ddb = ops.colreduce(dd.reshape(M, C), ops.RED_SUM, out=None if o_dwb is None else o_dwb.view(1, C)).reshape(-1)
+        if o_dww is not None and DWCONV_WGRAD_ON_SIDE_STREAM:
+            # the depthwise weight / bias gradients feed nothing but the optimiser: on the weight-gradient stream their
+            # (vector-memory-bound) kernels run beside the MFMA-bound GEMMs of the main chain instead of between them
+            side = ops.wgrad_stream(x.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.transpose(ops.dwconv7_wgrad(x, dd), out=o_dww.view(C, 49))
+                ops.colreduce(dd.reshape(M, C), ops.RED_SUM, out=o_dwb.view(1, C))
+            x.record_stream(side)
+            dd.record_stream(side)
+            ddw = ddb = None
+            dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
+        else:
+            dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
+            ddw = ops.transpose(ops.dwconv7_wgrad(x, dd), out=None if o_dww is None else o_dww.view(C, 49)).reshape(dw_shape)
+            ddb = ops.colreduce(dd.reshape(M, C), ops.RED_SUM, out=None if o_dwb is None else o_dwb.view(1, C)).reshape(-1)
         return (dx, ret(o_dww, ddw, p_dww), ret(o_dwb, ddb, p_dwb), ret(o_lnw, dln_w, p_lnw), ret(o_lnb, dln_b, p_lnb),
                 dw1, db1, ret(o_gg, dgrn_g.reshape(grn_shape), p_gg), ret(o_gb, dgrn_b.reshape(grn_shape), p_gb), dw2, db2)
 
