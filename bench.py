@@ -247,11 +247,14 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and args.batch == 64:
-            traffic = json.load(open(pmc))["kernels"].get("gemm_f32_v2_kernel", {}).get("traffic_bytes")
+            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if k.startswith("gemm_f32_")]  # dma + v2 kernels
+            if ks:
+                traffic = round(sum(v["traffic_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
         res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                            "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.md)",
-                           "kernel": "gemm_f32_v2_kernel (fp32 MFMA 16x16x4), every dkd_gemm_f32 launch of the step",
+                           "kernel": "gemm_f32_dma_kernel / gemm_f32_v2_kernel (fp32 MFMA 16x16x4; LDS-DMA staged for K >= 768, register "
+                                     "staged otherwise), every dkd_gemm_f32 launch of the step",
                            "achieved_timed_region": round(ach_timed, 2),
                            "note": "achieved/frac: every GEMM launch of 2 extra steps run on ONE stream right after the timed "
                                    "region (HIP events per launch; matches rocprofv3 with DKD_ASYNC_WGRAD=0, profiles/). "
