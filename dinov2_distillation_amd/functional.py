@@ -34,11 +34,11 @@ def ret(out, value, param):
     return None
 
 
-def wgrad(dy2, x2, w, b, need_w=True, need_b=True, transform=None, reshape=None):
+def wgrad(dy2, x2, w, b, need_w=True, need_b=True, transform=None, reshape=None, fork=True):
     """Weight (+bias) gradient of y = x W^T + b.  Returns (dW, db); in async mode (ops.can_async) the launches go to the side
     stream straight into w.grad / b.grad and (None, None) is returned."""
     if need_w and (b is None or need_b) and ops.can_async(w, b):
-        ops.wgrad_into(dy2, x2, w, b, transform)
+        ops.wgrad_into(dy2, x2, w, b, transform, fork=fork)
         return None, None
     dw = db = None
     if need_w and b is not None and need_b:
@@ -208,7 +208,6 @@ class ConvNeXtBlockFn(Function):
         dout = _c(dout)
         do2 = dout.reshape(M, C)
         pw1, pb1, pw2, pb2 = ctx.params
-        dw2, db2 = wgrad(do2, y, pw2, pb2)
         dy = ops.dgrad(do2, w2)  # [M, 4C]
         p_dww, p_dwb, p_lnw, p_lnb, p_gg, p_gb = ctx.small
         o_dww, o_dwb, o_lnw, o_lnb, o_gg, o_gb = direct(*ctx.small)
@@ -216,6 +215,7 @@ class ConvNeXtBlockFn(Function):
                                               None if o_gg is None else o_gg.view(-1), None if o_gb is None else o_gb.view(-1))
         n2 = n.reshape(M, C)
         dw1, db1 = wgrad(dh, n2, pw1, pb1)
+        dw2, db2 = wgrad(do2, y, pw2, pb2, fork=False)  # one fork of the weight-gradient stream for both linears
         dn = ops.dgrad(dh, w1)  # [M, C]
         dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w, dg_out=o_lnw, db_out=o_lnb)
         dd = dd.reshape(B, H, W, C)
@@ -387,12 +387,12 @@ class AttentionProjectorFn(Function):
         o_pos, o_bnw, o_bnb, o_n1w, o_n1b, o_n2w, o_n2b = direct(P_pos, P_bnw, P_bnb, P_n1w, P_n1b, P_n2w, P_n2b)
         M = B * N
         df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w, dg_out=o_n2w, db_out=o_n2b)
-        dw2, db2 = wgrad(df2, f1, P_w2, P_b2)
+        # weight gradients are launched in groups: every fork of the weight-gradient stream costs the main chain ~10 us
         df1 = ops.relu_bwd(ops.dgrad(df2, w2), f1)
         dw1, db1 = wgrad(df1, zn, P_w1, P_b1)
+        dw2, db2 = wgrad(df2, f1, P_w2, P_b2, fork=False)
         dzn = ops.dgrad(df1, w1, residual=df2)  # + FFN residual branch
         dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w, dg_out=o_n1w, db_out=o_n1b)
-        dwp, dbp = wgrad(dy, o.reshape(M, D), P_wp, P_bp)
         do = ops.dgrad(dy, wp).reshape(B, N, D)
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
@@ -413,14 +413,14 @@ class AttentionProjectorFn(Function):
                                    dq, dk, dv, st, st, st)
         dk, dv = dk.reshape(M, D), dv.reshape(M, D)
         dwk, dbk = wgrad(dk, tok, P_wk, P_bk)
-        dwv, dbv = wgrad(dv, tok, P_wv, P_bv)
+        dwv, dbv = wgrad(dv, tok, P_wv, P_bv, fork=False)
+        dwp, dbp = wgrad(dy, o.reshape(M, D), P_wp, P_bp, fork=False)
         dtok = ops.dgrad(dk, wk, residual=dy)  # + attention residual branch
         ops.dgrad(dv, wv, out=dtok, residual=dtok)
         if shared:
             dq2 = ops.colreduce(dq.reshape(B, N * D), ops.RED_SUM).reshape(N, D)
         else:
             dq2 = dq.reshape(M, D)
-        dwq, dbq = wgrad(dq2, qin, P_wq, P_bq)
         o_sq = ops.grad_out(ctx.sq) if shared else None  # the self-query embedding's gradient goes straight into the arena
         dqin = ops.dgrad(dq2, wq, out=None if o_sq is None else o_sq.view(N, D))
         dext = None if shared else dqin.reshape(B, N, D)
@@ -429,6 +429,7 @@ class AttentionProjectorFn(Function):
                              out=None if o_pos is None else o_pos.view(D, N)).reshape(pos_shape)
         dz, dbn_w, dbn_b = ops.bn_bwd(dtok, z, mean, rstd, bn_w, bn_b, relu=True, dgamma_out=o_bnw, dbeta_out=o_bnb)
         dwc, dbc = wgrad(dz, x2, P_wc, P_bc, reshape=lambda t: t.reshape(wc_shape))
+        dwq, dbq = wgrad(dq2, qin, P_wq, P_bq, fork=False)
         dx = ops.dgrad(dz, wc.reshape(D, Cs)).reshape(xshape) if ctx.needs_input_grad[0] else None
         return (dx, dext, dself, None, None, None, None, None,
                 ret(o_pos, dpos, P_pos), dwc, dbc, ret(o_bnw, dbn_w, P_bnw), ret(o_bnb, dbn_b, P_bnb), dwq, dbq, dwk, dbk,

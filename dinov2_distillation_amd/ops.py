@@ -176,11 +176,15 @@ def can_async(*params):
     return ASYNC_WGRAD and all(p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in params)
 
 
-def wgrad_into(dy2, x2, w, b=None, transform=None):
+def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True):
     """dW = dy2^T x2 (and db = column sums of dy2) written into w.grad / b.grad on the side stream.
-    transform(dw2) -> None may post-process the raw [N, K] result into w.grad (layout changes) on the same stream."""
+    transform(dw2) -> None may post-process the raw [N, K] result into w.grad (layout changes) on the same stream.
+    fork=False: the caller has enqueued nothing on the current stream since its previous wgrad_into (the side stream already
+    waits for everything this launch reads): skips the event record + wait, which costs the MAIN stream ~10 us each
+    (measured, scripts/ab_step.py; an event without the system-scope fence costs the same)."""
     side = wgrad_stream(dy2.device)
-    side.wait_stream(torch.cuda.current_stream())
+    if fork:
+        side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         N, K = dy2.shape[-1], x2.shape[-1]
         rs = b.grad.view(-1) if b is not None else None
