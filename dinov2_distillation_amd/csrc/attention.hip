@@ -404,19 +404,30 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int 
 }
 
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]
-__global__ void attn_delta_kernel(dkd_attn_args a) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// hd/4 consecutive lanes read the float4s of one (query, head) row of O and dO (dense, coalesced runs; one lane per row
+// made every load instruction touch 64 different cache lines), partial sums meet in LDS.  blockDim is a multiple of G.
+__global__ void attn_delta_kernel(dkd_attn_args a, int G) {
+    __shared__ float part[256];
+    const int tid = threadIdx.x, gi = tid / G, c = tid % G;
+    const long row = (long)blockIdx.x * (blockDim.x / G) + gi;  // (b * Nq + q) * H + h
     const long total = (long)a.B * a.H * a.Nq;
-    if (i >= total) return;
-    const int q = (int)(i % a.Nq), h = (int)((i / a.Nq) % a.H), b = (int)(i / ((long)a.Nq * a.H));
-    const float* o = a.o + b * a.o_bs + (long)q * a.o_rs + h * a.hd;
-    const float* d = a.d_o + b * a.do_bs + (long)q * a.do_rs + h * a.hd;
     float s = 0.f;
-    for (int c = 0; c < a.hd; c += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(o + c), y = *reinterpret_cast<const float4*>(d + c);
-        s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    int q = 0, h = 0, b = 0;
+    if (row < total) {
+        h = (int)(row % a.H);
+        q = (int)((row / a.H) % a.Nq);
+        b = (int)(row / ((long)a.H * a.Nq));
+        const float4 x = *reinterpret_cast<const float4*>(a.o + b * a.o_bs + (long)q * a.o_rs + h * a.hd + 4 * c);
+        const float4 y = *reinterpret_cast<const float4*>(a.d_o + b * a.do_bs + (long)q * a.do_rs + h * a.hd + 4 * c);
+        s = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
     }
-    a.delta[i] = s;
+    part[tid] = s;
+    __syncthreads();
+    if (c == 0 && row < total) {
+        float t = 0.f;
+        for (int j = 0; j < G; ++j) t += part[tid + j];
+        a.delta[((long)b * a.H + h) * a.Nq + q] = t;
+    }
 }
 
 // dQ: queries resident (one wave = 32 queries), keys/values streamed through LDS.
@@ -565,7 +576,8 @@ int launch_fwd(const dkd_attn_args* a, hipStream_t st) {
 template <int HD>
 int launch_bwd(const dkd_attn_args* a, hipStream_t st) {
     const long total = (long)a->B * a->H * a->Nq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, *a);
+    const int G = HD / 4, bd = 256 / G * G, rpb = bd / G;  // block: a whole number of (query, head) rows
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + rpb - 1) / rpb)), dim3(bd), 0, st, *a, G);
     DKD_LAUNCH_CHECK();
     int nw = pick_nw(a->Nq);
     dim3 gq((a->Nq + 32 * nw - 1) / (32 * nw), a->H, a->B);
