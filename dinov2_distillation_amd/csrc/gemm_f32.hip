@@ -474,6 +474,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
 // unchanged; an LDS-DMA writes wave-base + lane * 16 B, so the swizzle goes on the SOURCE address: the lane that owns LDS
 // slot (row r, slot c) fetches k-quad swz(r, c) of global row r (swz is an involution).  No VGPR round trip, no ds_write, no
 // vmcnt wait in front of it.  Rows past M / N are clamped (never stored); needs (kend - kbeg) % 16 == 0.
+// Knock-outs of this kernel (timing only, gpurun_out notes in DESIGN.md): without the DMA of both operands it runs 20 %
+// faster, without B's alone 7 %; the barrier is free.  The same pipeline on v_mfma_f32_32x32x2_f32 (half the fragment reads
+// per MAC: one b128 per operand feeds four MFMAs) was 2-3 % SLOWER on every shape (tune_v2_r.log) - the staging traffic, not
+// the fragment reads, is what the matrix pipes wait for.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
