@@ -14,6 +14,7 @@
 // loads issued before the MFMA block of the current one (double-buffered LDS, one barrier per k-tile).
 // fp32 MFMA is 64 cycles per 32x32x2 issue per SIMD, so LDS/VMEM bandwidth is far from limiting; what
 // matters is keeping 4 waves x (TM x TN) independent accumulators busy and the launch XCD-aware.
+#include <cstdlib>
 #include "common.h"
 #include "dkd_hip.h"
 
@@ -531,7 +532,9 @@ template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda,
                                                                     const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                     int M, int N, int K, int kchunk, Epilogue epi,
-                                                                    float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok) {
+                                                                    float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok,
+                                                                    int knock) {
+    // knock (DKD_GEMM_KNOCKOUT, timing experiments only - results are wrong): 2 = no DMA at all, 4 = no DMA of B, 8 = no barrier
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     using DA = DmaStager<BM, BK, A_KC, NT>;
     using DB = DmaStager<BN, BK, B_KC, NT>;
@@ -568,9 +571,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
         const int cur = kt & 1;
         const float* As = smem + cur * (A_SZ + B_SZ);
         float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
-        if (kt + 1 < nk) {  // every wave passed the barrier: nobody reads the other buffer any more
+        if (kt + 1 < nk && !(knock & 2)) {  // every wave passed the barrier: nobody reads the other buffer any more
             da.issue(An, tid);
-            db.issue(An + A_SZ, tid);
+            if (!(knock & 4)) db.issue(An + A_SZ, tid);
         }
         if (do_rowsum) {
 #pragma unroll
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt + 1 have landed
-        __syncthreads();
+        if (!(knock & 8)) __syncthreads();
     }
 
     const bool partial = ws != nullptr;
@@ -959,9 +962,10 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
     float* ws = splits > 1 ? g->workspace : nullptr;
     const int vec = epilogue_vec_ok(g);
+    static const int knock = getenv("DKD_GEMM_KNOCKOUT") ? atoi(getenv("DKD_GEMM_KNOCKOUT")) : 0;
 #define DKD_GEMM_LAUNCH3(AKC, BKC)                                                                                          \
     hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
-                       g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
+                       g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec, knock)
     if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH3(true, true);
     else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH3(true, false);
     else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH3(false, true);
