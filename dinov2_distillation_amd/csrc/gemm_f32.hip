@@ -478,7 +478,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
 // Knock-outs of this kernel (timing only, gpurun_out notes in DESIGN.md): without the DMA of both operands it runs 20 %
 // faster, without B's alone 7 %; the barrier is free.  The same pipeline on v_mfma_f32_32x32x2_f32 (half the fragment reads
 // per MAC: one b128 per operand feeds four MFMAs) was 2-3 % SLOWER on every shape (tune_v2_r.log) - the staging traffic, not
-// the fragment reads, is what the matrix pipes wait for.
+// the fragment reads, is what the matrix pipes wait for.  Moving all DMA issue to a fifth, loader-only wave per workgroup
+// (the four MFMA waves then only read fragments and multiply) was 10-20 % slower (tune_v2_s.log): one wave issuing the
+// workgroup's 16 pieces per tile back to back, one tile ahead, does not keep up.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
