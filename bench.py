@@ -16,7 +16,11 @@ import os
 import sys
 import time
 
-import torch
+# read by the HSA runtime when the GPU is first touched: RCCL / cross-process tensor sharing needs dmabuf IPC on this pool
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.pop("NCCL_P2P_DISABLE", None)  # the reference sets it (train.py:23); it would turn xGMI peer-to-peer off
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
