@@ -258,6 +258,39 @@ __global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __
         *d = v;
     }
 }
+// nn.AvgPool2d(2, 2, 0, ceil_mode=True) on NHWC (models/backbones/presnet.py:227,268: the "d" shortcut): windows hanging over
+// the bottom / right edge are clipped and divided by the number of in-bounds elements.  mode 1 = backward (in = dy [Ho,Wo]).
+__global__ void avgpool2_kernel(const float4* __restrict__ in, float4* __restrict__ out, int B, int H, int W, int cq, int Ho,
+                                int Wo, int backward) {
+    const long total = (long)B * (backward ? H * W : Ho * Wo) * cq;
+    GRID_STRIDE(i, total) {
+        long r = i;
+        const int c = (int)(r % cq); r /= cq;
+        if (!backward) {
+            const int ox = (int)(r % Wo); r /= Wo;
+            const int oy = (int)(r % Ho);
+            const int b = (int)(r / Ho);
+            const int ny = min(2, H - 2 * oy), nx = min(2, W - 2 * ox);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ky = 0; ky < ny; ++ky)
+                for (int kx = 0; kx < nx; ++kx) {
+                    const float4 v = in[(((long)b * H + 2 * oy + ky) * W + 2 * ox + kx) * cq + c];
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+            const float inv = 1.f / (float)(ny * nx);
+            out[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+        } else {
+            const int x = (int)(r % W); r /= W;
+            const int y = (int)(r % H);
+            const int b = (int)(r / H);
+            const int oy = y >> 1, ox = x >> 1;
+            const float inv = 1.f / (float)(min(2, H - 2 * oy) * min(2, W - 2 * ox));
+            const float4 v = in[(((long)b * Ho + oy) * Wo + ox) * cq + c];
+            out[i] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+        }
+    }
+}
+
 }  // namespace
 
 #define F4(p) reinterpret_cast<const float4*>(p)
@@ -347,6 +380,18 @@ extern "C" int dkd_maxpool3_f32(const float* in, float* out, int* argmax, int B,
     else
         hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(blocks_for((long)B * H * W * C)), dim3(256), 0, st, in, argmax, out, B, H,
                            W, C, stride, Ho, Wo);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_avgpool2_f32(const float* in, float* out, int B, int H, int W, int C, int mode, void* stream) {
+    // mode 0: forward (in = x [B,H,W,C], out = y [B,ceil(H/2),ceil(W/2),C]); mode 1: backward (in = dy, out = dx [B,H,W,C])
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    if (C & 3) return DKD_ERR_ALIGN;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)B * (mode ? H * W : Ho * Wo) * (C / 4);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), B, H, W, C / 4, Ho, Wo, mode);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

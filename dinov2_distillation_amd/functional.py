@@ -628,6 +628,20 @@ class MaxPool3Fn(Function):
         return ops.maxpool3_bwd(_c(dy), arg, *ctx.hw)
 
 
+class AvgPool2Fn(Function):
+    """nn.AvgPool2d(2, 2, 0, ceil_mode=True) on NHWC (models/backbones/presnet.py:227,268)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.hw = tuple(x.shape[1:3])
+        return ops.avgpool2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool2(_c(dy), backward_hw=ctx.hw)
+
+
 class AddReluFn(Function):
     """out = relu(a + b): the residual tail of a ResNet block (resnet.py:395-397, 507-511)"""
 

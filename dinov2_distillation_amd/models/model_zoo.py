@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .convnext import D2ConvNextV2
+from .presnet import D2Presnet
 from .resnet import BasicStem, ResNet, make_resnet_stages
 from .stdc import STDCNet
 from .swin import D2SwinTransformer
@@ -131,11 +132,41 @@ class D2SwinTransformerWrapper(nn.Module):
         return self._out_feature_channels
 
 
+PRESNET_CONFIGS = {"presnet_18": (18, "presnet18.pkl"), "presnet_34": (34, "presnet34.pkl"), "presnet_50": (50, "presnet50.pkl"),
+                   "presnet_101": (101, "presnet101.pkl")}  # models/wrappers/presnet_wrapper.py:11-16 (variant "d")
+
+
+class PResNetWrapper(nn.Module):
+    """models/wrappers/presnet_wrapper.py: D2Presnet(depth, variant="d", act="relu", freeze_norm=False, freeze_at=-1)"""
+
+    def __init__(self, model_name="presnet_50", out_features=None):
+        super().__init__()
+        if model_name not in PRESNET_CONFIGS:
+            raise NotImplementedError(f"There is not a PResNet config called {model_name}.")
+        depth, ckpt = PRESNET_CONFIGS[model_name]
+        self._out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", ckpt)
+        self.model = D2Presnet(depth=depth, out_features=self._out_features)
+        self._out_feature_channels = self.model._out_feature_channels
+
+    def get_features(self, x):
+        return self.model(x)
+
+    def get_features_nhwc(self, x):
+        feats = self.model.forward_features_nhwc(x)
+        return {k: v for k, v in feats.items() if k in self._out_features}
+
+    @property
+    def feature_channels(self):
+        return self._out_feature_channels
+
+
 class ModelWrapper(nn.Module):
     """models/model_zoo.py:18-145.  Only the student families built on the MI355X kernels are registered; asking for
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
-    MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper, "swin": D2SwinTransformerWrapper}
+    MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper, "swin": D2SwinTransformerWrapper,
+                 "presnet": PResNetWrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

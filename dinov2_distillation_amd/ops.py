@@ -605,6 +605,20 @@ def maxpool3_bwd(dy, arg, H, W, stride=2):
     return dx
 
 
+def avgpool2(x, backward_hw=None):
+    """nn.AvgPool2d(2, 2, 0, ceil_mode=True) on NHWC; backward_hw=(H, W): x is dy and the result is dx [B,H,W,C]"""
+    _chk(x, "x")
+    B, h, w, C = x.shape
+    if backward_hw is None:
+        out = torch.empty((B, (h + 1) // 2, (w + 1) // 2, C), dtype=torch.float32, device=x.device)
+        check(_lib.load().dkd_avgpool2_f32(_p(x), _p(out), B, h, w, C, 0, _stream()), "dkd_avgpool2_f32")
+    else:
+        H, W = backward_hw
+        out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+        check(_lib.load().dkd_avgpool2_f32(_p(x), _p(out), B, H, W, C, 1, _stream()), "dkd_avgpool2_f32(bwd)")
+    return out
+
+
 def add_relu(a, b):
     _chk(a, "a"), _chk(b, "b")
     out = torch.empty_like(a)

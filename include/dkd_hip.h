@@ -251,6 +251,10 @@ int dkd_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, 
 int dkd_maxpool3_f32(const float* in, float* out, int* argmax, int B, int H, int W, int C, int stride, int mode,
                      void* stream);
 int dkd_add_relu_f32(const float* a, const float* b, float* out, long n, void* stream);
+/* PResNet "d" shortcut (models/backbones/presnet.py:227,268): nn.AvgPool2d(2, 2, 0, ceil_mode=True) on NHWC, windows clipped at
+ * the bottom / right edge and divided by their in-bounds count.  mode 0: in = x [B,H,W,C] -> out [B,ceil(H/2),ceil(W/2),C];
+ * mode 1: backward, in = dy, out = dx [B,H,W,C] (H, W are the INPUT extents in both modes). */
+int dkd_avgpool2_f32(const float* in, float* out, int B, int H, int W, int C, int mode, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Swin-Transformer student (models/backbones/swin.py).

@@ -306,6 +306,44 @@ def gen_resnet():
     _save("resnet_small", **arrays)
 
 
+def gen_presnet():
+    """the reference's own D2Presnet (models/backbones/presnet.py needs nothing but torch), depth 18 (BasicBlock) and 50
+    (BottleNeck), variant "d", live BatchNorm, batch 4 at 98x98: the stages see 25 / 13 / 7 / 4 pixels a side, so two
+    average-pool shortcuts clip their last window, and the deepest BatchNorm still averages over 64 samples (with 2 x 3 x 3
+    the fp32 round-off of a 50-layer backward pass reaches 0.5 % of the first conv's gradient in any summation order).  The widths are
+    hard-wired in the reference (presnet.py:345), so the weights come from tests/golden/param_recipe.py instead of the file."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import param_recipe as pr_
+    pr = _load_file("ref_presnet", "models/backbones/presnet.py")
+    for depth in (18, 50):
+        net = pr.D2Presnet(depth=depth, variant="d", num_stages=4, act="relu", freeze_at=-1, freeze_norm=False, pretrained=False)
+        state = pr_.seeded_state({k: v.shape for k, v in net.state_dict().items()}, seed=40 + depth)
+        net.load_state_dict(state, strict=True)
+        net.train()
+        g = torch.Generator().manual_seed(depth)
+        x = torch.randn(4, 3, 98, 98, generator=g).requires_grad_(True)
+        arrays = {"in/x": _np(x), "meta/depth": np.array([depth]), "meta/seed": np.array([40 + depth]),
+                  "meta/param_checksum": np.array([pr_.checksum(state)])}
+        feats = net(x)
+        loss = 0
+        for k in ("res2", "res3"):  # large maps: digest only
+            arrays["out_digest/" + k] = _np(pr_.digest(feats[k]))
+        for k in ("res4", "res5"):
+            arrays["out/" + k] = _np(feats[k])
+        for k in ("res4", "res5"):
+            ct = torch.randn(feats[k].shape, generator=g)
+            arrays["in/cotangent_" + k] = _np(ct)
+            loss = loss + (feats[k] * ct).sum()
+        loss.backward()
+        arrays["grad/x"] = _np(x.grad)
+        for k, p_ in net.named_parameters():
+            arrays["pgrad_digest/" + k] = _np(pr_.digest(p_.grad))
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                arrays["after/" + k] = _np(v)
+        _save(f"presnet{depth}_small", **arrays)
+
+
 def gen_swin():
     """SwinTransformer (models/backbones/swin.py) at drop rate 0: odd grids, window padding, shifted masks, patch merging."""
     sw = _load_file("ref_swin", "models/backbones/swin.py")
@@ -435,6 +473,6 @@ def gen_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "swin", "step"]
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "presnet", "swin", "step"]
     for w in which:
         globals()["gen_" + w]()

@@ -69,6 +69,15 @@ def test_error_behaviour_matches_reference():
     assert "model.model.layers.0.downsample.reduction.weight" in sd and "model.model.norm3.bias" in sd
     r = ModelWrapper("resnet_50", [16, 16])
     assert abs(sum(p.numel() for p in r.parameters()) / 1e6 - 23.51) < 0.01 and r.feature_channels["res5"] == 2048
+    with pytest.raises(NotImplementedError, match="PResNet config"):   # models/wrappers/presnet_wrapper.py:24-29
+        ModelWrapper("presnet_20", [16, 16])
+    pr = ModelWrapper("presnet_50", [16, 16])   # counts taken from the reference's D2Presnet(50, variant="d") in this container
+    assert sum(p.numel() for p in pr.parameters()) == 23_527_264 and len(pr.model.model.state_dict()) == 330
+    assert pr.feature_channels == {"res2": 256, "res3": 512, "res4": 1024, "res5": 2048}
+    assert "model.model.res_layers.1.blocks.0.short.conv.conv.weight" in pr.state_dict()   # "d" shortcut after the pool
+    assert "model.model.res_layers.0.blocks.0.short.conv.weight" in pr.state_dict()        # stage 2: plain 1x1
+    p18 = ModelWrapper("presnet_18", [16, 16])
+    assert sum(p.numel() for p in p18.parameters()) == 11_199_968 and p18.feature_channels["res5"] == 512
     s = ModelWrapper("stdc_2", [16, 16])
     assert abs(sum(p.numel() for p in s.parameters()) / 1e6 - 9.35) < 0.01 and len(s.state_dict()) == 636
 

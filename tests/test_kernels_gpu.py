@@ -410,3 +410,18 @@ def test_bf16_modes_weight_gradient_layout(ops, M, N, K):
     out1 = ops.gemm(dev(dy), dev(x), a_layout=1, b_layout=1, precision=ops.PREC_BF16)
     close(out1, ref16.float(), "bf16 wgrad vs RNE emulation", rtol=5e-6)
     assert ((out1.cpu().double() - ref).norm() / ref.norm()).item() > 1e-3  # and it really is bf16
+
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 9, 7, 32), (3, 17, 17, 128)])
+def test_avgpool2_ceil(ops, B, H, W, C):
+    """nn.AvgPool2d(2, 2, 0, ceil_mode=True) (presnet.py:227): clipped windows at odd extents, in-bounds divisor"""
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    y = F.avg_pool2d(x, 2, 2, 0, ceil_mode=True)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    out = ops.avgpool2(dev(x.detach().permute(0, 2, 3, 1).contiguous()))
+    close(out.permute(0, 3, 1, 2), y, "avgpool2 fwd")
+    dx = ops.avgpool2(dev(dy.permute(0, 2, 3, 1).contiguous()), backward_hw=(H, W))
+    close(dx.permute(0, 3, 1, 2), x.grad, "avgpool2 bwd")

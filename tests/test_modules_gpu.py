@@ -429,6 +429,68 @@ def test_resnet_against_reference_golden(golden_dir):
             close(net.state_dict()[k[6:]], v, k)
 
 
+@pytest.mark.parametrize("depth", [18, 50])
+def test_presnet_against_reference_golden(golden_dir, depth):
+    """PResNet "d" (BasicBlock / BottleNeck) vs the reference's own D2Presnet: outputs, input gradient, gradient digests of
+    every parameter, running statistics (weights: tests/golden/param_recipe.py, checked by checksum)"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from dinov2_distillation_amd.models.presnet import D2Presnet
+    g = load(golden_dir, f"presnet{depth}_small")
+    net = D2Presnet(depth)
+    state = pr.seeded_state({k: v.shape for k, v in net.state_dict().items()}, int(g["meta/seed"][0]))
+    assert abs(pr.checksum(state) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
+    net.load_state_dict(state, strict=True)
+    net.cuda().train()
+    feats = net(g["in/x"].cuda())  # (the step never differentiates w.r.t. the image: the first conv returns no input gradient)
+    loss = 0
+    for k in ("res2", "res3"):
+        d, v = pr.digest(feats[k].permute(0, 1, 2, 3).contiguous().cpu()), g["out_digest/" + k]
+        close(d[:1], v[:1], k + " (norm)")
+        close(d[2:], v[2:], k + " (values)")
+    for k in ("res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+        loss = loss + (feats[k] * g["in/cotangent_" + k].cuda()).sum()
+    loss.backward()
+    # Tolerance: 3e-3 of the gradient's scale, or - for the layers at the far end of the 50-layer backward pass, where fp32
+    # round-off through 16 train-mode BatchNorms is amplified - 4x the distance of the REFERENCE's own fp32 result from the
+    # fp64 evaluation of the same network (oracle in double precision).
+    from oracle import presnet_oracle as po
+    from dinov2_distillation_amd.models.presnet import BLOCKS
+    p64 = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
+               (v.double() if v.dtype.is_floating_point else v)) for k, v in pr.seeded_state(
+                   {k: v.shape for k, v in net.state_dict().items()}, int(g["meta/seed"][0])).items()}
+    f64 = po.forward(p64, g["in/x"].double(), BLOCKS[depth], bottleneck=depth >= 50)
+    sum((f64[k] * g["in/cotangent_" + k].double()).sum() for k in ("res4", "res5")).backward()
+    sd = dict(net.named_parameters())
+    worst = 0.0
+    for k, v in g.items():
+        if k.startswith("pgrad_digest/"):
+            name = k[13:]
+            d = pr.digest(sd[name].grad.cpu()).double()   # [L2 norm, sum (cancellation-prone: not compared), first 64 values]
+            t = pr.digest(p64[name].grad).double()
+            v = v.double()
+            for sl, what in ((slice(0, 1), "norm"), (slice(2, None), "values")):
+                scale = t[sl].abs().max().item() + 1e-30
+                e_ours, e_ref = (d[sl] - t[sl]).abs().max().item(), (v[sl] - t[sl]).abs().max().item()
+                assert e_ours <= max(3e-3 * scale, 4 * e_ref) + 1e-7, f"{k} ({what}): ours {e_ours:.3e}, reference {e_ref:.3e}, scale {scale:.3e}"
+                worst = max(worst, e_ours / scale)
+        if k.startswith("after/"):
+            close(net.state_dict()[k[6:]], v, k)
+    assert worst < 5e-2, worst
+
+
+def test_presnet18_student_runs_full_step():
+    """dinov2_vits14 -> presnet_18 (res4 256 / res5 512 channels): one full optimiser step twice, finite losses"""
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(student="presnet_18")
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
+    l0 = float(st.step(x))
+    l1 = float(st.step(x))
+    assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
+
+
 def test_resnet50_student_runs_full_step():
     """BASELINE configs[2] pair at a small batch: dinov2_vitb14 -> resnet_50 (D=768, 12 heads), one full optimiser step"""
     from dinov2_distillation_amd.trainer import DistillationStepper

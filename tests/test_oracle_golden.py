@@ -229,3 +229,36 @@ def test_resnet(golden_dir):
             close(p[k[6:]].grad, v, k, rtol=5e-4, atol=1e-5)
         if k.startswith("after/"):
             close(p[k[6:]], v, k)
+
+
+@pytest.mark.parametrize("depth", [18, 50])
+def test_presnet(golden_dir, depth):
+    """oracle/presnet_oracle.py against the reference's own D2Presnet (weights: tests/golden/param_recipe.py)"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import presnet_oracle as po
+    from dinov2_distillation_amd.models.presnet import BLOCKS, D2Presnet
+    g = load(golden_dir, f"presnet{depth}_small")
+    shapes = {k: v.shape for k, v in D2Presnet(depth).state_dict().items()}  # the reference's state-dict keys and shapes
+    p = pr.seeded_state(shapes, int(g["meta/seed"][0]))
+    assert abs(pr.checksum(p) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = po.forward(p, x, BLOCKS[depth], bottleneck=depth >= 50)
+    loss = 0
+    for k in ("res2", "res3"):
+        close(pr.digest(feats[k]), g["out_digest/" + k], k + " (digest)", rtol=1e-3)
+    for k in ("res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+        loss = loss + (feats[k] * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x", rtol=5e-4)
+    for k, v in g.items():
+        if k.startswith("pgrad_digest/"):
+            close(pr.digest(p[k[13:]].grad), v, k, rtol=1e-3, atol=1e-5)
+        if k.startswith("after/"):
+            close(p[k[6:]], v, k)
+
