@@ -123,6 +123,7 @@ __global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4
         float4 o = make_float4(g.x * (x.x - mu.x) * rs.x + b.x, g.y * (x.y - mu.y) * rs.y + b.y,
                                g.z * (x.z - mu.z) * rs.z + b.z, g.w * (x.w - mu.w) * rs.w + b.w);
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        if (relu == 2) o = make_float4(fminf(o.x, 6.f), fminf(o.y, 6.f), fminf(o.z, 6.f), fminf(o.w, 6.f));  // ReLU6
         if (pos) {
             const float4 p = pos[(r % period) * nv + c];
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
@@ -131,7 +132,7 @@ __global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4
     }
 }
 
-// dbn = dt * [bn > 0] (bn recomputed), xhat = (z - mean) * rstd
+// dbn = dt * [0 < bn (< 6)] (bn recomputed), xhat = (z - mean) * rstd
 __global__ void bn_bwd_prep_kernel(const float4* __restrict__ dt, const float4* __restrict__ z,
                                    const float4* __restrict__ mean, const float4* __restrict__ rstd,
                                    const float4* __restrict__ gamma, const float4* __restrict__ beta,
@@ -141,11 +142,13 @@ __global__ void bn_bwd_prep_kernel(const float4* __restrict__ dt, const float4* 
         const float4 x = z[i], mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c], d = dt[i];
         const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
         float4 o = d;
-        if (relu) {
-            o.x = g.x * xh.x + b.x > 0.f ? d.x : 0.f;
-            o.y = g.y * xh.y + b.y > 0.f ? d.y : 0.f;
-            o.z = g.z * xh.z + b.z > 0.f ? d.z : 0.f;
-            o.w = g.w * xh.w + b.w > 0.f ? d.w : 0.f;
+        if (relu) {  // 1: ReLU, 2: ReLU6 (gradient 1 strictly inside (0, 6), as F.relu6 / hardtanh)
+            const float hi = relu == 2 ? 6.f : INFINITY;
+            const float4 y = make_float4(g.x * xh.x + b.x, g.y * xh.y + b.y, g.z * xh.z + b.z, g.w * xh.w + b.w);
+            o.x = y.x > 0.f && y.x < hi ? d.x : 0.f;
+            o.y = y.y > 0.f && y.y < hi ? d.y : 0.f;
+            o.z = y.z > 0.f && y.z < hi ? d.z : 0.f;
+            o.w = y.w > 0.f && y.w < hi ? d.w : 0.f;
         }
         dbn[i] = o;
         xhat[i] = xh;

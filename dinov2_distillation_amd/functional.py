@@ -534,10 +534,11 @@ class ConvBNActFn(Function):
 
 
 class DepthwiseBNFn(Function):
-    """depthwise 3x3 stride-s conv (no bias) + train-mode BatchNorm2d, no activation (stdc.py:113-126 ``avd_layer``)."""
+    """depthwise 3x3 stride-s conv (no bias) + train-mode BatchNorm2d (stdc.py:113-126 ``avd_layer``: no activation;
+    MobileNetV2's depthwise stage: act = 2, ReLU6)."""
 
     @staticmethod
-    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training):
+    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training, act=0):
         x = _c(x)
         C = x.shape[3]
         wt = ops.transpose(w.reshape(C, 9))
@@ -545,26 +546,26 @@ class DepthwiseBNFn(Function):
         y2 = y.reshape(-1, C)
         mean, rstd = _bn_fwd_stats(y2, bn_state, training)
         ctx.training = training
-        out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=False)
+        out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=act)
         ctx.save_for_backward(x, wt, y2, mean, rstd, bn_w, bn_b)
-        ctx.meta = (stride, tuple(w.shape), tuple(y.shape))
+        ctx.meta = (stride, tuple(w.shape), tuple(y.shape), act)
         ctx.params = (w, bn_w, bn_b)
         return out.reshape(y.shape)
 
     @staticmethod
     def backward(ctx, dout):
         x, wt, y2, mean, rstd, bn_w, bn_b = ctx.saved_tensors
-        stride, wshape, yshape = ctx.meta
+        stride, wshape, yshape, act = ctx.meta
         C = x.shape[3]
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         p_w, p_g, p_b = ctx.params
         o_w, o_g, o_b = direct(p_w, p_g, p_b)
-        dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=False, dgamma_out=o_g, dbeta_out=o_b)
+        dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=act, dgamma_out=o_g, dbeta_out=o_b)
         dy = dy.reshape(yshape)
         dx = ops.dwconv3(dy, wt, stride, dgrad_shape=x.shape[1:3]) if ctx.needs_input_grad[0] else None
         dw = ops.transpose(ops.dwconv3_wgrad(x, dy, stride), out=None if o_w is None else o_w.view(C, 9)).reshape(wshape)
-        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None
+        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None
 
 
 class AvgPool3Fn(Function):
@@ -626,6 +627,18 @@ class MaxPool3Fn(Function):
     def backward(ctx, dy):
         (arg,) = ctx.saved_tensors
         return ops.maxpool3_bwd(_c(dy), arg, *ctx.hw)
+
+
+class AddFn(Function):
+    """a + b on NHWC rows (MobileNetV2's ``x + self.conv(x)``, mobilenet_v2.py:369): no ATen kernel on the path"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpby(_c(a), _c(b), 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
 
 
 class AvgPool2Fn(Function):

@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .convnext import D2ConvNextV2
+from .mobilenet_v2 import D2MobileNetV2
 from .presnet import D2Presnet
 from .resnet import BasicStem, ResNet, make_resnet_stages
 from .stdc import STDCNet
@@ -161,12 +162,42 @@ class PResNetWrapper(nn.Module):
         return self._out_feature_channels
 
 
+MOBILENET_V2_CONFIGS = {  # models/wrappers/mobilenet_v2_wrapper.py:8-21
+    "mobilenet_v2": dict(strides=(1, 2, 2, 2, 1, 2, 1), dilations=(1, 1, 1, 1, 1, 1, 1)),
+    "mobilenet_v2_os8": dict(strides=(1, 2, 2, 1, 1, 1, 1), dilations=(1, 1, 1, 2, 2, 4, 4)),
+    "mobilenet_v2_os16": dict(strides=(1, 2, 2, 2, 1, 1, 1), dilations=(1, 1, 1, 1, 1, 2, 2)),
+}
+
+
+class MobileNetV2Wrapper(nn.Module):
+    """models/wrappers/mobilenet_v2_wrapper.py: D2MobileNetV2(widen_factor=1.0, strides, dilations, out_features)"""
+
+    def __init__(self, model_name="mobilenet_v2", out_features=None):
+        super().__init__()
+        if model_name not in MOBILENET_V2_CONFIGS:
+            raise NotImplementedError(f"There is not a MobileNet config called {model_name}.")
+        self._out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", "mobilenet_v2.pkl")
+        self.model = D2MobileNetV2(out_features=self._out_features, **MOBILENET_V2_CONFIGS[model_name])
+        self._out_feature_channels = self.model._out_feature_channels
+
+    def get_features(self, x):
+        return self.model(x)
+
+    def get_features_nhwc(self, x):
+        return self.model.forward_features_nhwc(x)
+
+    @property
+    def feature_channels(self):
+        return self._out_feature_channels
+
+
 class ModelWrapper(nn.Module):
     """models/model_zoo.py:18-145.  Only the student families built on the MI355X kernels are registered; asking for
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
     MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper, "swin": D2SwinTransformerWrapper,
-                 "presnet": PResNetWrapper}
+                 "presnet": PResNetWrapper, "mobilenet_v2": MobileNetV2Wrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

@@ -269,9 +269,11 @@ class DistillationModule(_Base):
             raise ValueError(f"Unsupported checkpoint format: {checkpoint_path}")
         checkpoint = {k: torch.from_numpy(v) if isinstance(v, np.ndarray) else v for k, v in checkpoint.items()}
         student_type = self.cfg["student"]["model_name"].split("_")[0].lower()
+        if student_type == "mobilenet":
+            student_type += "_" + self.cfg["student"]["model_name"].split("_")[1].lower()
         if student_type == "stdc":
             checkpoint = {f"model.model.{k.replace('cp.backbone.', '')}": v for k, v in checkpoint.items()}
-        elif student_type in ("mit", "darknet", "presnet"):
+        elif student_type in ("mit", "darknet", "presnet", "mobilenet_v2"):
             checkpoint = {f"model.model.{k.replace('backbone.', '')}": v for k, v in checkpoint.items()}
         else:
             checkpoint = {f"model.model.{k}": v for k, v in checkpoint.items()}

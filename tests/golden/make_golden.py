@@ -344,6 +344,39 @@ def gen_presnet():
         _save(f"presnet{depth}_small", **arrays)
 
 
+def gen_mobilenet_v2():
+    """the reference's own D2MobileNetV2 (models/backbones/mobilenet_v2.py needs nothing but torch), default configuration,
+    batch 4 at 96x96 (res5 is 3x3: the deepest BatchNorm averages over 36 samples)"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import param_recipe as pr_
+    mb = _load_file("ref_mobilenet_v2", "models/backbones/mobilenet_v2.py")
+    net = mb.D2MobileNetV2(widen_factor=1.0, strides=(1, 2, 2, 2, 1, 2, 1), dilations=(1, 1, 1, 1, 1, 1, 1),
+                           out_features=["res2", "res3", "res4", "res5"])
+    state = pr_.seeded_state({k: v.shape for k, v in net.state_dict().items()}, seed=77)
+    net.load_state_dict(state, strict=True)
+    net.train()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 3, 96, 96, generator=g).requires_grad_(True)
+    arrays = {"in/x": _np(x), "meta/seed": np.array([77]), "meta/param_checksum": np.array([pr_.checksum(state)])}
+    feats = net(x)
+    loss = 0
+    for k in ("res2", "res3"):
+        arrays["out_digest/" + k] = _np(pr_.digest(feats[k]))
+    for k in ("res4", "res5"):
+        arrays["out/" + k] = _np(feats[k])
+        ct = torch.randn(feats[k].shape, generator=g)
+        arrays["in/cotangent_" + k] = _np(ct)
+        loss = loss + (feats[k] * ct).sum()
+    loss.backward()
+    arrays["grad/x"] = _np(x.grad)
+    for k, p_ in net.named_parameters():
+        arrays["pgrad_digest/" + k] = _np(pr_.digest(p_.grad))
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            arrays["after/" + k] = _np(v)
+    _save("mobilenet_v2_small", **arrays)
+
+
 def gen_swin():
     """SwinTransformer (models/backbones/swin.py) at drop rate 0: odd grids, window padding, shifted masks, patch merging."""
     sw = _load_file("ref_swin", "models/backbones/swin.py")
@@ -473,6 +506,6 @@ def gen_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "presnet", "swin", "step"]
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "presnet", "mobilenet_v2", "swin", "step"]
     for w in which:
         globals()["gen_" + w]()

@@ -24,7 +24,7 @@ def seeded_state(shapes, seed):
             out[k] = 1.0 + 0.2 * torch.randn(shape, generator=g)
         elif k.endswith("norm.bias"):
             out[k] = 0.2 * torch.randn(shape, generator=g)
-        elif len(shape) == 4:
+        elif len(shape) == 4:  # (depthwise weights are [C, 1, k, k]: fan_in = k * k)
             fan_in = shape[1] * shape[2] * shape[3]
             out[k] = torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
         else:

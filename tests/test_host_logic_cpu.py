@@ -78,6 +78,14 @@ def test_error_behaviour_matches_reference():
     assert "model.model.res_layers.0.blocks.0.short.conv.weight" in pr.state_dict()        # stage 2: plain 1x1
     p18 = ModelWrapper("presnet_18", [16, 16])
     assert sum(p.numel() for p in p18.parameters()) == 11_199_968 and p18.feature_channels["res5"] == 512
+    mb = ModelWrapper("mobilenet_v2", [16, 16])   # counts from the reference's D2MobileNetV2() in this container
+    assert sum(p.numel() for p in mb.parameters()) == 1_811_712 and len(mb.model.model.state_dict()) == 306
+    assert mb.feature_channels == {"res2": 24, "res3": 32, "res4": 96, "res5": 320}
+    assert "model.model.layer1.0.conv.1.norm.running_var" in mb.state_dict()   # expand_ratio 1: two convs only
+    with pytest.raises(NotImplementedError, match="dilated"):
+        ModelWrapper("mobilenet_v2_os8", [16, 16])
+    with pytest.raises(NotImplementedError, match="MobileNet config"):
+        ModelWrapper("mobilenet_v2_os4", [16, 16])
     s = ModelWrapper("stdc_2", [16, 16])
     assert abs(sum(p.numel() for p in s.parameters()) / 1e6 - 9.35) < 0.01 and len(s.state_dict()) == 636
 

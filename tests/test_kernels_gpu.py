@@ -425,3 +425,45 @@ def test_avgpool2_ceil(ops, B, H, W, C):
     close(out.permute(0, 3, 1, 2), y, "avgpool2 fwd")
     dx = ops.avgpool2(dev(dy.permute(0, 2, 3, 1).contiguous()), backward_hw=(H, W))
     close(dx.permute(0, 3, 1, 2), x.grad, "avgpool2 bwd")
+
+
+def test_bn_relu6(ops):
+    """BatchNorm + ReLU6 (mobilenet_v2.py:421), forward and backward through the fused kernels"""
+    g = torch.Generator().manual_seed(6)
+    rows, C = 500, 96
+    z = (3.0 * torch.randn(rows, C, generator=g)).requires_grad_(True)
+    ga = (2.0 + 0.5 * torch.randn(C, generator=g)).requires_grad_(True)
+    be = (3.0 + 2.0 * torch.randn(C, generator=g)).requires_grad_(True)   # a good share of the outputs lands past 6
+    y = F.relu6(F.batch_norm(z, None, None, ga, be, True, 0.1, 1e-5))
+    assert (y == 6).float().mean() > 0.02 and (y == 0).float().mean() > 0.02
+    dy = torch.randn(rows, C, generator=g)
+    y.backward(dy)
+    zd = dev(z.detach())
+    mean, rstd = ops.bn_stats(zd, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), 0.1, 1e-5)
+    out = ops.bn_act_pos_fwd(zd, mean, rstd, dev(ga.detach()), dev(be.detach()), None, relu=2)
+    close(out, y, "bn relu6 fwd")
+    dz, dg, db = ops.bn_bwd(dev(dy), zd, mean, rstd, dev(ga.detach()), dev(be.detach()), relu=2)
+    close(dz, z.grad, "bn relu6 dz", rtol=2e-4)
+    close(dg, ga.grad, "bn relu6 dgamma", rtol=2e-4)
+    close(db, be.grad, "bn relu6 dbeta", rtol=2e-4)
+
+
+@pytest.mark.parametrize("B,H,C,stride", [(2, 12, 96, 1), (2, 13, 32, 2), (1, 7, 960, 1), (3, 14, 64, 2)])
+def test_dwconv3(ops, B, H, C, stride):
+    """depthwise 3x3, pad 1, stride 1 | 2 (stdc.py:113-126 avd_layer, mobilenet_v2.py:338-350): forward, dgrad, wgrad"""
+    g = torch.Generator().manual_seed(H * 7 + stride)
+    x = torch.randn(B, C, H, H, generator=g).requires_grad_(True)
+    w = torch.randn(C, 1, 3, 3, generator=g).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=stride, padding=1, groups=C)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xn = dev(x.detach().permute(0, 2, 3, 1).contiguous())
+    wt = ops.transpose(dev(w.detach().reshape(C, 9)))
+    out = ops.dwconv3(xn, wt, stride)
+    close(out.permute(0, 3, 1, 2), y, "dwconv3 fwd")
+    dyn = dev(dy.permute(0, 2, 3, 1).contiguous())
+    dx = ops.dwconv3(dyn, wt, stride, dgrad_shape=(H, H))
+    close(dx.permute(0, 3, 1, 2), x.grad, "dwconv3 dgrad")
+    dw = ops.dwconv3_wgrad(xn, dyn, stride)
+    close(ops.transpose(dw).reshape(C, 1, 3, 3), w.grad, "dwconv3 wgrad", rtol=3e-4)
+

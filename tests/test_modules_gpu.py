@@ -481,6 +481,94 @@ def test_presnet_against_reference_golden(golden_dir, depth):
     assert worst < 5e-2, worst
 
 
+@pytest.mark.parametrize("cin,cout,stride,expand", [(16, 24, 2, 6), (24, 24, 1, 6), (32, 16, 1, 1), (64, 96, 1, 6)])
+def test_mobilenet_v2_block_vs_oracle(golden_dir, cin, cout, stride, expand):
+    """InvertedResidual (1x1 expand / depthwise 3x3 stride 1|2 / 1x1 project, BatchNorm + ReLU6 after each, residual add):
+    output, input gradient and EVERY parameter gradient element by element against the oracle.  A ReLU6 network is piecewise
+    linear: an activation that sits within round-off of 0 or 6 flips its gradient mask and moves a whole row of a weight
+    gradient, so the comparison is made on an input whose pre-activations (fp64 oracle) all keep clear of both kinks."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import mobilenet_v2_oracle as mo
+    from dinov2_distillation_amd.models.mobilenet_v2 import InvertedResidual
+    blk = InvertedResidual(cin, cout, stride, expand)
+    shapes = {k: v.shape for k, v in blk.state_dict().items()}
+    for seed in range(1, 60):
+        state = pr.seeded_state(shapes, seed)
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(4, cin, 6, 6, generator=gen)
+        rec = []
+        p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in state.items()}
+        mo.inverted_residual(p64, "", x.double(), stride, expand, record=rec)
+        if min(min((t - 0.0).abs().min().item(), (t - 6.0).abs().min().item()) for t in rec) > 2e-5:
+            break
+    else:
+        raise AssertionError("no seed keeps every pre-activation away from the ReLU6 kinks")
+    p = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+         for k, v in state.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = mo.inverted_residual(p, "", xr, stride, expand)
+    ct = torch.randn(ref.shape, generator=gen)
+    (ref * ct).sum().backward()
+    blk.load_state_dict(state, strict=True)
+    blk.cuda().train()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)   # NHWC, as inside the backbone
+    out = blk(xg)
+    close(out.permute(0, 3, 1, 2), ref, "block fwd")
+    (out * ct.permute(0, 2, 3, 1).cuda()).sum().backward()
+    close(xg.grad.permute(0, 3, 1, 2), xr.grad, "block dx", rtol=1e-3)
+    for k, v in blk.named_parameters():
+        close(v.grad, p[k].grad, "block d" + k, rtol=1e-3)
+    for k, v in blk.state_dict().items():
+        if "running" in k:
+            close(v, p[k], k)
+
+
+def test_mobilenet_v2_against_reference_golden(golden_dir):
+    """whole MobileNetV2 vs the reference's own D2MobileNetV2: outputs of all four levels and every running statistic to
+    fp32 tolerance; gradients by their norms (52 ReLU6 layers at batch statistics over 36..9216 samples: mask flips at the
+    kinks make element-wise gradient comparison meaningless at this depth - the blocks are compared element-wise above)"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from dinov2_distillation_amd.models.mobilenet_v2 import D2MobileNetV2
+    g = load(golden_dir, "mobilenet_v2_small")
+    net = D2MobileNetV2()
+    shapes = {k: v.shape for k, v in net.state_dict().items()}
+    state = pr.seeded_state(shapes, int(g["meta/seed"][0]))
+    assert abs(pr.checksum(state) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
+    net.load_state_dict(state, strict=True)
+    net.cuda().train()
+    feats = net(g["in/x"].cuda())
+    loss = 0
+    for k in ("res2", "res3"):
+        d, v = pr.digest(feats[k].contiguous().cpu()), g["out_digest/" + k]
+        close(d[:1], v[:1], k + " (norm)")
+        close(d[2:], v[2:], k + " (values)")
+    for k in ("res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+        loss = loss + (feats[k] * g["in/cotangent_" + k].cuda()).sum()
+    loss.backward()
+    sd = dict(net.named_parameters())
+    for k, v in g.items():
+        if k.startswith("pgrad_digest/"):
+            n_ours, n_ref = sd[k[13:]].grad.double().norm().item(), v[0].item()
+            assert abs(n_ours - n_ref) <= 5e-2 * n_ref + 1e-6, f"{k}: |grad| {n_ours:.6e} vs {n_ref:.6e}"
+        if k.startswith("after/"):
+            close(net.state_dict()[k[6:]], v, k)
+
+
+def test_mobilenet_v2_student_runs_full_step():
+    """dinov2_vits14 -> mobilenet_v2 (res4 96 / res5 320 channels): one full optimiser step twice, finite losses"""
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(student="mobilenet_v2")
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
+    l0 = float(st.step(x).detach())
+    l1 = float(st.step(x).detach())
+    assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
+
+
 def test_presnet18_student_runs_full_step():
     """dinov2_vits14 -> presnet_18 (res4 256 / res5 512 channels): one full optimiser step twice, finite losses"""
     from dinov2_distillation_amd.trainer import DistillationStepper

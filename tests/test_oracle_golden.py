@@ -262,3 +262,34 @@ def test_presnet(golden_dir, depth):
         if k.startswith("after/"):
             close(p[k[6:]], v, k)
 
+
+def test_mobilenet_v2(golden_dir):
+    """oracle/mobilenet_v2_oracle.py against the reference's own D2MobileNetV2 (weights: tests/golden/param_recipe.py)"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import mobilenet_v2_oracle as mo
+    from dinov2_distillation_amd.models.mobilenet_v2 import D2MobileNetV2
+    g = load(golden_dir, "mobilenet_v2_small")
+    shapes = {k: v.shape for k, v in D2MobileNetV2().state_dict().items()}
+    p = pr.seeded_state(shapes, int(g["meta/seed"][0]))
+    assert abs(pr.checksum(p) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = mo.forward(p, x)
+    loss = 0
+    for k in ("res2", "res3"):
+        close(pr.digest(feats[k]), g["out_digest/" + k], k + " (digest)", rtol=1e-3)
+    for k in ("res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+        loss = loss + (feats[k] * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x", rtol=5e-4)
+    for k, v in g.items():
+        if k.startswith("pgrad_digest/"):
+            close(pr.digest(p[k[13:]].grad), v, k, rtol=1e-3, atol=1e-5)
+        if k.startswith("after/"):
+            close(p[k[6:]], v, k)
+
