@@ -17,6 +17,8 @@ CONFIGS = {
     "3": dict(teacher="dinov2_vitb14", student="resnet_50", crop=224, batch=128, heads=(16, 24)),
     "4": dict(teacher="dinov2_vitl14", student="swin_tiny", crop=518, batch=16, heads=(16, 32)),
     "5": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24), teacher_precision="bf16"),
+    "presnet50": dict(teacher="dinov2_vits14", student="presnet_50", crop=224, batch=64, heads=(16, 24)),
+    "mobilenet_v2": dict(teacher="dinov2_vits14", student="mobilenet_v2", crop=224, batch=64, heads=(16, 24)),
     "5f32": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24)),
 }
 
