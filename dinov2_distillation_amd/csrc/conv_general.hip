@@ -84,9 +84,10 @@ __global__ void im2col_nchw_kernel(const float* __restrict__ img, float* __restr
     }
 }
 
-// depthwise 3x3, pad 1, stride s, tap-major weights [9][C] (nullptr => all taps 1/9 == AvgPool2d(3, s, 1), count_include_pad)
+// depthwise 3x3, dilation d, pad d, stride s, tap-major weights [9][C] (nullptr => all taps 1/9 == AvgPool2d(3, s, 1),
+// count_include_pad).  Output extent (H - 1) / s + 1 for every dilation.
 __global__ void dwconv3_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ wt, float4* __restrict__ out,
-                                   int B, int H, int W, int C, int s, int Ho, int Wo) {
+                                   int B, int H, int W, int C, int s, int Ho, int Wo, int d) {
     const int cq = C >> 2;
     const long total = (long)B * Ho * Wo * cq;
     const float ninth = 1.f / 9.f;
@@ -99,11 +100,11 @@ __global__ void dwconv3_fwd_kernel(const float4* __restrict__ x, const float4* _
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int y = oy * s + ky - 1;
+            const int y = oy * s + (ky - 1) * d;
             if (y < 0 || y >= H) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int xx = ox * s + kx - 1;
+                const int xx = ox * s + (kx - 1) * d;
                 if (xx < 0 || xx >= W) continue;
                 const float4 v = x[(((long)b * H + y) * W + xx) * cq + c4];
                 const float4 w = wt ? wt[(ky * 3 + kx) * cq + c4] : make_float4(ninth, ninth, ninth, ninth);
@@ -115,7 +116,7 @@ __global__ void dwconv3_fwd_kernel(const float4* __restrict__ x, const float4* _
 }
 
 __global__ void dwconv3_dgrad_kernel(const float4* __restrict__ dout, const float4* __restrict__ wt, float4* __restrict__ dx,
-                                     int B, int H, int W, int C, int s, int Ho, int Wo) {
+                                     int B, int H, int W, int C, int s, int Ho, int Wo, int d) {
     const int cq = C >> 2;
     const long total = (long)B * H * W * cq;
     const float ninth = 1.f / 9.f;
@@ -128,13 +129,13 @@ __global__ void dwconv3_dgrad_kernel(const float4* __restrict__ dout, const floa
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int ty = y + 1 - ky;
+            const int ty = y + (1 - ky) * d;
             if (ty < 0 || ty % s) continue;
             const int oy = ty / s;
             if (oy >= Ho) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int tx = xx + 1 - kx;
+                const int tx = xx + (1 - kx) * d;
                 if (tx < 0 || tx % s) continue;
                 const int ox = tx / s;
                 if (ox >= Wo) continue;
@@ -149,7 +150,7 @@ __global__ void dwconv3_dgrad_kernel(const float4* __restrict__ dout, const floa
 
 // partial weight gradients: thread = (channel quad, image, output row); part[(b*Ho + oy)][tap][c]
 __global__ void dwconv3_wgrad_kernel(const float4* __restrict__ x, const float4* __restrict__ dout, float4* __restrict__ part,
-                                     int B, int H, int W, int C, int s, int Ho, int Wo) {
+                                     int B, int H, int W, int C, int s, int Ho, int Wo, int d) {
     const int cq = C >> 2;
     const long total = (long)B * Ho * cq;
     GRID_STRIDE(i, total) {
@@ -163,11 +164,11 @@ __global__ void dwconv3_wgrad_kernel(const float4* __restrict__ x, const float4*
             const float4 g = dout[(((long)b * Ho + oy) * Wo + ox) * cq + c4];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int y = oy * s + ky - 1;
+                const int y = oy * s + (ky - 1) * d;
                 if (y < 0 || y >= H) continue;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = ox * s + kx - 1;
+                    const int xx = ox * s + (kx - 1) * d;
                     if (xx < 0 || xx >= W) continue;
                     const float4 v = x[(((long)b * H + y) * W + xx) * cq + c4];
                     float4& a = acc[ky * 3 + kx];
@@ -327,33 +328,33 @@ extern "C" int dkd_im2col_nchw_f32(const float* img, float* rows, int B, int Cin
 }
 
 extern "C" int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int stride,
-                               int mode, void* stream) {
+                               int dilation, int mode, void* stream) {
     // mode 0: forward (in = x [B,H,W,C], out = y [B,Ho,Wo,C]); mode 1: dgrad (in = dy [B,Ho,Wo,C], out = dx [B,H,W,C])
-    if (!in || !out || B <= 0 || stride <= 0) return DKD_ERR_BAD_ARG;
+    if (!in || !out || B <= 0 || stride <= 0 || dilation <= 0) return DKD_ERR_BAD_ARG;
     if (C & 3) return DKD_ERR_ALIGN;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
     if (mode == 0) {
         const long total = (long)B * Ho * Wo * (C / 4);
         hipLaunchKernelGGL(dwconv3_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, st, F4(in), F4(w_tap_major), F4W(out), B,
-                           H, W, C, stride, Ho, Wo);
+                           H, W, C, stride, Ho, Wo, dilation);
     } else {
         const long total = (long)B * H * W * (C / 4);
         hipLaunchKernelGGL(dwconv3_dgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, st, F4(in), F4(w_tap_major), F4W(out),
-                           B, H, W, C, stride, Ho, Wo);
+                           B, H, W, C, stride, Ho, Wo, dilation);
     }
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 
 extern "C" int dkd_dwconv3_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C,
-                                     int stride, void* stream) {
-    if (!x || !dout || !partials || B <= 0 || stride <= 0) return DKD_ERR_BAD_ARG;
+                                     int stride, int dilation, void* stream) {
+    if (!x || !dout || !partials || B <= 0 || stride <= 0 || dilation <= 0) return DKD_ERR_BAD_ARG;
     if (C & 3) return DKD_ERR_ALIGN;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long total = (long)B * Ho * (C / 4);
     hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, F4(x), F4(dout),
-                       F4W(partials), B, H, W, C, stride, Ho, Wo);
+                       F4W(partials), B, H, W, C, stride, Ho, Wo, dilation);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -538,24 +538,24 @@ class DepthwiseBNFn(Function):
     MobileNetV2's depthwise stage: act = 2, ReLU6)."""
 
     @staticmethod
-    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training, act=0):
+    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training, act=0, dilation=1):
         x = _c(x)
         C = x.shape[3]
         wt = ops.transpose(w.reshape(C, 9))
-        y = ops.dwconv3(x, wt, stride)
+        y = ops.dwconv3(x, wt, stride, dilation=dilation)
         y2 = y.reshape(-1, C)
         mean, rstd = _bn_fwd_stats(y2, bn_state, training)
         ctx.training = training
         out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=act)
         ctx.save_for_backward(x, wt, y2, mean, rstd, bn_w, bn_b)
-        ctx.meta = (stride, tuple(w.shape), tuple(y.shape), act)
+        ctx.meta = (stride, tuple(w.shape), tuple(y.shape), act, dilation)
         ctx.params = (w, bn_w, bn_b)
         return out.reshape(y.shape)
 
     @staticmethod
     def backward(ctx, dout):
         x, wt, y2, mean, rstd, bn_w, bn_b = ctx.saved_tensors
-        stride, wshape, yshape, act = ctx.meta
+        stride, wshape, yshape, act, dilation = ctx.meta
         C = x.shape[3]
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
@@ -563,9 +563,9 @@ class DepthwiseBNFn(Function):
         o_w, o_g, o_b = direct(p_w, p_g, p_b)
         dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=act, dgamma_out=o_g, dbeta_out=o_b)
         dy = dy.reshape(yshape)
-        dx = ops.dwconv3(dy, wt, stride, dgrad_shape=x.shape[1:3]) if ctx.needs_input_grad[0] else None
-        dw = ops.transpose(ops.dwconv3_wgrad(x, dy, stride), out=None if o_w is None else o_w.view(C, 9)).reshape(wshape)
-        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None
+        dx = ops.dwconv3(dy, wt, stride, dgrad_shape=x.shape[1:3], dilation=dilation) if ctx.needs_input_grad[0] else None
+        dw = ops.transpose(ops.dwconv3_wgrad(x, dy, stride, dilation), out=None if o_w is None else o_w.view(C, 9)).reshape(wshape)
+        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None
 
 
 class AvgPool3Fn(Function):

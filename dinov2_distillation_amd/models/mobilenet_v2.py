@@ -1,8 +1,8 @@
 """MobileNetV2 student backbone on the MI355X kernels (NHWC inside), state-dict compatible with
 /root/reference/models/backbones/mobilenet_v2.py: ``conv1.{weight,norm.*}``, ``layer{i}.{j}.conv.{k}.{weight,norm.*}``.
 As in the reference every conv of an InvertedResidual - including the projecting 1x1 - is followed by BatchNorm and ReLU6
-(mobilenet_v2.py:326-366 passes ``activation`` to all three), BatchNorm is live, no bias anywhere.  Only the un-dilated
-configuration "mobilenet_v2" (strides 1,2,2,2,1,2,1) is built; the dilated os8/os16 variants fail loudly."""
+(mobilenet_v2.py:326-366 passes ``activation`` to all three), BatchNorm is live, no bias anywhere.  The dilated os8 / os16
+configurations use the same depthwise kernel (padding = dilation, first block of a layer only, mobilenet_v2.py:489-497)."""
 import math
 
 import torch
@@ -18,8 +18,9 @@ RELU6 = 2
 class ConvNormAct(nn.Module):
     """the reference's ``Conv2d(..., bias="", norm=BatchNorm2d, activation=relu6)``: parameter ``weight`` + ``norm``"""
 
-    def __init__(self, cin, cout, kernel, stride=1, depthwise=False):
+    def __init__(self, cin, cout, kernel, stride=1, depthwise=False, dilation=1):
         super().__init__()
+        self.dilation = dilation
         self.weight = nn.Parameter(torch.empty(cout, 1 if depthwise else cin, kernel, kernel))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv2d default
         self.norm = nn.BatchNorm2d(cout)
@@ -31,20 +32,20 @@ class ConvNormAct(nn.Module):
         state = (self.norm.running_mean, self.norm.running_var)
         if self.depthwise:
             return Fn.DepthwiseBNFn.apply(x, self.weight, self.norm.weight, self.norm.bias, state, self.stride, self.training,
-                                          RELU6)
+                                          RELU6, self.dilation)
         return Fn.ConvBNActFn.apply(x, self.weight, self.norm.weight, self.norm.bias, state, self.kernel, self.stride, RELU6,
                                     self.training, src_nchw)
 
 
 class InvertedResidual(nn.Module):
-    def __init__(self, cin, cout, stride, expand_ratio):
+    def __init__(self, cin, cout, stride, expand_ratio, dilation=1):
         super().__init__()
         self.use_res_connect = stride == 1 and cin == cout
         hidden = int(round(cin * expand_ratio))
         layers = []
         if expand_ratio != 1:
             layers.append(ConvNormAct(cin, hidden, 1))
-        layers += [ConvNormAct(hidden, hidden, 3, stride, depthwise=True), ConvNormAct(hidden, cout, 1)]
+        layers += [ConvNormAct(hidden, hidden, 3, stride, depthwise=True, dilation=dilation), ConvNormAct(hidden, cout, 1)]
         self.conv = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -56,19 +57,17 @@ class D2MobileNetV2(nn.Module):
     def __init__(self, widen_factor=1.0, strides=(1, 2, 2, 2, 1, 2, 1), dilations=(1, 1, 1, 1, 1, 1, 1),
                  out_features=("res2", "res3", "res4", "res5")):
         super().__init__()
-        if any(d != 1 for d in dilations):
-            raise NotImplementedError("dilated MobileNetV2 variants (os8 / os16) have no MI355X depthwise kernel yet")
         cin = int(32 * widen_factor)
         self.conv1 = ConvNormAct(3, cin, 3, 2)
         self._out_features = list(out_features)
         self._out_feature_channels, self._out_feature_strides = {}, {}
         self.layers = []
         tot = 1  # as the reference: the stem's stride is not counted in _out_feature_strides (mobilenet_v2.py:446)
-        for i, ((t, c, n), s) in enumerate(zip(ARCH, strides)):
+        for i, ((t, c, n), s, d) in enumerate(zip(ARCH, strides, dilations)):
             cout = int(c * widen_factor)
             blocks = []
             for j in range(n):
-                blocks.append(InvertedResidual(cin, cout, s if j == 0 else 1, t))
+                blocks.append(InvertedResidual(cin, cout, s if j == 0 else 1, t, d if j == 0 else 1))
                 cin = cout
             tot *= s
             name = f"layer{i + 1}"

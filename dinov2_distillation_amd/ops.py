@@ -555,9 +555,9 @@ def im2col_nchw(img, k, stride, pad):
     return rows
 
 
-def dwconv3(x, w_tap, stride, dgrad_shape=None):
+def dwconv3(x, w_tap, stride, dgrad_shape=None, dilation=1):
     """forward: x [B,H,W,C] -> [B,Ho,Wo,C]; dgrad (dgrad_shape=(H,W)): x is dy [B,Ho,Wo,C] -> dx [B,H,W,C].
-    w_tap None == AvgPool2d(3, stride, 1)."""
+    w_tap None == AvgPool2d(3, stride, 1).  padding = dilation (the output extent does not depend on it)."""
     _chk(x, "x"), _chk(w_tap, "w_tap")
     B, C = x.shape[0], x.shape[3]
     if dgrad_shape is None:
@@ -569,16 +569,18 @@ def dwconv3(x, w_tap, stride, dgrad_shape=None):
         H, W = dgrad_shape
         out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
         mode = 1
-    check(_lib.load().dkd_dwconv3_f32(_p(x), _p(w_tap), _p(out), B, H, W, C, stride, mode, _stream()), "dkd_dwconv3_f32")
+    check(_lib.load().dkd_dwconv3_f32(_p(x), _p(w_tap), _p(out), B, H, W, C, stride, dilation, mode, _stream()),
+          "dkd_dwconv3_f32")
     return out
 
 
-def dwconv3_wgrad(x, dout, stride):
+def dwconv3_wgrad(x, dout, stride, dilation=1):
     _chk(x, "x"), _chk(dout, "dout")
     B, H, W, C = x.shape
     Ho = dout.shape[1]
     part = workspace(B * Ho * 9 * C * 4, x.device, slot=1)
-    check(_lib.load().dkd_dwconv3_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, stride, _stream()), "dkd_dwconv3_wgrad_f32")
+    check(_lib.load().dkd_dwconv3_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, stride, dilation, _stream()),
+          "dkd_dwconv3_wgrad_f32")
     return colreduce(part[: B * Ho * 9 * C].view(B * Ho, 9 * C)).view(9, C)
 
 

@@ -241,10 +241,10 @@ int dkd_im2col_nhwc_f32(const float* x, float* rows, int B, int H, int W, int C,
                         void* stream);
 int dkd_im2col_nchw_f32(const float* img, float* rows, int B, int Cin, int H, int W, int k, int stride, int pad, int Kp,
                         void* stream);
-int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int stride, int mode,
-                    void* stream);
+int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int stride,
+                    int dilation, int mode, void* stream);
 int dkd_dwconv3_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C, int stride,
-                          void* stream);
+                          int dilation, void* stream);
 int dkd_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate, void* stream);
 /* ResNet pieces (models/backbones/resnet.py): F.max_pool2d(3, 2, 1) of the stem (:543) with the arg-max kept for the
  * backward pass (mode 0 forward, mode 1 backward: in = dy, out = dx; H,W are the input extents in both modes), and the

@@ -350,13 +350,19 @@ def gen_mobilenet_v2():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import param_recipe as pr_
     mb = _load_file("ref_mobilenet_v2", "models/backbones/mobilenet_v2.py")
-    net = mb.D2MobileNetV2(widen_factor=1.0, strides=(1, 2, 2, 2, 1, 2, 1), dilations=(1, 1, 1, 1, 1, 1, 1),
+    for name, strides, dilations in (("mobilenet_v2_small", (1, 2, 2, 2, 1, 2, 1), (1, 1, 1, 1, 1, 1, 1)),
+                                     ("mobilenet_v2_os8_small", (1, 2, 2, 1, 1, 1, 1), (1, 1, 1, 2, 2, 4, 4))):
+        _gen_mobilenet_v2(mb, pr_, name, strides, dilations)
+
+
+def _gen_mobilenet_v2(mb, pr_, name, strides, dilations):
+    net = mb.D2MobileNetV2(widen_factor=1.0, strides=strides, dilations=dilations,
                            out_features=["res2", "res3", "res4", "res5"])
     state = pr_.seeded_state({k: v.shape for k, v in net.state_dict().items()}, seed=77)
     net.load_state_dict(state, strict=True)
     net.train()
     g = torch.Generator().manual_seed(77)
-    x = torch.randn(4, 3, 96, 96, generator=g).requires_grad_(True)
+    x = torch.randn(4, 3, 96, 96 if dilations[-1] == 1 else 48, generator=g).requires_grad_(True)  # (os8 keeps stride 8)
     arrays = {"in/x": _np(x), "meta/seed": np.array([77]), "meta/param_checksum": np.array([pr_.checksum(state)])}
     feats = net(x)
     loss = 0
@@ -374,7 +380,7 @@ def gen_mobilenet_v2():
     for k, v in net.state_dict().items():
         if "running" in k:
             arrays["after/" + k] = _np(v)
-    _save("mobilenet_v2_small", **arrays)
+    _save(name, **arrays)
 
 
 def gen_swin():

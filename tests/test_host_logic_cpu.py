@@ -82,8 +82,7 @@ def test_error_behaviour_matches_reference():
     assert sum(p.numel() for p in mb.parameters()) == 1_811_712 and len(mb.model.model.state_dict()) == 306
     assert mb.feature_channels == {"res2": 24, "res3": 32, "res4": 96, "res5": 320}
     assert "model.model.layer1.0.conv.1.norm.running_var" in mb.state_dict()   # expand_ratio 1: two convs only
-    with pytest.raises(NotImplementedError, match="dilated"):
-        ModelWrapper("mobilenet_v2_os8", [16, 16])
+    assert ModelWrapper("mobilenet_v2_os8", [16, 16]).model.model.layer4[0].conv[1].dilation == 2   # mobilenet_v2_wrapper.py:13-16
     with pytest.raises(NotImplementedError, match="MobileNet config"):
         ModelWrapper("mobilenet_v2_os4", [16, 16])
     s = ModelWrapper("stdc_2", [16, 16])

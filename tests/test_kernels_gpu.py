@@ -448,22 +448,23 @@ def test_bn_relu6(ops):
     close(db, be.grad, "bn relu6 dbeta", rtol=2e-4)
 
 
-@pytest.mark.parametrize("B,H,C,stride", [(2, 12, 96, 1), (2, 13, 32, 2), (1, 7, 960, 1), (3, 14, 64, 2)])
-def test_dwconv3(ops, B, H, C, stride):
-    """depthwise 3x3, pad 1, stride 1 | 2 (stdc.py:113-126 avd_layer, mobilenet_v2.py:338-350): forward, dgrad, wgrad"""
+@pytest.mark.parametrize("B,H,C,stride,dil", [(2, 12, 96, 1, 1), (2, 13, 32, 2, 1), (1, 7, 960, 1, 1), (3, 14, 64, 2, 1),
+                                               (2, 12, 64, 1, 2), (2, 9, 32, 1, 4), (1, 11, 96, 2, 2)])
+def test_dwconv3(ops, B, H, C, stride, dil):
+    """depthwise 3x3, pad = dilation, stride 1 | 2 (stdc.py:113-126 avd_layer, mobilenet_v2.py:338-350): forward, dgrad, wgrad"""
     g = torch.Generator().manual_seed(H * 7 + stride)
     x = torch.randn(B, C, H, H, generator=g).requires_grad_(True)
     w = torch.randn(C, 1, 3, 3, generator=g).requires_grad_(True)
-    y = F.conv2d(x, w, None, stride=stride, padding=1, groups=C)
+    y = F.conv2d(x, w, None, stride=stride, padding=dil, dilation=dil, groups=C)
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy)
     xn = dev(x.detach().permute(0, 2, 3, 1).contiguous())
     wt = ops.transpose(dev(w.detach().reshape(C, 9)))
-    out = ops.dwconv3(xn, wt, stride)
+    out = ops.dwconv3(xn, wt, stride, dilation=dil)
     close(out.permute(0, 3, 1, 2), y, "dwconv3 fwd")
     dyn = dev(dy.permute(0, 2, 3, 1).contiguous())
-    dx = ops.dwconv3(dyn, wt, stride, dgrad_shape=(H, H))
+    dx = ops.dwconv3(dyn, wt, stride, dgrad_shape=(H, H), dilation=dil)
     close(dx.permute(0, 3, 1, 2), x.grad, "dwconv3 dgrad")
-    dw = ops.dwconv3_wgrad(xn, dyn, stride)
+    dw = ops.dwconv3_wgrad(xn, dyn, stride, dil)
     close(ops.transpose(dw).reshape(C, 1, 3, 3), w.grad, "dwconv3 wgrad", rtol=3e-4)
 

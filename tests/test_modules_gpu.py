@@ -481,8 +481,9 @@ def test_presnet_against_reference_golden(golden_dir, depth):
     assert worst < 5e-2, worst
 
 
-@pytest.mark.parametrize("cin,cout,stride,expand", [(16, 24, 2, 6), (24, 24, 1, 6), (32, 16, 1, 1), (64, 96, 1, 6)])
-def test_mobilenet_v2_block_vs_oracle(golden_dir, cin, cout, stride, expand):
+@pytest.mark.parametrize("cin,cout,stride,expand,dil", [(16, 24, 2, 6, 1), (24, 24, 1, 6, 1), (32, 16, 1, 1, 1), (64, 96, 1, 6, 1),
+                                                        (32, 64, 1, 6, 2), (32, 32, 1, 6, 4)])
+def test_mobilenet_v2_block_vs_oracle(golden_dir, cin, cout, stride, expand, dil):
     """InvertedResidual (1x1 expand / depthwise 3x3 stride 1|2 / 1x1 project, BatchNorm + ReLU6 after each, residual add):
     output, input gradient and EVERY parameter gradient element by element against the oracle.  A ReLU6 network is piecewise
     linear: an activation that sits within round-off of 0 or 6 flips its gradient mask and moves a whole row of a weight
@@ -492,7 +493,7 @@ def test_mobilenet_v2_block_vs_oracle(golden_dir, cin, cout, stride, expand):
     import param_recipe as pr
     from oracle import mobilenet_v2_oracle as mo
     from dinov2_distillation_amd.models.mobilenet_v2 import InvertedResidual
-    blk = InvertedResidual(cin, cout, stride, expand)
+    blk = InvertedResidual(cin, cout, stride, expand, dil)
     shapes = {k: v.shape for k, v in blk.state_dict().items()}
     for seed in range(1, 60):
         state = pr.seeded_state(shapes, seed)
@@ -500,7 +501,7 @@ def test_mobilenet_v2_block_vs_oracle(golden_dir, cin, cout, stride, expand):
         x = torch.randn(4, cin, 6, 6, generator=gen)
         rec = []
         p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in state.items()}
-        mo.inverted_residual(p64, "", x.double(), stride, expand, record=rec)
+        mo.inverted_residual(p64, "", x.double(), stride, expand, record=rec, dilation=dil)
         if min(min((t - 0.0).abs().min().item(), (t - 6.0).abs().min().item()) for t in rec) > 2e-5:
             break
     else:
@@ -508,7 +509,7 @@ def test_mobilenet_v2_block_vs_oracle(golden_dir, cin, cout, stride, expand):
     p = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
          for k, v in state.items()}
     xr = x.clone().requires_grad_(True)
-    ref = mo.inverted_residual(p, "", xr, stride, expand)
+    ref = mo.inverted_residual(p, "", xr, stride, expand, dilation=dil)
     ct = torch.randn(ref.shape, generator=gen)
     (ref * ct).sum().backward()
     blk.load_state_dict(state, strict=True)
@@ -525,7 +526,9 @@ def test_mobilenet_v2_block_vs_oracle(golden_dir, cin, cout, stride, expand):
             close(v, p[k], k)
 
 
-def test_mobilenet_v2_against_reference_golden(golden_dir):
+@pytest.mark.parametrize("name,strides,dilations", [("mobilenet_v2_small", (1, 2, 2, 2, 1, 2, 1), (1, 1, 1, 1, 1, 1, 1)),
+                                                    ("mobilenet_v2_os8_small", (1, 2, 2, 1, 1, 1, 1), (1, 1, 1, 2, 2, 4, 4))])
+def test_mobilenet_v2_against_reference_golden(golden_dir, name, strides, dilations):
     """whole MobileNetV2 vs the reference's own D2MobileNetV2: outputs of all four levels and every running statistic to
     fp32 tolerance; gradients by their norms (52 ReLU6 layers at batch statistics over 36..9216 samples: mask flips at the
     kinks make element-wise gradient comparison meaningless at this depth - the blocks are compared element-wise above)"""
@@ -533,8 +536,8 @@ def test_mobilenet_v2_against_reference_golden(golden_dir):
     sys.path.insert(0, golden_dir)
     import param_recipe as pr
     from dinov2_distillation_amd.models.mobilenet_v2 import D2MobileNetV2
-    g = load(golden_dir, "mobilenet_v2_small")
-    net = D2MobileNetV2()
+    g = load(golden_dir, name)
+    net = D2MobileNetV2(strides=strides, dilations=dilations)
     shapes = {k: v.shape for k, v in net.state_dict().items()}
     state = pr.seeded_state(shapes, int(g["meta/seed"][0]))
     assert abs(pr.checksum(state) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))

@@ -263,14 +263,17 @@ def test_presnet(golden_dir, depth):
             close(p[k[6:]], v, k)
 
 
-def test_mobilenet_v2(golden_dir):
-    """oracle/mobilenet_v2_oracle.py against the reference's own D2MobileNetV2 (weights: tests/golden/param_recipe.py)"""
+@pytest.mark.parametrize("name,strides,dilations", [("mobilenet_v2_small", (1, 2, 2, 2, 1, 2, 1), (1, 1, 1, 1, 1, 1, 1)),
+                                                    ("mobilenet_v2_os8_small", (1, 2, 2, 1, 1, 1, 1), (1, 1, 1, 2, 2, 4, 4))])
+def test_mobilenet_v2(golden_dir, name, strides, dilations):
+    """oracle/mobilenet_v2_oracle.py against the reference's own D2MobileNetV2 (weights: tests/golden/param_recipe.py),
+    default and dilated (os8) configuration"""
     import sys
     sys.path.insert(0, golden_dir)
     import param_recipe as pr
     from oracle import mobilenet_v2_oracle as mo
     from dinov2_distillation_amd.models.mobilenet_v2 import D2MobileNetV2
-    g = load(golden_dir, "mobilenet_v2_small")
+    g = load(golden_dir, name)
     shapes = {k: v.shape for k, v in D2MobileNetV2().state_dict().items()}
     p = pr.seeded_state(shapes, int(g["meta/seed"][0]))
     assert abs(pr.checksum(p) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
@@ -278,7 +281,7 @@ def test_mobilenet_v2(golden_dir):
         if v.dtype.is_floating_point and "running" not in k:
             v.requires_grad_(True)
     x = g["in/x"].clone().requires_grad_(True)
-    feats = mo.forward(p, x)
+    feats = mo.forward(p, x, strides, dilations=dilations)
     loss = 0
     for k in ("res2", "res3"):
         close(pr.digest(feats[k]), g["out_digest/" + k], k + " (digest)", rtol=1e-3)
