@@ -600,8 +600,10 @@ int launch_bwd(const dkd_attn_args* a, hipStream_t st) {
         case 16: return FN<16>(a, st);                 \
         case 24: return FN<24>(a, st);                 \
         case 32: return FN<32>(a, st);                 \
+        case 40: return FN<40>(a, st);                 \
         case 48: return FN<48>(a, st);                 \
         case 64: return FN<64>(a, st);                 \
+        case 80: return FN<80>(a, st);                 \
         case 96: return FN<96>(a, st);                 \
         default: return DKD_ERR_UNSUPPORTED;           \
     }

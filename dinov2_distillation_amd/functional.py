@@ -629,6 +629,112 @@ class MaxPool3Fn(Function):
         return ops.maxpool3_bwd(_c(dy), arg, *ctx.hw)
 
 
+class ConvBiasFn(Function):
+    """conv(k, stride, pad = k // 2) + bias, no norm (MiT ``OverlapPatchEmbed.proj``, models/backbones/mit.py:237-243): im2col
+    rows + GEMM with the bias in its epilogue.  src_nchw: the input is the NCHW image (first stage); returns [B,Ho,Wo,O]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, stride, src_nchw):
+        x = _c(x)
+        O, pad = w.shape[0], k // 2
+        if src_nchw:
+            B, Cin, H, W = x.shape
+            rows = ops.im2col_nchw(x, k, stride, pad)
+            w2 = torch.zeros((O, rows.shape[1]), dtype=F32, device=x.device)
+            w2[:, : Cin * k * k] = w.reshape(O, -1)  # layout plumbing on a few K floats
+        else:
+            B, H, W, Cin = x.shape
+            rows = ops.im2col_nhwc(x, k, stride, pad)
+            w2 = ops.transpose(w.reshape(O, Cin, k * k)).reshape(O, k * k * Cin)  # [O][ky][kx][c]
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        y = ops.gemm(rows, w2, bias=b)
+        ctx.save_for_backward(rows, w2)
+        ctx.meta = (k, stride, pad, src_nchw, tuple(x.shape), tuple(w.shape))
+        ctx.params = (w, b)
+        return y.reshape(B, Ho, Wo, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, w2 = ctx.saved_tensors
+        k, stride, pad, src_nchw, xshape, wshape = ctx.meta
+        O = wshape[0]
+        dy2 = _c(dy).reshape(-1, O)
+        p_w, p_b = ctx.params
+        dx = None
+        if src_nchw:
+            kk = xshape[1] * k * k  # the im2col rows are padded to a multiple of 4 columns: keep the real ones
+            dw, db = wgrad(dy2, rows, p_w, p_b, transform=lambda t: p_w.grad.view(O, kk).copy_(t[:, :kk]),
+                           reshape=lambda t: t[:, :kk].reshape(wshape))
+        else:
+            B, H, W, Cin = xshape
+            dw, db = wgrad(dy2, rows, p_w, p_b,
+                           transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
+                           reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
+            if ctx.needs_input_grad[0]:
+                dx = ops.col2im_nhwc(ops.dgrad(dy2, w2), B, H, W, Cin, k, stride, pad)
+        return dx, dw, db, None, None, None
+
+
+class CrossAttnFn(Function):
+    """softmax(q k^T * scale) v with q [B,N,D] and packed kv [B,Nk,2D] = [k | v] (MiT's spatial-reduction attention,
+    models/backbones/mit.py:128-165: the keys / values come from the sr-reduced tokens); flash kernels, nothing materialised"""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        q, kv = _c(q), _c(kv)
+        B, N, D = q.shape
+        Nk = kv.shape[1]
+        hd = D // heads
+        kst = (Nk * 2 * D, 2 * D)
+        o, lse = ops.attention_forward(q, kv, kv[..., D:], heads, hd, scale, B, N, Nk, (N * D, D), kst, kst)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.meta = (heads, hd, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        heads, hd, scale = ctx.meta
+        B, N, D = q.shape
+        Nk = kv.shape[1]
+        kst = (Nk * 2 * D, 2 * D)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        ops.attention_backward(_c(do), q, kv, kv[..., D:], o, lse, heads, hd, scale, B, N, Nk, (N * D, D), kst, kst,
+                               dq, dkv, dkv[..., D:], (N * D, D), kst, kst)
+        return dq, dkv, None, None
+
+
+class DWConvBiasGeluFn(Function):
+    """gelu(depthwise 3x3 (stride 1, pad 1) + bias) on NHWC tokens: the middle of MiT's Mix-FFN (mit.py:22-34, 70-77)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _c(x)
+        C = x.shape[3]
+        wt = ops.transpose(w.reshape(C, 9))
+        z = ops.dwconv3(x, wt, 1).reshape(-1, C)
+        one, zero = torch.ones(C, dtype=F32, device=x.device), torch.zeros(C, dtype=F32, device=x.device)
+        pre = ops.bn_act_pos_fwd(z, zero, one, one, b, None, relu=0)  # z + b through the affine kernel (mean 0, rstd 1, gamma 1)
+        ctx.save_for_backward(x, wt, pre)
+        ctx.wshape = tuple(w.shape)
+        ctx.params = (w, b)
+        return ops.gelu_fwd(pre).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt, pre = ctx.saved_tensors
+        C = x.shape[3]
+        p_w, p_b = ctx.params
+        o_w, o_b = direct(p_w, p_b)
+        dz = ops.gelu_bwd(_c(dy).reshape(-1, C), pre)
+        db = ops.colreduce(dz, ops.RED_SUM, out=None if o_b is None else o_b.view(1, C)).reshape(C)
+        dz4 = dz.reshape(x.shape)
+        dx = ops.dwconv3(dz4, wt, 1, dgrad_shape=x.shape[1:3]) if ctx.needs_input_grad[0] else None
+        dw = ops.transpose(ops.dwconv3_wgrad(x, dz4, 1), out=None if o_w is None else o_w.view(C, 9)).reshape(ctx.wshape)
+        return dx, ret(o_w, dw, p_w), ret(o_b, db, p_b)
+
+
 class AddFn(Function):
     """a + b on NHWC rows (MobileNetV2's ``x + self.conv(x)``, mobilenet_v2.py:369): no ATen kernel on the path"""
 

@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .convnext import D2ConvNextV2
+from .mit import MultiscaleImageTransformer
 from .mobilenet_v2 import D2MobileNetV2
 from .presnet import D2Presnet
 from .resnet import BasicStem, ResNet, make_resnet_stages
@@ -192,12 +193,42 @@ class MobileNetV2Wrapper(nn.Module):
         return self._out_feature_channels
 
 
+MIT_CONFIGS = {"0": ([2, 2, 2, 2], [32, 64, 160, 256]), "1": ([2, 2, 2, 2], [64, 128, 320, 512]),  # mit_wrapper.py:6-13
+               "2": ([3, 4, 6, 3], [64, 128, 320, 512]), "3": ([3, 4, 18, 3], [64, 128, 320, 512]),
+               "4": ([3, 8, 27, 3], [64, 128, 320, 512]), "5": ([3, 6, 40, 3], [64, 128, 320, 512])}
+
+
+class MITWrapper(nn.Module):
+    """models/wrappers/mit_wrapper.py: MultiscaleImageTransformer(embed_dims, depths, num_heads=[1, 2, 4, 8], mlp_ratios 4,
+    qkv_bias=True, every dropout / drop-path rate 0); the version is the LAST character of the name (mit_wrapper.py:18)"""
+
+    def __init__(self, model_name="mit_b0", out_features=None):
+        super().__init__()
+        if model_name[-1] not in MIT_CONFIGS:
+            raise NotImplementedError(f"There is not a MiT config called {model_name}.")
+        depths, dims = MIT_CONFIGS[model_name[-1]]
+        self._out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", f"mit_b{model_name[-1]}.pkl")
+        self.model = MultiscaleImageTransformer(embed_dims=dims, depths=depths, out_features=self._out_features)
+        self._out_feature_channels = {f"res{i + 2}": dims[i] for i in range(4)}
+
+    def get_features(self, x):
+        return self.model(x)
+
+    def get_features_nhwc(self, x):
+        return self.model.forward_features_nhwc(x)
+
+    @property
+    def feature_channels(self):
+        return self._out_feature_channels
+
+
 class ModelWrapper(nn.Module):
     """models/model_zoo.py:18-145.  Only the student families built on the MI355X kernels are registered; asking for
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
     MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper, "swin": D2SwinTransformerWrapper,
-                 "presnet": PResNetWrapper, "mobilenet_v2": MobileNetV2Wrapper}
+                 "presnet": PResNetWrapper, "mobilenet_v2": MobileNetV2Wrapper, "mit": MITWrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

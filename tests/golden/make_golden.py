@@ -383,6 +383,41 @@ def _gen_mobilenet_v2(mb, pr_, name, strides, dilations):
     _save(name, **arrays)
 
 
+def gen_mit():
+    """the reference's own MultiscaleImageTransformer, configured as MITWrapper("mit_b0") does (mit_wrapper.py:76-86): heads
+    1/2/4/8 (head dims 32, 32, 40, 32), sr ratios 8/4/2/1, every dropout rate 0.  timm is absent: DropPath (identity at rate 0),
+    to_2tuple and trunc_normal_ are the stand-ins of _install_standins()."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import param_recipe as pr_
+    _install_standins()
+    mit = _load_file("ref_mit", "models/backbones/mit.py")
+    depths, dims = [2, 2, 2, 2], [32, 64, 160, 256]
+    net = mit.MultiscaleImageTransformer(embed_dims=dims, depths=depths, num_heads=[1, 2, 4, 8], mlp_ratios=[4, 4, 4, 4],
+                                         qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0)
+    state = pr_.seeded_state({k: v.shape for k, v in net.state_dict().items()}, seed=91)
+    net.load_state_dict(state, strict=True)
+    net.train()
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(2, 3, 128, 96, generator=g).requires_grad_(True)   # stage grids 32x24, 16x12, 8x6, 4x3
+    arrays = {"in/x": _np(x), "meta/seed": np.array([91]), "meta/param_checksum": np.array([pr_.checksum(state)]),
+              "meta/depths": np.array(depths), "meta/dims": np.array(dims)}
+    feats = net(x)
+    loss = 0
+    for k in ("res2", "res3"):
+        arrays["out_digest/" + k] = _np(pr_.digest(feats[k]))
+    for k in ("res4", "res5"):
+        arrays["out/" + k] = _np(feats[k])
+        ct = torch.randn(feats[k].shape, generator=g)
+        arrays["in/cotangent_" + k] = _np(ct)
+        loss = loss + (feats[k] * ct).sum()
+    loss.backward()
+    arrays["grad/x"] = _np(x.grad)
+    for k, p_ in net.named_parameters():
+        if p_.grad is not None:
+            arrays["pgrad_digest/" + k] = _np(pr_.digest(p_.grad))
+    _save("mit_b0_small", **arrays)
+
+
 def gen_swin():
     """SwinTransformer (models/backbones/swin.py) at drop rate 0: odd grids, window padding, shifted masks, patch merging."""
     sw = _load_file("ref_swin", "models/backbones/swin.py")
@@ -512,6 +547,6 @@ def gen_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "presnet", "mobilenet_v2", "swin", "step"]
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "presnet", "mobilenet_v2", "mit", "swin", "step"]
     for w in which:
         globals()["gen_" + w]()

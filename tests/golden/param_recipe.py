@@ -9,7 +9,8 @@ import torch
 
 def seeded_state(shapes, seed):
     """shapes: {state-dict key: shape}.  conv weights ~ N(0, 2/fan_in); norm.weight 1 + 0.2 N; norm.bias 0.2 N;
-    running_mean 0.1 N; running_var 1 + 0.1 U; num_batches_tracked 0."""
+    running_mean 0.1 N; running_var 1 + 0.1 U; num_batches_tracked 0; Linear weights ~ N(0, 1/fan_in); every other 1-D
+    weight 1 + 0.2 N and bias 0.2 N (LayerNorm, Linear / conv biases)."""
     out = {}
     for k, shape in shapes.items():
         g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(k.encode()))
@@ -27,6 +28,12 @@ def seeded_state(shapes, seed):
         elif len(shape) == 4:  # (depthwise weights are [C, 1, k, k]: fan_in = k * k)
             fan_in = shape[1] * shape[2] * shape[3]
             out[k] = torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
+        elif len(shape) == 2:  # Linear weight [out, in]
+            out[k] = torch.randn(shape, generator=g) * (1.0 / shape[1]) ** 0.5
+        elif len(shape) == 1 and k.endswith("weight"):  # LayerNorm weight (keys like norm1.weight, attn.norm.weight)
+            out[k] = 1.0 + 0.2 * torch.randn(shape, generator=g)
+        elif len(shape) == 1 and k.endswith("bias"):
+            out[k] = 0.2 * torch.randn(shape, generator=g)
         else:
             raise KeyError(f"no recipe for {k} {shape}")
     return out

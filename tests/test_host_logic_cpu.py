@@ -59,7 +59,12 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(ValueError):   # 24 does not divide 1024
         AttentionProjector(8, 1024, (2, 2), 1024, num_heads=24)
     with pytest.raises(NotImplementedError):
-        ModelWrapper("mit_b0", [16, 16])      # a family without an MI355X backbone fails loudly
+        ModelWrapper("darknet_s", [16, 16])   # a family without an MI355X backbone fails loudly
+    mit = ModelWrapper("mit_b0", [16, 16])    # counts from the reference's MultiscaleImageTransformer in this container
+    assert sum(p.numel() for p in mit.parameters()) == 3_319_392 and len(mit.model.model.state_dict()) == 176
+    assert mit.feature_channels == {"res2": 32, "res3": 64, "res4": 160, "res5": 256}
+    assert "model.model.block1.0.attn.sr.weight" in mit.state_dict() and "model.model.block4.0.attn.sr.weight" not in mit.state_dict()
+    assert sum(p.numel() for p in ModelWrapper("mit_b2", [16, 16]).parameters()) == 24_196_288
     with pytest.raises(NotImplementedError, match="Swin config"):   # models/wrappers/swin_wrapper.py:39-41
         ModelWrapper("swin_huge", [16, 16])
     w = ModelWrapper("swin_tiny", [37, 37])

@@ -128,7 +128,8 @@ def test_colreduce_transpose_pointwise(ops):
                                                   (24, 4, 256, 256, 3, False), (32, 2, 100, 70, 2, False),
                                                   (48, 2, 64, 64, 1, True), (64, 2, 33, 1369, 1, False), (16, 2, 64, 67, 2, False),
                                                   (64, 2, 130, 260, 1, False), (16, 4, 129, 70, 2, False),
-                                                  (24, 2, 257, 33, 2, False), (32, 2, 129, 20, 1, False)])
+                                                  (24, 2, 257, 33, 2, False), (32, 2, 129, 20, 1, False),
+                                                  (40, 4, 96, 24, 2, False), (80, 2, 64, 100, 1, False)])  # MiT head dims
 def test_attention(ops, hd, H, Nq, Nk, B, shared_q):
     g = torch.Generator().manual_seed(hd * 7 + Nq)
     D = H * hd

@@ -572,6 +572,50 @@ def test_mobilenet_v2_student_runs_full_step():
     assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
 
 
+def test_mit_b0_against_reference_golden(golden_dir):
+    """MiT-b0 (overlapping patch embeddings, spatial-reduction attention with head dims 32 / 40, Mix-FFN with a depthwise conv)
+    vs the reference's own MultiscaleImageTransformer: outputs against the fixture, every parameter gradient element by
+    element against the oracle (pinned to the reference by the same fixture; the network is smooth: no kinks)"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import mit_oracle as mo
+    from dinov2_distillation_amd.models.mit import MultiscaleImageTransformer
+    g = load(golden_dir, "mit_b0_small")
+    depths, dims = [int(v) for v in g["meta/depths"]], [int(v) for v in g["meta/dims"]]
+    net = MultiscaleImageTransformer(embed_dims=dims, depths=depths)
+    state = pr.seeded_state({k: v.shape for k, v in net.state_dict().items()}, int(g["meta/seed"][0]))
+    assert abs(pr.checksum(state) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
+    net.load_state_dict(state, strict=True)
+    net.cuda().train()
+    feats = net(g["in/x"].cuda())
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    ref = mo.forward(p, g["in/x"], depths)
+    loss = rloss = 0
+    for k in ("res2", "res3", "res4", "res5"):
+        close(feats[k], ref[k], k + " vs oracle")
+    for k in ("res4", "res5"):
+        close(feats[k], g["out/" + k], k + " vs reference fixture")
+        loss = loss + (feats[k] * g["in/cotangent_" + k].cuda()).sum()
+        rloss = rloss + (ref[k] * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    rloss.backward()
+    for k, v in net.named_parameters():
+        close(v.grad, p[k].grad, "d" + k, rtol=2e-3)
+        d = pr.digest(v.grad.cpu())
+        close(d[:1], g["pgrad_digest/" + k][:1], "|d" + k + "| vs reference fixture", rtol=2e-3)
+
+
+def test_mit_b0_student_runs_full_step():
+    """dinov2_vits14 -> mit_b0 (res4 160 / res5 256 channels): one full optimiser step twice, finite losses"""
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(student="mit_b0")
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
+    l0 = float(st.step(x).detach())
+    l1 = float(st.step(x).detach())
+    assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
+
+
 def test_presnet18_student_runs_full_step():
     """dinov2_vits14 -> presnet_18 (res4 256 / res5 512 channels): one full optimiser step twice, finite losses"""
     from dinov2_distillation_amd.trainer import DistillationStepper

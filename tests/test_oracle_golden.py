@@ -296,3 +296,35 @@ def test_mobilenet_v2(golden_dir, name, strides, dilations):
         if k.startswith("after/"):
             close(p[k[6:]], v, k)
 
+
+def test_mit(golden_dir):
+    """oracle/mit_oracle.py against the reference's own MultiscaleImageTransformer configured as MITWrapper("mit_b0")"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import mit_oracle as mo
+    from dinov2_distillation_amd.models.mit import MultiscaleImageTransformer
+    g = load(golden_dir, "mit_b0_small")
+    depths, dims = [int(v) for v in g["meta/depths"]], [int(v) for v in g["meta/dims"]]
+    shapes = {k: v.shape for k, v in MultiscaleImageTransformer(embed_dims=dims, depths=depths).state_dict().items()}
+    p = pr.seeded_state(shapes, int(g["meta/seed"][0]))
+    assert abs(pr.checksum(p) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
+    for v in p.values():
+        v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = mo.forward(p, x, depths)
+    loss = 0
+    for k in ("res2", "res3"):
+        close(pr.digest(feats[k]), g["out_digest/" + k], k + " (digest)", rtol=1e-3)
+    for k in ("res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+        loss = loss + (feats[k] * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x", rtol=5e-4)
+    n = 0
+    for k, v in g.items():
+        if k.startswith("pgrad_digest/"):
+            close(pr.digest(p[k[13:]].grad), v, k, rtol=1e-3, atol=1e-5)
+            n += 1
+    assert n == len(p)
+
