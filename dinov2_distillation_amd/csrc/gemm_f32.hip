@@ -475,8 +475,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
 // unchanged; an LDS-DMA writes wave-base + lane * 16 B, so the swizzle goes on the SOURCE address: the lane that owns LDS
 // slot (row r, slot c) fetches k-quad swz(r, c) of global row r (swz is an involution).  No VGPR round trip, no ds_write, no
 // vmcnt wait in front of it.  Rows past M / N are clamped (never stored); needs (kend - kbeg) % 16 == 0.
-// Knock-outs of this kernel (timing only, gpurun_out notes in DESIGN.md): without the DMA of both operands it runs 20 %
-// faster, without B's alone 7 %; the barrier is free.  The same pipeline on v_mfma_f32_32x32x2_f32 (half the fragment reads
+// Knock-outs of this kernel (timing only, variants 130-132, scripts/knockout_dma.py): without the DMA of both operands it runs
+// 9-14 % faster, without B's alone 3-4 %; without the barrier 5-10 % SLOWER.  The same pipeline on v_mfma_f32_32x32x2_f32 (half the fragment reads
 // per MAC: one b128 per operand feeds four MFMAs) was 2-3 % SLOWER on every shape (tune_v2_r.log) - the staging traffic, not
 // the fragment reads, is what the matrix pipes wait for.  Moving all DMA issue to a fifth, loader-only wave per workgroup
 // (the four MFMA waves then only read fragments and multiply) was 10-20 % slower (tune_v2_s.log): one wave issuing the
@@ -530,13 +530,14 @@ struct DmaStager {
     }
 };
 
-template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC>
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda,
                                                                     const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                     int M, int N, int K, int kchunk, Epilogue epi,
-                                                                    float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok,
-                                                                    int knock) {
-    // knock (DKD_GEMM_KNOCKOUT, timing experiments only - results are wrong): 2 = no DMA at all, 4 = no DMA of B, 8 = no barrier
+                                                                    float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok) {
+    // KNOCK (variants 130-132, timing experiments only - results are wrong): 2 = no DMA at all, 4 = no DMA of B, 8 = no barrier.
+    // A template parameter on purpose: as a run-time argument the same three tests cost the production kernel 6 %.
+    constexpr int knock = KNOCK;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     using DA = DmaStager<BM, BK, A_KC, NT>;
     using DB = DmaStager<BN, BK, B_KC, NT>;
@@ -957,17 +958,16 @@ static bool dma_ok(const dkd_gemm_args* g, int kchunk) {
     if (g->rowsum && g->a_layout == 0) return false;
     return true;
 }
-template <int WM, int WN, int TM, int TN, int BK>
+template <int WM, int WN, int TM, int TN, int BK, int KNOCK = 0>
 int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
     if (!dma_ok<BK>(g, kchunk)) return DKD_ERR_UNSUPPORTED;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
     float* ws = splits > 1 ? g->workspace : nullptr;
     const int vec = epilogue_vec_ok(g);
-    static const int knock = getenv("DKD_GEMM_KNOCKOUT") ? atoi(getenv("DKD_GEMM_KNOCKOUT")) : 0;
 #define DKD_GEMM_LAUNCH3(AKC, BKC)                                                                                          \
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
-                       g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec, knock)
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
+                       g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
     if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH3(true, true);
     else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH3(true, false);
     else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH3(false, true);
@@ -1009,7 +1009,7 @@ static void cfg_tile(int cfg, int* bm, int* bn) {
         case 40: *bm = 128; *bn = 64; break;
         case CFG_128x96_4W: *bm = 128; *bn = 96; break;
         case 43: case 55: *bm = 64; *bn = 96; break;
-        case 44: case 64: case 100: case 101: case 102: case 104: case 105: *bm = 64; *bn = 64; break;
+        case 44: case 64: case 100: case 101: case 102: case 104: case 105: case 130: case 131: case 132: *bm = 64; *bn = 64; break;
         case 106: case 107: *bm = 128; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
         default: *bm = 64; *bn = 128; break;  // 3, 5, 34, 45, 65
@@ -1121,6 +1121,9 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 101: return launch_dma<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, BK 32
         case 102: return launch_dma<2, 2, 2, 2, 64>(g, epi, splits, kchunk, st);     // 64 x 64, BK 64
         case 103: return launch_dma<2, 2, 2, 4, 32>(g, epi, splits, kchunk, st);     // 64 x 128, BK 32
+        case 130: return launch_dma<2, 2, 2, 2, 32, 2>(g, epi, splits, kchunk, st);  // knock-outs of variant 101 (timing only)
+        case 131: return launch_dma<2, 2, 2, 2, 32, 4>(g, epi, splits, kchunk, st);
+        case 132: return launch_dma<2, 2, 2, 2, 32, 8>(g, epi, splits, kchunk, st);
         case 104: return launch_dma<1, 2, 4, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, 2 waves of 64 x 32, BK 16
         case 105: return launch_dma<1, 2, 4, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, 2 waves of 64 x 32, BK 32
         case 106: return launch_dma<2, 2, 4, 2, 16>(g, epi, splits, kchunk, st);     // 128 x 64, 4 waves of 64 x 32, BK 16
