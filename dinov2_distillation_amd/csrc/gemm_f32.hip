@@ -264,6 +264,10 @@ struct Stager2 {
         if (BK == 32) return c ^ ((row >> 1) & 7);
         return c ^ (row & 15);
     }
+    // EDGE = false: the launcher has checked that the reduction is a whole number of BK tiles (and, for an operand contiguous
+    // along M / N, that its extent is a multiple of 4): rows past the edge are read from the last row instead of zero-filled
+    // (their results are never stored) and no load is predicated - the tests and zero moves around every load cost 3-6 %.
+    template <bool EDGE = true>
     __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int rows, int k0, int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -273,11 +277,13 @@ struct Stager2 {
             } else if (KC) {
                 const int r = idx / (BK / 4), kq = idx % (BK / 4);
                 const int gr = row0 + r, gk = k0 + 4 * kq;
-                if (gr < rows && gk < kend) x = *reinterpret_cast<const float4*>(P + (long)gr * ld + gk);
+                if (!EDGE) x = *reinterpret_cast<const float4*>(P + (long)min(gr, rows - 1) * ld + gk);
+                else if (gr < rows && gk < kend) x = *reinterpret_cast<const float4*>(P + (long)gr * ld + gk);
             } else {
                 const int k = idx / (EXT / 4), mq = idx % (EXT / 4);
                 const int gk = k0 + k, gr = row0 + 4 * mq;
-                if (gk < kend && gr < rows) x = *reinterpret_cast<const float4*>(P + (long)gk * ld + gr);
+                if (!EDGE) x = *reinterpret_cast<const float4*>(P + (long)gk * ld + min(gr, rows - 4));
+                else if (gk < kend && gr < rows) x = *reinterpret_cast<const float4*>(P + (long)gk * ld + gr);
             }
             v[i] = x;
         }
@@ -332,7 +338,7 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& e, float* C, lon
     *reinterpret_cast<float4*>(C + orow * ldc + n) = v;
 }
 
-template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int PF = 2>
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int PF = 2, bool EDGE = true>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* __restrict__ A, long lda,
                                                                    const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                    int M, int N, int K, int kchunk, Epilogue epi,
@@ -400,17 +406,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
     SA sa2;
     SB sb2;
     if (nk > 0) {
-        sa.load(A, lda, bm0, M, kbeg, kend, tid);
-        sb.load(B, ldb, bn0, N, kbeg, kend, tid);
+        sa.template load<EDGE>(A, lda, bm0, M, kbeg, kend, tid);
+        sb.template load<EDGE>(B, ldb, bn0, N, kbeg, kend, tid);
         sa.store(smem, tid);
         sb.store(smem + A_SZ, tid);
         if (nk > 1) {
-            sa.load(A, lda, bm0, M, kbeg + BK, kend, tid);
-            sb.load(B, ldb, bn0, N, kbeg + BK, kend, tid);
+            sa.template load<EDGE>(A, lda, bm0, M, kbeg + BK, kend, tid);
+            sb.template load<EDGE>(B, ldb, bn0, N, kbeg + BK, kend, tid);
         }
         if (PF == 3 && nk > 2) {
-            sa2.load(A, lda, bm0, M, kbeg + 2 * BK, kend, tid);
-            sb2.load(B, ldb, bn0, N, kbeg + 2 * BK, kend, tid);
+            sa2.template load<EDGE>(A, lda, bm0, M, kbeg + 2 * BK, kend, tid);
+            sb2.template load<EDGE>(B, ldb, bn0, N, kbeg + 2 * BK, kend, tid);
         }
     }
     __syncthreads();
@@ -423,8 +429,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* _
             rb.store(An + A_SZ, tid);
         }
         if (kt + PF < nk) {
-            ra.load(A, lda, bm0, M, kbeg + (kt + PF) * BK, kend, tid);
-            rb.load(B, ldb, bn0, N, kbeg + (kt + PF) * BK, kend, tid);
+            ra.template load<EDGE>(A, lda, bm0, M, kbeg + (kt + PF) * BK, kend, tid);
+            rb.template load<EDGE>(B, ldb, bn0, N, kbeg + (kt + PF) * BK, kend, tid);
         }
         compute(As, As + A_SZ);
         __syncthreads();
@@ -935,14 +941,21 @@ int launch_v2(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchun
     dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(WM * WN * 64);
     float* ws = splits > 1 ? g->workspace : nullptr;
     const int vec = epilogue_vec_ok(g);
-#define DKD_GEMM_LAUNCH2(AKC, BKC)                                                                                      \
-    hipLaunchKernelGGL((gemm_f32_v2_kernel<WM, WN, TM, TN, BK, AKC, BKC, PF>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, \
-                       g->C, g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
-    if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH2(true, true);
-    else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH2(true, false);
-    else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH2(false, true);
-    else DKD_GEMM_LAUNCH2(false, false);
+    // whole BK tiles and (for M / N contiguous operands) whole float4 at the edge: the unpredicated loads (EDGE = false)
+    static const bool force_edge = getenv("DKD_GEMM_EDGE") != nullptr;  // A/B: always take the predicated loads
+    const bool full = !force_edge && g->K % BK == 0 && kchunk % BK == 0 && (g->a_layout == 0 || g->M % 4 == 0) &&
+                      (g->b_layout == 0 || g->N % 4 == 0) && g->M >= 4 && g->N >= 4 && PF == 2;
+#define DKD_GEMM_LAUNCH2E(AKC, BKC, EDGE)                                                                                      \
+    hipLaunchKernelGGL((gemm_f32_v2_kernel<WM, WN, TM, TN, BK, AKC, BKC, PF, EDGE>), grid, block, 0, st, g->A, g->lda, g->B, \
+                       g->ldb, g->C, g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
+#define DKD_GEMM_LAUNCH2(AKC, BKC) \
+    if (full) DKD_GEMM_LAUNCH2E(AKC, BKC, false); else DKD_GEMM_LAUNCH2E(AKC, BKC, true)
+    if (g->a_layout == 0 && g->b_layout == 0) { DKD_GEMM_LAUNCH2(true, true); }
+    else if (g->a_layout == 0 && g->b_layout == 1) { DKD_GEMM_LAUNCH2(true, false); }
+    else if (g->a_layout == 1 && g->b_layout == 0) { DKD_GEMM_LAUNCH2(false, true); }
+    else { DKD_GEMM_LAUNCH2(false, false); }
 #undef DKD_GEMM_LAUNCH2
+#undef DKD_GEMM_LAUNCH2E
     DKD_LAUNCH_CHECK();
     if (splits > 1) return launch_splitk_reduce(g, epi, splits, st);
     return DKD_OK;
@@ -1005,14 +1018,12 @@ static int pick_cfg(int M, int N, int K, int a_layout, int b_layout, int variant
 }
 static void cfg_tile(int cfg, int* bm, int* bn) {
     switch (cfg) {
-        case 1: case CFG_128x128_8W: case 31: *bm = 128; *bn = 128; break;
-        case 40: *bm = 128; *bn = 64; break;
+        case 1: case CFG_128x128_8W: *bm = 128; *bn = 128; break;
         case CFG_128x96_4W: *bm = 128; *bn = 96; break;
         case 43: case 55: *bm = 64; *bn = 96; break;
-        case 44: case 64: case 100: case 101: case 102: case 104: case 105: case 130: case 131: case 132: *bm = 64; *bn = 64; break;
-        case 106: case 107: *bm = 128; *bn = 64; break;
+        case 44: case 100: case 101: case 130: case 131: case 132: *bm = 64; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
-        default: *bm = 64; *bn = 128; break;  // 3, 5, 34, 45, 65
+        default: *bm = 64; *bn = 128; break;  // 3, 5
     }
 }
 // Split the reduction only when the output grid alone cannot fill the chip (weight gradients: small M x N, reduction
@@ -1111,28 +1122,17 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case CFG_64x128_4W: return launch_cfg<1, 4, 2, 1, 16, 1>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 64 x 32
         case CFG_128x96_4W: return launch_cfg<4, 1, 1, 3, 16, 1>(g, epi, splits, kchunk, st);   // 128 x 96, 4 waves of 32 x 96
         case 5: return launch_cfg<2, 2, 1, 2, 16, 1>(g, epi, splits, kchunk, st);               // 64 x 128, 4 waves of 32 x 64
-        // v2 family (16x16x4 MFMA, K-contiguous LDS rows): tuning variants 31..
-        case 31: return launch_v2<2, 2, 4, 4, 16>(g, epi, splits, kchunk, st);   // 128 x 128, 4 waves of 64 x 64, BK 16
-        case 34: return launch_v2<2, 2, 2, 4, 16>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 32 x 64, BK 16
-        case 40: return launch_v2<2, 2, 4, 2, 16>(g, epi, splits, kchunk, st);   // 128 x 64, 4 waves of 64 x 32
+        // v2 family (16x16x4 MFMA, K-contiguous LDS rows); the larger-tile / BK 32-64 tuning variants (31, 34, 40, 45, 64, 65,
+        // 102-107) were measured slower (see the notes above) and are no longer instantiated
         case 43: return launch_v2<2, 2, 2, 3, 16>(g, epi, splits, kchunk, st);   // 64 x 96, 4 waves of 32 x 48
         case 44: return launch_v2<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 4 waves of 32 x 32
-        case 100: return launch_dma<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, LDS-DMA staging (NT only)
+        case 100: return launch_dma<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, LDS-DMA staging, BK 16
         case 101: return launch_dma<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, BK 32
-        case 102: return launch_dma<2, 2, 2, 2, 64>(g, epi, splits, kchunk, st);     // 64 x 64, BK 64
-        case 103: return launch_dma<2, 2, 2, 4, 32>(g, epi, splits, kchunk, st);     // 64 x 128, BK 32
         case 130: return launch_dma<2, 2, 2, 2, 32, 2>(g, epi, splits, kchunk, st);  // knock-outs of variant 101 (timing only)
         case 131: return launch_dma<2, 2, 2, 2, 32, 4>(g, epi, splits, kchunk, st);
         case 132: return launch_dma<2, 2, 2, 2, 32, 8>(g, epi, splits, kchunk, st);
-        case 104: return launch_dma<1, 2, 4, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, 2 waves of 64 x 32, BK 16
-        case 105: return launch_dma<1, 2, 4, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, 2 waves of 64 x 32, BK 32
-        case 106: return launch_dma<2, 2, 4, 2, 16>(g, epi, splits, kchunk, st);     // 128 x 64, 4 waves of 64 x 32, BK 16
-        case 107: return launch_dma<2, 2, 4, 2, 32>(g, epi, splits, kchunk, st);     // 128 x 64, BK 32
-        case 45: return launch_v2<4, 1, 1, 8, 16>(g, epi, splits, kchunk, st);   // 64 x 128, 4 waves of 16 x 128
         case 52: return launch_v2<2, 2, 1, 2, 16>(g, epi, splits, kchunk, st);   // 32 x 64, 4 waves of 16 x 32
         case 55: return launch_v2<2, 2, 2, 3, 32>(g, epi, splits, kchunk, st);   // 64 x 96, BK 32
-        case 65: return launch_v2<2, 2, 2, 4, 32>(g, epi, splits, kchunk, st);      // 64 x 128, 4 waves of 32 x 64, BK 32
-        case 64: return launch_v2<2, 2, 2, 2, 16, 3>(g, epi, splits, kchunk, st);   // 64 x 64, two tiles of global loads in flight
         default: return DKD_ERR_BAD_ARG;
     }
 }
