@@ -33,10 +33,12 @@ def init_process_group_from_env(backend=None):
 
 
 class GradBucketReducer:
-    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None, force=False):
+        """force: run the bucketed exchange even in a one-rank group (lets a one-GPU box drive the RCCL code path)"""
         self.opt = optimizer
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.flat_g = optimizer.flat_g
         self.cuda = self.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.cuda else None
@@ -56,7 +58,7 @@ class GradBucketReducer:
         self.launched = [False] * len(self.buckets)
         self.handles = []
         self.hooks = []
-        if self.world > 1:
+        if self.active:
             for p, _, _ in optimizer.layout:
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             ops.add_grad_listener(self._on_grad)  # gradients written from the side stream bypass autograd's accumulation
@@ -98,7 +100,7 @@ class GradBucketReducer:
     def finish(self):
         """call after backward, before the optimiser: reduces buckets whose hooks never all fired (unused
         parameters) and makes the compute stream wait for the exchange."""
-        if self.world > 1:
+        if self.active:
             for bi in range(len(self.buckets)):
                 if not self.launched[bi]:
                     self._launch(bi)
@@ -111,7 +113,7 @@ class GradBucketReducer:
     def broadcast_parameters(self, src=0):
         """once, at start-up (C2 of SURVEY 2.1): trainable arena from rank 0; teacher weights are frozen and seeded
         identically, so nothing else moves."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.opt.flat_p, src=src, group=self.pg)
 
     def remove(self):

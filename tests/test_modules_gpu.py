@@ -805,6 +805,60 @@ def _ddp_gpu_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _rccl_one_rank_worker(port, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.ddp import GradBucketReducer, init_process_group_from_env
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    torch.cuda.set_device(0)
+    init_process_group_from_env("nccl")  # "nccl" IS RCCL here: communicator init, broadcast, async all-reduce on the side stream
+    st = DistillationStepper(device="cuda:0", bucket_bytes=8 << 20)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1234)).cuda()
+    st.reducer.remove()
+    st.optimizer.zero_grad()
+    st.module.training_step(x, 0).backward()
+    ops.wgrad_join()
+    expect = st.optimizer.flat_g.clone()
+    st.reducer = GradBucketReducer(st.optimizer, 8 << 20, force=True)
+    st.reducer.broadcast_parameters(0)
+    st.optimizer.zero_grad()
+    st.module.training_step(x, 0).backward()
+    launched = sum(st.reducer.launched)
+    st.reducer.finish()
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    err = ((st.optimizer.flat_g - expect).abs().max() / expect.abs().max()).item()
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((err, launched, len(st.reducer.buckets), float(t.sum())))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_drives_the_reducer():
+    """the real RCCL backend on the one GPU of the box (a one-rank group: the mean over one rank is the identity): communicator
+    creation, parameter broadcast, bucketed asynchronous all-reduce launched from the backward hooks on the side stream, the
+    waits in finish(), MAX all-reduce and barrier as bench.py issues them"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, q))
+    p.start()
+    err, launched, nb, tsum = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert err < 1e-6, err
+    assert launched >= nb - 2 and tsum == 4.0, (launched, nb, tsum)
+
+
 def test_ddp_two_ranks_on_gpu_average_matches_manual():
     """2 processes sharing the GPU (gloo): bucketed gradient exchange driven by autograd hooks AND side-stream listeners ==
     the mean of the two ranks' stand-alone gradients; most buckets must be launched before backward returns (overlap)."""
