@@ -705,6 +705,17 @@ class CrossAttnFn(Function):
         return dq, dkv, None, None
 
 
+_CONST_VECS = {}
+
+
+def _ones_zeros(C, device):
+    """constant [C] vectors of ones / zeros, made once per (device, C): no ATen fill kernels inside a step"""
+    key = (device.index, C)
+    if key not in _CONST_VECS:
+        _CONST_VECS[key] = (torch.ones(C, dtype=F32, device=device), torch.zeros(C, dtype=F32, device=device))
+    return _CONST_VECS[key]
+
+
 class DWConvBiasGeluFn(Function):
     """gelu(depthwise 3x3 (stride 1, pad 1) + bias) on NHWC tokens: the middle of MiT's Mix-FFN (mit.py:22-34, 70-77)"""
 
@@ -714,7 +725,7 @@ class DWConvBiasGeluFn(Function):
         C = x.shape[3]
         wt = ops.transpose(w.reshape(C, 9))
         z = ops.dwconv3(x, wt, 1).reshape(-1, C)
-        one, zero = torch.ones(C, dtype=F32, device=x.device), torch.zeros(C, dtype=F32, device=x.device)
+        one, zero = _ones_zeros(C, x.device)
         pre = ops.bn_act_pos_fwd(z, zero, one, one, b, None, relu=0)  # z + b through the affine kernel (mean 0, rstd 1, gamma 1)
         ctx.save_for_backward(x, wt, pre)
         ctx.wshape = tuple(w.shape)
