@@ -32,7 +32,9 @@ def dev(t):
 
 
 @pytest.mark.parametrize("M,N,K", [(257 * 3, 384, 384), (512, 1152, 384), (300, 96, 384), (1000, 192, 96),
-                                   (256, 384, 588), (130, 1536, 384), (64, 48, 96)])
+                                   (256, 384, 588), (130, 1536, 384), (64, 48, 96),
+                                   # reductions >= 768 take the LDS-DMA kernel: ragged M / N edges (clamped rows), all four layouts
+                                   (1024, 200, 768), (512, 768, 136), (1000, 72, 1536), (2048, 100, 800)])
 def test_gemm_forward_layouts(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
@@ -51,6 +53,19 @@ def test_gemm_splitk_wgrad(ops):
     from dinov2_distillation_amd import _lib
     assert _lib.load().dkd_gemm_f32_splits(K, N, M) > 1
     close(ops.linear_wgrad(dev(dy), dev(x)), dy.t() @ x, "split-K wgrad", rtol=2e-4)
+
+
+def test_gemm_dma_wgrad_with_bias_gradient_and_splitk(ops):
+    """weight gradient + fused bias gradient through the LDS-DMA kernel (k-major images, row sums read through the XOR),
+    without and with split-K slabs"""
+    from dinov2_distillation_amd import _lib
+    for rows, n_out, k_in in ((1024, 136, 264), (16384, 200, 136)):
+        g = torch.Generator().manual_seed(rows + n_out)
+        dy, x = torch.randn(rows, n_out, generator=g) * 0.1, torch.randn(rows, k_in, generator=g)
+        dw, db = ops.linear_wgrad(dev(dy), dev(x), with_bias_grad=True)
+        close(dw, dy.t() @ x, f"dma wgrad {rows}", rtol=3e-4)
+        close(db, dy.sum(0), f"dma bias grad {rows}", rtol=3e-4)
+    assert _lib.load().dkd_gemm_f32_splits(200, 136, 16384) > 1
 
 
 def test_gemm_epilogues(ops):
