@@ -261,11 +261,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 }
 
 // out[g][n] = scale * sum_p ws[g][p][n]: 32 column lanes x 8 split lanes per block (grid: column chunks x groups)
+// (grid.z = result planes: the two planes of DKD_RED_DOT_SUM / DOTGELU_SUM are folded by ONE launch)
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int groups,
                                                               int nsplit, int N, float scale) {
     __shared__ float red[256];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + cl, g = blockIdx.y;
+    ws += (long)blockIdx.z * groups * nsplit * N;
+    out += (long)blockIdx.z * groups * N;
     float s0 = 0.f, s1 = 0.f;
     if (n < N) {
         const float* w = ws + (long)g * nsplit * N + n;
@@ -427,15 +430,9 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
 #undef DKD_CR
     DKD_LAUNCH_CHECK();
     if (ns > 1) {
-        const long total = (long)groups * N;
-        const dim3 fgrid((N + 31) / 32, groups);
+        const dim3 fgrid((N + 31) / 32, groups, two ? 2 : 1);
         hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale);
         DKD_LAUNCH_CHECK();
-        if (two) {
-            hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws + (long)groups * ns * N, out + total, groups, ns,
-                               N, scale);
-            DKD_LAUNCH_CHECK();
-        }
     }
     return DKD_OK;
 }
