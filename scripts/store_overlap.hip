@@ -1,0 +1,81 @@
+// Do memory operations between MFMA phases slow the MFMA phases of the OTHER waves of a CU?  Each wave: `tiles` x { 4 * nm
+// register-only MFMAs, then four 16-byte-per-lane memory instructions }.  MODE 1 = MFMAs only, 2 = memory only, 3 = both.
+// PAT 0: stores in the GEMM epilogue's pattern (16 rows x 64 B per wave-instruction), streaming (302 MB to HBM);
+// PAT 1: the same stores, every tile of a block onto the same 16 KB (L2 hits, no HBM traffic); PAT 2: loads instead of stores;
+// PAT 3: non-temporal stores; PAT 4: stores cycling within 32 MB (tile index modulo 1); PAT 5: 1 KiB contiguous per instruction.
+// 2048 workgroups of 4 waves = 8 waves per SIMD, all resident: the residency of the 64x64 GEMM.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int MODE, int PAT, int STAG = 0>
+__global__ __launch_bounds__(256) void k(float* out, int tiles, int nm, float a0, long stride_tile, unsigned long long* clk = nullptr) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float a = a0 + threadIdx.x * 1e-3f, b = a0 * 0.5f + threadIdx.x * 2e-3f;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, i16 = lane & 15;
+    float extra = 0.f;
+    // STAG: the eight co-resident workgroups of a CU start 1/8 of a tile time apart (all waves otherwise march in lockstep:
+    // everybody multiplies, then everybody touches memory)
+    if (STAG) for (int d = 0; d < (int)((blockIdx.x >> 8) & 7) * nm / 8; ++d) __builtin_amdgcn_s_sleep(16);
+    for (int t = 0; t < tiles; ++t) {
+        if (MODE & 1)
+            for (int it = 0; it < nm; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        if (MODE & 2) {
+            float* base = PAT == 4 ? out + ((long)blockIdx.x + (t & 0) * 0) * stride_tile + (long)(t % 1) * stride_tile
+                                   : out + ((long)blockIdx.x * tiles + (PAT == 1 ? 0 : t)) * stride_tile;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (wid >> 1) * 32 + (i >> 1) * 16 + i16, n = (wid & 1) * 32 + (i & 1) * 16 + 4 * g;
+                if (PAT == 2) { const float4 r = *reinterpret_cast<const float4*>(base + m * 64 + n); extra += r.x; }
+                else if (PAT == 3) __builtin_nontemporal_store(f32x4{a + t, b, a, b + i}, reinterpret_cast<f32x4*>(base + m * 64 + n));
+                else if (PAT == 5) *reinterpret_cast<float4*>(base + (wid * 4 + i) * 256 + lane * 4) = make_float4(a + t, b, a, b + i);
+                else *reinterpret_cast<float4*>(base + m * 64 + n) = make_float4(a + t, b, a, b + i);
+            }
+        }
+    }
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + extra == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = 1.f;  // keeps the MFMAs live
+    if (clk && threadIdx.x == 0 && blockIdx.x == 777) {  // shader clock: cycle counter against the 100 MHz real-time counter
+        clk[0] = __builtin_readcyclecounter() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+template <int PAT>
+void run(float* out, int blocks, int tiles, long stride_tile, hipEvent_t e0, hipEvent_t e1) {
+    for (int nm : {24}) {
+        float ms[4] = {0, 0, 0, 0};
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0); hipLaunchKernelGGL((k<1, PAT>), dim3(blocks), dim3(256), 0, 0, out, tiles, nm, 0.5f, stride_tile); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms[1], e0, e1);
+            (void)hipEventRecord(e0); hipLaunchKernelGGL((k<2, PAT>), dim3(blocks), dim3(256), 0, 0, out, tiles, nm, 0.5f, stride_tile); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms[2], e0, e1);
+            (void)hipEventRecord(e0); hipLaunchKernelGGL((k<3, PAT>), dim3(blocks), dim3(256), 0, 0, out, tiles, nm, 0.5f, stride_tile); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms[3], e0, e1);
+            (void)hipEventRecord(e0); hipLaunchKernelGGL((k<3, PAT, 1>), dim3(blocks), dim3(256), 0, 0, out, tiles, nm, 0.5f, stride_tile); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms[0], e0, e1);
+        }
+        printf("pattern %d, %3d MFMAs per wave-tile: mfma only %.1f us, memory only %.1f us, both %.1f us, both staggered %.1f us  (sum %.1f, max %.1f)\n", PAT, 4 * nm,
+               ms[1] * 1e3, ms[2] * 1e3, ms[3] * 1e3, ms[0] * 1e3, (ms[1] + ms[2]) * 1e3, (ms[1] > ms[2] ? ms[1] : ms[2]) * 1e3);
+    }
+}
+int main() {
+    const int blocks = 2048, tiles = 9;
+    const long stride_tile = 64 * 64;
+    float* out; (void)hipMalloc(&out, (size_t)blocks * tiles * stride_tile * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    unsigned long long *clk, h[2];
+    (void)hipMalloc(&clk, 16);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL((k<1, 0>), dim3(blocks), dim3(256), 0, 0, out, tiles, 96, 0.5f, stride_tile, clk);
+        (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        if (rep == 2) printf("MFMA only      : %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
+        hipLaunchKernelGGL((k<3, 0>), dim3(blocks), dim3(256), 0, 0, out, tiles, 96, 0.5f, stride_tile, clk);
+        (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        if (rep == 2) printf("MFMA + stores  : %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
+        hipLaunchKernelGGL((k<3, 1>), dim3(blocks), dim3(256), 0, 0, out, tiles, 96, 0.5f, stride_tile, clk);
+        (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        if (rep == 2) printf("MFMA + L2 stores: %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
+    }
+    run<0>(out, blocks, tiles, stride_tile, e0, e1);
+    run<3>(out, blocks, tiles, stride_tile, e0, e1);
+    run<5>(out, blocks, tiles, stride_tile, e0, e1);
+    return 0;
+}
