@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, int nm, float a0
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
         if (MODE & 2) {
-            float* base = PAT == 4 ? out + ((long)blockIdx.x + (t & 0) * 0) * stride_tile + (long)(t % 1) * stride_tile
-                                   : out + ((long)blockIdx.x * tiles + (PAT == 1 ? 0 : t)) * stride_tile;
+            // PAT 4 / 6 / 7: a block cycles over 2 / 4 / 1 tiles: 64 / 128 / 32 MB footprint (MALL-resident, not L2-resident)
+            float* base = out + ((long)blockIdx.x * tiles + (PAT == 1 ? 0 : PAT == 4 ? t % 2 : PAT == 6 ? t % 4 : PAT == 7 ? 0 : t)) * stride_tile + (PAT == 7 ? (long)(t % 1) : 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = (wid >> 1) * 32 + (i >> 1) * 16 + i16, n = (wid & 1) * 32 + (i & 1) * 16 + 4 * g;
@@ -75,7 +75,8 @@ int main() {
         if (rep == 2) printf("MFMA + L2 stores: %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
     }
     run<0>(out, blocks, tiles, stride_tile, e0, e1);
-    run<3>(out, blocks, tiles, stride_tile, e0, e1);
-    run<5>(out, blocks, tiles, stride_tile, e0, e1);
+    run<1>(out, blocks, tiles, stride_tile, e0, e1);
+    run<4>(out, blocks, tiles, stride_tile, e0, e1);
+    run<6>(out, blocks, tiles, stride_tile, e0, e1);
     return 0;
 }
