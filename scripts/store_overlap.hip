@@ -31,6 +31,14 @@ __global__ __launch_bounds__(256) void k(float* out, int tiles, int nm, float a0
                 const int m = (wid >> 1) * 32 + (i >> 1) * 16 + i16, n = (wid & 1) * 32 + (i & 1) * 16 + 4 * g;
                 if (PAT == 2) { const float4 r = *reinterpret_cast<const float4*>(base + m * 64 + n); extra += r.x; }
                 else if (PAT == 3) __builtin_nontemporal_store(f32x4{a + t, b, a, b + i}, reinterpret_cast<f32x4*>(base + m * 64 + n));
+                else if (PAT >= 10) {  // cache-policy bits on the store: 10 = sc0, 11 = sc1, 12 = sc0 sc1, 13 = sc0 sc1 nt
+                    const f32x4 v = {a + t, b, a, b + i};
+                    float* dst = base + m * 64 + n;
+                    if (PAT == 10) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(dst), "v"(v) : "memory");
+                    if (PAT == 11) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+                    if (PAT == 12) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+                    if (PAT == 13) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(v) : "memory");
+                }
                 else if (PAT == 5) *reinterpret_cast<float4*>(base + (wid * 4 + i) * 256 + lane * 4) = make_float4(a + t, b, a, b + i);
                 else *reinterpret_cast<float4*>(base + m * 64 + n) = make_float4(a + t, b, a, b + i);
             }
@@ -75,8 +83,9 @@ int main() {
         if (rep == 2) printf("MFMA + L2 stores: %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
     }
     run<0>(out, blocks, tiles, stride_tile, e0, e1);
-    run<1>(out, blocks, tiles, stride_tile, e0, e1);
-    run<4>(out, blocks, tiles, stride_tile, e0, e1);
-    run<6>(out, blocks, tiles, stride_tile, e0, e1);
+    run<10>(out, blocks, tiles, stride_tile, e0, e1);
+    run<11>(out, blocks, tiles, stride_tile, e0, e1);
+    run<12>(out, blocks, tiles, stride_tile, e0, e1);
+    run<13>(out, blocks, tiles, stride_tile, e0, e1);
     return 0;
 }
