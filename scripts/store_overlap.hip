@@ -64,28 +64,31 @@ void run(float* out, int blocks, int tiles, long stride_tile, hipEvent_t e0, hip
                ms[1] * 1e3, ms[2] * 1e3, ms[3] * 1e3, ms[0] * 1e3, (ms[1] + ms[2]) * 1e3, (ms[1] > ms[2] ? ms[1] : ms[2]) * 1e3);
     }
 }
+template <int MODE, int PAT, int STAG>
+float timed(float* out, int blocks, int tiles, int nm, long stride_tile, hipEvent_t e0, hipEvent_t e1) {
+    float ms;
+    (void)hipEventRecord(e0); hipLaunchKernelGGL((k<MODE, PAT, STAG>), dim3(blocks), dim3(256), 0, 0, out, tiles, nm, 0.5f, stride_tile, nullptr); (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f;
+}
 int main() {
-    const int blocks = 2048, tiles = 9;
+    const int blocks = 2048, tiles = 9, nm = 24;
     const long stride_tile = 64 * 64;
     float* out; (void)hipMalloc(&out, (size_t)blocks * tiles * stride_tile * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    unsigned long long *clk, h[2];
-    (void)hipMalloc(&clk, 16);
-    for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL((k<1, 0>), dim3(blocks), dim3(256), 0, 0, out, tiles, 96, 0.5f, stride_tile, clk);
-        (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
-        if (rep == 2) printf("MFMA only      : %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
-        hipLaunchKernelGGL((k<3, 0>), dim3(blocks), dim3(256), 0, 0, out, tiles, 96, 0.5f, stride_tile, clk);
-        (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
-        if (rep == 2) printf("MFMA + stores  : %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
-        hipLaunchKernelGGL((k<3, 1>), dim3(blocks), dim3(256), 0, 0, out, tiles, 96, 0.5f, stride_tile, clk);
-        (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
-        if (rep == 2) printf("MFMA + L2 stores: %.0f MHz shader clock (%llu cycles in %.1f us)\n", h[0] / (h[1] / 100.0), h[0], h[1] / 100.0);
+    // what does the time of "MFMAs + streaming stores" depend on?  the kernel that ran before it:
+    for (int rep = 0; rep < 2; ++rep) {
+        float a = timed<1, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float b = timed<3, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float c = timed<3, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float d = timed<3, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float e = timed<2, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float f = timed<3, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float g = timed<1, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float h = timed<3, 0, 1>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float i = timed<3, 0, 1>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        float j = timed<3, 0, 0>(out, blocks, tiles, nm, stride_tile, e0, e1);
+        printf("mfma %.0f | both %.0f, both %.0f, both %.0f | stores %.0f | both %.0f | mfma %.0f | both-stag %.0f, both-stag %.0f | both %.0f\n", a, b, c, d, e, f, g, h, i, j);
     }
-    run<0>(out, blocks, tiles, stride_tile, e0, e1);
-    run<10>(out, blocks, tiles, stride_tile, e0, e1);
-    run<11>(out, blocks, tiles, stride_tile, e0, e1);
-    run<12>(out, blocks, tiles, stride_tile, e0, e1);
-    run<13>(out, blocks, tiles, stride_tile, e0, e1);
     return 0;
 }
