@@ -232,9 +232,11 @@ int dkd_clip_grad_f32(float* g, long n, const float* gnorm2, float max_norm, voi
  * 3x3 s2 + AvgPool2d(3,2,1) skip), :153-172 (channel concat).  Adjoints are gather-form (deterministic).
  * im2col_nhwc: rows[(b,oy,ox)][(ky,kx,c)] (weights permuted to [O][ky][kx][c]); inverse=1 writes dx = col2im(rows)
  *   into `x` (the adjoint).  im2col_nchw: first layer from the NCHW image, K order (c,ky,kx) zero-padded to Kp % 4 == 0.
- * dwconv3: depthwise 3x3 pad 1 stride s, tap-major weights [9][C]; w == NULL means every tap = 1/9, i.e.
- *   AvgPool2d(3, s, 1) with count_include_pad.  mode 0 forward, mode 1 dgrad (in = dy, out = dx; H,W are the
- *   INPUT extents in both modes).  wgrad writes partials [B*Ho][9][C] to be folded by dkd_colreduce_f32.
+ * dwconv3: depthwise 3x3 stride s, padding = dilation (1 for STDC; the MobileNetV2 depthwise stage,
+ *   models/backbones/mobilenet_v2.py:338-350, passes dilation 2/4 at output stride 8/16), tap-major weights [9][C];
+ *   w == NULL means every tap = 1/9, i.e. AvgPool2d(3, s, 1) with count_include_pad.  mode 0 forward, mode 1 dgrad
+ *   (in = dy, out = dx; H,W are the INPUT extents in both modes).  wgrad writes partials [B*Ho][9][C] to be folded
+ *   by dkd_colreduce_f32.
  * copy2d: dst[r*ldd + c] (+)= src[r*lds + c]: channel concat / slice of token-major tensors.
  */
 int dkd_im2col_nhwc_f32(const float* x, float* rows, int B, int H, int W, int C, int k, int stride, int pad, int inverse,
