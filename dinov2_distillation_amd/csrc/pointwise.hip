@@ -100,6 +100,12 @@ __global__ void window_permute_kernel(const float4* __restrict__ in, float4* __r
     }
 }
 
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float y) {
+    const float sg = sigmoid_f(y);
+    return sg * fmaf(y, 1.f - sg, 1.f);
+}
+
 // ---- BatchNorm (train mode) ------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, int N, float count,
@@ -122,8 +128,12 @@ __global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4
         const float4 x = z[i], mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
         float4 o = make_float4(g.x * (x.x - mu.x) * rs.x + b.x, g.y * (x.y - mu.y) * rs.y + b.y,
                                g.z * (x.z - mu.z) * rs.z + b.z, g.w * (x.w - mu.w) * rs.w + b.w);
-        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-        if (relu == 2) o = make_float4(fminf(o.x, 6.f), fminf(o.y, 6.f), fminf(o.z, 6.f), fminf(o.w, 6.f));  // ReLU6
+        if (relu == 3) {  // SiLU (DarkNet's Conv, models/backbones/darknet.py:47)
+            o = make_float4(o.x * sigmoid_f(o.x), o.y * sigmoid_f(o.y), o.z * sigmoid_f(o.z), o.w * sigmoid_f(o.w));
+        } else if (relu) {
+            o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+            if (relu == 2) o = make_float4(fminf(o.x, 6.f), fminf(o.y, 6.f), fminf(o.z, 6.f), fminf(o.w, 6.f));  // ReLU6
+        }
         if (pos) {
             const float4 p = pos[(r % period) * nv + c];
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
@@ -132,7 +142,7 @@ __global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4
     }
 }
 
-// dbn = dt * [0 < bn (< 6)] (bn recomputed), xhat = (z - mean) * rstd
+// dbn = dt * act'(bn) (bn recomputed; act' = [0 < bn (< 6)] for ReLU / ReLU6), xhat = (z - mean) * rstd
 __global__ void bn_bwd_prep_kernel(const float4* __restrict__ dt, const float4* __restrict__ z,
                                    const float4* __restrict__ mean, const float4* __restrict__ rstd,
                                    const float4* __restrict__ gamma, const float4* __restrict__ beta,
@@ -142,7 +152,10 @@ __global__ void bn_bwd_prep_kernel(const float4* __restrict__ dt, const float4* 
         const float4 x = z[i], mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c], d = dt[i];
         const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
         float4 o = d;
-        if (relu) {  // 1: ReLU, 2: ReLU6 (gradient 1 strictly inside (0, 6), as F.relu6 / hardtanh)
+        if (relu == 3) {  // SiLU: d/dy [y s(y)] = s (1 + y (1 - s))
+            const float4 y = make_float4(g.x * xh.x + b.x, g.y * xh.y + b.y, g.z * xh.z + b.z, g.w * xh.w + b.w);
+            o = make_float4(d.x * silu_grad_f(y.x), d.y * silu_grad_f(y.y), d.z * silu_grad_f(y.z), d.w * silu_grad_f(y.w));
+        } else if (relu) {  // 1: ReLU, 2: ReLU6 (gradient 1 strictly inside (0, 6), as F.relu6 / hardtanh)
             const float hi = relu == 2 ? 6.f : INFINITY;
             const float4 y = make_float4(g.x * xh.x + b.x, g.y * xh.y + b.y, g.z * xh.z + b.z, g.w * xh.w + b.w);
             o.x = y.x > 0.f && y.x < hi ? d.x : 0.f;

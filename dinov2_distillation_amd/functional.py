@@ -307,13 +307,15 @@ class ViTBlockFrozenFn(Function):
 
 # =====================================================================================================================
 def _bn_fwd_stats(z, bn_state, training):
-    """train: batch statistics (+ running update); eval: the running statistics (no update)"""
-    running_mean, running_var = bn_state
+    """train: batch statistics (+ running update); eval: the running statistics (no update).
+    bn_state = (running_mean, running_var[, momentum, eps]); nn.BatchNorm2d's defaults 0.1 / 1e-5 when omitted"""
+    running_mean, running_var = bn_state[:2]
+    momentum, eps = bn_state[2:] if len(bn_state) == 4 else (0.1, 1e-5)
     if training:
-        return ops.bn_stats(z, running_mean, running_var, 0.1, 1e-5)
+        return ops.bn_stats(z, running_mean, running_var, momentum, eps)
     rstd = torch.empty_like(running_var)
     ops.check(ops._lib.load().dkd_bn_finalize_f32(ops._p(running_mean), ops._p(running_var), ops._p(rstd), None, None,
-                                                  running_var.numel(), 2, 0.0, 1e-5, ops._stream()), "dkd_bn_finalize_f32")
+                                                  running_var.numel(), 2, 0.0, eps, ops._stream()), "dkd_bn_finalize_f32")
     return running_mean, rstd
 
 
@@ -471,8 +473,9 @@ class KDLossFn(Function):
 # =====================================================================================================================
 # STDC / ResNet building blocks (NHWC)
 class ConvBNActFn(Function):
-    """conv(k in {1,3,7}, stride, pad=k//2, no bias) -> train-mode BatchNorm2d -> optional ReLU
-    (models/backbones/stdc.py:8-24 ``ConvX``).  src_nchw: the input is the NCHW image (first layer)."""
+    """conv(k in {1,3,7}, stride, pad=k//2, no bias) -> train-mode BatchNorm2d -> optional activation
+    (models/backbones/stdc.py:8-24 ``ConvX``; ``relu`` = 0 none / 1 ReLU / 2 ReLU6 / 3 SiLU, the last for
+    models/backbones/darknet.py:44-64 ``Conv``).  src_nchw: the input is the NCHW image (first layer)."""
 
     @staticmethod
     def forward(ctx, x, w, bn_w, bn_b, bn_state, k, stride, relu, training, src_nchw):
@@ -610,6 +613,26 @@ class ConcatChannelsFn(Function):
             outs.append(g)
             off += c
         return tuple(outs)
+
+
+class SliceChannelsFn(Function):
+    """x[:, off:off+c] of an NCHW map == a dense copy of a channel slice of the NHWC rows (the second half of
+    ``cv1(x).chunk(2, 1)``, models/backbones/darknet.py:103).  Backward: zeros outside the slice."""
+
+    @staticmethod
+    def forward(ctx, x, off, c):
+        x = _c(x)
+        B, H, W, Ct = x.shape
+        ctx.meta = (off, c, tuple(x.shape))
+        out = torch.empty((B, H, W, c), dtype=F32, device=x.device)
+        return ops.copy2d(x.view(-1)[off:], Ct, out, c, B * H * W, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        off, c, shape = ctx.meta
+        dx = torch.zeros(shape, dtype=F32, device=dy.device)
+        ops.copy2d(_c(dy), c, dx.view(-1)[off:], shape[3], shape[0] * shape[1] * shape[2], c)
+        return dx, None, None
 
 
 class MaxPool3Fn(Function):

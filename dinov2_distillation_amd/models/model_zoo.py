@@ -6,6 +6,8 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .convnext import D2ConvNextV2
+from .darknet import VERSIONS as DARKNET_VERSIONS
+from .darknet import DarkNet
 from .mit import MultiscaleImageTransformer
 from .mobilenet_v2 import D2MobileNetV2
 from .presnet import D2Presnet
@@ -163,6 +165,32 @@ class PResNetWrapper(nn.Module):
         return self._out_feature_channels
 
 
+class DarkNetWrapper(nn.Module):
+    """models/wrappers/darknet_wrapper.py:16-30,55-76: DarkNet(depth, width) of yolov8{n,s,m,l,x}"""
+
+    def __init__(self, model_name="darknet_s", out_features=None):
+        super().__init__()
+        version = model_name[-1]
+        if model_name not in [f"darknet_{v}" for v in DARKNET_VERSIONS]:
+            raise NotImplementedError(f"There is not a DarkNet config called {model_name}.")
+        depth, width = DARKNET_VERSIONS[version]
+        self._out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", f"yolov8{version}.pkl")
+        self.model = DarkNet(depth=depth, width=width)
+        self._out_feature_channels = {f: self.model._out_feature_channels[f] for f in self._out_features}
+
+    def get_features(self, x):
+        return self.model(x)
+
+    def get_features_nhwc(self, x):
+        feats = self.model.forward_features_nhwc(x)
+        return {k: v for k, v in feats.items() if k in self._out_features}
+
+    @property
+    def feature_channels(self):
+        return self._out_feature_channels
+
+
 MOBILENET_V2_CONFIGS = {  # models/wrappers/mobilenet_v2_wrapper.py:8-21
     "mobilenet_v2": dict(strides=(1, 2, 2, 2, 1, 2, 1), dilations=(1, 1, 1, 1, 1, 1, 1)),
     "mobilenet_v2_os8": dict(strides=(1, 2, 2, 1, 1, 1, 1), dilations=(1, 1, 1, 2, 2, 4, 4)),
@@ -228,7 +256,7 @@ class ModelWrapper(nn.Module):
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
     MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper, "swin": D2SwinTransformerWrapper,
-                 "presnet": PResNetWrapper, "mobilenet_v2": MobileNetV2Wrapper, "mit": MITWrapper}
+                 "presnet": PResNetWrapper, "mobilenet_v2": MobileNetV2Wrapper, "mit": MITWrapper, "darknet": DarkNetWrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

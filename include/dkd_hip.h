@@ -129,7 +129,8 @@ int dkd_sub_group_vec_f32(const float* x, const float* vec, float* out, long row
 /* train-mode BatchNorm2d of the projector input (losses/scalekd.py:199-201,238): statistics come from
  * dkd_colreduce_f32 (mean, then centred variance); finalize makes rstd and updates the running stats
  * (momentum 0.1, unbiased running_var); apply fuses BN + activation + pos_embed add (pos is [period, N] token-major).
- * `relu`: 0 = none, 1 = ReLU, 2 = ReLU6 (MobileNetV2, models/backbones/mobilenet_v2.py:421: F.relu6; gradient inside (0, 6)). */
+ * `relu`: 0 = none, 1 = ReLU, 2 = ReLU6 (MobileNetV2, models/backbones/mobilenet_v2.py:421: F.relu6; gradient inside (0, 6)),
+ * 3 = SiLU (DarkNet's Conv, models/backbones/darknet.py:47,62-64; the backward recomputes the BN output from z). */
 int dkd_bn_finalize_f32(const float* mean, const float* var, float* rstd, float* running_mean, float* running_var,
                         int N, long count, float momentum, float eps, void* stream);
 int dkd_bn_act_pos_fwd_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,

@@ -19,6 +19,7 @@ CONFIGS = {
     "5": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24), teacher_precision="bf16"),
     "presnet50": dict(teacher="dinov2_vits14", student="presnet_50", crop=224, batch=64, heads=(16, 24)),
     "mobilenet_v2": dict(teacher="dinov2_vits14", student="mobilenet_v2", crop=224, batch=64, heads=(16, 24)),
+    "darknet_m": dict(teacher="dinov2_vits14", student="darknet_m", crop=224, batch=64, heads=(16, 24)),
     "mit_b2": dict(teacher="dinov2_vits14", student="mit_b2", crop=224, batch=64, heads=(16, 24)),
     "5f32": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24)),
 }

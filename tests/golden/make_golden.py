@@ -383,6 +383,40 @@ def _gen_mobilenet_v2(mb, pr_, name, strides, dilations):
     _save(name, **arrays)
 
 
+def gen_darknet():
+    """the reference's own DarkNet (models/backbones/darknet.py needs nothing but torch) at the "n" widths of
+    darknet_wrapper.py:9 (C2f depths 1/2/2/1), batch 4 at 96x96: res5 is 3x3, so the deepest BatchNorm averages over 36 samples"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import param_recipe as pr_
+    dk = _load_file("ref_darknet", "models/backbones/darknet.py")
+    depth, width = [1, 2, 2, 1], [3, 16, 32, 64, 128, 256]
+    net = dk.DarkNet(depth, width)
+    state = pr_.seeded_state({k: v.shape for k, v in net.state_dict().items()}, seed=58)
+    net.load_state_dict(state, strict=True)
+    net.train()
+    g = torch.Generator().manual_seed(58)
+    x = torch.randn(4, 3, 96, 96, generator=g).requires_grad_(True)
+    arrays = {"in/x": _np(x), "meta/seed": np.array([58]), "meta/param_checksum": np.array([pr_.checksum(state)]),
+              "meta/depth": np.array(depth), "meta/width": np.array(width)}
+    feats = net(x)
+    loss = 0
+    for k in ("res2", "res3"):
+        arrays["out_digest/" + k] = _np(pr_.digest(feats[k]))
+    for k in ("res4", "res5"):
+        arrays["out/" + k] = _np(feats[k])
+        ct = torch.randn(feats[k].shape, generator=g)
+        arrays["in/cotangent_" + k] = _np(ct)
+        loss = loss + (feats[k] * ct).sum()
+    loss.backward()
+    arrays["grad/x"] = _np(x.grad)
+    for k, p_ in net.named_parameters():
+        arrays["pgrad_digest/" + k] = _np(pr_.digest(p_.grad))
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            arrays["after/" + k] = _np(v)
+    _save("darknet_n_small", **arrays)
+
+
 def gen_mit():
     """the reference's own MultiscaleImageTransformer, configured as MITWrapper("mit_b0") does (mit_wrapper.py:76-86): heads
     1/2/4/8 (head dims 32, 32, 40, 32), sr ratios 8/4/2/1, every dropout rate 0.  timm is absent: DropPath (identity at rate 0),
@@ -547,6 +581,6 @@ def gen_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "presnet", "mobilenet_v2", "mit", "swin", "step"]
+    which = sys.argv[1:] or ["scalekd", "loss_tail", "convnext", "stdc", "resnet", "presnet", "mobilenet_v2", "darknet", "mit", "swin", "step"]
     for w in which:
         globals()["gen_" + w]()

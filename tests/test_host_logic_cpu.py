@@ -59,7 +59,14 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(ValueError):   # 24 does not divide 1024
         AttentionProjector(8, 1024, (2, 2), 1024, num_heads=24)
     with pytest.raises(NotImplementedError):
-        ModelWrapper("darknet_s", [16, 16])   # a family without an MI355X backbone fails loudly
+        ModelWrapper("efficientnet_b0", [16, 16])   # a family without an MI355X backbone fails loudly
+    dk = ModelWrapper("darknet_s", [16, 16])   # counts from the reference's DarkNet(*versions["s"]) in this container
+    assert sum(p.numel() for p in dk.parameters()) == 4_422_816 and len(dk.model.model.state_dict()) == 150
+    assert dk.feature_channels == {"res5": 512, "res4": 256} and dk.model.ckpt_dir.endswith("yolov8s.pkl")
+    assert "model.model.p3.1.m.1.cv2.bn.running_var" in dk.state_dict() and dk.model.model.p2[0].bn.momentum == 0.03
+    assert sum(p.numel() for p in ModelWrapper("darknet_m", [16, 16]).parameters()) == 11_024_688
+    with pytest.raises(NotImplementedError, match="DarkNet config"):
+        ModelWrapper("darknet_q", [16, 16])
     mit = ModelWrapper("mit_b0", [16, 16])    # counts from the reference's MultiscaleImageTransformer in this container
     assert sum(p.numel() for p in mit.parameters()) == 3_319_392 and len(mit.model.model.state_dict()) == 176
     assert mit.feature_channels == {"res2": 32, "res3": 64, "res4": 160, "res5": 256}

@@ -464,6 +464,30 @@ def test_bn_relu6(ops):
     close(db, be.grad, "bn relu6 dbeta", rtol=2e-4)
 
 
+def test_bn_silu(ops):
+    """BatchNorm(eps 1e-3, momentum 0.03) + SiLU (darknet.py:44-64), forward, running statistics and backward"""
+    g = torch.Generator().manual_seed(8)
+    rows, C = 500, 64
+    z = (2.0 * torch.randn(rows, C, generator=g) + 0.5).requires_grad_(True)
+    ga = (1.0 + 0.5 * torch.randn(C, generator=g)).requires_grad_(True)
+    be = (0.5 * torch.randn(C, generator=g)).requires_grad_(True)
+    rm, rv = 0.1 * torch.randn(C, generator=g), 1.0 + torch.rand(C, generator=g)
+    rm_d, rv_d = dev(rm), dev(rv)
+    y = F.silu(F.batch_norm(z, rm, rv, ga, be, True, 0.03, 1e-3))
+    dy = torch.randn(rows, C, generator=g)
+    y.backward(dy)
+    zd = dev(z.detach())
+    mean, rstd = ops.bn_stats(zd, rm_d, rv_d, 0.03, 1e-3)
+    close(rm_d, rm, "running mean (momentum 0.03)")
+    close(rv_d, rv, "running var (momentum 0.03)")
+    out = ops.bn_act_pos_fwd(zd, mean, rstd, dev(ga.detach()), dev(be.detach()), None, relu=3)
+    close(out, y, "bn silu fwd")
+    dz, dg, db = ops.bn_bwd(dev(dy), zd, mean, rstd, dev(ga.detach()), dev(be.detach()), relu=3)
+    close(dz, z.grad, "bn silu dz", rtol=2e-4)
+    close(dg, ga.grad, "bn silu dgamma", rtol=2e-4)
+    close(db, be.grad, "bn silu dbeta", rtol=2e-4)
+
+
 @pytest.mark.parametrize("B,H,C,stride,dil", [(2, 12, 96, 1, 1), (2, 13, 32, 2, 1), (1, 7, 960, 1, 1), (3, 14, 64, 2, 1),
                                                (2, 12, 64, 1, 2), (2, 9, 32, 1, 4), (1, 11, 96, 2, 2)])
 def test_dwconv3(ops, B, H, C, stride, dil):

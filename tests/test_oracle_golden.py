@@ -297,6 +297,42 @@ def test_mobilenet_v2(golden_dir, name, strides, dilations):
             close(p[k[6:]], v, k)
 
 
+def test_darknet(golden_dir):
+    """oracle/darknet_oracle.py against the reference's own DarkNet at the "n" widths (weights: tests/golden/param_recipe.py);
+    the build's DarkNet must expose exactly the reference's state-dict keys and shapes for the recipe checksum to match"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import darknet_oracle as do
+    from dinov2_distillation_amd.models.darknet import DarkNet
+    g = load(golden_dir, "darknet_n_small")
+    depth, width = [int(v) for v in g["meta/depth"]], [int(v) for v in g["meta/width"]]
+    shapes = {k: v.shape for k, v in DarkNet(depth, width).state_dict().items()}
+    p = pr.seeded_state(shapes, int(g["meta/seed"][0]))
+    assert abs(pr.checksum(p) - float(g["meta/param_checksum"][0])) < 1e-6 * max(1.0, abs(float(g["meta/param_checksum"][0])))
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = g["in/x"].clone().requires_grad_(True)
+    feats = do.forward(p, x, depth)
+    loss = 0
+    for k in ("res2", "res3"):
+        close(pr.digest(feats[k]), g["out_digest/" + k], k + " (digest)", rtol=1e-3)
+    for k in ("res4", "res5"):
+        close(feats[k], g["out/" + k], k)
+        loss = loss + (feats[k] * g["in/cotangent_" + k]).sum()
+    loss.backward()
+    close(x.grad, g["grad/x"], "grad x", rtol=5e-4)
+    n = 0
+    for k, v in g.items():
+        if k.startswith("pgrad_digest/"):
+            close(pr.digest(p[k[13:]].grad), v, k, rtol=1e-3, atol=1e-5)
+            n += 1
+        if k.startswith("after/"):
+            close(p[k[6:]], v, k)
+    assert n == sum(1 for k in shapes if "running" not in k and "num_batches" not in k)
+
+
 def test_mit(golden_dir):
     """oracle/mit_oracle.py against the reference's own MultiscaleImageTransformer configured as MITWrapper("mit_b0")"""
     import sys
