@@ -535,8 +535,8 @@ def test_darknet_student_runs_full_step():
     from dinov2_distillation_amd.trainer import DistillationStepper
     st = DistillationStepper(student="darknet_s")
     x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
-    l0 = float(st.step(x))
-    l1 = float(st.step(x))
+    l0 = float(st.step(x).detach())
+    l1 = float(st.step(x).detach())
     assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
 
 
@@ -680,8 +680,8 @@ def test_presnet18_student_runs_full_step():
     from dinov2_distillation_amd.trainer import DistillationStepper
     st = DistillationStepper(student="presnet_18")
     x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
-    l0 = float(st.step(x))
-    l1 = float(st.step(x))
+    l0 = float(st.step(x).detach())
+    l1 = float(st.step(x).detach())
     assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
 
 
@@ -690,8 +690,8 @@ def test_resnet50_student_runs_full_step():
     from dinov2_distillation_amd.trainer import DistillationStepper
     st = DistillationStepper(teacher="dinov2_vitb14", student="resnet_50", heads=(16, 24))
     x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
-    l0 = float(st.step(x))
-    l1 = float(st.step(x))
+    l0 = float(st.step(x).detach())
+    l1 = float(st.step(x).detach())
     assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
 
 
