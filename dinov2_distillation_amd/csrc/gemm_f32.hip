@@ -868,8 +868,77 @@ static int epilogue_vec_ok(const dkd_gemm_args* g) {
     return vec;
 }
 
+// Split-parallel fold for MANY slabs (the K = 12544 ... 200704 weight gradients run 32 ... 128 of them over a small output):
+// the kernel above walks a quad's slabs in one thread, four loads at a time - 16 to 32 dependent load rounds on a grid of a few
+// dozen workgroups (23 us at 64 slabs, 43 us at 128: latency, not bytes).  Here G threads own one output float4, thread g sums
+// the slabs g, g + G, g + 2G, ... (four in flight), the G partial sums meet in LDS and are added in the fixed order 0 .. G-1:
+// deterministic, 1 (64 slabs) / 2 (128) load rounds deep, G times the workgroups.  The fused bias-gradient row sums ride along as
+// pseudo quads behind the M * N / 4 real ones.
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_par_kernel(const float* __restrict__ ws, int splits, int M, int N, float* C,
+                                                                long ldc, Epilogue epi, float* __restrict__ rowsum) {
+    constexpr int QB = 256 / G;
+    __shared__ float4 part[G][QB];
+    const long total = (long)M * N, tq = total >> 2;
+    const long mq = rowsum ? (M + 3) / 4 : 0;
+    const int g = threadIdx.x / QB, ql = threadIdx.x % QB;
+    const long q = (long)blockIdx.x * QB + ql;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < tq) {
+        const float4* p = reinterpret_cast<const float4*>(ws) + q;
+        int z = g;
+        for (; z + 3 * G < splits; z += 4 * G) {
+            const float4 a = p[(long)z * tq], b = p[(long)(z + G) * tq], c = p[(long)(z + 2 * G) * tq], d = p[(long)(z + 3 * G) * tq];
+            s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+            s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; z < splits; z += G) {
+            const float4 a = p[(long)z * tq];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    } else if (q < tq + mq) {
+        const int m0 = (int)(q - tq) * 4;
+        const float* r = ws + (long)splits * total + m0;
+        for (int z = g; z < splits; z += G) {
+            const float* rz = r + (long)z * M;
+            s.x += rz[0];
+            if (m0 + 1 < M) s.y += rz[1];
+            if (m0 + 2 < M) s.z += rz[2];
+            if (m0 + 3 < M) s.w += rz[3];
+        }
+    }
+    part[g][ql] = s;
+    __syncthreads();
+    if (g == 0 && q < tq + mq) {
+#pragma unroll
+        for (int k = 1; k < G; ++k) {
+            const float4 a = part[k][ql];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        if (q < tq) {
+            const long i = q << 2;
+            epilogue_store4(epi, C, ldc, (int)(i / N), (int)(i % N), N, f32x4{s.x, s.y, s.z, s.w}, true);
+        } else {
+            const int m0 = (int)(q - tq) * 4;
+            rowsum[m0] = s.x * epi.alpha;
+            if (m0 + 1 < M) rowsum[m0 + 1] = s.y * epi.alpha;
+            if (m0 + 2 < M) rowsum[m0 + 2] = s.z * epi.alpha;
+            if (m0 + 3 < M) rowsum[m0 + 3] = s.w * epi.alpha;
+        }
+    }
+}
+
 static int launch_splitk_reduce(const dkd_gemm_args* g, const Epilogue& epi, int splits, hipStream_t st) {
     const int vec = epilogue_vec_ok(g) && dkd_aligned16(g->workspace);
+    static const bool serial_fold = getenv("DKD_SPLITK_SERIAL_FOLD") != nullptr;  // A/B: always the one-thread-per-quad fold
+    if (vec && splits >= 32 && !serial_fold && ((long)g->M * g->N & 3) == 0) {
+        constexpr int G = 16, QB = 256 / G;
+        const long items = (long)g->M * g->N / 4 + (g->rowsum ? (g->M + 3) / 4 : 0);
+        hipLaunchKernelGGL(splitk_reduce_par_kernel<G>, dim3((unsigned)((items + QB - 1) / QB)), dim3(256), 0, st, g->workspace, splits,
+                           g->M, g->N, g->C, g->ldc, epi, g->rowsum);
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
     const long work = (long)g->M * g->N / (vec ? 4 : 1);
     const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g->workspace, splits, g->M, g->N, g->C, g->ldc, epi,

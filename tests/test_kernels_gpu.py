@@ -318,9 +318,11 @@ def test_grn(ops):
     close(dbe, be.grad.reshape(C), "grn dbeta from preact", rtol=2e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(20000, 96, 384), (3000, 384, 1536), (512, 768, 192), (200704, 96, 384)])
+@pytest.mark.parametrize("M,N,K", [(20000, 96, 384), (3000, 384, 1536), (512, 768, 192), (200704, 96, 384), (200704, 384, 96),
+                                   (50176, 768, 192), (16384, 384, 384)])
 def test_wgrad_with_fused_bias_grad(ops, M, N, K):
-    """dW = dy^T x and db = sum_rows dy from ONE launch (rowsum of the A operand), incl. the split-K path"""
+    """dW = dy^T x and db = sum_rows dy from ONE launch (rowsum of the A operand), incl. the split-K path with few slabs (one
+    thread folds a quad) and with 32 ... 128 slabs (16 threads per quad, partial sums through LDS)"""
     g = torch.Generator().manual_seed(M)
     dy, x = torch.randn(M, K, generator=g) * 0.1, torch.randn(M, N, generator=g)
     dw, db = ops.linear_wgrad(dev(dy), dev(x), True)
