@@ -168,6 +168,7 @@ class PatchConvFn(Function):
 # =====================================================================================================================
 CONVNEXT_KEEP_GELU_OUT = False
 DWCONV_WGRAD_ON_SIDE_STREAM = True
+CONVNEXT_WGRAD2_FIRST = True  # False: both linears' weight gradients after the GRN backward, one fork (A/B: scripts/ab_step.py, +0.25 ms)
 
 
 class ConvNeXtBlockFn(Function):
@@ -208,6 +209,11 @@ class ConvNeXtBlockFn(Function):
         dout = _c(dout)
         do2 = dout.reshape(M, C)
         pw1, pb1, pw2, pb2 = ctx.params
+        if CONVNEXT_WGRAD2_FIRST:
+            # dW2 needs nothing but the incoming gradient and the saved GRN output: on the weight-gradient stream from the start
+            # of the block it runs beside the dgrad GEMM and then under the HBM-bound GRN/GELU backward kernels of the main chain
+            # (forking after the dgrad launch instead - so that it starts with the GRN kernels - measures the same)
+            dw2, db2 = wgrad(do2, y, pw2, pb2)
         dy = ops.dgrad(do2, w2)  # [M, 4C]
         p_dww, p_dwb, p_lnw, p_lnb, p_gg, p_gb = ctx.small
         o_dww, o_dwb, o_lnw, o_lnb, o_gg, o_gb = direct(*ctx.small)
@@ -215,7 +221,8 @@ class ConvNeXtBlockFn(Function):
                                               None if o_gg is None else o_gg.view(-1), None if o_gb is None else o_gb.view(-1))
         n2 = n.reshape(M, C)
         dw1, db1 = wgrad(dh, n2, pw1, pb1)
-        dw2, db2 = wgrad(do2, y, pw2, pb2, fork=False)  # one fork of the weight-gradient stream for both linears
+        if not CONVNEXT_WGRAD2_FIRST:
+            dw2, db2 = wgrad(do2, y, pw2, pb2, fork=False)  # one fork of the weight-gradient stream for both linears
         dn = ops.dgrad(dh, w1)  # [M, C]
         dd, dln_w, dln_b = ops.layernorm_bwd(dn, d.reshape(M, C), mean, rstd, ln_w, dg_out=o_lnw, db_out=o_lnb)
         dd = dd.reshape(B, H, W, C)
