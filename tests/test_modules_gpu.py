@@ -519,7 +519,7 @@ def test_darknet_against_reference_golden(golden_dir):
     f64 = do.forward(p64, g["in/x"].double(), depth)
     sum((f64[k] * g["in/cotangent_" + k].double()).sum() for k in ("res4", "res5")).backward()
     sd = dict(net.named_parameters())
-    n = 0
+    n, rows = 0, []
     for k, v in g.items():
         if k.startswith("pgrad_digest/"):
             name = k[13:]
@@ -528,12 +528,15 @@ def test_darknet_against_reference_golden(golden_dir):
             v = v.double()
             for sl, what in ((slice(0, 1), "norm"), (slice(2, None), "values")):
                 scale = t[sl].abs().max().item() + 1e-30
-                e_ours, e_ref = (d[sl] - t[sl]).abs().max().item(), (v[sl] - t[sl]).abs().max().item()
-                assert e_ours <= max(2e-3 * scale, 4 * e_ref) + 1e-7, f"{k} ({what}): ours {e_ours:.3e}, reference {e_ref:.3e}, scale {scale:.3e}"
+                rows.append((k, what, (d[sl] - t[sl]).abs().max().item(), (v[sl] - t[sl]).abs().max().item(), scale))
             n += 1
         if k.startswith("after/"):
             close(net.state_dict()[k[6:]], v, k)
     assert n == len(sd)
+    worst_ref = max(e_ref / scale for _, _, _, e_ref, scale in rows)   # (as in the PResNet test: the reference's own worst case)
+    for k, what, e_ours, e_ref, scale in rows:
+        assert e_ours <= max(2e-3 * scale, 4 * e_ref, 2 * worst_ref * scale) + 1e-7, \
+            f"{k} ({what}): ours {e_ours:.3e}, reference {e_ref:.3e}, scale {scale:.3e}, reference's worst {worst_ref:.2e}"
 
 
 def test_darknet_student_runs_full_step():
