@@ -1070,7 +1070,7 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
 // the 256 CUs more evenly.  Exceptions: N = 96 likes a single 64x96 column tile (BK = 32 for the weight-gradient layout),
 // and grids under 3 tiles per CU like 32x64.
 // The 32x32x2 kernels stay reachable through `variant` (1..5) for A/B measurements.
-enum { CFG_128x128_8W = 2, CFG_64x128_4W = 3, CFG_128x96_4W = 4, V2_64x64 = 44, V2_64x96 = 43, V2_64x96_BK32 = 55, V2_32x64 = 52,
+enum { CFG_128x128_8W = 2, CFG_64x128_4W = 3, CFG_128x96_4W = 4, V2_64x64 = 44, V2_64x96 = 43, V2_64x96_BK32 = 55, V2_96x64_BK32 = 56, V2_32x64 = 52,
        DMA_64x64_BK32 = 101 };
 
 // LDS-DMA staging: measured +1..14 % over the register-staged 64x64 kernel in every layout once the reduction is long
@@ -1081,6 +1081,8 @@ static bool dma_shape(int N, int K, int a_layout, int b_layout) {
 static int pick_cfg(int M, int N, int K, int a_layout, int b_layout, int variant) {
     if (variant > 0) return variant;
     if (N == 96) return a_layout == 1 && b_layout == 1 ? V2_64x96_BK32 : V2_64x96;
+    // the mirror image: a 96-row weight gradient (pwconv2 of the first ConvNeXt stage) wastes a quarter of two 64-row tiles
+    if (M == 96 && N % 64 == 0 && a_layout == 1 && b_layout == 1) return V2_96x64_BK32;
     if (dma_shape(N, K, a_layout, b_layout)) return DMA_64x64_BK32;
     const long t64 = (long)dkd_cdiv(M, 64) * dkd_cdiv(N, 64);
     return t64 < 768 && !(a_layout == 1 && b_layout == 1) ? V2_32x64 : V2_64x64;
@@ -1090,6 +1092,7 @@ static void cfg_tile(int cfg, int* bm, int* bn) {
         case 1: case CFG_128x128_8W: *bm = 128; *bn = 128; break;
         case CFG_128x96_4W: *bm = 128; *bn = 96; break;
         case 43: case 55: *bm = 64; *bn = 96; break;
+        case 56: *bm = 96; *bn = 64; break;
         case 44: case 100: case 101: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
         default: *bm = 64; *bn = 128; break;  // 3, 5
@@ -1204,6 +1207,7 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 134: return launch_dma<2, 2, 2, 2, 32, 18>(g, epi, splits, kchunk, st);  // no DMA, no epilogue stores
         case 52: return launch_v2<2, 2, 1, 2, 16>(g, epi, splits, kchunk, st);   // 32 x 64, 4 waves of 16 x 32
         case 55: return launch_v2<2, 2, 2, 3, 32>(g, epi, splits, kchunk, st);   // 64 x 96, BK 32
+        case 56: return launch_v2<2, 2, 3, 2, 32>(g, epi, splits, kchunk, st);   // 96 x 64, BK 32
         default: return DKD_ERR_BAD_ARG;
     }
 }
