@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dinov2_distillation_amd import ops, _lib
-for (rows, n_out, k_in) in [(200704, 96, 384), (200704, 384, 96), (50176, 192, 768), (50176, 768, 192), (16384, 384, 384),
+for (rows, n_out, k_in) in [(200704, 96, 48), (200704, 96, 384), (200704, 384, 96), (50176, 192, 768), (50176, 768, 192), (16384, 384, 384),
                             (12544, 384, 1536), (16384, 384, 1536), (3136, 768, 3072)]:
     dy, x = torch.randn(rows, n_out).cuda(), torch.randn(rows, k_in).cuda()
     for _ in range(3): ops.linear_wgrad(dy, x, True)
