@@ -21,6 +21,8 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INC, "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 # per-file code generation switches (measured)
 FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+if os.environ.get("DKD_TUNING") == "1":  # also instantiate the timing-only knock-out kernels (scripts/knockout_*.py)
+    FLAGS.append("-DDKD_TUNING")
 
 
 def _hipcc():

@@ -1200,11 +1200,15 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 44: return launch_v2<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 4 waves of 32 x 32
         case 100: return launch_dma<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, LDS-DMA staging, BK 16
         case 101: return launch_dma<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, BK 32
-        case 130: return launch_dma<2, 2, 2, 2, 32, 2>(g, epi, splits, kchunk, st);  // knock-outs of variant 101 (timing only)
+#ifdef DKD_TUNING  // knock-outs of variant 101: timing experiments whose RESULTS ARE WRONG - never part of the shipped library
+        case 130: return launch_dma<2, 2, 2, 2, 32, 2>(g, epi, splits, kchunk, st);
         case 131: return launch_dma<2, 2, 2, 2, 32, 4>(g, epi, splits, kchunk, st);
         case 132: return launch_dma<2, 2, 2, 2, 32, 8>(g, epi, splits, kchunk, st);
         case 133: return launch_dma<2, 2, 2, 2, 32, 16>(g, epi, splits, kchunk, st);  // no epilogue stores
         case 134: return launch_dma<2, 2, 2, 2, 32, 18>(g, epi, splits, kchunk, st);  // no DMA, no epilogue stores
+#else
+        case 130: case 131: case 132: case 133: case 134: return DKD_ERR_UNSUPPORTED;  // build with -DDKD_TUNING (DKD_TUNING=1 python -m ...build)
+#endif
         case 52: return launch_v2<2, 2, 1, 2, 16>(g, epi, splits, kchunk, st);   // 32 x 64, 4 waves of 16 x 32
         case 55: return launch_v2<2, 2, 2, 3, 32>(g, epi, splits, kchunk, st);   // 64 x 96, BK 32
         case 56: return launch_v2<2, 2, 3, 2, 32>(g, epi, splits, kchunk, st);   // 96 x 64, BK 32

@@ -198,6 +198,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// s += v with the rounding error of the addition carried in c (Kahan); the caller finishes with s -= c
+__device__ __forceinline__ void kahan1(float& s, float& c, const float v) {
+    const float y = v - c;
+    const float t = s + y;
+    c = (t - s) - y;
+    s = t;
+}
+__device__ __forceinline__ void kahan4(float4& s, float4& c, const float4 v) {
+    kahan1(s.x, c.x, v.x); kahan1(s.y, c.y, v.y); kahan1(s.z, c.z, v.z); kahan1(s.w, c.w, v.w);
+}
+
 // ---- grouped column reduction -----------------------------------------------------------------------------
 // out[g][n] = scale * sum_{r < rows_per_group} f(X[(g*rows_per_group + r)*ldx + n], Y[...], aux[n])
 template <int OP>
@@ -227,16 +238,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     const int g = blockIdx.z, sp = blockIdx.y;
     const long r0 = (long)sp * rows_per_split;
     const long r1 = min(rows_per_group, r0 + rows_per_split);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc, cmp = acc, cmp2 = acc;
     constexpr bool TWO = OP == DKD_RED_DOT_SUM || OP == DKD_RED_DOTGELU_SUM;
     if (4 * c4 < N) {
         const float4 a = OP == DKD_RED_SQDIFF ? reinterpret_cast<const float4*>(aux)[c4] : acc;
         const long base = (long)g * rows_per_group;
+        // Kahan-compensated accumulation: a column of B*H*W gradients summed in plain fp32 carries an error that grows with the
+        // number of rows a thread folds; the BatchNorm / bias gradients of a 50-layer student amplify it (the PResNet-50 case of
+        // round 1).  The kernel is HBM-bound, the three extra VALU ops per element are free (scripts/bench_colreduce.py).
         auto fold = [&](const float4 x, float4 y) {
             if (OP == DKD_RED_DOTGELU_SUM) y = make_float4(gelu_f(y.x), gelu_f(y.y), gelu_f(y.z), gelu_f(y.w));
             const float4 v = colop<TWO ? DKD_RED_DOT : OP>(x, y, a);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            if (TWO) { acc2.x += x.x; acc2.y += x.y; acc2.z += x.z; acc2.w += x.w; }
+            kahan4(acc, cmp, v);
+            if (TWO) kahan4(acc2, cmp2, x);
         };
         constexpr bool HAS_Y = OP == DKD_RED_DOT || TWO;
         long r = r0 + rl;
@@ -259,14 +273,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
     const long second = (long)gridDim.z * nsplit * N;  // offset of the second result plane
     for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
-        if (pass == 1) { __syncthreads(); acc = acc2; }
+        if (pass == 1) { __syncthreads(); acc = acc2; cmp = cmp2; }
+        acc.x -= cmp.x; acc.y -= cmp.y; acc.z -= cmp.z; acc.w -= cmp.w;
         red[threadIdx.x] = acc;
         __syncthreads();
         if (rl == 0 && 4 * c4 < N) {
-            for (int k = 1; k < RL; ++k) {
-                const float4 v = red[k * CL + cl];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
+            cmp = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 1; k < RL; ++k) kahan4(acc, cmp, red[k * CL + cl]);
+            acc.x -= cmp.x; acc.y -= cmp.y; acc.z -= cmp.z; acc.w -= cmp.w;
             // partial layout [g][split][N]; with nsplit == 1 this IS the output
             float4* o = reinterpret_cast<float4*>(out + pass * second + ((long)g * nsplit + sp) * N) + c4;
             if (nsplit == 1) { acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale; }
@@ -284,23 +298,24 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
     const int n = blockIdx.x * 32 + cl, g = blockIdx.y;
     ws += (long)blockIdx.z * groups * nsplit * N;
     out += (long)blockIdx.z * groups * N;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, c0 = 0.f, c1 = 0.f;
     if (n < N) {
         const float* w = ws + (long)g * nsplit * N + n;
         int p = pl;
         for (; p + 8 < nsplit; p += 16) {
-            s0 += w[(long)p * N];
-            s1 += w[(long)(p + 8) * N];
+            kahan1(s0, c0, w[(long)p * N]);
+            kahan1(s1, c1, w[(long)(p + 8) * N]);
         }
-        if (p < nsplit) s0 += w[(long)p * N];
+        if (p < nsplit) kahan1(s0, c0, w[(long)p * N]);
     }
-    red[threadIdx.x] = s0 + s1;
+    kahan1(s0, c0, s1 - c1);
+    red[threadIdx.x] = s0 - c0;
     __syncthreads();
     if (pl == 0 && n < N) {
-        float s = 0.f;
+        float s = 0.f, c = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k * 32 + cl];
-        out[(long)g * N + n] = s * scale;
+        for (int k = 0; k < 8; ++k) kahan1(s, c, red[k * 32 + cl]);
+        out[(long)g * N + n] = (s - c) * scale;
     }
 }
 

@@ -190,17 +190,16 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_fwd_kernel(dkd_winattn_
 
 // Backward.  Phase 1 (lane = query i): recompute the softmax row, delta_i = dO_i . O_i, dQ_i.  Phase 2 (lane = key j): walk the
 // queries (their Q / dO rows wave-uniform, their row statistics fetched from lane i with v_readlane), recompute column j of P and
-// accumulate dK_j, dV_j in registers and dS into the workgroup's [N][N] bias-gradient tile (LDS atomics, one address per lane).
+// accumulate dK_j, dV_j in registers and dS into the workgroup's [N][N] bias-gradient tile (one LDS tile per wave, one address per lane: plain read-modify-write).
 template <int N, int HD>
 __global__ __launch_bounds__(WA_WAVES * 64) void winattn_bwd_kernel(dkd_winattn_args a) {
     constexpr int NP = WinCfg<N>::NP;
     __shared__ float sBias[N * NP];
-    __shared__ float sDb[N * NP];
+    __shared__ float sDbAll[WA_WAVES * N * NP];  // one d(bias) tile per wave, folded in a fixed order (bit-reproducible)
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
-    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
-        sBias[(e / N) * NP + (e % N)] = a.bias[(long)e * a.H + h];
-        sDb[(e / N) * NP + (e % N)] = 0.f;
-    }
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) sBias[(e / N) * NP + (e % N)] = a.bias[(long)e * a.H + h];
+    for (int e = threadIdx.x; e < WA_WAVES * N * NP; e += blockDim.x) sDbAll[e] = 0.f;
+    float* sDb = sDbAll + wave * N * NP;
     __syncthreads();
     const bool active = lane < N;
     const int li = active ? lane : N - 1;
@@ -316,7 +315,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_bwd_kernel(dkd_winattn_
                     dk[d] = fmaf(ds, qq[d], dk[d]);
                     dv[d] = fmaf(p, gg[d], dv[d]);
                 }
-                if (active) atomicAdd(&sDb[i * NP + lane], ds);
+                if (active) sDb[i * NP + lane] += ds;
             }
             if (active) {
                 float* dkp = a.dk + (row0 + lane) * a.dk_rs + h * HD;
@@ -331,7 +330,13 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_bwd_kernel(dkd_winattn_
     }
     __syncthreads();
     float* part = a.dbias_part + ((long)blockIdx.x * a.H + h) * N * N;
-    for (int e = threadIdx.x; e < N * N; e += blockDim.x) part[e] = sDb[(e / N) * NP + (e % N)];
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+        const int o = (e / N) * NP + (e % N);
+        float t = sDbAll[o];
+#pragma unroll
+        for (int wv = 1; wv < WA_WAVES; ++wv) t += sDbAll[wv * N * NP + o];
+        part[e] = t;
+    }
 }
 
 int check_args(const dkd_winattn_args* a, bool bwd) {

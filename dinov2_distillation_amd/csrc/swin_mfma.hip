@@ -188,12 +188,17 @@ template <int HD, int PART>
 __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_winattn_args a) {
     constexpr int KB = HD / 16, DT = HD / 16;
     __shared__ float sBias[N * NP];
-    __shared__ float sDb[PART != 1 ? N * NP : 1];
+    // d(bias): ONE tile PER WAVE.  Inside a wave every lane owns its (i, j) of the current sub-tile, so plain read-modify-write
+    // accumulates in program order; the four wave tiles are added in a fixed order at the end.  (One shared tile with LDS
+    // float atomics made the sum depend on how the waves interleave: gradients were not bit-reproducible run to run.)
+    __shared__ float sDbAll[PART != 1 ? WA_WAVES * N * NP : 1];
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
     for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
         sBias[e] = a.bias[(long)e * a.H + h];
-        if (PART != 1) sDb[e] = 0.f;
     }
+    if (PART != 1)
+        for (int e = threadIdx.x; e < WA_WAVES * N * NP; e += blockDim.x) sDbAll[e] = 0.f;
+    float* sDb = sDbAll + (PART != 1 ? wave * N * NP : 0);
     __syncthreads();
     for (int w = blockIdx.x * WA_WAVES + wave; w < a.Bw; w += gridDim.x * WA_WAVES) {
         const long row0 = (long)w * N;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
                         const float v = pt[jt][it][r] * (ds[jt][it][r] - delta);
                         ds[jt][it][r] = v;  // dS^T
                         const int j = 16 * jt + 4 * g + r;
-                        if (i < N && j < N) atomicAdd(&sDb[i * NP + j], v);
+                        if (i < N && j < N) sDb[i * NP + j] += v;
                     }
             }
             // dQ^T[d][i] = scale * sum_j K[j][d] dS^T[j][i]
@@ -393,7 +398,12 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
     if (PART != 1) {
         __syncthreads();
         float* part = a.dbias_part + ((long)blockIdx.x * a.H + h) * N * N;
-        for (int e = threadIdx.x; e < N * N; e += blockDim.x) part[e] = sDb[e];
+        for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+            float t = sDbAll[e];
+#pragma unroll
+            for (int wv = 1; wv < WA_WAVES; ++wv) t += sDbAll[wv * N * NP + e];
+            part[e] = t;
+        }
     }
 }
 

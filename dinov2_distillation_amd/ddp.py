@@ -2,8 +2,9 @@
 (torch.distributed backend "nccl" IS RCCL on ROCm; "gloo" on CPU for tests).
 
 Replaces Lightning's ``strategy: ddp`` (train.py:256-270, config/config.yaml:62-69) for this path:
-  * only student + projector gradients are exchanged (the teacher is frozen and identical on every rank by
-    construction: same seed / same checkpoint; ``broadcast_parameters`` sends the trainable arena once);
+  * only student + projector gradients are exchanged; the teacher is frozen and is broadcast ONCE at start-up together with
+    the trainable arena and every buffer (``broadcast_parameters(src, module)``: what torch DDP's constructor broadcast does
+    for the reference, train.py:256-262) - a checkpoint loaded on rank 0 only cannot silently diverge;
   * gradients live in FusedAdamW's flat arena, so a bucket is a contiguous slice - no flatten/unflatten copies;
   * buckets are launched from post-accumulate-grad hooks as soon as every parameter of the bucket has its gradient,
     on a side HIP stream, so the all-reduce overlaps the rest of the backward pass;
@@ -58,6 +59,7 @@ class GradBucketReducer:
         self.launched = [False] * len(self.buckets)
         self.handles = []
         self.hooks = []
+        self.paused = False
         if self.active:
             for p, _, _ in optimizer.layout:
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -89,7 +91,7 @@ class GradBucketReducer:
         # A parameter whose gradient was written straight into the arena is announced by the ops listener (after its
         # kernel has been enqueued); autograd then STILL runs the post-accumulate hook for the None that backward returned.
         # Count each parameter once per step, or buckets launch before their last gradients have been enqueued.
-        if id(p) not in self.param_bucket or id(p) in self.seen:
+        if self.paused or id(p) not in self.param_bucket or id(p) in self.seen:
             return
         self.seen.add(id(p))
         bi = self.param_bucket[id(p)]
@@ -110,17 +112,66 @@ class GradBucketReducer:
                 torch.cuda.current_stream().wait_stream(self.side)
         self.reset()
 
-    def broadcast_parameters(self, src=0):
-        """once, at start-up (C2 of SURVEY 2.1): trainable arena from rank 0; teacher weights are frozen and seeded
-        identically, so nothing else moves."""
-        if self.active:
-            dist.broadcast(self.opt.flat_p, src=src, group=self.pg)
+    def broadcast_parameters(self, src=0, module=None):
+        """once, at start-up (C2 of SURVEY 2.1): the trainable arena from rank ``src`` and - given the step module - every
+        other tensor of its state dict: the frozen teacher ("teacher frozen, broadcast once", BASELINE north_star) and the
+        BatchNorm running statistics / integer buffers of the student and the projectors."""
+        if not self.active:
+            return
+        dist.broadcast(self.opt.flat_p, src=src, group=self.pg)
+        if module is not None:
+            lo, hi = self.opt.flat_p.data_ptr(), self.opt.flat_p.data_ptr() + 4 * self.opt.flat_p.numel()
+            rest = [t for t in list(module.parameters()) + list(module.buffers()) if not (lo <= t.data_ptr() < hi)]
+            broadcast_tensors(rest, src, self.pg)
+
+    class _NoSync:
+        def __init__(self, red):
+            self.red = red
+
+        def __enter__(self):
+            self.red.paused = True
+
+        def __exit__(self, *exc):
+            self.red.paused = False
+
+    def no_sync(self):
+        """gradient accumulation (train.py:269 ``accumulate_grad_batches``): backward passes inside this context exchange
+        nothing; the gradients accumulate in the arena and the LAST micro-batch's backward (outside) reduces the sums."""
+        return GradBucketReducer._NoSync(self)
 
     def remove(self):
         for h in self.hooks:
             h.remove()
         self.hooks = []
         ops.remove_grad_listener(self._on_grad)
+
+
+def broadcast_tensors(tensors, src=0, process_group=None, chunk_bytes=256 << 20):
+    """in-place broadcast of a list of tensors from rank ``src``: large ones directly, small ones coalesced per dtype into
+    flat buffers of up to ``chunk_bytes`` (a ViT-g teacher is ~650 tensors / 4.4 GB: a handful of large messages)"""
+    with torch.no_grad():
+        groups = {}
+        for t in tensors:
+            if t.numel() == 0:
+                continue
+            if t.numel() * t.element_size() >= (4 << 20) and t.is_contiguous():
+                dist.broadcast(t, src=src, group=process_group)
+            else:
+                groups.setdefault((t.dtype, t.device), []).append(t)
+        for (dtype, device), ts in groups.items():
+            i = 0
+            while i < len(ts):
+                j, n = i, 0
+                while j < len(ts) and (j == i or (n + ts[j].numel()) * ts[j].element_size() <= chunk_bytes):
+                    n += ts[j].numel()
+                    j += 1
+                flat = torch.cat([t.reshape(-1) for t in ts[i:j]])
+                dist.broadcast(flat, src=src, group=process_group)
+                off = 0
+                for t in ts[i:j]:
+                    t.copy_(flat[off:off + t.numel()].view(t.shape))
+                    off += t.numel()
+                i = j
 
 
 def allreduce_metrics(values, process_group=None):

@@ -22,8 +22,10 @@ def colsum(x2d):
 def direct(*params):
     """gradient destinations for small (used-once) parameters: their arena views when every one of them can be written in
     place, else Nones (-> the gradients are returned to autograd)"""
-    outs = [ops.grad_out(p) for p in params]
-    return outs if all(o is not None for o in outs) else [None] * len(params)
+    if not ops.can_async(*params):
+        return [None] * len(params)
+    ops.claim(*params)
+    return [p.grad for p in params]
 
 
 def ret(out, value, param):

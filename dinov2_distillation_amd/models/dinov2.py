@@ -63,14 +63,21 @@ class Block(nn.Module):
         self.precision = None  # GEMM precision of this frozen block: None (global default) / ops.PREC_F32 / PREC_BF16X3 / PREC_BF16
 
     def transposed(self, name):
-        """cached [K, N] copy of a prepared weight for the NT-only bf16 kernels' dgrad; None in the exact mode"""
+        """cached [K, N] copy of a prepared weight for the NT-only bf16 kernels' dgrad; None in the exact mode.
+        The four copies of a block are made together the first time one is asked for, and the host waits for them: the two
+        loss chains re-use the same frozen blocks from two HIP streams with no dependency between them, so a copy enqueued by
+        one chain must be complete before the other chain can even enqueue a read (once per block and precision change;
+        inside a hipGraph capture the copies exist already from the warm-up steps)."""
         prec = ops.GEMM_PRECISION if self.precision is None else self.precision
         if prec == ops.PREC_F32:
             return None
         p = self.prepared()
         if "t_" + name not in p:
             with torch.no_grad():
-                p["t_" + name] = ops.transpose(p[name])
+                for k in ("wqkv", "wproj", "w1", "w2"):
+                    p["t_" + k] = ops.transpose(p[k])
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
         return p["t_" + name]
 
     def prepared(self):

@@ -157,6 +157,8 @@ def producer_streams(device=None):
 
 def wgrad_join():
     """make the current stream wait for every gradient-producing side stream (weight-gradient stream, loss-chain stream)"""
+    if not _side_streams and not _producer_streams:
+        return
     cur = torch.cuda.current_stream()
     for s in producer_streams():
         if s != cur:
@@ -172,8 +174,46 @@ def remove_grad_listener(fn):
         _grad_listeners.remove(fn)
 
 
+_written = set()         # id(param) of every arena gradient written in place since the optimiser last zeroed the arena
+
+
+def mark_grads_fresh():
+    """FusedAdamW.zero_grad(): the arena is zero again - the next in-place gradient write of a parameter may overwrite"""
+    _written.clear()
+
+
+def exchange_ok():
+    """In-place gradient writes bypass autograd's AccumulateGrad hooks.  That is only sound when nobody else listens on those
+    hooks: one rank, or a multi-rank job whose exchange is ddp.GradBucketReducer (registered through add_grad_listener).  Under
+    torch's DistributedDataParallel (Lightning ``strategy: ddp``, the reference default, config/config.yaml:67) every gradient is
+    returned to autograd on the main stream instead, so DDP's reducer sees all of them."""
+    if _grad_listeners:
+        return True
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def can_async(*params):
-    return ASYNC_WGRAD and all(p is None or (p.is_leaf and p.grad is not None and p.grad.is_contiguous()) for p in params)
+    """may these parameters' gradients be written straight into their arena views (overwriting)?  Not after an earlier write
+    since the last zero_grad (a second backward pass - Lightning's accumulate_grad_batches, train.py:269 - or a parameter used
+    twice): then the gradient goes back to autograd, whose AccumulateGrad ADDS it to the arena view, after the side streams'
+    earlier in-place writes have landed."""
+    if not ASYNC_WGRAD:
+        return False
+    ps = [p for p in params if p is not None]
+    if not all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() for p in ps):
+        return False
+    if any(id(p) in _written for p in ps):
+        wgrad_join()
+        return False
+    return exchange_ok()
+
+
+def claim(*params):
+    """record that these parameters' arena gradients are being written in place (see can_async)"""
+    for p in params:
+        if p is not None:
+            _written.add(id(p))
 
 
 def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True):
@@ -183,6 +223,7 @@ def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True):
     waits for everything this launch reads): skips the event record + wait, which costs the MAIN stream ~10 us each
     (measured, scripts/ab_step.py; an event without the system-scope fence costs the same)."""
     side = wgrad_stream(dy2.device)
+    claim(w, b)
     if fork:
         side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -205,7 +246,10 @@ def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True):
 
 def grad_out(p):
     """the parameter's arena gradient view to write a (used-once) gradient into directly, or None (-> return it to autograd)"""
-    return p.grad if can_async(p) else None
+    if not can_async(p):
+        return None
+    claim(p)
+    return p.grad
 
 
 def grad_done(*params):

@@ -24,10 +24,15 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._build_arena()
         self._steps = 0
+        self._step_t = torch.zeros((), dtype=torch.float32)  # the "step" entry shared by every parameter's state (host side)
         self.graph_safe = False  # True: every optimiser scalar lives in device memory (hipGraph capture of the step)
         self._hyper = None
-        # weight gradients may now be written into the arena from the side stream (DKD_ASYNC_WGRAD=0 keeps one stream)
+        self._expose_state()
+        # Weight gradients may now be written into the arena from the side stream (DKD_ASYNC_WGRAD=0 keeps one stream).  Whether a
+        # given backward pass actually does so is decided per call by ops.can_async: never under torch DistributedDataParallel
+        # (its reducer must see every gradient through autograd), never for a gradient that was already written since zero_grad.
         ops.ASYNC_WGRAD = self.flat_g.is_cuda and os.environ.get("DKD_ASYNC_WGRAD", "1") != "0"
+        ops.mark_grads_fresh()
 
     def _build_arena(self):
         plist = []
@@ -58,6 +63,52 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.layout.append((p, off, p.numel()))
         self.total = total
         self._gnorm = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._grad_views = [p.grad for p, _, _ in self.layout]
+
+    # ---- optimizer.state in torch.optim.AdamW's layout (Lightning ModelCheckpoint / resume, train.py:83,284) -------------------
+    def _expose_state(self):
+        """self.state[p] = {step, exp_avg, exp_avg_sq} with the moments as VIEWS of the arena, so the base class's state_dict()
+        exports exactly what torch.optim.AdamW would and a reference checkpoint's optimizer state loads unchanged."""
+        for p, off, n in self.layout:
+            self.state[p] = {"step": self._step_t, "exp_avg": self.flat_m[off:off + n].view(p.shape),
+                             "exp_avg_sq": self.flat_v[off:off + n].view(p.shape)}
+
+    def state_dict(self):
+        sd = super().state_dict()
+        # snapshots, not views: a checkpoint written later in the run must not alias the live arena
+        for st in sd["state"].values():
+            for k, v in list(st.items()):
+                if torch.is_tensor(v):
+                    st[k] = v.detach().clone()
+        for g in sd["param_groups"]:
+            g.pop("_range", None)
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        ranges = [g["_range"] for g in self.param_groups]
+        sd = {"state": state_dict["state"], "param_groups": [dict(g) for g in state_dict["param_groups"]]}
+        for g, r in zip(sd["param_groups"], ranges):
+            g["_range"] = r
+        super().load_state_dict(sd)  # casts the loaded tensors to each parameter's device / dtype into self.state[p]
+        steps = 0
+        for p, off, n in self.layout:
+            st = self.state.get(p, {})
+            if "exp_avg" in st:
+                self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps = max(steps, int(float(st["step"])))
+            else:  # a parameter the checkpoint has no state for (torch's AdamW creates state lazily): fresh moments
+                self.flat_m[off:off + n].zero_()
+                self.flat_v[off:off + n].zero_()
+        self._steps = steps
+        self._step_t = torch.tensor(float(steps), dtype=torch.float32)
+        self._expose_state()
+        for g, r in zip(self.param_groups, ranges):
+            g["_range"] = r
+        if self._hyper is not None:  # graph-safe mode keeps the step counter on the device
+            self._hyper[:, 5] = float(steps)
+            self.sync_hyper()
 
     def sync_hyper(self):
         """(graph-safe mode) push lr / betas / eps / weight_decay of every param group to the device; the step counter is kept.
@@ -71,10 +122,27 @@ class FusedAdamW(torch.optim.Optimizer):
             self._hyper[:, :5].copy_(host[:, :5], non_blocking=True)
 
     def zero_grad(self, set_to_none=False):
-        self.flat_g.zero_()
-        for p, off, n in self.layout:  # re-attach if something replaced .grad
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
-                p.grad = self.flat_g[off:off + n].view(p.shape)
+        """always zero-fills (``set_to_none`` is ignored: the .grad views ARE the arena the kernels write into)"""
+        if not (self.flat_g.is_cuda and torch.cuda.is_current_stream_capturing()):
+            ops.wgrad_join()  # a side-stream gradient write still in flight must not land after the fill (inside a captured
+        self.flat_g.zero_()   # step the side streams have re-joined at the previous optimiser step by construction)
+        self._reattach(adopt=False)
+        ops.mark_grads_fresh()
+
+    def _reattach(self, adopt):
+        """Every parameter's .grad must be its arena view.  Something outside may have replaced it (``module.zero_grad()`` sets
+        None; a foreign backward pass then allocates a fresh tensor): with adopt=True such a gradient is copied into the arena
+        (None -> zeros) instead of being silently ignored by the fused update."""
+        for i, (p, off, n) in enumerate(self.layout):
+            view = self._grad_views[i]
+            if p.grad is view:
+                continue
+            if adopt:
+                if p.grad is None:
+                    view.zero_()
+                else:
+                    view.copy_(p.grad)
+            p.grad = view
 
     def grad_norm(self):
         """global L2 norm of all gradients, left on the device: tensor [sum_sq, norm]"""
@@ -92,12 +160,16 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if not self.flat_g.is_cuda:
+            raise _lib.DkdError("FusedAdamW needs parameters on the GPU (no CPU path)")
         lib = _lib.load()
         ops.wgrad_join()  # the side-stream weight gradients must have landed in the arena
+        self._reattach(adopt=True)
         gn = self.grad_norm() if clip_grad_norm is not None else None
         if self.graph_safe and self._hyper is None:
             self.sync_hyper()
         self._steps += 1
+        self._step_t += 1.0
         if self.graph_safe:
             self._hyper[:, 5] += 1.0  # the step counter advances on the device (captured with the graph)
             for i, g in enumerate(self.param_groups):

@@ -11,7 +11,7 @@ from .train import DistillationModule
 
 class DistillationStepper:
     def __init__(self, teacher="dinov2_vits14", student="convnext_tiny", crop=224, device="cuda", heads=(16, 24),
-                 clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None):
+                 clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None, accumulate_grad_batches=1):
         self.cfg = make_config(teacher, student, crop, heads=heads, lr=lr)
         torch.manual_seed(seed)  # student seed 1, ScaleKD follows; identical on every rank
         self.student = ModelWrapper(student, self.cfg.teacher.n_patches, self.cfg.student.student_keys)
@@ -23,9 +23,10 @@ class DistillationStepper:
             self.optimizer = self.optimizer["optimizer"]
         self.reducer = GradBucketReducer(self.optimizer, bucket_bytes) if dist.is_initialized() else None
         if self.reducer is not None:
-            self.reducer.broadcast_parameters(0)
+            self.reducer.broadcast_parameters(0, self.module)  # arena + frozen teacher + buffers, once
         self.clip = clip
         self.step_idx = 0
+        self.accumulate, self.micro = int(accumulate_grad_batches), 0  # train.py:269
 
     # ---- hipGraph replay of the whole step -----------------------------------------------------------------------------
     # Every launch of the step is capture-safe (no allocation or synchronisation inside the library, side streams fork from and
@@ -67,11 +68,22 @@ class DistillationStepper:
         return loss.detach()
 
     def step(self, batch):
-        self.optimizer.zero_grad()
+        """one micro-batch.  With accumulate_grad_batches = n (train.py:269) the gradients of n consecutive calls add up in the
+        arena (loss scaled by 1/n as Lightning does), the exchange and the optimiser run on every n-th call."""
+        n = self.accumulate
+        last = self.micro == n - 1
+        if self.micro == 0:
+            self.optimizer.zero_grad()
         loss = self.module.training_step(batch, self.step_idx)
-        loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        self.optimizer.step(clip_grad_norm=self.clip)
-        self.step_idx += 1
+        if self.reducer is not None and not last:
+            with self.reducer.no_sync():
+                (loss / n).backward()
+        else:
+            (loss / n if n > 1 else loss).backward()
+        self.micro = (self.micro + 1) % n
+        if last:
+            if self.reducer is not None:
+                self.reducer.finish()
+            self.optimizer.step(clip_grad_norm=self.clip)
+            self.step_idx += 1
         return loss

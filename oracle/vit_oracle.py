@@ -74,14 +74,14 @@ class _Bf16Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        wr = w.bfloat16().float()
+        wr = w.bfloat16().to(w.dtype)
         ctx.save_for_backward(wr)
-        return F.linear(x.bfloat16().float(), wr, b)
+        return F.linear(x.bfloat16().to(x.dtype), wr, b)
 
     @staticmethod
     def backward(ctx, dy):
         (wr,) = ctx.saved_tensors
-        return dy.bfloat16().float() @ wr, None, None
+        return dy.bfloat16().to(dy.dtype) @ wr, None, None
 
 
 def _linear(x, w, b, bf16, scale=None):
@@ -143,7 +143,8 @@ def vit_tokens(p, x, cfg, depth=None, bf16=False):
     ph, pw = H // PATCH, W // PATCH
     depth = cfg["depth"] if depth is None else depth
     if bf16:
-        t = F.conv2d(x.bfloat16().float(), p["patch_embed.proj.weight"].bfloat16().float(), p["patch_embed.proj.bias"], stride=PATCH)
+        t = F.conv2d(x.bfloat16().to(x.dtype), p["patch_embed.proj.weight"].bfloat16().to(x.dtype), p["patch_embed.proj.bias"],
+                     stride=PATCH)
     else:
         t = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=PATCH)
     t = t.flatten(2).transpose(1, 2)  # [B, P*P, D]

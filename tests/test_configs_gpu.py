@@ -1,0 +1,269 @@
+"""Whole-step parity at EVERY BASELINE.json workload (configs[1]..[4]) - the HIP step against the CPU oracle at each config's
+real shapes with a reduced batch, plus size-independent properties at the configs' full batch sizes.
+
+Per config: every logged scalar within 1e-3 (north star) of the fp32 oracle; gradients judged with the fp64 run of the
+same oracle as arbiter, because ReLU kinks and small-batch BatchNorm make the fp32 CPU result
+itself only "close to" the exact gradient: err(ours, fp64) <= 2 * err(cpu fp32, fp64) + 1e-3 in global relative L2, for
+the student gradient and for the projector gradient separately.  Shapes follow /root/reference/train.py:103-119 (teacher
+dims, n_patches = crop // 14, heads must divide the teacher width) and models/backbones/swin.py:696-727.
+"""
+import pytest
+import torch
+
+from step_parity import close, flat, module_grads, oracle_step, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(teacher, student, crop, heads, seed, teacher_precision=None):
+    from dinov2_distillation_amd.config import make_config, set_student_dims
+    from dinov2_distillation_amd.models import DINOv2ViT, ModelWrapper
+    from dinov2_distillation_amd.train import DistillationModule
+    cfg = make_config(teacher, student, crop, heads=heads)
+    torch.manual_seed(seed)
+    s = ModelWrapper(student, cfg.teacher.n_patches, cfg.student.student_keys)
+    set_student_dims(cfg, s)
+    t = DINOv2ViT(teacher, seed=0, precision=teacher_precision)
+    return DistillationModule(s, t, cfg), cfg
+
+
+def _set_swin_drop(student, p):
+    swin = student.model.model
+    swin.drop_rate = p
+    for m in swin.modules():
+        if hasattr(m, "drop"):
+            m.drop = p
+
+
+def _check_scalars(logged, ref, rtol=1e-3):
+    """losses: 1e-3 relative.  The two similarity logs are MEANS of cosines in [-1, 1] (losses/scalekd.py:88-91) that may
+    cancel to ~1e-5 (a randomly initialised student is orthogonal to the teacher): their natural scale is 1, so they also get
+    the absolute allowance of an fp32 mean of O(1) terms."""
+    for k, v in ref.items():
+        a, b = float(logged["train_" + k]), float(v)
+        tol = rtol * abs(b) + (2e-6 if "similarity" in k else 1e-7)
+        assert a == a and abs(a - b) <= tol, f"{k}: {a!r} vs oracle {b!r}"
+
+
+def _check_step(mod, cfg, x, what, arbiter=True, teacher_bf16=False, scalar_rtol=1e-3, grad_bound=None):
+    from dinov2_distillation_amd import ops
+    ref, gs32, gl32 = oracle_step(mod, cfg, x, torch.float32, teacher_bf16)
+    gs64, gl64 = (gs32, gl32)
+    if arbiter:
+        _, gs64, gl64 = oracle_step(mod, cfg, x, torch.float64, teacher_bf16)
+    mod.cuda().train()
+    loss = mod.training_step(x.cuda(), 0)
+    worst = max(abs(float(mod.logged["train_" + k]) - float(v)) / (abs(float(v)) + 1e-30) for k, v in ref.items() if "loss" in k)
+    print(f"{what}: {len(ref)} logged scalars, worst relative deviation of a loss from the fp32 oracle {worst:.2e}")
+    _check_scalars(mod.logged, ref, scalar_rtol)
+    loss.backward()
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    gs, gl = module_grads(mod)
+    assert all(p.grad is None for p in mod.teacher.parameters())
+    res = {}
+    for tag, ours, g32, g64 in (("student", gs, gs32, gs64), ("projectors", gl, gl32, gl64)):
+        gmax = max(v.abs().max().item() for v in g64.values())
+        names = []
+        for k in sorted(g64):
+            if g64[k].abs().max().item() < 1e-6 * gmax:  # mathematically zero (bias before a norm, unused norms, ...)
+                assert k not in ours or float(ours[k].abs().max()) < 1e-4 * gmax, k
+                continue
+            assert k in ours, f"{what}: no gradient for {k}"
+            names.append(k)
+        e_ours = rel_l2(flat(ours, names), flat(g64, names))
+        e_cpu = rel_l2(flat(g32, names), flat(g64, names)) if arbiter else 0.0
+        per = max((rel_l2(ours[k].detach().cpu().double().reshape(-1), g64[k].double().reshape(-1)), k) for k in names)
+        print(f"{what}: {tag} gradient ({len(names)} tensors) global relL2 vs {'fp64' if arbiter else 'fp32'} oracle: ours "
+              f"{e_ours:.2e}, cpu fp32 oracle {e_cpu:.2e}; worst tensor {per[0]:.2e} ({per[1]})")
+        res[tag] = (e_ours, e_cpu, per)
+        bound = 2 * e_cpu + 1e-3 if grad_bound is None else grad_bound
+        assert e_ours <= bound, (what, tag, e_ours, e_cpu)
+    return res
+
+
+# ---- configs[1]: dinov2_vits14 -> convnext_tiny, 224x224 ------------------------------------------------------------------------
+def test_config1_vits14_convnext_tiny_fp64_arbiter():
+    mod, cfg = _build("dinov2_vits14", "convnext_tiny", 224, (16, 24), seed=1)
+    with torch.no_grad():  # the reference init leaves GRN at zero: perturb so that the GRN path carries signal
+        for n_, p_ in mod.student.named_parameters():
+            if "grn" in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+            elif p_.dim() > 1:
+                p_.mul_(4.0)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    _check_step(mod, cfg, x, "configs[1] vits14->convnext_tiny B=2")
+
+
+# ---- configs[2]: dinov2_vitb14 -> resnet_50, 224x224 -------------------------------------------------------------------------
+def test_config2_vitb14_resnet50_step_vs_oracle():
+    """D = 768, 12 teacher heads, ScaleKD heads 16 / 24 (head dims 48 / 32), ResNet-50 with live BatchNorm over B = 2"""
+    mod, cfg = _build("dinov2_vitb14", "resnet_50", 224, (16, 24), seed=5)
+    assert mod.student.feature_channels["res4"] == 1024 and mod.student.feature_channels["res5"] == 2048
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(77))
+    _check_step(mod, cfg, x, "configs[2] vitb14->resnet_50 B=2")
+
+
+# ---- configs[3]: dinov2_vitl14 -> swin_tiny, 518x518 -------------------------------------------------------------------------
+def test_config3_vitl14_swin_tiny_518_step_vs_oracle():
+    """P = 37 (the position table's native grid: no interpolation), N = 1369 + CLS, D = 1024 / 24 blocks / 16 heads;
+    the Swin student pads 518 -> 520 (grids 130/65/33/17) and its 33 x 33 / 17 x 17 features are resized UP to 37 x 37;
+    ScaleKD heads 16 / 32 (divisors of 1024); dropout 0 for parity."""
+    mod, cfg = _build("dinov2_vitl14", "swin_tiny", 518, (16, 32), seed=7)
+    assert cfg.teacher.n_patches == [37, 37]
+    _set_swin_drop(mod.student, 0.0)
+    with torch.no_grad():
+        for n_, p_ in mod.student.named_parameters():
+            if "relative_position_bias_table" in n_:
+                p_.mul_(25.0)
+    x = torch.randn(1, 3, 518, 518, generator=torch.Generator().manual_seed(9))
+    _check_step(mod, cfg, x, "configs[3] vitl14->swin_tiny 518 B=1")
+    mod.eval()
+    with torch.no_grad():
+        f = mod.student(x.cuda())
+    assert f["res4"].shape == (1, 384, 37, 37) and f["res5"].shape == (1, 768, 37, 37)
+
+
+# ---- configs[4]: dinov2_vitg14 (bf16 teacher) -> convnext_base, 224x224 ------------------------------------------------------
+def _config4_module(teacher_precision):
+    mod, cfg = _build("dinov2_vitg14", "convnext_base", 224, (16, 24), seed=1, teacher_precision=teacher_precision)
+    with torch.no_grad():
+        for n_, p_ in mod.student.named_parameters():
+            if "grn" in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+            elif p_.dim() > 1:
+                p_.mul_(4.0)
+    return mod, cfg
+
+
+def test_config4_vitg14_convnext_base_fp32_teacher_step_vs_oracle():
+    """The shapes of configs[4] in exact fp32 first: D = 1536 / 40 blocks / 24 heads / SwiGLU FFN (hidden 4096), blocks 30..38
+    re-used on the student tokens, convnext_base (depths 3/3/27/3, dims 128..1024), ScaleKD head dims 96 / 64.  No fp64
+    arbiter here (a 1.1 B-parameter teacher in double precision): the kink-robust bound of the other step tests applies."""
+    mod, cfg = _config4_module(None)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    _check_step(mod, cfg, x, "configs[4] vitg14(fp32)->convnext_base B=1", arbiter=False, grad_bound=3e-3)
+
+
+def test_config4_vitg14_bf16_teacher_convnext_base_step_vs_bf16_oracle():
+    """BASELINE configs[4]'s "bf16 teacher on MFMA": the frozen teacher (forward AND the re-use of blocks 30..38 on student
+    tokens, forward + dgrad) computes with GEMM operands rounded to bf16 and fp32 accumulation, against the oracle that
+    emulates exactly that arithmetic.  bf16 rounding is discontinuous (an fp32-ulp difference at a rounding boundary moves an
+    operand by 4e-3), so two exact implementations of the same bf16 model separate at the bf16 noise level over 40 blocks;
+    the distance between the bf16-teacher and the fp32-teacher oracle runs measures that level and bounds the comparison
+    (block-level agreement of the bf16 arithmetic itself: test_bf16_swiglu_block_vs_bf16_oracle, 3e-3 per element)."""
+    mod, cfg = _config4_module("bf16")
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    ref16, gs16, gl16 = oracle_step(mod, cfg, x, torch.float32, teacher_bf16=True)
+    ref32, gs32, gl32 = oracle_step(mod, cfg, x, torch.float32, teacher_bf16=False)
+    from dinov2_distillation_amd import ops
+    mod.cuda().train()
+    loss = mod.training_step(x.cuda(), 0)
+    loss.backward()
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    lk = [k for k in ref32 if "loss" in k]
+    noise = max(abs(float(ref16[k]) - float(ref32[k])) / abs(float(ref32[k])) for k in lk)
+    dev = max(abs(float(mod.logged["train_" + k]) - float(ref16[k])) / abs(float(ref16[k])) for k in lk)
+    print(f"configs[4]: logged losses vs bf16-teacher oracle {dev:.2e}; bf16-teacher oracle vs fp32-teacher oracle {noise:.2e}")
+    assert dev <= max(1e-3, 0.75 * noise), (dev, noise)
+    gs, gl = module_grads(mod)
+    for tag, ours, g16, g32 in (("student", gs, gs16, gs32), ("projectors", gl, gl16, gl32)):
+        gmax = max(v.abs().max().item() for v in g16.values())
+        names = [k for k in sorted(g16) if g16[k].abs().max().item() >= 1e-6 * gmax]
+        e16 = rel_l2(flat(ours, names), flat(g16, names))
+        e32 = rel_l2(flat(ours, names), flat(g32, names))
+        o = rel_l2(flat(g16, names), flat(g32, names))
+        print(f"configs[4]: {tag} gradient relL2: ours vs bf16 oracle {e16:.2e}, ours vs fp32 oracle {e32:.2e}, "
+              f"bf16 oracle vs fp32 oracle {o:.2e}")
+        assert e16 <= max(3e-3, 0.75 * o), (tag, e16, o)
+
+
+def test_bf16_swiglu_block_vs_bf16_oracle():
+    """one ViT-g block (D = 1536, 24 heads, SwiGLU hidden 4096) in the bf16-operand mode, forward + dgrad, against the
+    bf16-emulating oracle element by element: pins the ARITHMETIC of configs[4]'s teacher mode where chaos cannot hide it"""
+    from dinov2_distillation_amd.models.dinov2 import Block
+    from oracle import vit_oracle as vo
+    gen = torch.Generator().manual_seed(3)
+    D, H = 1536, 24
+    blk = Block(D, H, gen, ffn="swiglu")
+    from dinov2_distillation_amd import ops
+    blk.precision = ops.PREC_BF16
+    with torch.no_grad():
+        for k, v in blk.state_dict().items():
+            if k.endswith("gamma"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+            elif k.endswith("bias"):
+                v.copy_(0.05 * torch.randn(v.shape, generator=gen))
+    p = {"blocks.0." + k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(2, 257, D, generator=gen).requires_grad_(True)
+    ref = vo.vit_block(p, "blocks.0.", x, H, bf16=True)
+    ct = torch.randn(2, 257, D, generator=gen)
+    ref.backward(ct)
+    blk.cuda()
+    xg = x.detach().cuda().requires_grad_(True)
+    out = blk(xg)
+    close(out, ref, "bf16 swiglu block fwd", rtol=3e-3)
+    out.backward(ct.cuda())
+    close(xg.grad, x.grad, "bf16 swiglu block dgrad", rtol=3e-3)
+
+
+# ---- full batch sizes: size-independent properties ---------------------------------------------------------------------------
+def _full_size_properties(st, x, what, per_image_student):
+    """(i) determinism: two passes from the same state are bit-identical (no floating-point atomics on the path);
+    (ii) linearity of the backward pass: the gradient of 2 * loss is exactly 2 x the gradient (powers of two are exact in
+    fp32, so any data-dependent branch or stale accumulator shows up as a bit difference); (iii) logged totals are the sum
+    of their parts; (iv) per-image independence of the teacher (and of students without cross-image statistics)."""
+    from dinov2_distillation_amd import functional as Fn, ops
+
+    def grads(scale=1.0):
+        Fn._DROP_CALLS[0] = 0  # same dropout masks in every pass (Swin's drop_rate 0.3 stays live)
+        st.optimizer.zero_grad()
+        loss = st.module.training_step(x, 0)
+        (loss * scale).backward()
+        ops.wgrad_join()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), st.optimizer.flat_g.clone()
+
+    l1, g1 = grads()
+    for _ in range(2):
+        l2, g2 = grads()
+        assert torch.equal(l1, l2), what + f": loss not reproducible ({float(l1)!r} vs {float(l2)!r})"
+        assert torch.equal(g1, g2), what + f": gradients not reproducible (max diff {(g1 - g2).abs().max().item():.3e})"
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    _, g3 = grads(2.0)
+    assert torch.equal(g3, 2.0 * g1), what + f": backward not linear ({(g3 - 2 * g1).abs().max().item():.3e})"
+    lg = st.module.logged
+    for lvl in ("scalekd_res4", "scalekd_res5"):
+        close(lg[f"train_{lvl}_total_loss"], lg[f"train_{lvl}_spatial_loss"] + lg[f"train_{lvl}_frequency_loss"], lvl, rtol=1e-6)
+    half = x.shape[0] // 2
+    st.module.eval()
+    with torch.no_grad():
+        close(st.teacher(x[:half])["feature_map"], st.teacher(x)["feature_map"][:half], what + " teacher per image", rtol=5e-5)
+        if per_image_student:
+            a, b = st.student(x[:half]), st.student(x)
+            for k in a:
+                close(a[k], b[k][:half], f"{what} student {k} per image", rtol=5e-5)
+    print(f"{what}: deterministic, backward linear, loss {float(l1):.5f}")
+
+
+def test_full_size_config2_vitb14_resnet50_bs128_properties():
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(teacher="dinov2_vitb14", student="resnet_50", heads=(16, 24), device="cuda:0")
+    x = torch.randn(128, 3, 224, 224, generator=torch.Generator().manual_seed(1234)).cuda()
+    _full_size_properties(st, x, "configs[2] bs128", per_image_student=True)  # eval mode: BatchNorm on running statistics
+
+
+def test_full_size_config3_vitl14_swin_tiny_518_bs16_properties():
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(teacher="dinov2_vitl14", student="swin_tiny", crop=518, heads=(16, 32), device="cuda:0")
+    x = torch.randn(16, 3, 518, 518, generator=torch.Generator().manual_seed(1234)).cuda()
+    _full_size_properties(st, x, "configs[3] bs16 518", per_image_student=True)
+
+
+def test_full_size_config4_vitg14_bf16_convnext_base_bs32_properties():
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(teacher="dinov2_vitg14", student="convnext_base", heads=(16, 24), device="cuda:0",
+                             teacher_precision="bf16")
+    x = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(1234)).cuda()
+    _full_size_properties(st, x, "configs[4] bs32 bf16 teacher", per_image_student=True)

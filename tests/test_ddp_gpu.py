@@ -1,0 +1,172 @@
+"""GPU tests of the data-parallel / Lightning integration surface:
+gradient accumulation over two backward passes, the L.LightningModule branch driven by a stand-in fit loop, optimiser
+checkpoint round trip, and torch's own DistributedDataParallel wrapped around the step module (Lightning ``strategy: ddp``,
+the reference default, config/config.yaml:67)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_backward_passes_accumulate_like_autograd():
+    """accumulate_grad_batches (train.py:269): a second backward without zero_grad must ADD to every gradient - the ones the
+    kernels write in place on the side stream as well as the ones autograd accumulates.  Round 1 overwrote the former."""
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    st = DistillationStepper(device="cuda:0")
+    xs = [torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(60 + i)).cuda() for i in range(2)]
+
+    def backward(x, zero):
+        if zero:
+            st.optimizer.zero_grad()
+        st.module.training_step(x, 0).backward()
+        ops.wgrad_join()
+        torch.cuda.synchronize()
+        return st.optimizer.flat_g.clone()
+
+    g1 = backward(xs[0], True)
+    g2 = backward(xs[1], True)
+    backward(xs[0], True)
+    acc = backward(xs[1], False)
+    assert float(g2.abs().max()) > 0 and not torch.equal(g1, g2)
+    err = ((acc - (g1 + g2)).norm() / (g1 + g2).norm()).item()
+    worst = ((acc - (g1 + g2)).abs().max() / (g1 + g2).abs().max()).item()
+    print(f"accumulated vs g1 + g2: relL2 {err:.2e}, max-norm {worst:.2e}")
+    assert err < 1e-6 and worst < 1e-5
+    # and the stepper's own accumulate mode: two micro-batches == one optimiser step on the mean gradient
+    a = DistillationStepper(device="cuda:0", accumulate_grad_batches=2)
+    for x in xs:
+        a.step(x)
+    assert a.step_idx == 1 and a.optimizer._steps == 1
+    b = DistillationStepper(device="cuda:0")
+    b.optimizer.zero_grad()
+    for x in xs:
+        (b.module.training_step(x, 0) / 2).backward()
+    b.optimizer.step(clip_grad_norm=1.0)
+    torch.cuda.synchronize()
+    d = ((a.optimizer.flat_p - b.optimizer.flat_p).norm() / b.optimizer.flat_p.norm()).item()
+    assert d < 1e-6, d
+
+
+def test_lightning_branch_on_gpu_matches_the_stepper():
+    """the L.LightningModule branch under a stand-in Lightning fit loop (automatic optimisation order, clip_grad_norm_ on the
+    .grad views after on_after_backward joined the side streams, accumulate 2, optimizer.step() without the fused clip) gives
+    the losses and parameters of the build's own stepper on the same four micro-batches"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "lightning_standin.py"), "gpu"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print(out)
+    assert out["global_step"] == 2 and len(out["losses"]) == 4 and out["async_wgrad"]
+    for a, b in zip(out["losses"], out["ref_losses"]):
+        assert abs(a - b) <= 1e-5 * abs(b), (out["losses"], out["ref_losses"])
+    assert out["param_rel_diff"] < 1e-5, out["param_rel_diff"]
+
+
+def test_optimizer_checkpoint_resume_is_bit_equal():
+    """save optimizer.state_dict() + parameters after 2 steps, restore into a fresh stepper, take step 3 on both: identical"""
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    xs = [torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(80 + i)).cuda() for i in range(3)]
+    a = DistillationStepper(device="cuda:0")
+    for x in xs[:2]:
+        a.step(x)
+    ck = {"opt": a.optimizer.state_dict(), "mod": {k: v.clone() for k, v in a.module.state_dict().items()}}
+    b = DistillationStepper(device="cuda:0", seed=5)  # different initial weights: everything must come from the checkpoint
+    b.module.load_state_dict(ck["mod"])
+    b.optimizer.load_state_dict(ck["opt"])
+    assert b.optimizer._steps == 2
+    la, lb = a.step(xs[2]), b.step(xs[2])
+    torch.cuda.synchronize()
+    assert torch.equal(la.detach(), lb.detach())
+    assert torch.equal(a.optimizer.flat_p, b.optimizer.flat_p) and torch.equal(a.optimizer.flat_m, b.optimizer.flat_m)
+
+
+def _torch_ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.config import make_config, set_student_dims
+    from dinov2_distillation_amd.ddp import init_process_group_from_env
+    from dinov2_distillation_amd.models import DINOv2ViT, ModelWrapper
+    from dinov2_distillation_amd.train import DistillationModule
+    torch.cuda.set_device(0)
+    init_process_group_from_env("gloo")  # two ranks share the one GPU of the box: gloo (RCCL needs a GPU per rank)
+    cfg = make_config()
+    torch.manual_seed(1)
+    student = ModelWrapper("convnext_tiny", cfg.teacher.n_patches, cfg.student.student_keys)
+    set_student_dims(cfg, student)
+    mod = DistillationModule(student, DINOv2ViT("dinov2_vits14", seed=0), cfg).cuda().train()
+    opt = mod.configure_optimizers()
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1234 + rank)).cuda()
+    assert ops.ASYNC_WGRAD and not ops.exchange_ok()  # a multi-rank job without the bucket reducer: in-place writes are off
+
+    class Step(torch.nn.Module):  # what Lightning's DDP strategy does: training_step behind the wrapper's forward
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, batch):
+            return self.m.training_step(batch, 0)
+
+    # (1) local gradients, no exchange
+    opt.zero_grad()
+    mod.training_step(x, 0).backward()
+    mod.on_after_backward()
+    torch.cuda.synchronize()
+    local = opt.flat_g.clone()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = sum(gathered) / world
+    # (2) torch DDP around the module
+    ddp = DDP(Step(mod), device_ids=[0], find_unused_parameters=True)
+    opt.zero_grad()
+    ddp(x).backward()
+    mod.on_after_backward()
+    torch.cuda.synchronize()
+    got = opt.flat_g
+    err = ((got - expect).abs().max() / expect.abs().max()).item()
+    views_kept = all(p.grad is v for (p, _, _), v in zip(opt.layout, opt._grad_views))
+    opt.step(clip_grad_norm=1.0)
+    torch.cuda.synchronize()
+    flat = opt.flat_p.clone()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    q.put((rank, err, views_kept, bool(torch.equal(both[0], both[1]))))
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_wrapper_sees_every_gradient():
+    """INTEGRATION.md section 1 "keep strategy: ddp": with torch's DistributedDataParallel around the module and NO
+    GradBucketReducer, gradients must flow through autograd (ops.exchange_ok() is False), DDP averages all of them, the
+    arena views stay attached and the ranks' parameters stay identical after the fused step."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_torch_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, views_kept, same_params in res:
+        assert err < 1e-5, (rank, err)
+        assert views_kept and same_params, (rank, views_kept, same_params)

@@ -272,3 +272,167 @@ def test_student_checkpoint_warm_start_and_export_keys(tmp_path):
     assert exported and all(k.startswith("backbone.") for k in exported)
     assert "backbone.stages.3.1.pwconv2.weight" in exported and not any("projector" in k for k in exported)
     assert any(k.startswith("losses.scalekd_res4.projector_0") for k in m2.state_dict())
+
+
+# ---- round 2: the Lightning branch, optimiser state, teacher broadcast, in-place gradient rules ------------------------------
+def test_lightning_branch_drives_log_optimizers_and_fit_order():
+    """train/distillation_module.py's ``L.LightningModule`` branch, driven the way /root/reference/train.py:209-213,256-288 drives
+    the reference's module (stand-in ``lightning`` package, tests/lightning_standin.py; subprocess because the stand-in must be
+    importable before the package is): configure_optimizers' dict layout, one optimizer with the reference's three parameter
+    groups (distillation_module.py:457-479), the epoch-interval cosine scheduler, every metric name of
+    ``_log_training_metrics`` with sync_dist=True plus the ``lr`` log that reads ``self.optimizers()``."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "lightning_standin.py"), "cpu"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["groups"] == ["student", "loss_scalekd_res4", "loss_scalekd_res5"]
+    assert out["n_log_calls"] == 8 * 12 and out["sync_dist_all"]  # 8 micro-batches x (11 scalars + lr)
+    assert "lr" in out["logged_names"] and "train_loss" in out["logged_names"]
+    assert sum(n.startswith("train_scalekd_res") for n in out["logged_names"]) == 10
+    assert out["global_step"] == 4  # 2 epochs x 4 micro-batches / accumulate 2
+    assert out["lr_logged"][0] == pytest.approx(1e-3) and out["lr_logged"][-1] < 1e-3  # the scheduler stepped after epoch 0
+    from oracle.step_oracle import cosine_lr
+    assert out["final_lr"] == pytest.approx(cosine_lr(1e-3, 2), rel=1e-6)
+
+
+def test_fused_adamw_state_dict_is_torch_adamw_layout_and_round_trips():
+    """Lightning ModelCheckpoint / resume (train.py:83,284) go through optimizer.state_dict(): per-parameter step / exp_avg /
+    exp_avg_sq in torch.optim.AdamW's layout, so a reference run's optimizer state loads into the fused optimiser and back."""
+    from dinov2_distillation_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Linear(10, 3))
+    net[0].bias.requires_grad_(False)  # frozen parameters stay in the group but own no arena slot (distillation_module.py:457-461)
+    ref_net = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Linear(10, 3))
+    ref_net.load_state_dict(net.state_dict())
+    ref_net[0].bias.requires_grad_(False)
+    ref = torch.optim.AdamW([{"params": list(ref_net.parameters())}], lr=1e-3, weight_decay=0.01)
+    for i in range(3):  # a few real torch steps: non-trivial moments and step counters
+        ref.zero_grad()
+        ref_net(torch.randn(4, 6, generator=torch.Generator().manual_seed(i))).pow(2).sum().backward()
+        ref.step()
+    opt = FusedAdamW([{"params": list(net.parameters()), "name": "student"}], lr=1e-3)
+    opt.load_state_dict(ref.state_dict())
+    assert opt._steps == 3
+    rs = ref.state_dict()["state"]
+    for i, p in enumerate(net.parameters()):
+        if not p.requires_grad:
+            continue
+        assert torch.equal(opt.state[p]["exp_avg"], rs[i]["exp_avg"]) and torch.equal(opt.state[p]["exp_avg_sq"], rs[i]["exp_avg_sq"])
+        assert opt.state[p]["exp_avg"].data_ptr() >= opt.flat_m.data_ptr()  # views of the arena, not copies
+    sd = opt.state_dict()
+    assert set(sd["state"]) == set(rs) and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd["state"].values())
+    assert all(float(v["step"]) == 3.0 for v in sd["state"].values())
+    assert "_range" not in sd["param_groups"][0] and sd["param_groups"][0]["params"] == [0, 1, 2, 3]
+    opt.flat_m.add_(1.0)  # the exported state is a snapshot, not an alias of the live arena
+    assert torch.equal(sd["state"][0]["exp_avg"], rs[0]["exp_avg"])
+    opt2 = FusedAdamW([{"params": list(net.parameters()), "name": "student"}], lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert opt2._steps == 3 and torch.equal(opt2.flat_v, opt.flat_v) and not torch.equal(opt2.flat_m, opt.flat_m)
+    # torch's own AdamW accepts the export as well
+    back = torch.optim.AdamW([{"params": list(ref_net.parameters())}], lr=1e-3)
+    back.load_state_dict(sd)
+    assert torch.equal(back.state_dict()["state"][2]["exp_avg_sq"], rs[2]["exp_avg_sq"])
+    with pytest.raises(Exception, match="GPU"):
+        opt.step()  # no CPU path: loud
+
+
+def test_foreign_gradients_are_adopted_not_ignored():
+    """``module.zero_grad()`` (set_to_none) detaches the arena views; a later backward allocates fresh .grad tensors.  The fused
+    update must adopt them into the arena (and re-attach the views) instead of stepping on stale zeros."""
+    from dinov2_distillation_amd.optim import FusedAdamW
+    net = torch.nn.Linear(4, 4)
+    opt = FusedAdamW(net.parameters(), lr=1e-3)
+    net.zero_grad(set_to_none=True)
+    assert net.weight.grad is None
+    net(torch.ones(2, 4)).sum().backward()
+    foreign = net.weight.grad.clone()
+    assert net.weight.grad.data_ptr() != opt._grad_views[0].data_ptr()
+    opt._reattach(adopt=True)
+    assert net.weight.grad is opt._grad_views[0] and torch.equal(opt.flat_g[:16].view(4, 4), foreign)
+
+
+def test_inplace_gradient_rules():
+    """ops.can_async: in-place arena writes only (a) once per parameter between two zero_grad() calls - a second backward pass
+    (accumulate_grad_batches, train.py:269) goes back to autograd, which ADDS - and (b) when the gradient exchange is aware
+    of them (one rank, or ddp.GradBucketReducer registered as listener; never under a foreign DDP wrapper)."""
+    from dinov2_distillation_amd import ops
+    w = torch.nn.Parameter(torch.zeros(4, 4))
+    w.grad = torch.zeros(4, 4)
+    was = ops.ASYNC_WGRAD
+    try:
+        ops.ASYNC_WGRAD = True
+        ops.mark_grads_fresh()
+        assert ops.can_async(w)
+        ops.claim(w)
+        assert not ops.can_async(w)          # second write since zero_grad: accumulate through autograd
+        ops.mark_grads_fresh()
+        assert ops.can_async(w)
+        ops.ASYNC_WGRAD = False
+        assert not ops.can_async(w)
+    finally:
+        ops.ASYNC_WGRAD = was
+        ops.mark_grads_fresh()
+
+
+def _bcast_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo")
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.ddp import GradBucketReducer
+    from dinov2_distillation_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+
+    class Step(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.teacher = torch.nn.Sequential(torch.nn.Linear(300, 1200), torch.nn.Linear(1200, 8))  # > 4 MiB? no: coalesced path
+            self.big = torch.nn.Linear(1100, 1100)                                                     # 4.8 MB: direct path
+            self.student = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.BatchNorm1d(8))
+            for p in list(self.teacher.parameters()) + list(self.big.parameters()):
+                p.requires_grad = False
+
+    m = Step()
+    opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    if rank == 1:  # a rank whose teacher checkpoint / BatchNorm statistics / student weights differ
+        with torch.no_grad():
+            for t in list(m.parameters()) + list(m.buffers()):
+                t.add_(1) if t.dtype.is_floating_point else t.add_(5)
+    red = GradBucketReducer(opt)
+    # without a listener a multi-rank job must not write gradients in place (foreign DDP wrapper case)
+    ops.ASYNC_WGRAD = True
+    ops.remove_grad_listener(red._on_grad)
+    no_listener = ops.exchange_ok()
+    ops.add_grad_listener(red._on_grad)
+    with_listener = ops.exchange_ok()
+    ops.ASYNC_WGRAD = False
+    red.broadcast_parameters(0, m)
+    flat = torch.cat([t.detach().double().reshape(-1) for t in list(m.parameters()) + list(m.buffers())])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, bool(torch.equal(gathered[0], gathered[1])), no_listener, with_listener,
+           int(m.student[1].num_batches_tracked)))
+    dist.destroy_process_group()
+
+
+def test_teacher_and_buffers_are_broadcast_once_gloo_world2():
+    """north_star: "teacher frozen, broadcast once".  Rank 1 starts with different teacher weights, BatchNorm statistics and
+    student weights; after broadcast_parameters(0, module) every tensor of the module equals rank 0's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, equal, no_listener, with_listener, nbt in res:
+        assert equal, rank
+        assert no_listener is False and with_listener is True
+        assert nbt == 0  # rank 1's +5 was overwritten by rank 0's value

@@ -464,8 +464,8 @@ def test_presnet_against_reference_golden(golden_dir, depth):
     f64 = po.forward(p64, g["in/x"].double(), BLOCKS[depth], bottleneck=depth >= 50)
     sum((f64[k] * g["in/cotangent_" + k].double()).sum() for k in ("res4", "res5")).backward()
     sd = dict(net.named_parameters())
-    # Which tensor a given rounding pattern hits hardest is a matter of luck (any change of a summation order moves it), so the
-    # reference's own WORST relative deviation over all tensors is part of the allowance, not only its deviation on this tensor.
+    # The column reductions behind the BatchNorm / bias gradients are Kahan-compensated (csrc/rowops.hip): per call they are closer
+    # to the fp64 sum of the same input than torch's own fp32 sum (tests/diag/diag_colreduce_accuracy.py).
     rows = []
     for k, v in g.items():
         if k.startswith("pgrad_digest/"):
@@ -478,11 +478,9 @@ def test_presnet_against_reference_golden(golden_dir, depth):
                 rows.append((k, what, (d[sl] - t[sl]).abs().max().item(), (v[sl] - t[sl]).abs().max().item(), scale))
         if k.startswith("after/"):
             close(net.state_dict()[k[6:]], v, k)
-    worst_ref = max(e_ref / scale for _, _, _, e_ref, scale in rows)
     worst = 0.0
     for k, what, e_ours, e_ref, scale in rows:
-        assert e_ours <= max(3e-3 * scale, 4 * e_ref, 2 * worst_ref * scale) + 1e-7, \
-            f"{k} ({what}): ours {e_ours:.3e}, reference {e_ref:.3e}, scale {scale:.3e}, reference's worst {worst_ref:.2e}"
+        assert e_ours <= max(3e-3 * scale, 4 * e_ref) + 1e-7, f"{k} ({what}): ours {e_ours:.3e}, reference {e_ref:.3e}, scale {scale:.3e}"
         worst = max(worst, e_ours / scale)
     assert worst < 5e-2, worst
 
@@ -533,10 +531,8 @@ def test_darknet_against_reference_golden(golden_dir):
         if k.startswith("after/"):
             close(net.state_dict()[k[6:]], v, k)
     assert n == len(sd)
-    worst_ref = max(e_ref / scale for _, _, _, e_ref, scale in rows)   # (as in the PResNet test: the reference's own worst case)
     for k, what, e_ours, e_ref, scale in rows:
-        assert e_ours <= max(2e-3 * scale, 4 * e_ref, 2 * worst_ref * scale) + 1e-7, \
-            f"{k} ({what}): ours {e_ours:.3e}, reference {e_ref:.3e}, scale {scale:.3e}, reference's worst {worst_ref:.2e}"
+        assert e_ours <= max(2e-3 * scale, 4 * e_ref) + 1e-7, f"{k} ({what}): ours {e_ours:.3e}, reference {e_ref:.3e}, scale {scale:.3e}"
 
 
 def test_darknet_student_runs_full_step():
