@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+PMC_FILE = "r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
 
 
 class GemmProfiler:
@@ -62,12 +63,55 @@ class GemmProfiler:
         return n, tot_ms, tot_fl
 
 
-def cpu_baseline(seconds_budget=25.0, batch=2):
+class HbmProfiler:
+    """HIP-event pairs around the ScaleKD loss-tail launches (the kernel BASELINE.json's north_star singles out for the 8 TB/s
+    roofline), on their launch stream; algorithmic bytes per launch from SURVEY 8(d): forward reads S and T once
+    (2 * rows * D * 4), backward reads both and writes dS (3 * rows * D * 4)."""
+
+    def __init__(self):
+        self.records = {"kd_loss_fwd": [], "kd_loss_bwd": []}
+        self.enabled = False
+
+    def wrap(self, ops):
+        def make(name, inner, nbuf):
+            def f(s, t, *a, **kw):
+                if not self.enabled:
+                    return inner(s, t, *a, **kw)
+                st = torch.cuda.current_stream()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                out = inner(s, t, *a, **kw)
+                e1.record(st)
+                self.records[name].append((e0, e1, nbuf * s.numel() * 4))
+                return out
+            return f
+        ops.kd_loss_fwd = make("kd_loss_fwd", ops.kd_loss_fwd, 2)
+        ops.kd_loss_bwd = make("kd_loss_bwd", ops.kd_loss_bwd, 3)
+
+    def summary(self, pmc):
+        out = []
+        for name, recs in self.records.items():
+            if not recs:
+                continue
+            us = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) * 1e3 / len(recs)
+            by = sum(b for _, _, b in recs) / len(recs)
+            traffic = None
+            for k, v in pmc.items():
+                if k.startswith(name):
+                    traffic = v.get("traffic_bytes")
+            out.append({"kernel": name + "_kernel (csrc/loss.hip)", "bound": "hbm", "achieved": round(by / us * 1e-3, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(by / us * 1e-3 / 8000.0, 4), "traffic": traffic,
+                        "avg_launch_us": round(us, 2), "bytes_per_launch": int(by), "launches": len(recs)})
+        return out
+
+
+def cpu_baseline(seconds_budget=25.0, batch=2, max_steps=None):
     """The CPU oracle (oracle/, kind 'port') timed on the host cores on a bounded sample of the SAME workload:
     full step = teacher fwd + student fwd/bwd + ScaleKD fwd/bwd + clip + AdamW, config[1] shapes at a small batch."""
     from oracle import convnext_oracle as cno, step_oracle as so, vit_oracle as vo
     from dinov2_distillation_amd.config import make_config
-    ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("DKD_CPU_THREADS", "16")))  # the box's CPU share
+    ncpu = len(os.sched_getaffinity(0))  # every host core this process may run on (SURVEY 8d); DKD_CPU_THREADS overrides
+    ncpu = int(os.environ.get("DKD_CPU_THREADS", ncpu))
     torch.set_num_threads(ncpu)
     cfg = make_config()
     tcfg = vo.VIT_CONFIGS["dinov2_vits14"]
@@ -105,9 +149,10 @@ def cpu_baseline(seconds_budget=25.0, batch=2):
             so.adamw_step_(train, grads, m_, v_, steps + 1)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_budget * 0.6:
+        if dt > seconds_budget * 0.6 or (max_steps and steps >= max_steps):
             break
-    return {"value": round(steps * batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(steps * batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "affinity_cores": len(os.sched_getaffinity(0)), "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{steps} full steps (teacher fwd + student fwd/bwd + ScaleKD + clip + AdamW) of config[1] at batch "
                       f"{batch} on the host CPU, fp32 torch oracle, {dt:.1f} s"}
 
@@ -119,6 +164,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config[1]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-bs64", action="store_true", help="skip the bs-64 leg of the CPU baseline (~20 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3-split-GEMM timing (reported separately)")
     args = ap.parse_args()
@@ -140,9 +186,10 @@ def main():
 
     from dinov2_distillation_amd import ops
     from dinov2_distillation_amd.trainer import DistillationStepper
-    prof = GemmProfiler()
+    prof, hprof = GemmProfiler(), HbmProfiler()
     if not args.no_roofline:
         prof.wrap(ops)
+        hprof.wrap(ops)
     t_start = time.perf_counter()
     stepper = DistillationStepper(device=f"cuda:{local}")
     gen = torch.Generator().manual_seed(1234 + rank)
@@ -185,11 +232,11 @@ def main():
         ops.ASYNC_WGRAD = False            # every kernel of these two steps on ONE stream: weight gradients ...
         dm.TEACHER_ON_SIDE_STREAM = False  # ... the teacher forward ...
         dm.TWO_CHAIN_STREAMS = False       # ... and the frequency loss chain are not co-scheduled with anything
-        prof.enabled = True
+        prof.enabled = hprof.enabled = True
         for _ in range(2):
             stepper.step(batch)
         sync()
-        prof.enabled = False
+        prof.enabled = hprof.enabled = False
         ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS = async_was, side_was, chain_was
         recs = prof.records[n0:]
         prof.records = prof.records[:n0]
@@ -248,15 +295,21 @@ def main():
         ach = serial if serial else ach_timed
         # HBM-side bytes per launch of this kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH x2 gfx950 correction; scripts/pmc_summarize.py)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        traffic, pmc_kernels = None, {}
+        pmc = os.path.join(ROOT, "profiles", PMC_FILE)
         if os.path.exists(pmc) and args.batch == 64:
-            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if k.startswith("gemm_f32_")]  # dma + v2 kernels
+            pmc_kernels = json.load(open(pmc))["kernels"]
+            ks = [v for k, v in pmc_kernels.items() if k.startswith("gemm_f32_")]  # dma + v2 kernels
             if ks:
                 traffic = round(sum(v["traffic_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
+        flop_per_step = gemm_fl / args.steps
         res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                           "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.md)",
+                           "traffic_unit": f"HBM-side bytes per launch (PMC, profiles/{PMC_FILE})",
+                           # the unambiguous whole-step figure: every GEMM FLOP of a step / the step's wall time / the peak
+                           "whole_step_achieved": round(flop_per_step / (ms * 1e-3) / 1e12, 2),
+                           "whole_step_frac": round(flop_per_step / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                           "gemm_flop_per_step": round(flop_per_step),
                            "kernel": "gemm_f32_dma_kernel / gemm_f32_v2_kernel (fp32 MFMA 16x16x4; LDS-DMA staged for K >= 768, register "
                                      "staged otherwise), every dkd_gemm_f32 launch of the step",
                            "achieved_timed_region": round(ach_timed, 2),
@@ -269,9 +322,14 @@ def main():
                            "avg_launch_us_timed_region": round(gemm_ms * 1e3 / max(n, 1), 2),
                            "avg_flop_per_launch": round(gemm_fl / max(n, 1)),
                            "gemm_share_of_step": round(gemm_ms / args.steps / ms, 3)}
+        # second roofline class: the HBM-bound ScaleKD loss tail (same single-stream pass; peak = 8 TB/s spec, 6.3 achievable)
+        res["roofline_hbm"] = hprof.summary(pmc_kernels)
     if not args.no_cpu_baseline and world == 1:
         note("timing the CPU oracle (cpu_baseline) ...")
         res["cpu_baseline"] = cpu_baseline()
+        if args.batch == 64 and not args.no_cpu_bs64:
+            note("timing the CPU oracle at the bench batch size (cpu_baseline_bs64) ...")
+            res["cpu_baseline_bs64"] = cpu_baseline(seconds_budget=40.0, batch=64, max_steps=2)
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -9,170 +9,274 @@
 
 namespace {
 constexpr int KD_MAXV = 8;  // float4 per lane: D <= 2048
+constexpr int KD_U = 1;     // row groups per wave and pass (2 measured no better: hipcc sinks the second group's loads below the first reduction)
 
+// Rows narrower than 64 float4 share a wave (LPR lanes per row, 64 / LPR rows per wave), VPL float4 per lane; with KD_U = 2 a
+// lane has 2 * 2 * VPL 16-byte loads in flight (D = 384: 12) instead of the 4 of the one-row-per-wave version, which ran at
+// 2.7 TB/s because of it (traffic == algorithmic bytes, so latency-bound: profiles/r01_pmc_traffic.md).
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int VPL>
 struct RowVals {
-    float4 s[KD_MAXV], t[KD_MAXV];
+    float4 s[VPL], t[VPL];
 };
 
-__device__ __forceinline__ void load_row(RowVals& v, const float* __restrict__ S, const float* __restrict__ T,
-                                         const float* __restrict__ ms, const float* __restrict__ mt, long row, long b,
-                                         int D, int lane) {
+// Straight-line loads: out-of-range lanes / rows read a clamped (valid) address and are zeroed by a select afterwards, and the
+// frequency variant is a template flag - with run-time "if (ms)" branches hipcc put an s_waitcnt vmcnt(0) behind every mean
+// load, which serialised the row loads (seen in the ISA); now every load of a row group is issued before the first use.
+template <int LPR, int VPL, bool FREQ>
+__device__ __forceinline__ void load_row(RowVals<VPL>& v, const float* __restrict__ S, const float* __restrict__ T,
+                                         const float* __restrict__ ms, const float* __restrict__ mt, long row, long rows,
+                                         long rows_per_img, int D, int lir) {
     const int nv = D >> 2;
-    const float4* sr = reinterpret_cast<const float4*>(S + row * D);
-    const float4* tr = reinterpret_cast<const float4*>(T + row * D);
+    const bool ok = row < rows;
+    const long r = ok ? row : rows - 1;
+    const float4* sr = reinterpret_cast<const float4*>(S + r * D);
+    const float4* tr = reinterpret_cast<const float4*>(T + r * D);
+    float4 m_s[VPL], m_t[VPL];
 #pragma unroll
-    for (int i = 0; i < KD_MAXV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            float4 a = sr[c], d = tr[c];
-            if (ms) {
-                const float4 m = reinterpret_cast<const float4*>(ms + b * D)[c];
-                a.x -= m.x; a.y -= m.y; a.z -= m.z; a.w -= m.w;
-            }
-            if (mt) {
-                const float4 m = reinterpret_cast<const float4*>(mt + b * D)[c];
-                d.x -= m.x; d.y -= m.y; d.z -= m.z; d.w -= m.w;
-            }
-            v.s[i] = a;
-            v.t[i] = d;
-        } else {
-            v.s[i] = v.t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < VPL; ++i) {
+        const int c = min(lir + i * LPR, nv - 1);
+        v.s[i] = sr[c];
+        v.t[i] = tr[c];
+    }
+    if (FREQ) {
+        const long b = r / rows_per_img;
+        const float4* msr = reinterpret_cast<const float4*>(ms + b * D);
+        const float4* mtr = reinterpret_cast<const float4*>(mt + b * D);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = min(lir + i * LPR, nv - 1);
+            m_s[i] = msr[c];
+            m_t[i] = mtr[c];
         }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const bool live = ok && lir + i * LPR < nv;
+        float4 a = v.s[i], d = v.t[i];
+        if (FREQ) {
+            a.x -= m_s[i].x; a.y -= m_s[i].y; a.z -= m_s[i].z; a.w -= m_s[i].w;
+            d.x -= m_t[i].x; d.y -= m_t[i].y; d.z -= m_t[i].z; d.w -= m_t[i].w;
+        }
+        v.s[i] = live ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+        v.t[i] = live ? d : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
-__global__ __launch_bounds__(256) void kd_loss_fwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
+// ws layout: [0] ticket counter (int, zero before the first launch, left zero), [4 ...] per-block partial pairs.
+// The block whose ticket is the last one folds every partial in index order (fp64) and writes the two results: the separate
+// one-block "final" launch of round 1 (a ~2 us kernel plus a ~1.5 us boundary behind an 8-10 us kernel) is gone.  Hand-off
+// (MI355X_MICROARCH.md, inter-workgroup visibility): partials are written with agent-scope (sc1, write-through) stores, drained
+// with s_waitcnt vmcnt(0) before the ticket add, and read back with agent-scope (sc1) loads by the last block only.
+template <int LPR, int VPL, bool FREQ>
+__global__ __launch_bounds__(256, (VPL <= 3 && !FREQ) ? 8 : 1) void kd_loss_fwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
                                                           const float* __restrict__ ms, const float* __restrict__ mt,
-                                                          float* __restrict__ partials, long rows, long rows_per_img,
-                                                          int D) {
+                                                          float* __restrict__ ws, float* __restrict__ out, long rows,
+                                                          long rows_per_img, int D, float loss_scale, float sim_scale) {
+    constexpr int RPW = 64 / LPR;
     __shared__ float red[2][4];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ int last_flag;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane / LPR, lir = lane % LPR;
     float acc_sq = 0.f, acc_cos = 0.f;
-    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
-        RowVals v;
-        load_row(v, S, T, ms, mt, row, row / rows_per_img, D, lane);
-        float ss = 0.f, tt = 0.f;
+    const long stride = (long)gridDim.x * 4 * RPW;
+    for (long row0 = ((long)blockIdx.x * 4 + wid) * RPW + sub; row0 < rows; row0 += stride * KD_U) {
+        RowVals<VPL> v[KD_U];
 #pragma unroll
-        for (int i = 0; i < KD_MAXV; ++i) {
-            ss += dot4(v.s[i], v.s[i]);
-            tt += dot4(v.t[i], v.t[i]);
-        }
-        ss = wave_sum(ss);
-        tt = wave_sum(tt);
-        const float ns = sqrtf(ss), nt = sqrtf(tt);
-        const float is = 1.f / fmaxf(ns, 1e-12f), it = 1.f / fmaxf(nt, 1e-12f);  // F.normalize eps
-        float sq = 0.f, dt = 0.f;
+        for (int u = 0; u < KD_U; ++u) load_row<LPR, VPL, FREQ>(v[u], S, T, ms, mt, row0 + u * stride, rows, rows_per_img, D, lir);
 #pragma unroll
-        for (int i = 0; i < KD_MAXV; ++i) {
-            const float4 a = make_float4(v.s[i].x * is, v.s[i].y * is, v.s[i].z * is, v.s[i].w * is);
-            const float4 b = make_float4(v.t[i].x * it, v.t[i].y * it, v.t[i].z * it, v.t[i].w * it);
-            const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-            sq += dot4(d, d);
-            dt += dot4(a, b);
+        for (int u = 0; u < KD_U; ++u) {
+            float ss = 0.f, tt = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                ss += dot4(v[u].s[i], v[u].s[i]);
+                tt += dot4(v[u].t[i], v[u].t[i]);
+            }
+            ss = group_sum<LPR>(ss);
+            tt = group_sum<LPR>(tt);
+            const float ns = sqrtf(ss), nt = sqrtf(tt);
+            const float is = 1.f / fmaxf(ns, 1e-12f), it = 1.f / fmaxf(nt, 1e-12f);  // F.normalize eps
+            float sq = 0.f, dt = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float4 a = make_float4(v[u].s[i].x * is, v[u].s[i].y * is, v[u].s[i].z * is, v[u].s[i].w * is);
+                const float4 b = make_float4(v[u].t[i].x * it, v[u].t[i].y * it, v[u].t[i].z * it, v[u].t[i].w * it);
+                const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+                sq += dot4(d, d);
+                dt += dot4(a, b);
+            }
+            sq = group_sum<LPR>(sq);
+            dt = group_sum<LPR>(dt);
+            // cosine_similarity of the normalised maps: norms of s^ and t^ clamped at 1e-8
+            const float nsh = ns * is, nth = nt * it;
+            if (lir == 0 && row0 + u * stride < rows) {
+                acc_sq += sq;
+                acc_cos += dt / (fmaxf(nsh, 1e-8f) * fmaxf(nth, 1e-8f));
+            }
         }
-        sq = wave_sum(sq);
-        dt = wave_sum(dt);
-        // cosine_similarity of the normalised maps: norms of s^ and t^ clamped at 1e-8
-        const float nsh = ns * is, nth = nt * it;
-        acc_sq += sq;
-        acc_cos += dt / (fmaxf(nsh, 1e-8f) * fmaxf(nth, 1e-8f));
+    }
+    // rows of one wave sit in lanes 0, LPR, 2 LPR ...: fold them in lane order
+    if (RPW > 1) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+            acc_sq += __shfl_xor(acc_sq, o, 64);
+            acc_cos += __shfl_xor(acc_cos, o, 64);
+        }
     }
     if (lane == 0) {
         red[0][wid] = acc_sq;
         red[1][wid] = acc_cos;
     }
     __syncthreads();
+    int* ticket = reinterpret_cast<int*>(ws);
+    float* partials = ws + 4;
     if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        partials[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const float p0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float p1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        __hip_atomic_store(partials + 2 * blockIdx.x + 0, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partials + 2 * blockIdx.x + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (t == (int)gridDim.x - 1);
     }
-}
-
-__global__ __launch_bounds__(256) void kd_loss_final_kernel(const float* __restrict__ partials, int n, float* __restrict__ out,
-                                                            float loss_scale, float sim_scale) {
-    __shared__ double red[2][4];
+    __syncthreads();
+    if (!last_flag) return;
+    __shared__ double dred[2][4];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        a += (double)partials[2 * i];
-        b += (double)partials[2 * i + 1];
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        a += (double)__hip_atomic_load(partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += (double)__hip_atomic_load(partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int o = 32; o > 0; o >>= 1) {
         a += __shfl_xor(a, o, 64);
         b += __shfl_xor(b, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = a;
-        red[1][threadIdx.x >> 6] = b;
+    if (lane == 0) {
+        dred[0][wid] = a;
+        dred[1][wid] = b;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (double)loss_scale);
-        out[1] = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (double)sim_scale);
+        out[0] = (float)(((dred[0][0] + dred[0][1]) + (dred[0][2] + dred[0][3])) * (double)loss_scale);
+        out[1] = (float)(((dred[1][0] + dred[1][1]) + (dred[1][2] + dred[1][3])) * (double)sim_scale);
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this workspace
     }
 }
 
 // d loss / d s (centred s when ms != null):  g = 2*coef*gout*(s^ - t^);  ds = (g - s^ (s^ . g)) / |s|
-__global__ __launch_bounds__(256) void kd_loss_bwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
+template <int LPR, int VPL, bool FREQ>
+__global__ __launch_bounds__(256, (VPL <= 3 && !FREQ) ? 8 : 1) void kd_loss_bwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
                                                           const float* __restrict__ ms, const float* __restrict__ mt,
                                                           const float* __restrict__ gout, float* __restrict__ dS,
                                                           long rows, long rows_per_img, int D, float coef) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane / LPR, lir = lane % LPR;
     const float c2 = 2.f * coef * (gout ? gout[0] : 1.f);
     const int nv = D >> 2;
-    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
-        RowVals v;
-        load_row(v, S, T, ms, mt, row, row / rows_per_img, D, lane);
-        float ss = 0.f, tt = 0.f, st = 0.f;
+    const long stride = (long)gridDim.x * 4 * RPW;
+    for (long row0 = ((long)blockIdx.x * 4 + wid) * RPW + sub; row0 < rows; row0 += stride * KD_U) {
+        RowVals<VPL> v[KD_U];
 #pragma unroll
-        for (int i = 0; i < KD_MAXV; ++i) {
-            ss += dot4(v.s[i], v.s[i]);
-            tt += dot4(v.t[i], v.t[i]);
-            st += dot4(v.s[i], v.t[i]);
-        }
-        ss = wave_sum(ss);
-        tt = wave_sum(tt);
-        st = wave_sum(st);
-        const float ns = sqrtf(ss), nt = sqrtf(tt);
-        const float is = 1.f / fmaxf(ns, 1e-12f), it = 1.f / fmaxf(nt, 1e-12f);
-        // s^.g = c2 (s^.s^ - s^.t^)
-        const float shsh = ss * is * is, shth = st * is * it;
-        const bool clamped = ns <= 1e-12f;
-        const float proj = clamped ? 0.f : c2 * (shsh - shth);
-        float4* dr = reinterpret_cast<float4*>(dS + row * D);
+        for (int u = 0; u < KD_U; ++u) load_row<LPR, VPL, FREQ>(v[u], S, T, ms, mt, row0 + u * stride, rows, rows_per_img, D, lir);
 #pragma unroll
-        for (int i = 0; i < KD_MAXV; ++i) {
-            const int c = lane + i * 64;
-            if (c < nv) {
-                const float4 a = make_float4(v.s[i].x * is, v.s[i].y * is, v.s[i].z * is, v.s[i].w * is);
-                const float4 b = make_float4(v.t[i].x * it, v.t[i].y * it, v.t[i].z * it, v.t[i].w * it);
-                float4 o;
-                o.x = (c2 * (a.x - b.x) - a.x * proj) * is;
-                o.y = (c2 * (a.y - b.y) - a.y * proj) * is;
-                o.z = (c2 * (a.z - b.z) - a.z * proj) * is;
-                o.w = (c2 * (a.w - b.w) - a.w * proj) * is;
-                dr[c] = o;
+        for (int u = 0; u < KD_U; ++u) {
+            const long row = row0 + u * stride;
+            float ss = 0.f, tt = 0.f, st = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                ss += dot4(v[u].s[i], v[u].s[i]);
+                tt += dot4(v[u].t[i], v[u].t[i]);
+                st += dot4(v[u].s[i], v[u].t[i]);
+            }
+            ss = group_sum<LPR>(ss);
+            tt = group_sum<LPR>(tt);
+            st = group_sum<LPR>(st);
+            const float ns = sqrtf(ss), nt = sqrtf(tt);
+            const float is = 1.f / fmaxf(ns, 1e-12f), it = 1.f / fmaxf(nt, 1e-12f);
+            // s^.g = c2 (s^.s^ - s^.t^)
+            const float shsh = ss * is * is, shth = st * is * it;
+            const bool clamped = ns <= 1e-12f;
+            const float proj = clamped ? 0.f : c2 * (shsh - shth);
+            if (row >= rows) continue;
+            float4* dr = reinterpret_cast<float4*>(dS + row * D);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = lir + i * LPR;
+                if (c < nv) {
+                    const float4 a = make_float4(v[u].s[i].x * is, v[u].s[i].y * is, v[u].s[i].z * is, v[u].s[i].w * is);
+                    const float4 b = make_float4(v[u].t[i].x * it, v[u].t[i].y * it, v[u].t[i].z * it, v[u].t[i].w * it);
+                    float4 o;
+                    o.x = (c2 * (a.x - b.x) - a.x * proj) * is;
+                    o.y = (c2 * (a.y - b.y) - a.y * proj) * is;
+                    o.z = (c2 * (a.z - b.z) - a.z * proj) * is;
+                    o.w = (c2 * (a.w - b.w) - a.w * proj) * is;
+                    dr[c] = o;
+                }
             }
         }
     }
 }
 
-int kd_blocks(long rows) { return (int)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024); }
+// (LPR, VPL) for a row of nv float4: the narrowest lane group that holds it in <= 3 float4 per lane, else a whole wave
+#define DKD_KD_DISPATCH(nv, CALL)          \
+    do {                                   \
+        if ((nv) <= 48) { CALL(16, 3); }   \
+        else if ((nv) <= 96) { CALL(32, 3); } \
+        else if ((nv) <= 192) { CALL(64, 3); } \
+        else if ((nv) <= 256) { CALL(64, 4); } \
+        else if ((nv) <= 384) { CALL(64, 6); } \
+        else { CALL(64, 8); }              \
+    } while (0)
+
+int kd_rows_per_block(int nv) { return 4 * (nv <= 48 ? 4 : (nv <= 96 ? 2 : 1)); }
+constexpr int KD_MAX_BLOCKS = 2048;
+// Every row in flight at once where the chip can hold it: one row group per wave, but never more workgroups than are resident
+// together (a partial second round of a 10 us kernel costs a whole round) - the kernel's own occupancy, asked once per variant.
+template <auto kernel>  // (a non-type parameter: instantiations of one signature must not share the cached value)
+int kd_blocks(long rows, int D) {
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        resident = per_cu * prop.multiProcessorCount;
+        if (resident > KD_MAX_BLOCKS) resident = KD_MAX_BLOCKS;
+    }
+    const long per = (long)kd_rows_per_block(D >> 2) * KD_U;
+    const long b = (rows + per - 1) / per;
+    return (int)(b < resident ? b : resident);
+}
 }  // namespace
 
-extern "C" long dkd_kd_loss_f32_workspace_bytes(long rows) { return (long)kd_blocks(rows) * 2 * sizeof(float); }
+extern "C" long dkd_kd_loss_f32_workspace_bytes(long rows) { return (4 + 2L * KD_MAX_BLOCKS) * sizeof(float); }
 
 extern "C" int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* mean_s, const float* mean_t, float* out2,
                                    float* ws, long rows, long rows_per_img, int D, float alpha, void* stream) {
     if (!S || !T || !out2 || !ws || rows <= 0 || rows_per_img <= 0 || rows % rows_per_img) return DKD_ERR_BAD_ARG;
     if ((D & 3) || D > KD_MAXV * 256) return DKD_ERR_UNSUPPORTED;
-    const int blocks = kd_blocks(rows);
+    const int nv = D >> 2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(kd_loss_fwd_kernel, dim3(blocks), dim3(256), 0, st, S, T, mean_s, mean_t, ws, rows, rows_per_img, D);
-    DKD_LAUNCH_CHECK();
     const float batch = (float)(rows / rows_per_img);
-    hipLaunchKernelGGL(kd_loss_final_kernel, dim3(1), dim3(256), 0, st, ws, blocks, out2, alpha / batch, 1.0f / (float)rows);
+    if ((mean_s == nullptr) != (mean_t == nullptr)) return DKD_ERR_BAD_ARG;  // the frequency variant centres BOTH maps
+#define DKD_KD_FWD(L, V)                                                                                                         \
+    if (mean_s)                                                                                                                  \
+        hipLaunchKernelGGL((kd_loss_fwd_kernel<L, V, true>), dim3(kd_blocks<kd_loss_fwd_kernel<L, V, true>>(rows, D)),          \
+                           dim3(256), 0, st, S, T, mean_s, mean_t, ws, out2, rows, rows_per_img, D, alpha / batch,              \
+                           1.0f / (float)rows);                                                                                  \
+    else                                                                                                                         \
+        hipLaunchKernelGGL((kd_loss_fwd_kernel<L, V, false>), dim3(kd_blocks<kd_loss_fwd_kernel<L, V, false>>(rows, D)),        \
+                           dim3(256), 0, st, S, T, mean_s, mean_t, ws, out2, rows, rows_per_img, D, alpha / batch,              \
+                           1.0f / (float)rows)
+    DKD_KD_DISPATCH(nv, DKD_KD_FWD);
+#undef DKD_KD_FWD
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
@@ -183,8 +287,18 @@ extern "C" int dkd_kd_loss_bwd_f32(const float* S, const float* T, const float* 
     if (!S || !T || !dS || rows <= 0 || rows_per_img <= 0 || rows % rows_per_img) return DKD_ERR_BAD_ARG;
     if ((D & 3) || D > KD_MAXV * 256) return DKD_ERR_UNSUPPORTED;
     const float batch = (float)(rows / rows_per_img);
-    hipLaunchKernelGGL(kd_loss_bwd_kernel, dim3(kd_blocks(rows)), dim3(256), 0, (hipStream_t)stream, S, T, mean_s, mean_t,
-                       grad_out, dS, rows, rows_per_img, D, alpha / batch);
+    const int nv = D >> 2;
+    if ((mean_s == nullptr) != (mean_t == nullptr)) return DKD_ERR_BAD_ARG;
+#define DKD_KD_BWD(L, V)                                                                                                           \
+    if (mean_s)                                                                                                                    \
+        hipLaunchKernelGGL((kd_loss_bwd_kernel<L, V, true>), dim3(kd_blocks<kd_loss_bwd_kernel<L, V, true>>(rows, D)), dim3(256), \
+                           0, (hipStream_t)stream, S, T, mean_s, mean_t, grad_out, dS, rows, rows_per_img, D, alpha / batch);      \
+    else                                                                                                                           \
+        hipLaunchKernelGGL((kd_loss_bwd_kernel<L, V, false>), dim3(kd_blocks<kd_loss_bwd_kernel<L, V, false>>(rows, D)),          \
+                           dim3(256), 0, (hipStream_t)stream, S, T, mean_s, mean_t, grad_out, dS, rows, rows_per_img, D,           \
+                           alpha / batch)
+    DKD_KD_DISPATCH(nv, DKD_KD_BWD);
+#undef DKD_KD_BWD
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -231,7 +231,12 @@ class DistillationModule(_Base):
         for k, v in losses.items():
             self.log(f"train_{k}", v, sync_dist=True)
         if _Base is not nn.Module:
-            self.log("lr", self.optimizers().param_groups[0]["lr"], sync_dist=True, prog_bar=True)
+            try:  # (the module may also be stepped without a Trainer attached: dinov2_distillation_amd.trainer)
+                opt = self.optimizers()
+            except (RuntimeError, AttributeError):
+                opt = None
+            if opt is not None:
+                self.log("lr", opt.param_groups[0]["lr"], sync_dist=True, prog_bar=True)
 
     # ---- optimiser (train/distillation_module.py:440-502) ------------------------------------------------------------
     def configure_optimizers(self):
