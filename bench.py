@@ -105,12 +105,33 @@ class HbmProfiler:
         return out
 
 
+def cpu_share():
+    """host cores this process can really use: the scheduler affinity capped by the cgroup CPU quota (a gpurun box shows 256
+    logical CPUs and an affinity of 256 but a cpu.max quota of 16 cores: 256 oracle threads on that quota thrash for minutes)"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return n, aff, quota
+
+
 def cpu_baseline(seconds_budget=25.0, batch=2, max_steps=None):
     """The CPU oracle (oracle/, kind 'port') timed on the host cores on a bounded sample of the SAME workload:
     full step = teacher fwd + student fwd/bwd + ScaleKD fwd/bwd + clip + AdamW, config[1] shapes at a small batch."""
     from oracle import convnext_oracle as cno, step_oracle as so, vit_oracle as vo
     from dinov2_distillation_amd.config import make_config
-    ncpu = len(os.sched_getaffinity(0))  # every host core this process may run on (SURVEY 8d); DKD_CPU_THREADS overrides
+    ncpu, aff, quota = cpu_share()  # every host core this process may really use (SURVEY 8d); DKD_CPU_THREADS overrides
     ncpu = int(os.environ.get("DKD_CPU_THREADS", ncpu))
     torch.set_num_threads(ncpu)
     cfg = make_config()
@@ -152,7 +173,7 @@ def cpu_baseline(seconds_budget=25.0, batch=2, max_steps=None):
         if dt > seconds_budget * 0.6 or (max_steps and steps >= max_steps):
             break
     return {"value": round(steps * batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-            "affinity_cores": len(os.sched_getaffinity(0)), "host_cpus": os.cpu_count(), "kind": "port",
+            "affinity_cores": aff, "cgroup_quota_cores": quota, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{steps} full steps (teacher fwd + student fwd/bwd + ScaleKD + clip + AdamW) of config[1] at batch "
                       f"{batch} on the host CPU, fp32 torch oracle, {dt:.1f} s"}
 
@@ -327,7 +348,8 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         note("timing the CPU oracle (cpu_baseline) ...")
         res["cpu_baseline"] = cpu_baseline()
-        if args.batch == 64 and not args.no_cpu_bs64:
+        rate = res["cpu_baseline"]["value"]
+        if args.batch == 64 and not args.no_cpu_bs64 and rate * 25.0 >= 64:  # (one bs-64 step must fit ~25 s at the bs-2 rate)
             note("timing the CPU oracle at the bench batch size (cpu_baseline_bs64) ...")
             res["cpu_baseline_bs64"] = cpu_baseline(seconds_budget=40.0, batch=64, max_steps=2)
     print(json.dumps(res))

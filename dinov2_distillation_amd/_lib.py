@@ -109,6 +109,105 @@ def declared_functions():
     return dict(_FUNC_DEFS)
 
 
+# ---- which binding carries the launches -----------------------------------------------------------------------------------------
+# "torch" (default when lib/libdkd_torch.so exists): every launcher is called as torch.ops.dkd.<op> (TORCH_LIBRARY registration,
+# torchlib.py; the C++ wrapper takes tensors, picks the current HIP stream, raises on a non-zero status).  "ctypes": the raw C
+# ABI through ctypes.  Both drive the SAME libdkd_hip.so; DKD_BINDING=ctypes|torch overrides.  Call sites are written once
+# against the helpers below: binding() / ptr() / stream() / args() / ref().
+_TORCH_LIB = os.path.join(_PKG, "lib", "libdkd_torch.so")
+BINDING = os.environ.get("DKD_BINDING", "torch" if os.path.exists(_TORCH_LIB) else "ctypes").lower()
+if BINDING not in ("torch", "ctypes"):
+    raise ValueError(f"DKD_BINDING={BINDING!r}: expected 'torch' or 'ctypes'")
+_STREAM_FUNCS = {n for n, (_, a) in _FUNC_DEFS.items() if a and a[-1][0] == "stream"}
+
+
+class _ArgBag:
+    """torch binding's stand-in for a ctypes argument struct: the header's fields as plain attributes (pointers hold tensors)"""
+    __slots__ = ("_fields", "__dict__")
+
+    def __init__(self, fields):
+        self._fields = fields
+        for f, ty in fields:
+            self.__dict__[f] = None if ty is ctypes.c_void_p else 0
+
+
+class _TorchBinding:
+    """lib-like object: ``lib.dkd_xxx(args..., stream)`` -> ``torch.ops.dkd.xxx(args...)`` returning the status 0 (the op raises
+    on failure); struct arguments are flattened field by field; host-only queries go straight to the C library"""
+
+    def __init__(self):
+        from . import torchlib
+        self._ops = torchlib.load()
+        self._c = load()
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            if name not in _FUNC_DEFS:
+                raise AttributeError(name)
+            if name not in _STREAM_FUNCS:
+                fn = getattr(self._c, name)
+            else:
+                op = getattr(self._ops, name[4:])
+                structs = [isinstance(t, str) for _, t in _FUNC_DEFS[name][1][:-1]]
+                if any(structs):
+                    def fn(*a, _op=op, _structs=structs):
+                        flat = []
+                        for v, is_s in zip(a[:-1], _structs):
+                            if is_s:
+                                d = v.__dict__
+                                flat.extend(d[f] for f, _ in v._fields)
+                            else:
+                                flat.append(v)
+                        _op(*flat)
+                        return 0
+                else:
+                    def fn(*a, _op=op):
+                        _op(*a[:-1])
+                        return 0
+            self._cache[name] = fn
+        return fn
+
+
+_binding = None
+
+
+def binding():
+    """the object launches are issued through: ``binding().dkd_gemm_f32(ref(args), stream())``"""
+    global _binding
+    if _binding is None:
+        _binding = _TorchBinding() if BINDING == "torch" else load()
+    return _binding
+
+
+if BINDING == "torch":
+    def ptr(t):
+        return t
+
+    def stream():
+        return None
+
+    def args(name):
+        return _ArgBag(_STRUCT_DEFS[name])
+
+    def ref(a):
+        return a
+else:
+    def ptr(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    def stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def args(name):
+        return STRUCTS[name]()
+
+    def ref(a):
+        return ctypes.byref(a)
+
+
 _ERRS = {-1: "DKD_ERR_BAD_ARG", -2: "DKD_ERR_ALIGN", -3: "DKD_ERR_UNSUPPORTED"}
 
 

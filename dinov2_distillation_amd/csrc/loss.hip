@@ -4,6 +4,9 @@
 // memory, models/backbones/dinov2.py:40), so "normalize over dim=1 of NCHW" is a contiguous row reduction.
 // The frequency variant (DCT -> zero DC -> IDCT, :107-118) equals removing each (image, channel) map's spatial
 // mean; the means arrive as [B, D] vectors (dkd_colreduce_f32) and are subtracted on the fly.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 #include "dkd_hip.h"
 
@@ -76,18 +79,21 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (
 // one-block "final" launch of round 1 (a ~2 us kernel plus a ~1.5 us boundary behind an 8-10 us kernel) is gone.  Hand-off
 // (MI355X_MICROARCH.md, inter-workgroup visibility): partials are written with agent-scope (sc1, write-through) stores, drained
 // with s_waitcnt vmcnt(0) before the ticket add, and read back with agent-scope (sc1) loads by the last block only.
-template <int LPR, int VPL, bool FREQ>
-__global__ __launch_bounds__(256, (VPL <= 3 && !FREQ) ? 8 : 1) void kd_loss_fwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
-                                                          const float* __restrict__ ms, const float* __restrict__ mt,
-                                                          float* __restrict__ ws, float* __restrict__ out, long rows,
-                                                          long rows_per_img, int D, float loss_scale, float sim_scale) {
+// NW waves per workgroup: 16 (1024 threads) for the forward at full size - the single-launch reduction below costs one
+// device-scope atomic per WORKGROUP on one counter (~12 ns each, serialised at the memory side: 2048 four-wave workgroups
+// arriving together were a 23 us tail, measured), so the same 8 waves per SIMD are packed into a quarter of the workgroups.
+template <int LPR, int VPL, bool FREQ, int NW>
+__global__ __launch_bounds__(NW * 64, (VPL <= 3 && !FREQ) ? (NW == 16 ? 8 : 8) : 1) void kd_loss_fwd_kernel(
+    const float* __restrict__ S, const float* __restrict__ T, const float* __restrict__ ms, const float* __restrict__ mt,
+    float* __restrict__ ws, float* __restrict__ out, long rows, long rows_per_img, int D, float loss_scale, float sim_scale,
+    int fused_final) {
     constexpr int RPW = 64 / LPR;
-    __shared__ float red[2][4];
+    __shared__ float red[2][NW];
     __shared__ int last_flag;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane / LPR, lir = lane % LPR;
     float acc_sq = 0.f, acc_cos = 0.f;
-    const long stride = (long)gridDim.x * 4 * RPW;
-    for (long row0 = ((long)blockIdx.x * 4 + wid) * RPW + sub; row0 < rows; row0 += stride * KD_U) {
+    const long stride = (long)gridDim.x * NW * RPW;
+    for (long row0 = ((long)blockIdx.x * NW + wid) * RPW + sub; row0 < rows; row0 += stride * KD_U) {
         RowVals<VPL> v[KD_U];
 #pragma unroll
         for (int u = 0; u < KD_U; ++u) load_row<LPR, VPL, FREQ>(v[u], S, T, ms, mt, row0 + u * stride, rows, rows_per_img, D, lir);
@@ -138,19 +144,29 @@ __global__ __launch_bounds__(256, (VPL <= 3 && !FREQ) ? 8 : 1) void kd_loss_fwd_
     int* ticket = reinterpret_cast<int*>(ws);
     float* partials = ws + 4;
     if (threadIdx.x == 0) {
-        const float p0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const float p1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            p0 += red[0][w];
+            p1 += red[1][w];
+        }
+        if (!fused_final) {  // two-launch form (kd_loss_final_kernel folds the partials): plain stores, the kernel boundary orders them
+            partials[2 * blockIdx.x + 0] = p0;
+            partials[2 * blockIdx.x + 1] = p1;
+            return;
+        }
         __hip_atomic_store(partials + 2 * blockIdx.x + 0, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(partials + 2 * blockIdx.x + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (t == (int)gridDim.x - 1);
     }
+    if (!fused_final) return;
     __syncthreads();
     if (!last_flag) return;
-    __shared__ double dred[2][4];
+    __shared__ double dred[2][NW];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += NW * 64) {
         a += (double)__hip_atomic_load(partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         b += (double)__hip_atomic_load(partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -164,9 +180,39 @@ __global__ __launch_bounds__(256, (VPL <= 3 && !FREQ) ? 8 : 1) void kd_loss_fwd_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = (float)(((dred[0][0] + dred[0][1]) + (dred[0][2] + dred[0][3])) * (double)loss_scale);
-        out[1] = (float)(((dred[1][0] + dred[1][1]) + (dred[1][2] + dred[1][3])) * (double)sim_scale);
+        double ta = 0.0, tb = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            ta += dred[0][w];
+            tb += dred[1][w];
+        }
+        out[0] = (float)(ta * (double)loss_scale);
+        out[1] = (float)(tb * (double)sim_scale);
         __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this workspace
+    }
+}
+
+// the two-launch form's second kernel (A/B: DKD_KD_FINAL=kernel): one workgroup folds the per-workgroup partials in fp64
+__global__ __launch_bounds__(256) void kd_loss_final_kernel(const float* __restrict__ partials, int n, float* __restrict__ out,
+                                                            float loss_scale, float sim_scale) {
+    __shared__ double red[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        a += (double)partials[2 * i];
+        b += (double)partials[2 * i + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (double)loss_scale);
+        out[1] = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (double)sim_scale);
     }
 }
 
@@ -239,18 +285,18 @@ int kd_rows_per_block(int nv) { return 4 * (nv <= 48 ? 4 : (nv <= 96 ? 2 : 1)); 
 constexpr int KD_MAX_BLOCKS = 2048;
 // Every row in flight at once where the chip can hold it: one row group per wave, but never more workgroups than are resident
 // together (a partial second round of a 10 us kernel costs a whole round) - the kernel's own occupancy, asked once per variant.
-template <auto kernel>  // (a non-type parameter: instantiations of one signature must not share the cached value)
+template <auto kernel, int NW = 4>  // (a non-type parameter: instantiations of one signature must not share the cached value)
 int kd_blocks(long rows, int D) {
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NW * 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         resident = per_cu * prop.multiProcessorCount;
         if (resident > KD_MAX_BLOCKS) resident = KD_MAX_BLOCKS;
     }
-    const long per = (long)kd_rows_per_block(D >> 2) * KD_U;
+    const long per = (long)kd_rows_per_block(D >> 2) * KD_U * (NW / 4);
     const long b = (rows + per - 1) / per;
     return (int)(b < resident ? b : resident);
 }
@@ -266,18 +312,33 @@ extern "C" int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* 
     hipStream_t st = (hipStream_t)stream;
     const float batch = (float)(rows / rows_per_img);
     if ((mean_s == nullptr) != (mean_t == nullptr)) return DKD_ERR_BAD_ARG;  // the frequency variant centres BOTH maps
-#define DKD_KD_FWD(L, V)                                                                                                         \
-    if (mean_s)                                                                                                                  \
-        hipLaunchKernelGGL((kd_loss_fwd_kernel<L, V, true>), dim3(kd_blocks<kd_loss_fwd_kernel<L, V, true>>(rows, D)),          \
-                           dim3(256), 0, st, S, T, mean_s, mean_t, ws, out2, rows, rows_per_img, D, alpha / batch,              \
-                           1.0f / (float)rows);                                                                                  \
-    else                                                                                                                         \
-        hipLaunchKernelGGL((kd_loss_fwd_kernel<L, V, false>), dim3(kd_blocks<kd_loss_fwd_kernel<L, V, false>>(rows, D)),        \
-                           dim3(256), 0, st, S, T, mean_s, mean_t, ws, out2, rows, rows_per_img, D, alpha / batch,              \
-                           1.0f / (float)rows)
+    // A/B switches (scripts/bench_loss.py): DKD_KD_FINAL=kernel -> two launches; DKD_KD_WAVES=4 -> 256-thread workgroups
+    static const bool two_launch = getenv("DKD_KD_FINAL") && !strcmp(getenv("DKD_KD_FINAL"), "kernel");
+    static const bool small_wg = getenv("DKD_KD_WAVES") && !strcmp(getenv("DKD_KD_WAVES"), "4");
+    const bool big = !small_wg && rows >= 4096;
+    int blocks = 0;
+#define DKD_KD_FWD1(L, V, F, W)                                                                                               \
+    do {                                                                                                                      \
+        blocks = kd_blocks<kd_loss_fwd_kernel<L, V, F, W>, W>(rows, D);                                                       \
+        hipLaunchKernelGGL((kd_loss_fwd_kernel<L, V, F, W>), dim3(blocks), dim3(W * 64), 0, st, S, T, mean_s, mean_t, ws,    \
+                           out2, rows, rows_per_img, D, alpha / batch, 1.0f / (float)rows, two_launch ? 0 : 1);              \
+    } while (0)
+#define DKD_KD_FWD(L, V)                                   \
+    if (mean_s) {                                          \
+        if (big && V <= 4) DKD_KD_FWD1(L, V, true, (V <= 4 ? 16 : 4)); /* (wide rows: 1024 threads would spill) */ \
+        else DKD_KD_FWD1(L, V, true, 4);                   \
+    } else {                                               \
+        if (big && V <= 4) DKD_KD_FWD1(L, V, false, (V <= 4 ? 16 : 4)); \
+        else DKD_KD_FWD1(L, V, false, 4);                  \
+    }
     DKD_KD_DISPATCH(nv, DKD_KD_FWD);
+#undef DKD_KD_FWD1
 #undef DKD_KD_FWD
     DKD_LAUNCH_CHECK();
+    if (two_launch) {
+        hipLaunchKernelGGL(kd_loss_final_kernel, dim3(1), dim3(256), 0, st, ws + 4, blocks, out2, alpha / batch, 1.0f / (float)rows);
+        DKD_LAUNCH_CHECK();
+    }
     return DKD_OK;
 }
 

@@ -323,7 +323,7 @@ def _bn_fwd_stats(z, bn_state, training):
     if training:
         return ops.bn_stats(z, running_mean, running_var, momentum, eps)
     rstd = torch.empty_like(running_var)
-    ops.check(ops._lib.load().dkd_bn_finalize_f32(ops._p(running_mean), ops._p(running_var), ops._p(rstd), None, None,
+    ops.check(ops._lib.binding().dkd_bn_finalize_f32(ops._p(running_mean), ops._p(running_var), ops._p(rstd), None, None,
                                                   running_var.numel(), 2, 0.0, eps, ops._stream()), "dkd_bn_finalize_f32")
     return running_mean, rstd
 

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import AttnArgs, GemmArgs, check  # noqa: F401
+from ._lib import check  # noqa: F401
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM, RED_GELUSQ, RED_DOTGELU_SUM = 0, 1, 2, 3, 4, 5, 6
@@ -22,12 +22,8 @@ PRECISIONS = {None: None, "f32": PREC_F32, "fp32": PREC_F32, "bf16x3": PREC_BF16
 GEMM_PRECISION = PRECISIONS.get(os.environ.get("DKD_GEMM_PRECISION", "f32").lower(), PREC_F32)  # process-wide default
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+_stream = _lib.stream  # the launch stream argument (ctypes binding: the current HIP stream; torch binding: taken inside the op)
+_p = _lib.ptr          # a device pointer argument (ctypes binding: c_void_p; torch binding: the tensor itself)
 
 
 def _chk(t, name, contiguous=True):
@@ -56,7 +52,7 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
          variant=0, rowsum=None, precision=None, ws_slot=0):
     """C = epi(alpha * Aop @ Bop^T).  a/b are 2-D (or flattened-leading-dims) dense tensors:
     a_layout 0: a is [M,K]; 1: a is [K,M].   b_layout 0: b is [N,K]; 1: b is [K,N]."""
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(a, "a"), _chk(b, "b"), _chk(bias, "bias"), _chk(colscale, "colscale"), _chk(residual, "residual")
     a2 = a.reshape(-1, a.shape[-1])
     b2 = b.reshape(-1, b.shape[-1])
@@ -69,7 +65,7 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     lda = a2.shape[1] if lda is None else lda
     ldb = b2.shape[1] if ldb is None else ldb
     out_rows = M
-    g = GemmArgs()
+    g = _lib.args("dkd_gemm_args")
     if row_map is not None:
         g.row_grp, g.row_grp_stride, g.row_off, out_rows = row_map
     if out is None:
@@ -85,7 +81,7 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     g.ldr = (N if ldr is None else ldr)
     g.a_layout, g.b_layout, g.M, g.N, g.K = a_layout, b_layout, M, N, K
     g.act, g.res_mod, g.alpha, g.variant = act, res_mod, alpha, variant
-    check(lib.dkd_gemm_f32(ctypes.byref(g), _stream()), f"dkd_gemm_f32[{M}x{N}x{K} a{a_layout} b{b_layout}]")
+    check(lib.dkd_gemm_f32(_lib.ref(g), _stream()), f"dkd_gemm_f32[{M}x{N}x{K} a{a_layout} b{b_layout}]")
     return out
 
 
@@ -263,7 +259,7 @@ def grad_done(*params):
 
 def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):
     """x viewed as [groups, rows_per_group, N] -> out[groups, N]."""
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(x, "x"), _chk(y, "y"), _chk(aux, "aux")
     N = x.shape[-1]
     rows = x.numel() // N
@@ -279,7 +275,7 @@ def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):
 
 def transpose(x, out=None):
     """[..., R, C] -> [..., C, R] (dense copy)."""
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(x, "x")
     R, C = x.shape[-2:]
     batch = x.numel() // (R * C)
@@ -291,7 +287,7 @@ def transpose(x, out=None):
 
 def layernorm_fwd(x, gamma, beta, eps, need_stats=True, in_rows=None):
     """in_rows=(grp, grp_stride, off, n_out_rows): gather input rows (see dkd_hip.h); output is dense [n_out_rows, C]."""
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
     C = x.shape[-1]
     rows = x.numel() // C
@@ -311,7 +307,7 @@ def layernorm_fwd(x, gamma, beta, eps, need_stats=True, in_rows=None):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True, add=None, dg_out=None, db_out=None):
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(dy, "dy"), _chk(x, "x")
     C = x.shape[-1]
     rows = x.numel() // C
@@ -333,21 +329,21 @@ def _ew(fn, name, *tensors, n):
 def gelu_fwd(x):
     _chk(x, "x")
     y = torch.empty_like(x)
-    _ew(_lib.load().dkd_gelu_fwd_f32, "dkd_gelu_fwd_f32", x, y, n=x.numel())
+    _ew(_lib.binding().dkd_gelu_fwd_f32, "dkd_gelu_fwd_f32", x, y, n=x.numel())
     return y
 
 
 def gelu_bwd(dy, x):
     _chk(dy, "dy"), _chk(x, "x")
     dx = torch.empty_like(x)
-    _ew(_lib.load().dkd_gelu_bwd_f32, "dkd_gelu_bwd_f32", dy, x, dx, n=x.numel())
+    _ew(_lib.binding().dkd_gelu_bwd_f32, "dkd_gelu_bwd_f32", dy, x, dx, n=x.numel())
     return dx
 
 
 def relu_bwd(dy, y):
     _chk(dy, "dy"), _chk(y, "y")
     dx = torch.empty_like(y)
-    _ew(_lib.load().dkd_relu_bwd_f32, "dkd_relu_bwd_f32", dy, y, dx, n=y.numel())
+    _ew(_lib.binding().dkd_relu_bwd_f32, "dkd_relu_bwd_f32", dy, y, dx, n=y.numel())
     return dx
 
 
@@ -355,7 +351,7 @@ def axpby(a, b, alpha=1.0, beta=1.0, out=None):
     _chk(a, "a"), _chk(b, "b")
     if out is None:
         out = torch.empty_like(a)
-    check(_lib.load().dkd_axpby_f32(_p(a), _p(b), _p(out), alpha, beta, a.numel(), _stream()), "dkd_axpby_f32")
+    check(_lib.binding().dkd_axpby_f32(_p(a), _p(b), _p(out), alpha, beta, a.numel(), _stream()), "dkd_axpby_f32")
     return out
 
 
@@ -365,13 +361,13 @@ def sub_group_vec(x, vec, groups, out=None):
     rpg = x.numel() // N // groups
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.load().dkd_sub_group_vec_f32(_p(x), _p(vec), _p(out), rpg, groups, N, _stream()), "dkd_sub_group_vec_f32")
+    check(_lib.binding().dkd_sub_group_vec_f32(_p(x), _p(vec), _p(out), rpg, groups, N, _stream()), "dkd_sub_group_vec_f32")
     return out
 
 
 # ---- attention -------------------------------------------------------------------------------------------------
 def _attn_args(q, k, v, o, H, hd, scale, strides):
-    a = AttnArgs()
+    a = _lib.args("dkd_attn_args")
     a.q, a.k, a.v, a.o = _p(q), _p(k), _p(v), _p(o)
     (a.q_bs, a.q_rs), (a.k_bs, a.k_rs), (a.v_bs, a.v_rs), (a.o_bs, a.o_rs) = strides
     a.H, a.hd, a.scale = H, hd, scale
@@ -379,18 +375,18 @@ def _attn_args(q, k, v, o, H, hd, scale, strides):
 
 
 def attention_forward(q, k, v, H, hd, scale, B, Nq, Nk, q_st, k_st, v_st):
-    lib = _lib.load()
+    lib = _lib.binding()
     D = H * hd
     o = torch.empty((B, Nq, D), dtype=torch.float32, device=k.device)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=k.device)
     a = _attn_args(q, k, v, o, H, hd, scale, (q_st, k_st, v_st, (Nq * D, D)))
     a.B, a.Nq, a.Nk, a.lse = B, Nq, Nk, _p(lse)
-    check(lib.dkd_attn_fwd_f32(ctypes.byref(a), _stream()), f"dkd_attn_fwd_f32[hd={hd}]")
+    check(lib.dkd_attn_fwd_f32(_lib.ref(a), _stream()), f"dkd_attn_fwd_f32[hd={hd}]")
     return o, lse
 
 
 def attention_backward(do, q, k, v, o, lse, H, hd, scale, B, Nq, Nk, q_st, k_st, v_st, dq, dk, dv, dq_st, dk_st, dv_st):
-    lib = _lib.load()
+    lib = _lib.binding()
     D = H * hd
     _chk(do, "do")
     delta = torch.empty((B, H, Nq), dtype=torch.float32, device=k.device)
@@ -399,12 +395,12 @@ def attention_backward(do, q, k, v, o, lse, H, hd, scale, B, Nq, Nk, q_st, k_st,
     a.do_bs, a.do_rs = Nq * D, D
     a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
     (a.dq_bs, a.dq_rs), (a.dk_bs, a.dk_rs), (a.dv_bs, a.dv_rs) = dq_st, dk_st, dv_st
-    check(lib.dkd_attn_bwd_f32(ctypes.byref(a), _stream()), f"dkd_attn_bwd_f32[hd={hd}]")
+    check(lib.dkd_attn_bwd_f32(_lib.ref(a), _stream()), f"dkd_attn_bwd_f32[hd={hd}]")
 
 
 # ---- ScaleKD loss tail -----------------------------------------------------------------------------------------
 def kd_loss_fwd(s, t, rows_per_img, alpha, mean_s=None, mean_t=None):
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(s, "s"), _chk(t, "t"), _chk(mean_s, "mean_s"), _chk(mean_t, "mean_t")
     D = s.shape[-1]
     rows = s.numel() // D
@@ -421,7 +417,7 @@ def kd_loss_fwd(s, t, rows_per_img, alpha, mean_s=None, mean_t=None):
 
 
 def kd_loss_bwd(s, t, rows_per_img, alpha, grad_out=None, mean_s=None, mean_t=None):
-    lib = _lib.load()
+    lib = _lib.binding()
     D = s.shape[-1]
     rows = s.numel() // D
     ds = torch.empty_like(s)
@@ -433,7 +429,7 @@ def kd_loss_bwd(s, t, rows_per_img, alpha, grad_out=None, mean_s=None, mean_t=No
 # ---- BatchNorm / GRN helpers -----------------------------------------------------------------------------------
 def bn_stats(z, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """Train-mode batch statistics of z [rows, N] (two-pass: mean, centred variance) -> mean, rstd [N]."""
-    lib = _lib.load()
+    lib = _lib.binding()
     N = z.shape[-1]
     rows = z.numel() // N
     mean = colreduce(z, RED_SUM, scale=1.0 / rows).reshape(N)
@@ -445,7 +441,7 @@ def bn_stats(z, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
 
 
 def bn_act_pos_fwd(z, mean, rstd, gamma, beta, pos=None, relu=True):
-    lib = _lib.load()
+    lib = _lib.binding()
     N = z.shape[-1]
     rows = z.numel() // N
     out = torch.empty_like(z)
@@ -457,7 +453,7 @@ def bn_act_pos_fwd(z, mean, rstd, gamma, beta, pos=None, relu=True):
 
 def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True, dgamma_out=None, dbeta_out=None):
     """-> dz, dgamma, dbeta for out = relu(bn(z)) (+ pos)."""
-    lib = _lib.load()
+    lib = _lib.binding()
     N = z.shape[-1]
     rows = z.numel() // N
     dbn = torch.empty_like(z)
@@ -478,14 +474,14 @@ def dwconv7(x, w_tap, bias=None, add=None, flip=False):
     _chk(x, "x"), _chk(w_tap, "w_tap"), _chk(bias, "bias"), _chk(add, "add")
     B, H, W, C = x.shape
     out = torch.empty_like(x)
-    check(_lib.load().dkd_dwconv7_fwd_f32(_p(x), _p(w_tap), _p(bias), _p(add), _p(out), B, H, W, C, int(flip), _stream()),
+    check(_lib.binding().dkd_dwconv7_fwd_f32(_p(x), _p(w_tap), _p(bias), _p(add), _p(out), B, H, W, C, int(flip), _stream()),
           "dkd_dwconv7_fwd_f32")
     return out
 
 
 def dwconv7_wgrad(x, dout):
     """-> dW tap-major [49, C]"""
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(x, "x"), _chk(dout, "dout")
     B, H, W, C = x.shape
     parts = lib.dkd_dwconv7_wgrad_f32_parts(B, H)
@@ -499,7 +495,7 @@ def patchify_nchw(img, k):
     _chk(img, "img")
     B, Cin, H, W = img.shape
     out = torch.empty((B * (-(-H // k)) * (-(-W // k)), Cin * k * k), dtype=torch.float32, device=img.device)
-    check(_lib.load().dkd_patchify_nchw_f32(_p(img), _p(out), B, Cin, H, W, k, _stream()), "dkd_patchify_nchw_f32")
+    check(_lib.binding().dkd_patchify_nchw_f32(_p(img), _p(out), B, Cin, H, W, k, _stream()), "dkd_patchify_nchw_f32")
     return out
 
 
@@ -507,14 +503,14 @@ def patchify_nhwc(x, k):
     _chk(x, "x")
     B, H, W, C = x.shape
     out = torch.empty((B * (H // k) * (W // k), k * k * C), dtype=torch.float32, device=x.device)
-    check(_lib.load().dkd_patchify_nhwc_f32(_p(x), _p(out), B, H, W, C, k, 0, _stream()), "dkd_patchify_nhwc_f32")
+    check(_lib.binding().dkd_patchify_nhwc_f32(_p(x), _p(out), B, H, W, C, k, 0, _stream()), "dkd_patchify_nhwc_f32")
     return out
 
 
 def unpatchify_nhwc(rows, B, H, W, C, k):
     _chk(rows, "rows")
     out = torch.empty((B, H, W, C), dtype=torch.float32, device=rows.device)
-    check(_lib.load().dkd_patchify_nhwc_f32(_p(rows), _p(out), B, H, W, C, k, 1, _stream()), "dkd_patchify_nhwc_f32(inv)")
+    check(_lib.binding().dkd_patchify_nhwc_f32(_p(rows), _p(out), B, H, W, C, k, 1, _stream()), "dkd_patchify_nhwc_f32(inv)")
     return out
 
 
@@ -522,7 +518,7 @@ def resize_fwd(x, Ho, Wo):
     _chk(x, "x")
     B, Hi, Wi, C = x.shape
     out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    check(_lib.load().dkd_resize_bilinear_fwd_f32(_p(x), _p(out), B, Hi, Wi, Ho, Wo, C, _stream()), "dkd_resize_fwd")
+    check(_lib.binding().dkd_resize_bilinear_fwd_f32(_p(x), _p(out), B, Hi, Wi, Ho, Wo, C, _stream()), "dkd_resize_fwd")
     return out
 
 
@@ -530,18 +526,18 @@ def resize_bwd(dout, Hi, Wi):
     _chk(dout, "dout")
     B, Ho, Wo, C = dout.shape
     din = torch.empty((B, Hi, Wi, C), dtype=torch.float32, device=dout.device)
-    check(_lib.load().dkd_resize_bilinear_bwd_f32(_p(dout), _p(din), B, Hi, Wi, Ho, Wo, C, _stream()), "dkd_resize_bwd")
+    check(_lib.binding().dkd_resize_bilinear_bwd_f32(_p(dout), _p(din), B, Hi, Wi, Ho, Wo, C, _stream()), "dkd_resize_bwd")
     return din
 
 
 def set_rows(out, vec, B, row_stride):
-    check(_lib.load().dkd_set_rows_f32(_p(out), _p(vec), B, row_stride, vec.numel(), _stream()), "dkd_set_rows_f32")
+    check(_lib.binding().dkd_set_rows_f32(_p(out), _p(vec), B, row_stride, vec.numel(), _stream()), "dkd_set_rows_f32")
     return out
 
 
 def grn_fwd(g, gamma, beta, B, preact=False):
     """g [B*HW, C] post-GELU (preact=True: the pre-activation h, gelu recomputed on the fly) -> y, (gx, nx, denom)"""
-    lib = _lib.load()
+    lib = _lib.binding()
     C = g.shape[-1]
     rpi = g.numel() // C // B
     sumsq = colreduce(g, RED_GELUSQ if preact else RED_SUMSQ, groups=B)
@@ -556,7 +552,7 @@ def grn_fwd(g, gamma, beta, B, preact=False):
 
 def grn_gelu_bwd(dy, g, h, stats, gamma, B, dgamma_out=None, dbeta_out=None):
     """-> dh (through GRN and GELU), dgamma, dbeta.  g=None: only the pre-activation h was kept, g = gelu(h) is recomputed"""
-    lib = _lib.load()
+    lib = _lib.binding()
     gx, nx, denom = stats
     C = h.shape[-1]
     rpi = h.numel() // C // B
@@ -584,14 +580,14 @@ def im2col_nhwc(x, k, stride, pad):
     B, H, W, C = x.shape
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
     rows = torch.empty((B * Ho * Wo, k * k * C), dtype=torch.float32, device=x.device)
-    check(_lib.load().dkd_im2col_nhwc_f32(_p(x), _p(rows), B, H, W, C, k, stride, pad, 0, _stream()), "dkd_im2col_nhwc_f32")
+    check(_lib.binding().dkd_im2col_nhwc_f32(_p(x), _p(rows), B, H, W, C, k, stride, pad, 0, _stream()), "dkd_im2col_nhwc_f32")
     return rows
 
 
 def col2im_nhwc(drows, B, H, W, C, k, stride, pad):
     _chk(drows, "drows")
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=drows.device)
-    check(_lib.load().dkd_im2col_nhwc_f32(_p(dx), _p(drows), B, H, W, C, k, stride, pad, 1, _stream()), "dkd_col2im_nhwc_f32")
+    check(_lib.binding().dkd_im2col_nhwc_f32(_p(dx), _p(drows), B, H, W, C, k, stride, pad, 1, _stream()), "dkd_col2im_nhwc_f32")
     return dx
 
 
@@ -601,7 +597,7 @@ def im2col_nchw(img, k, stride, pad):
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
     Kp = (Cin * k * k + 3) // 4 * 4
     rows = torch.empty((B * Ho * Wo, Kp), dtype=torch.float32, device=img.device)
-    check(_lib.load().dkd_im2col_nchw_f32(_p(img), _p(rows), B, Cin, H, W, k, stride, pad, Kp, _stream()), "dkd_im2col_nchw_f32")
+    check(_lib.binding().dkd_im2col_nchw_f32(_p(img), _p(rows), B, Cin, H, W, k, stride, pad, Kp, _stream()), "dkd_im2col_nchw_f32")
     return rows
 
 
@@ -619,7 +615,7 @@ def dwconv3(x, w_tap, stride, dgrad_shape=None, dilation=1):
         H, W = dgrad_shape
         out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
         mode = 1
-    check(_lib.load().dkd_dwconv3_f32(_p(x), _p(w_tap), _p(out), B, H, W, C, stride, dilation, mode, _stream()),
+    check(_lib.binding().dkd_dwconv3_f32(_p(x), _p(w_tap), _p(out), B, H, W, C, stride, dilation, mode, _stream()),
           "dkd_dwconv3_f32")
     return out
 
@@ -629,13 +625,13 @@ def dwconv3_wgrad(x, dout, stride, dilation=1):
     B, H, W, C = x.shape
     Ho = dout.shape[1]
     part = workspace(B * Ho * 9 * C * 4, x.device, slot=1)
-    check(_lib.load().dkd_dwconv3_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, stride, dilation, _stream()),
+    check(_lib.binding().dkd_dwconv3_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, stride, dilation, _stream()),
           "dkd_dwconv3_wgrad_f32")
     return colreduce(part[: B * Ho * 9 * C].view(B * Ho, 9 * C)).view(9, C)
 
 
 def copy2d(src, lds, dst, ldd, rows, cols, accumulate=False):
-    check(_lib.load().dkd_copy2d_f32(_p(src), lds, _p(dst), ldd, rows, cols, int(accumulate), _stream()), "dkd_copy2d_f32")
+    check(_lib.binding().dkd_copy2d_f32(_p(src), lds, _p(dst), ldd, rows, cols, int(accumulate), _stream()), "dkd_copy2d_f32")
     return dst
 
 
@@ -645,7 +641,7 @@ def maxpool3(x, stride=2):
     Ho, Wo = conv_out_hw(H, W, 3, stride, 1)
     out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
     arg = torch.empty((B, Ho, Wo, C), dtype=torch.int32, device=x.device)
-    check(_lib.load().dkd_maxpool3_f32(_p(x), _p(out), _p(arg), B, H, W, C, stride, 0, _stream()), "dkd_maxpool3_f32")
+    check(_lib.binding().dkd_maxpool3_f32(_p(x), _p(out), _p(arg), B, H, W, C, stride, 0, _stream()), "dkd_maxpool3_f32")
     return out, arg
 
 
@@ -653,7 +649,7 @@ def maxpool3_bwd(dy, arg, H, W, stride=2):
     _chk(dy, "dy")
     B, _, _, C = dy.shape
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
-    check(_lib.load().dkd_maxpool3_f32(_p(dy), _p(dx), _p(arg), B, H, W, C, stride, 1, _stream()), "dkd_maxpool3_f32(bwd)")
+    check(_lib.binding().dkd_maxpool3_f32(_p(dy), _p(dx), _p(arg), B, H, W, C, stride, 1, _stream()), "dkd_maxpool3_f32(bwd)")
     return dx
 
 
@@ -663,18 +659,18 @@ def avgpool2(x, backward_hw=None):
     B, h, w, C = x.shape
     if backward_hw is None:
         out = torch.empty((B, (h + 1) // 2, (w + 1) // 2, C), dtype=torch.float32, device=x.device)
-        check(_lib.load().dkd_avgpool2_f32(_p(x), _p(out), B, h, w, C, 0, _stream()), "dkd_avgpool2_f32")
+        check(_lib.binding().dkd_avgpool2_f32(_p(x), _p(out), B, h, w, C, 0, _stream()), "dkd_avgpool2_f32")
     else:
         H, W = backward_hw
         out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
-        check(_lib.load().dkd_avgpool2_f32(_p(x), _p(out), B, H, W, C, 1, _stream()), "dkd_avgpool2_f32(bwd)")
+        check(_lib.binding().dkd_avgpool2_f32(_p(x), _p(out), B, H, W, C, 1, _stream()), "dkd_avgpool2_f32(bwd)")
     return out
 
 
 def add_relu(a, b):
     _chk(a, "a"), _chk(b, "b")
     out = torch.empty_like(a)
-    check(_lib.load().dkd_add_relu_f32(_p(a), _p(b), _p(out), a.numel(), _stream()), "dkd_add_relu_f32")
+    check(_lib.binding().dkd_add_relu_f32(_p(a), _p(b), _p(out), a.numel(), _stream()), "dkd_add_relu_f32")
     return out
 
 
@@ -683,7 +679,7 @@ def swiglu_fwd(x12):
     hidden = x12.shape[-1] // 2
     rows = x12.numel() // (2 * hidden)
     out = torch.empty((*x12.shape[:-1], hidden), dtype=torch.float32, device=x12.device)
-    check(_lib.load().dkd_swiglu_f32(_p(x12), None, _p(out), rows, hidden, 0, _stream()), "dkd_swiglu_f32")
+    check(_lib.binding().dkd_swiglu_f32(_p(x12), None, _p(out), rows, hidden, 0, _stream()), "dkd_swiglu_f32")
     return out
 
 
@@ -692,7 +688,7 @@ def swiglu_bwd(dout, x12):
     hidden = x12.shape[-1] // 2
     rows = x12.numel() // (2 * hidden)
     dx = torch.empty_like(x12)
-    check(_lib.load().dkd_swiglu_f32(_p(x12), _p(dout), _p(dx), rows, hidden, 1, _stream()), "dkd_swiglu_f32(bwd)")
+    check(_lib.binding().dkd_swiglu_f32(_p(x12), _p(dout), _p(dx), rows, hidden, 1, _stream()), "dkd_swiglu_f32(bwd)")
     return dx
 
 
@@ -701,7 +697,7 @@ def window_permute(x, Ph, Pw, wh, ww, inverse=False):
     _chk(x, "x")
     B, N, D = x.shape
     out = torch.empty_like(x)
-    check(_lib.load().dkd_window_permute_f32(_p(x), _p(out), B, Ph, Pw, wh, ww, D, int(inverse), _stream()), "dkd_window_permute_f32")
+    check(_lib.binding().dkd_window_permute_f32(_p(x), _p(out), B, Ph, Pw, wh, ww, D, int(inverse), _stream()), "dkd_window_permute_f32")
     return out
 
 
@@ -721,7 +717,7 @@ def gather_rows(x, idx, res=None, out=None):
         out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
     if out.numel() != rows * C or (res is not None and res.numel() != rows * C):
         raise _lib.DkdError("gather_rows: out / res must hold idx.numel() rows of x's width")
-    check(_lib.load().dkd_gather_rows_f32(_p(x), _p(idx), _p(res), _p(out), rows, C, _stream()), "dkd_gather_rows_f32")
+    check(_lib.binding().dkd_gather_rows_f32(_p(x), _p(idx), _p(res), _p(out), rows, C, _stream()), "dkd_gather_rows_f32")
     return out
 
 
@@ -732,7 +728,7 @@ def index_add_rows(src, idx, T, out=None):
     rows, C = src.shape
     if out is None:
         out = torch.empty((T, C), dtype=torch.float32, device=src.device)
-    check(_lib.load().dkd_index_add_rows_f32(_p(src), _p(idx), _p(out), rows, T, C, _stream()), "dkd_index_add_rows_f32")
+    check(_lib.binding().dkd_index_add_rows_f32(_p(src), _p(idx), _p(out), rows, T, C, _stream()), "dkd_index_add_rows_f32")
     return out
 
 
@@ -741,12 +737,12 @@ def dropout(x, p, seed, offset, out=None):
     _chk(x, "x"), _chk(out, "out")
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.load().dkd_dropout_f32(_p(x), _p(out), x.numel(), float(p), int(seed), int(offset), _stream()), "dkd_dropout_f32")
+    check(_lib.binding().dkd_dropout_f32(_p(x), _p(out), x.numel(), float(p), int(seed), int(offset), _stream()), "dkd_dropout_f32")
     return out
 
 
 def _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
-    a = _lib.WinAttnArgs()
+    a = _lib.args("dkd_winattn_args")
     C = H * hd
     _chk(qkv, "qkv"), _chk(o, "o"), _chk(bias, "bias")
     if labels is not None:
@@ -755,9 +751,8 @@ def _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
             raise _lib.DkdError("winattn: labels must be [nW, N]")
     if qkv.shape != (Bw * N, 3 * C) or bias.shape != (N * N, H):
         raise _lib.DkdError(f"winattn: qkv {tuple(qkv.shape)} / bias {tuple(bias.shape)} do not match Bw={Bw} N={N} H={H} hd={hd}")
-    esz = qkv.element_size()
-    a.q, a.k, a.v = qkv.data_ptr(), qkv.data_ptr() + C * esz, qkv.data_ptr() + 2 * C * esz
-    a.o, a.bias, a.labels = o.data_ptr(), bias.data_ptr(), None if labels is None else labels.data_ptr()
+    a.q, a.k, a.v = _p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:])  # (views: the pointer includes the column offset)
+    a.o, a.bias, a.labels = _p(o), _p(bias), _p(labels)
     a.q_rs = a.k_rs = a.v_rs = 3 * C
     a.o_rs = C
     a.Bw, a.nW, a.H, a.N, a.hd, a.scale = Bw, nW, H, N, hd, scale
@@ -768,25 +763,24 @@ def winattn_forward(qkv, bias, labels, Bw, nW, H, N, hd, scale):
     """qkv [Bw*N, 3*H*hd] packed (3, H, hd) per row -> context [Bw*N, H*hd]"""
     o = torch.empty((Bw * N, H * hd), dtype=torch.float32, device=qkv.device)
     a = _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale)
-    check(_lib.load().dkd_winattn_fwd_f32(ctypes.byref(a), _stream()), f"dkd_winattn_fwd_f32[N={N},hd={hd}]")
+    check(_lib.binding().dkd_winattn_fwd_f32(_lib.ref(a), _stream()), f"dkd_winattn_fwd_f32[N={N},hd={hd}]")
     return o
 
 
 def winattn_backward(do, qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
     """-> (dqkv [Bw*N, 3C], dbias [N*N, H])"""
-    lib = _lib.load()
+    lib = _lib.binding()
     _chk(do, "do")
     C = H * hd
     dqkv = torch.empty_like(qkv)
     parts = lib.dkd_winattn_parts(Bw, H)
     part = torch.empty((parts, H * N * N), dtype=torch.float32, device=qkv.device)
     a = _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale)
-    esz = qkv.element_size()
-    a.d_o, a.do_rs = do.data_ptr(), C
-    a.dq, a.dk, a.dv = dqkv.data_ptr(), dqkv.data_ptr() + C * esz, dqkv.data_ptr() + 2 * C * esz
+    a.d_o, a.do_rs = _p(do), C
+    a.dq, a.dk, a.dv = _p(dqkv), _p(dqkv[:, C:]), _p(dqkv[:, 2 * C:])
     a.dq_rs = a.dk_rs = a.dv_rs = 3 * C
-    a.dbias_part, a.parts = part.data_ptr(), parts
-    check(lib.dkd_winattn_bwd_f32(ctypes.byref(a), _stream()), f"dkd_winattn_bwd_f32[N={N},hd={hd}]")
+    a.dbias_part, a.parts = _p(part), parts
+    check(lib.dkd_winattn_bwd_f32(_lib.ref(a), _stream()), f"dkd_winattn_bwd_f32[N={N},hd={hd}]")
     dbias = torch.empty((N * N, H), dtype=torch.float32, device=qkv.device)
     check(lib.dkd_winattn_dbias_f32(_p(part), _p(dbias), parts, H, N, _stream()), "dkd_winattn_dbias_f32")
     return dqkv, dbias

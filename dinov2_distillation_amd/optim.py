@@ -146,7 +146,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def grad_norm(self):
         """global L2 norm of all gradients, left on the device: tensor [sum_sq, norm]"""
-        lib = _lib.load()
+        lib = _lib.binding()
         if not self.flat_g.is_cuda:
             raise _lib.DkdError("FusedAdamW needs parameters on the GPU (no CPU path)")
         ops.wgrad_join()
@@ -162,7 +162,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         if not self.flat_g.is_cuda:
             raise _lib.DkdError("FusedAdamW needs parameters on the GPU (no CPU path)")
-        lib = _lib.load()
+        lib = _lib.binding()
         ops.wgrad_join()  # the side-stream weight gradients must have landed in the arena
         self._reattach(adopt=True)
         gn = self.grad_norm() if clip_grad_norm is not None else None
@@ -175,21 +175,16 @@ class FusedAdamW(torch.optim.Optimizer):
             for i, g in enumerate(self.param_groups):
                 a, b = g["_range"]
                 if b > a:
-                    _lib.check(lib.dkd_adamw_dev_f32(ctypes.c_void_p(self.flat_p.data_ptr() + 4 * a),
-                                                     ctypes.c_void_p(self.flat_g.data_ptr() + 4 * a),
-                                                     ctypes.c_void_p(self.flat_m.data_ptr() + 4 * a),
-                                                     ctypes.c_void_p(self.flat_v.data_ptr() + 4 * a), b - a,
-                                                     ctypes.c_void_p(self._hyper.data_ptr() + 24 * i), _p(gn),
+                    _lib.check(lib.dkd_adamw_dev_f32(_p(self.flat_p[a:b]), _p(self.flat_g[a:b]), _p(self.flat_m[a:b]),
+                                                     _p(self.flat_v[a:b]), b - a, _p(self._hyper[i]), _p(gn),
                                                      float(clip_grad_norm or 0.0), _stream()), "dkd_adamw_dev_f32")
             return loss
         for g in self.param_groups:
             a, b = g["_range"]
             if b <= a:
                 continue
-            _lib.check(lib.dkd_adamw_f32(ctypes.c_void_p(self.flat_p.data_ptr() + 4 * a),
-                                         ctypes.c_void_p(self.flat_g.data_ptr() + 4 * a),
-                                         ctypes.c_void_p(self.flat_m.data_ptr() + 4 * a),
-                                         ctypes.c_void_p(self.flat_v.data_ptr() + 4 * a), b - a, g["lr"], g["betas"][0],
+            _lib.check(lib.dkd_adamw_f32(_p(self.flat_p[a:b]), _p(self.flat_g[a:b]), _p(self.flat_m[a:b]),
+                                         _p(self.flat_v[a:b]), b - a, g["lr"], g["betas"][0],
                                          g["betas"][1], g["eps"], g["weight_decay"], self._steps, _p(gn),
                                          float(clip_grad_norm or 0.0), _stream()), "dkd_adamw_f32")
         return loss

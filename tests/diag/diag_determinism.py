@@ -44,8 +44,29 @@ with torch.no_grad():
         Fn._DROP_CALLS[0] = 0
         s.append({k: v.clone() for k, v in st.student(x).items()})
     print("student forward bit-identical:", [{k: same(s[0][k], si[k]) for k in si} for si in s[1:]], flush=True)
+POISON = os.environ.get("DKD_DIAG_POISON")  # "nan" / "big": fill the allocator's free memory with NaNs / 1e30 before every pass
+
+
+def poison():
+    """an uninitialised read shows up as NaN (or a wildly different loss): every stream's pool gets a freed block of poison"""
+    from dinov2_distillation_amd.train import distillation_module as dm
+    val = float("nan") if POISON == "nan" else 1e30
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    streams = [torch.cuda.current_stream()] + list(dm._TEACHER_STREAMS.values()) + list(dm._CHAIN_STREAMS.values()) + \
+        list(ops._side_streams.values())
+    for s_ in streams:
+        with torch.cuda.stream(s_):
+            blocks = [torch.full((int(float(os.environ.get("DKD_DIAG_POISON_GB", "6")) * 2 ** 28),), val, device="cuda") for _ in range(1)]
+            small = [torch.full((n,), val, device="cuda") for n in (1 << 8, 1 << 12, 1 << 16, 1 << 18) for _ in range(64)]
+            del blocks, small
+    torch.cuda.synchronize()
+
+
 runs = []
 for i in range(passes):
+    if POISON:
+        poison()
     Fn._DROP_CALLS[0] = 0
     st.optimizer.zero_grad()
     loss = st.module.training_step(x, 0)
@@ -54,6 +75,10 @@ for i in range(passes):
     ops.wgrad_join()
     torch.cuda.synchronize()
     runs.append((loss.detach().clone(), logged, st.optimizer.flat_g.clone()))
+if POISON:
+    for i, (l, lg, g) in enumerate(runs):
+        print(f"pass {i} (poisoned free memory): loss {float(l)!r}; non-finite logged: {[k for k, v in lg.items() if not torch.isfinite(v)]}; "
+              f"non-finite gradient entries {int((~torch.isfinite(g)).sum())}")
 for i in range(1, passes):
     l0, lg0, g0 = runs[0]
     l, lg, g = runs[i]

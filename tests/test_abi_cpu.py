@@ -94,3 +94,36 @@ def test_integration_doc_struct_matches_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     doc = re.findall(r'\("(\w+)", ctypes', open(os.path.join(root, "INTEGRATION.md")).read())
     assert doc == [f for f, _ in _lib._STRUCT_DEFS["dkd_gemm_args"]]
+
+
+def test_torch_library_registers_every_launcher():
+    """"a C++/HIP shared library registered through TORCH_LIBRARY (ops callable as torch.ops.<ns>.<op>), each op a
+    thin wrapper over a C-ABI launcher".  The wrappers are generated from include/dkd_hip.h: every declared function must be
+    callable as torch.ops.dkd.<name without dkd_>, host-only queries must answer like the C library, and a launcher handed a
+    CPU tensor must raise instead of passing a host pointer to a kernel."""
+    import torch
+    from dinov2_distillation_amd import _lib, torchlib
+    torchlib.build(verbose=False)
+    ops = torchlib.load()
+    for name in _lib.declared_functions():
+        assert hasattr(ops, name[len("dkd_"):]), name
+    c = _lib.load()
+    assert ops.abi_version() == c.dkd_abi_version()
+    assert ops.gemm_f32_workspace_bytes(384, 1536, 16384, 1, 1) == c.dkd_gemm_f32_workspace_bytes(384, 1536, 16384, 1, 1) > 0
+    schema = str(ops.layernorm_fwd_f32.default._schema)
+    assert "Tensor? x" in schema and "float eps" in schema and "stream" not in schema
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.gelu_fwd_f32(torch.zeros(4), torch.zeros(4), 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):  # struct arguments are flattened: the 26 fields of dkd_gemm_args
+        z = torch.zeros(4, 4)
+        ops.gemm_f32(z, 4, z, 4, z, 4, None, None, None, 4, None, None, None, 0, 0, 4, 4, 4, 0, 0, 0, 0, 0, 1.0, 0, 0)
+
+
+def test_binding_helpers_match_the_selected_binding():
+    from dinov2_distillation_amd import _lib
+    assert _lib.BINDING in ("torch", "ctypes")
+    a = _lib.args("dkd_gemm_args")
+    a.M = 3
+    assert [f for f, _ in _lib._STRUCT_DEFS["dkd_gemm_args"]][:2] == ["A", "lda"] and a.M == 3
+    b = _lib.binding()
+    assert b.dkd_abi_version() == _lib.DEFINES["DKD_ABI_VERSION"]
