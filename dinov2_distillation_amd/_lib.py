@@ -115,7 +115,9 @@ def declared_functions():
 # ABI through ctypes.  Both drive the SAME libdkd_hip.so; DKD_BINDING=ctypes|torch overrides.  Call sites are written once
 # against the helpers below: binding() / ptr() / stream() / args() / ref().
 _TORCH_LIB = os.path.join(_PKG, "lib", "libdkd_torch.so")
-BINDING = os.environ.get("DKD_BINDING", "torch" if os.path.exists(_TORCH_LIB) else "ctypes").lower()
+# (an A/B build selected with DKD_HIP_LIB is driven through ctypes: libdkd_torch.so is linked against the in-tree library)
+BINDING = os.environ.get("DKD_BINDING", "torch" if os.path.exists(_TORCH_LIB) and not os.environ.get("DKD_HIP_LIB")
+                         else "ctypes").lower()
 if BINDING not in ("torch", "ctypes"):
     raise ValueError(f"DKD_BINDING={BINDING!r}: expected 'torch' or 'ctypes'")
 _STREAM_FUNCS = {n for n, (_, a) in _FUNC_DEFS.items() if a and a[-1][0] == "stream"}
@@ -160,14 +162,29 @@ class _TorchBinding:
                                 flat.extend(d[f] for f, _ in v._fields)
                             else:
                                 flat.append(v)
-                        _op(*flat)
+                        try:
+                            _op(*flat)
+                        except RuntimeError as e:
+                            return _status_of(e)
                         return 0
                 else:
                     def fn(*a, _op=op):
-                        _op(*a[:-1])
+                        try:
+                            _op(*a[:-1])
+                        except RuntimeError as e:
+                            return _status_of(e)
                         return 0
             self._cache[name] = fn
         return fn
+
+
+def _status_of(err):
+    """the C status the op's TORCH_CHECK reported ("... failed with status N ..."), so that check() raises the same DkdError
+    under both bindings; anything else (a CPU tensor, a wrong device) is re-raised as DkdError with the op's message"""
+    m = re.search(r"failed with status (-?\d+)", str(err))
+    if m:
+        return int(m.group(1))
+    raise DkdError(str(err).split("\n")[0]) from err
 
 
 _binding = None

@@ -18,7 +18,12 @@ OBJ = os.path.join(ROOT, "build", "obj")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libdkd_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INC, "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs adjacent scalar fp32 arithmetic into v_pk_*_f32.  Round 2 measured a kernel
+# built that way (resize_fwd_kernel) returning DIFFERENT bits for the same input whenever bf16-MFMA waves of another stream
+# were co-resident (tests/test_corun_gpu.py; the same source without packed math is immune), packed fp32 beside MFMAs is an
+# issue-slot anti-lever anyway (MI355X_MICROARCH.md, cycle constants), and the step time is unchanged without it (44.0 ms).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INC, "-I" + CSRC, "-Wall", "-Wno-unused-function",
+         "-fno-slp-vectorize"]
 # per-file code generation switches (measured)
 FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 if os.environ.get("DKD_TUNING") == "1":  # also instantiate the timing-only knock-out kernels (scripts/knockout_*.py)

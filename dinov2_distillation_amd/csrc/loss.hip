@@ -74,22 +74,18 @@ __device__ __forceinline__ void load_row(RowVals<VPL>& v, const float* __restric
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
-// ws layout: [0] ticket counter (int, zero before the first launch, left zero), [4 ...] per-block partial pairs.
-// The block whose ticket is the last one folds every partial in index order (fp64) and writes the two results: the separate
-// one-block "final" launch of round 1 (a ~2 us kernel plus a ~1.5 us boundary behind an 8-10 us kernel) is gone.  Hand-off
-// (MI355X_MICROARCH.md, inter-workgroup visibility): partials are written with agent-scope (sc1, write-through) stores, drained
-// with s_waitcnt vmcnt(0) before the ticket add, and read back with agent-scope (sc1) loads by the last block only.
-// NW waves per workgroup: 16 (1024 threads) for the forward at full size - the single-launch reduction below costs one
-// device-scope atomic per WORKGROUP on one counter (~12 ns each, serialised at the memory side: 2048 four-wave workgroups
-// arriving together were a 23 us tail, measured), so the same 8 waves per SIMD are packed into a quarter of the workgroups.
+// Forward: per-workgroup partial sums -> ws, folded in fp64 by kd_loss_final_kernel (second launch).  NW = 16 waves per
+// workgroup at full size: the same 8 waves per SIMD in a quarter of the workgroups, i.e. a quarter of the partials to fold.
+// A single-launch form (last-arriving workgroup folds: sc1 partial stores, s_waitcnt, one device-scope ticket atomic per
+// workgroup, sc1 loads) was built and measured in round 2 and is NOT kept: the ~12 ns per atomic serialise at the memory side
+// when all workgroups finish together - 2048 arrivals 36 us, 512 arrivals 19.2 us, against 15.9 us for the two launches
+// (bs 64, D 384, scripts/bench_loss.py, gpurun_out/r2d_loss*.log).
 template <int LPR, int VPL, bool FREQ, int NW>
-__global__ __launch_bounds__(NW * 64, (VPL <= 3 && !FREQ) ? (NW == 16 ? 8 : 8) : 1) void kd_loss_fwd_kernel(
+__global__ __launch_bounds__(NW * 64) void kd_loss_fwd_kernel(
     const float* __restrict__ S, const float* __restrict__ T, const float* __restrict__ ms, const float* __restrict__ mt,
-    float* __restrict__ ws, float* __restrict__ out, long rows, long rows_per_img, int D, float loss_scale, float sim_scale,
-    int fused_final) {
+    float* __restrict__ partials, long rows, long rows_per_img, int D) {
     constexpr int RPW = 64 / LPR;
     __shared__ float red[2][NW];
-    __shared__ int last_flag;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane / LPR, lir = lane % LPR;
     float acc_sq = 0.f, acc_cos = 0.f;
     const long stride = (long)gridDim.x * NW * RPW;
@@ -141,8 +137,6 @@ __global__ __launch_bounds__(NW * 64, (VPL <= 3 && !FREQ) ? (NW == 16 ? 8 : 8) :
         red[1][wid] = acc_cos;
     }
     __syncthreads();
-    int* ticket = reinterpret_cast<int*>(ws);
-    float* partials = ws + 4;
     if (threadIdx.x == 0) {
         float p0 = 0.f, p1 = 0.f;
 #pragma unroll
@@ -150,49 +144,12 @@ __global__ __launch_bounds__(NW * 64, (VPL <= 3 && !FREQ) ? (NW == 16 ? 8 : 8) :
             p0 += red[0][w];
             p1 += red[1][w];
         }
-        if (!fused_final) {  // two-launch form (kd_loss_final_kernel folds the partials): plain stores, the kernel boundary orders them
-            partials[2 * blockIdx.x + 0] = p0;
-            partials[2 * blockIdx.x + 1] = p1;
-            return;
-        }
-        __hip_atomic_store(partials + 2 * blockIdx.x + 0, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(partials + 2 * blockIdx.x + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (t == (int)gridDim.x - 1);
-    }
-    if (!fused_final) return;
-    __syncthreads();
-    if (!last_flag) return;
-    __shared__ double dred[2][NW];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += NW * 64) {
-        a += (double)__hip_atomic_load(partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b += (double)__hip_atomic_load(partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-    }
-    if (lane == 0) {
-        dred[0][wid] = a;
-        dred[1][wid] = b;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ta = 0.0, tb = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            ta += dred[0][w];
-            tb += dred[1][w];
-        }
-        out[0] = (float)(ta * (double)loss_scale);
-        out[1] = (float)(tb * (double)sim_scale);
-        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this workspace
+        partials[2 * blockIdx.x + 0] = p0;
+        partials[2 * blockIdx.x + 1] = p1;
     }
 }
 
-// the two-launch form's second kernel (A/B: DKD_KD_FINAL=kernel): one workgroup folds the per-workgroup partials in fp64
+// second launch: one workgroup folds the per-workgroup partials in fp64, in index order (deterministic)
 __global__ __launch_bounds__(256) void kd_loss_final_kernel(const float* __restrict__ partials, int n, float* __restrict__ out,
                                                             float loss_scale, float sim_scale) {
     __shared__ double red[2][4];
@@ -218,7 +175,7 @@ __global__ __launch_bounds__(256) void kd_loss_final_kernel(const float* __restr
 
 // d loss / d s (centred s when ms != null):  g = 2*coef*gout*(s^ - t^);  ds = (g - s^ (s^ . g)) / |s|
 template <int LPR, int VPL, bool FREQ>
-__global__ __launch_bounds__(256, (VPL <= 3 && !FREQ) ? 8 : 1) void kd_loss_bwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
+__global__ __launch_bounds__(256) void kd_loss_bwd_kernel(const float* __restrict__ S, const float* __restrict__ T,
                                                           const float* __restrict__ ms, const float* __restrict__ mt,
                                                           const float* __restrict__ gout, float* __restrict__ dS,
                                                           long rows, long rows_per_img, int D, float coef) {
@@ -302,7 +259,7 @@ int kd_blocks(long rows, int D) {
 }
 }  // namespace
 
-extern "C" long dkd_kd_loss_f32_workspace_bytes(long rows) { return (4 + 2L * KD_MAX_BLOCKS) * sizeof(float); }
+extern "C" long dkd_kd_loss_f32_workspace_bytes(long rows) { return 2L * KD_MAX_BLOCKS * sizeof(float); }
 
 extern "C" int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* mean_s, const float* mean_t, float* out2,
                                    float* ws, long rows, long rows_per_img, int D, float alpha, void* stream) {
@@ -312,16 +269,14 @@ extern "C" int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* 
     hipStream_t st = (hipStream_t)stream;
     const float batch = (float)(rows / rows_per_img);
     if ((mean_s == nullptr) != (mean_t == nullptr)) return DKD_ERR_BAD_ARG;  // the frequency variant centres BOTH maps
-    // A/B switches (scripts/bench_loss.py): DKD_KD_FINAL=kernel -> two launches; DKD_KD_WAVES=4 -> 256-thread workgroups
-    static const bool two_launch = getenv("DKD_KD_FINAL") && !strcmp(getenv("DKD_KD_FINAL"), "kernel");
-    static const bool small_wg = getenv("DKD_KD_WAVES") && !strcmp(getenv("DKD_KD_WAVES"), "4");
+    static const bool small_wg = getenv("DKD_KD_WAVES") && !strcmp(getenv("DKD_KD_WAVES"), "4");  // A/B (scripts/bench_loss.py)
     const bool big = !small_wg && rows >= 4096;
     int blocks = 0;
 #define DKD_KD_FWD1(L, V, F, W)                                                                                               \
     do {                                                                                                                      \
         blocks = kd_blocks<kd_loss_fwd_kernel<L, V, F, W>, W>(rows, D);                                                       \
         hipLaunchKernelGGL((kd_loss_fwd_kernel<L, V, F, W>), dim3(blocks), dim3(W * 64), 0, st, S, T, mean_s, mean_t, ws,    \
-                           out2, rows, rows_per_img, D, alpha / batch, 1.0f / (float)rows, two_launch ? 0 : 1);              \
+                           rows, rows_per_img, D);                                                                           \
     } while (0)
 #define DKD_KD_FWD(L, V)                                   \
     if (mean_s) {                                          \
@@ -335,10 +290,8 @@ extern "C" int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* 
 #undef DKD_KD_FWD1
 #undef DKD_KD_FWD
     DKD_LAUNCH_CHECK();
-    if (two_launch) {
-        hipLaunchKernelGGL(kd_loss_final_kernel, dim3(1), dim3(256), 0, st, ws + 4, blocks, out2, alpha / batch, 1.0f / (float)rows);
-        DKD_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(kd_loss_final_kernel, dim3(1), dim3(256), 0, st, ws, blocks, out2, alpha / batch, 1.0f / (float)rows);
+    DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 

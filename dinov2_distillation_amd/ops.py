@@ -16,7 +16,6 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM, RED_GELUSQ, RED_DOTGELU_SUM = 0, 1, 2, 3, 4, 5, 6
 
 _ws = {}
-_kd_ws = {}
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {None: None, "f32": PREC_F32, "fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 GEMM_PRECISION = PRECISIONS.get(os.environ.get("DKD_GEMM_PRECISION", "f32").lower(), PREC_F32)  # process-wide default
@@ -405,12 +404,7 @@ def kd_loss_fwd(s, t, rows_per_img, alpha, mean_s=None, mean_t=None):
     D = s.shape[-1]
     rows = s.numel() // D
     out = torch.empty(2, dtype=torch.float32, device=s.device)
-    # the reduction's arrival counter lives in the workspace and must start at zero: a dedicated, once-zeroed buffer per stream
-    # (the two loss chains run concurrently on two streams), never the shared scratch other kernels scribble on
-    key = (s.device.index, torch.cuda.current_stream(s.device).cuda_stream)
-    ws = _kd_ws.get(key)
-    if ws is None:
-        ws = _kd_ws[key] = torch.zeros(lib.dkd_kd_loss_f32_workspace_bytes(rows) // 4, dtype=torch.float32, device=s.device)
+    ws = workspace(lib.dkd_kd_loss_f32_workspace_bytes(rows), s.device)  # per-stream scratch: the two chains run concurrently
     check(lib.dkd_kd_loss_fwd_f32(_p(s), _p(t), _p(mean_s), _p(mean_t), _p(out), _p(ws), rows, rows_per_img, D, alpha,
                                   _stream()), "dkd_kd_loss_fwd_f32")
     return out

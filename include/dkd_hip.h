@@ -158,10 +158,8 @@ int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const 
  * out2[0] = alpha/B * sum |s^ - t^|^2, out2[1] = mean cosine.  mean_s/mean_t: NULL (spatial) or [B, D] spatial
  * means (frequency variant == DCT / zero DC / IDCT).  bwd writes d loss / d (centred) S scaled by *grad_out
  * (device scalar, NULL = 1).
- * ws (forward): dkd_kd_loss_f32_workspace_bytes(rows) bytes owned by ONE stream at a time.  Its first 16 bytes hold the
- * arrival counter of the single-launch reduction: they must be ZERO before the first launch and are left zero by every
- * launch (the last-arriving workgroup folds all per-workgroup partials in index order in fp64 - deterministic - and
- * resets the counter), so a caller zeroes the buffer once and re-uses it.
+ * ws (forward): dkd_kd_loss_f32_workspace_bytes(rows) bytes of scratch (per-workgroup partial sums, folded in fp64 in index
+ * order by a second one-workgroup launch: deterministic), owned by ONE stream at a time.
  */
 int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* mean_s, const float* mean_t, float* out2, float* ws,
                         long rows, long rows_per_img, int D, float alpha, void* stream);
