@@ -23,6 +23,13 @@ constexpr float LN2 = 0.6931471805599453f;
 // exp2f's denormal-range scaffolding (compare, two selects, add, ldexp per call: 5 extra VALU ops next to every MFMA)
 // buys nothing; results below 2^-126 flush to 0
 __device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+// RND (autocast teacher): eager attention under torch autocast rounds the logits (a matmul result) and the
+// probabilities (the second matmul's operand) to bf16.  Logits live in log2 units here: round the natural-unit value.
+__device__ __forceinline__ float rnd16(float v) { return (float)(__bf16)v; }
+template <bool RND>
+__device__ __forceinline__ float rnd_logit(float s_log2) { return RND ? rnd16(s_log2 * LN2) * LOG2E : s_log2; }
+template <bool RND>
+__device__ __forceinline__ float rnd_prob(float p) { return RND ? rnd16(p) : p; }
 
 __device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -235,15 +242,16 @@ __device__ void attn_fwd_row(const dkd_attn_args& a, int q, int h, int b, float*
 // One extra key handled on the VALU (online-softmax update with a single logit): used for the <= REM_MAX keys left over
 // after the last full 32-key tile (the CLS token makes the teacher's N = 32 k + 1), instead of a whole padded MFMA tile.
 constexpr int REM_MAX = 4;
-template <int HD>
+template <int HD, bool RND = false>
 __device__ __forceinline__ void attn_one_key(const float* __restrict__ krow, const float* __restrict__ vrow,
                                              const float (&qf)[HD / 2], f32x16 (&o)[Cfg<HD>::DCH], float& m, float& l, int half) {
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < HD / 2; ++d) s = fmaf(krow[half * (HD / 2) + d], qf[d], s);
     s += __shfl_xor(s, 32, 64);
+    s = rnd_logit<RND>(s);
     const float mn = fmaxf(m, s);
-    const float alpha = exp2_raw(m - mn), p = exp2_raw(s - mn);
+    const float alpha = exp2_raw(m - mn), p = rnd_prob<RND>(exp2_raw(s - mn));
     l = l * alpha + (half == 0 ? p : 0.f);  // the two halves' partial sums are added at the end: count p once
     m = mn;
 #pragma unroll
@@ -252,7 +260,7 @@ __device__ __forceinline__ void attn_one_key(const float* __restrict__ krow, con
         for (int r = 0; r < 16; ++r) o[c][r] = fmaf(p, vrow[32 * c + frag_row(r, half)], o[c][r] * alpha);
 }
 
-template <int HD, int NW>
+template <int HD, int NW, bool RND = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int nq_limit) {
     using C = Cfg<HD>;
     constexpr int NT = NW * 64, TSZ = 32 * C::LDW;
@@ -317,13 +325,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int 
             s += __shfl_xor(s, 1, 64);
             s += __shfl_xor(s, 2, 64);
             s += __shfl_xor(s, 4, 64);
+            s = rnd_logit<RND>(s);
             if (kt * 32 + j >= a.Nk) s = -INFINITY;
             float mt = fmaxf(s, __shfl_xor(s, 8, 64));
             mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float mn = fmaxf(xm, mt);
             if (mn > -INFINITY) {  // wave-uniform
-                const float alpha = exp2_raw(xm - mn), p = exp2_raw(s - mn);
+                const float alpha = exp2_raw(xm - mn), p = rnd_prob<RND>(exp2_raw(s - mn));
                 xl = xl * alpha + p;
                 xm = mn;
                 const float* vp = Vs + wid * 8 * C::LDW + (lane < C::HDP ? lane : C::HDP - 1);
@@ -335,9 +344,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int 
             }
         }
         if (active && valu_tail && kt == nkt - 1) {
-            for (int j = 0; j < rem; ++j) attn_one_key<HD>(Ks + j * C::LDW, Vs + j * C::LDW, qf, o, m, l, half);
+            for (int j = 0; j < rem; ++j) attn_one_key<HD, RND>(Ks + j * C::LDW, Vs + j * C::LDW, qf, o, m, l, half);
         } else if (active) {
             f32x16 s = tile_times_frag<HD>(Ks, qf, l31, half);
+            if (RND) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = rnd_logit<true>(s[r]);
+            }
             if (kt == nkt - 1 && rem != 0) {  // only the last key tile can hold padded keys
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(dkd_attn_args a, int 
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2_raw(s[r] - mn);
+                s[r] = rnd_prob<RND>(exp2_raw(s[r] - mn));
                 ls += s[r];
             }
             l = l * alpha + ls;
@@ -562,6 +575,13 @@ int launch_fwd(const dkd_attn_args* a, hipStream_t st) {
     const int nq_main = row_tail ? a->Nq - qrem : a->Nq;
     const int nw = pick_nw_fwd(nq_main);
     dim3 grid((nq_main + 32 * nw - 1) / (32 * nw), a->H, a->B);
+    if (a->round_bf16) {  // the autocast teacher (DINOv2 heads are 64 wide): always the 4-wave kernel
+        if (HD != 64) return DKD_ERR_UNSUPPORTED;
+        const dim3 grid4((nq_main + 127) / 128, a->H, a->B);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD == 64 ? 64 : HD, 4, HD == 64>), grid4, dim3(256), 0, st, *a, nq_main);
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
     switch (nw) {
         case 1: hipLaunchKernelGGL((attn_fwd_kernel<HD, 1>), grid, dim3(64), 0, st, *a, nq_main); break;
         case 2: hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, dim3(128), 0, st, *a, nq_main); break;

@@ -1,0 +1,224 @@
+// bf16 GEMM with bf16 operands IN HBM for the "autocast" teacher (the reference's default precision=16 step,
+// /root/reference/train.py:263, is torch autocast: every nn.Linear computes on 16-bit operands, accumulates in fp32 and
+// ROUNDS ITS OUTPUT to 16 bit; LayerNorm, softmax and the residual stream stay fp32).  bf16 instead of fp16: native on the
+// MI355X matrix cores at the same rate, fp32's exponent range, no loss scaling.
+//
+//   C = epi(A[M,K] . B[N,K]^T)      A, B: bf16, K-contiguous (activations / nn.Linear weights); fp32 accumulation on
+//                                   v_mfma_f32_32x32x16_bf16
+//   EPI_BF16        C bf16 = rnd(acc + bias)                                    (qkv, w12)
+//   EPI_BF16_GELU   C bf16 = rnd(gelu(rnd(acc + bias)))                         (fc1: F.gelu on a bf16 tensor rounds again)
+//   EPI_F32_RESID   C f32  = residual + colscale * rnd(acc + bias)              (proj / fc2 / w3 + LayerScale + residual; the
+//                                                                                 residual stream is fp32 under autocast)
+//   EPI_F32         C f32  = rnd(acc + bias) [+ residual, periodic res_mod]     (qkv for the fp32 flash attention; patch embed
+//                                                                                 + position table with an output-row remap)
+//
+// Tile 128 x 128 x 64, 8 waves (512 threads), each wave a 32 (m) x 64 (n) slab = 1 x 2 MFMA tiles.  The product is issued as
+// D^T (first operand = the weight fragment): a lane then holds, for ITS output row m, four consecutive n per register quad, so
+// epilogue traffic is 8-byte (bf16) / 16-byte (fp32) per lane and bias / colscale / residual loads are vector loads.  LDS rows
+// are K-contiguous with a 144-byte pitch (64 bf16 + 8 pad): the ds_read_b128 of a fragment (16 rows x 16 B per lane group)
+// is bank-conflict-free (pitch 36 dwords: the 16 rows of a service group start on 16 distinct 4-bank sets).  Register-staged
+// prefetch: the next tile's global loads are issued before the MFMA block and written to LDS after it (one LDS image, two
+// barriers per 64-deep k-tile, 8 MFMAs per wave between them).
+#include "common.h"
+#include "dkd_hip.h"
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64, RS = 72, NT = 512;  // RS: bf16 per LDS row
+
+__device__ __forceinline__ int xcd_remap_b(int bid, int nblk) {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+__device__ __forceinline__ float rnd_bf16(float v) { return (float)(__bf16)v; }
+
+template <int EPI>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[(BM + BN) * RS];
+    __bf16* As = smem;
+    __bf16* Bs = smem + BM * RS;
+    const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(g.A);
+    const __bf16* __restrict__ B = reinterpret_cast<const __bf16*>(g.B);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;  // 4 (m) x 2 (n) waves
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
+    const int tile = xcd_remap_b(blockIdx.x, nbm * nbn);
+    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // staging: a tile is 128 rows x 64 bf16 = 1024 16-byte pieces; thread t moves pieces t and t + 512 of A and of B
+    uint4 ra[2], rb[2];
+    const int pr = tid >> 3, pk = (tid & 7) * 8;  // row 0..63 (+64 for the second piece), k offset in bf16
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = pr + 64 * i;
+            const int gm = bm0 + r, gn = bn0 + r, gk = k0 + pk;
+            ra[i] = (gm < g.M && gk < g.K) ? *reinterpret_cast<const uint4*>(A + (long)gm * g.lda + gk) : make_uint4(0, 0, 0, 0);
+            rb[i] = (gn < g.N && gk < g.K) ? *reinterpret_cast<const uint4*>(B + (long)gn * g.ldb + gk) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = pr + 64 * i;
+            *reinterpret_cast<uint4*>(As + r * RS + pk) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + r * RS + pk) = rb[i];
+        }
+    };
+    const int nk = (g.K + BK - 1) / BK;
+    load(0);
+    store();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + l31) * RS + ks * 16 + half * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + j * 32 + l31) * RS + ks * 16 + half * 8);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[j], 0, 0, 0);  // D^T: rows = n, columns (lanes) = m
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) store();
+        __syncthreads();
+    }
+    // epilogue: lane (l31, half) owns output row m and, per register quad q, the columns n0 + 8q + 4 half + (0..3)
+    const int m = bm0 + wm * 32 + l31;
+    if (m >= g.M) return;
+    long orow = m;
+    if (g.row_grp > 0) orow = (long)(m / g.row_grp) * g.row_grp_stride + (m % g.row_grp) + g.row_off;
+    const __bf16* __restrict__ bias = reinterpret_cast<const __bf16*>(g.bias);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * half;
+            if (n >= g.N) continue;  // (N % 4 == 0 is checked on the host)
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * q + e];
+            if (bias) {
+                const bf16x4 bq = *reinterpret_cast<const bf16x4*>(bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)bq[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rnd_bf16(v[e]);  // the Linear's 16-bit output
+            if (EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU) {
+                if (EPI == DKD_BF16_EPI_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                }
+                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + orow * g.ldc + n) = o;
+            } else {
+                if (g.colscale) {
+                    const float4 c = *reinterpret_cast<const float4*>(g.colscale + n);
+                    v[0] *= c.x; v[1] *= c.y; v[2] *= c.z; v[3] *= c.w;
+                }
+                if (g.residual) {
+                    const long rr = g.res_mod > 0 ? (long)(m % g.res_mod) : orow;
+                    const float4 r = *reinterpret_cast<const float4*>(g.residual + rr * g.ldr + n);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + orow * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+}
+
+// fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even), columns cols .. out_ld-1 zero-filled (K padding)
+__global__ void cast_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, long rows, int cols, int out_ld) {
+    const int oq = out_ld >> 2;
+    const long total = rows * oq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / oq;
+        const int c = (int)(i % oq) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 3 < cols && (cols & 3) == 0) v = *reinterpret_cast<const float4*>(in + r * cols + c);
+        else {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; ++e)
+                if (c + e < cols) t[e] = in[r * cols + c + e];
+            v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4*>(out + r * out_ld + c) = o;
+    }
+}
+
+// SwiGLU on bf16 as autocast computes it: silu(x1) on a bf16 tensor (fp32 inside, rounded), times x2 (rounded again)
+__global__ void swiglu_bf16_kernel(const __bf16* __restrict__ x12, __bf16* __restrict__ out, long rows, int hidden) {
+    const int hq = hidden >> 2;
+    const long total = rows * hq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / hq;
+        const int c = (int)(i % hq) * 4;
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(x12 + r * 2 * hidden + c);
+        const bf16x4 b = *reinterpret_cast<const bf16x4*>(x12 + r * 2 * hidden + hidden + c);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = (float)a[e];
+            const float s = rnd_bf16(x / (1.f + __expf(-x)));
+            o[e] = (__bf16)(s * (float)b[e]);
+        }
+        *reinterpret_cast<bf16x4*>(out + r * hidden + c) = o;
+    }
+}
+
+int blocks_1d(long total) {
+    const long b = (total + 255) / 256;
+    return (int)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
+}
+}  // namespace
+
+extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
+    if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0) return DKD_ERR_BAD_ARG;
+    if ((g->K & 7) || (g->lda & 7) || (g->ldb & 7) || (g->N & 3) || (g->ldc & 3)) return DKD_ERR_ALIGN;
+    if (!dkd_aligned16(g->A) || !dkd_aligned16(g->B) || !dkd_aligned16(g->C)) return DKD_ERR_ALIGN;
+    if (g->residual && ((g->ldr & 3) || !dkd_aligned16(g->residual))) return DKD_ERR_ALIGN;
+    if (g->colscale && !dkd_aligned16(g->colscale)) return DKD_ERR_ALIGN;
+    const bool f32_out = g->epi == DKD_BF16_EPI_F32_RESID || g->epi == DKD_BF16_EPI_F32;
+    if (!f32_out && (g->residual || g->colscale)) return DKD_ERR_BAD_ARG;
+    const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN)), block(NT);
+    hipStream_t st = (hipStream_t)stream;
+    switch (g->epi) {
+        case DKD_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<DKD_BF16_EPI_BF16>, grid, block, 0, st, *g); break;
+        case DKD_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<DKD_BF16_EPI_BF16_GELU>, grid, block, 0, st, *g); break;
+        case DKD_BF16_EPI_F32_RESID:
+        case DKD_BF16_EPI_F32: hipLaunchKernelGGL(gemm_bf16_kernel<DKD_BF16_EPI_F32>, grid, block, 0, st, *g); break;
+        default: return DKD_ERR_BAD_ARG;
+    }
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_cast_bf16(const float* in, void* out, long rows, int cols, int out_ld, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0 || out_ld < cols) return DKD_ERR_BAD_ARG;
+    if (out_ld & 3) return DKD_ERR_ALIGN;
+    if ((cols & 3) == 0 && !dkd_aligned16(in)) return DKD_ERR_ALIGN;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_1d(rows * (out_ld / 4))), dim3(256), 0, (hipStream_t)stream, in,
+                       reinterpret_cast<__bf16*>(out), rows, cols, out_ld);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_swiglu_bf16(const void* x12, void* out, long rows, int hidden, void* stream) {
+    if (!x12 || !out || rows <= 0 || hidden <= 0) return DKD_ERR_BAD_ARG;
+    if (hidden & 3) return DKD_ERR_ALIGN;
+    hipLaunchKernelGGL(swiglu_bf16_kernel, dim3(blocks_1d(rows * (hidden / 4))), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(x12), reinterpret_cast<__bf16*>(out), rows, hidden);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}

@@ -17,7 +17,11 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int LPR, int VPL, bool WRITE_STATS>
+typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+
+// OUT_BF16: y is bf16 (the autocast teacher: LayerNorm computes in fp32 and its only consumer, an nn.Linear, rounds its input
+// to 16 bit - the rounding is done here and the [rows, C] tensor costs half the bytes)
+template <int LPR, int VPL, bool WRITE_STATS, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         }
         const float rs = rsqrtf(group_sum<LPR>(q) * invC + eps);
         float4* yr = reinterpret_cast<float4*>(y + row * C);
+        ln_bf16x4* yb = reinterpret_cast<ln_bf16x4*>(reinterpret_cast<__bf16*>(y) + row * C);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = lir + i * LPR;
@@ -66,7 +71,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 o.y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
                 o.z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
                 o.w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
-                yr[c] = o;
+                if (OUT_BF16) yb[c] = ln_bf16x4{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+                else yr[c] = o;
             }
         }
         if (WRITE_STATS && lir == 0) {
@@ -388,6 +394,22 @@ extern "C" int dkd_layernorm_fwd_f32(const float* x, const float* gamma, const f
                            rstd, rows, C, eps, in_row_grp, in_row_grp_stride, in_row_off)
     DKD_LN_DISPATCH(nv, DKD_LN_FWD);
 #undef DKD_LN_FWD
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_layernorm_fwd_bf16out_f32(const float* x, const float* gamma, const float* beta, void* y_bf16, long rows, int C,
+                                             float eps, int in_row_grp, int in_row_grp_stride, int in_row_off, void* stream) {
+    if (!x || !gamma || !beta || !y_bf16 || rows <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    if ((C & 3) || C > LN_MAXV * 256) return DKD_ERR_UNSUPPORTED;
+    const int nv = C / 4, rpb = ln_rows_per_block(nv);
+    const int blocks = (int)((rows + rpb - 1) / rpb < 4096 ? (rows + rpb - 1) / rpb : 4096);
+#define DKD_LN_FWD16(L, V)                                                                                                     \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<L, V, false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma,   \
+                       beta, reinterpret_cast<float*>(y_bf16), nullptr, nullptr, rows, C, eps, in_row_grp, in_row_grp_stride,  \
+                       in_row_off)
+    DKD_LN_DISPATCH(nv, DKD_LN_FWD16);
+#undef DKD_LN_FWD16
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -60,6 +60,7 @@ class Block(nn.Module):
             self.mlp.fc1.weight, self.mlp.fc1.bias = _tn(4 * dim, dim, gen=gen), z(4 * dim)
             self.mlp.fc2.weight, self.mlp.fc2.bias = _tn(dim, 4 * dim, gen=gen), z(dim)
         self._prep = None
+        self._prep16 = None
         self.precision = None  # GEMM precision of this frozen block: None (global default) / ops.PREC_F32 / PREC_BF16X3 / PREC_BF16
 
     def transposed(self, name):
@@ -98,8 +99,47 @@ class Block(nn.Module):
                                    "b2": fout.bias * ls2})
         return self._prep
 
+    def prepared16(self):
+        """bf16 copies of the frozen weights / biases for the autocast forward (made once): torch autocast casts weight AND
+        bias of every nn.Linear to the 16-bit type; LayerScale stays a separate fp32 multiply after the Linear's rounding"""
+        w = self.attn.qkv.weight
+        if self._prep16 is None or self._prep16["_ptr"] != w.data_ptr() or self._prep16["_ver"] != w._version:
+            with torch.no_grad():
+                b = lambda t: t.detach().to(torch.bfloat16).contiguous()
+                fin, fout = (self.mlp.w12, self.mlp.w3) if self.ffn == "swiglu" else (self.mlp.fc1, self.mlp.fc2)
+                self._prep16 = {"_ptr": w.data_ptr(), "_ver": w._version, "swiglu": self.ffn == "swiglu",
+                                "n1w": self.norm1.weight, "n1b": self.norm1.bias, "n2w": self.norm2.weight, "n2b": self.norm2.bias,
+                                "wqkv": b(w), "bqkv": b(self.attn.qkv.bias), "wproj": b(self.attn.proj.weight),
+                                "bproj": b(self.attn.proj.bias), "ls1": self.ls1.gamma, "ls2": self.ls2.gamma,
+                                "w1": b(fin.weight), "b1": b(fin.bias), "w2": b(fout.weight), "b2": b(fout.bias)}
+        return self._prep16
+
+    def forward_autocast(self, x2, B, N):
+        """one block of the autocast teacher on the fp32 residual stream x2 [B*N, D] (no autograd: the frozen teacher's own
+        forward).  Op policy of torch.autocast: LayerNorm / softmax / residual adds in fp32, every nn.Linear on bf16 operands
+        with a bf16 result, GELU / SiLU on the bf16 tensor."""
+        p, H = self.prepared16(), self.num_heads
+        D = x2.shape[1]
+        hd = D // H
+        h1 = ops.layernorm_fwd_bf16out(x2, p["n1w"], p["n1b"], 1e-6)
+        # q, k, v as bf16 VALUES in an fp32 buffer: the flash kernel multiplies them exactly (bf16 x bf16 products are exact in
+        # fp32), rounds logits and probabilities to bf16 where eager attention under autocast does (matmul result / operand;
+        # the softmax itself is fp32) and accumulates in fp32; q * hd^-0.5 is exact for the 64-wide heads of every DINOv2 model
+        qkv = ops.gemm_bf16(h1, p["wqkv"], epi=ops.EPI_F32, bias=p["bqkv"])
+        st = (N * 3 * D, 3 * D)
+        o, _ = ops.attention_forward(qkv, qkv[:, D:], qkv[:, 2 * D:], H, hd, hd ** -0.5, B, N, N, st, st, st, round_bf16=True)
+        x1 = ops.gemm_bf16(ops.cast_bf16(o.reshape(B * N, D)), p["wproj"], epi=ops.EPI_F32_RESID, bias=p["bproj"],
+                           colscale=p["ls1"], residual=x2)
+        h2 = ops.layernorm_fwd_bf16out(x1, p["n2w"], p["n2b"], 1e-6)
+        if p["swiglu"]:
+            a = ops.swiglu_bf16(ops.gemm_bf16(h2, p["w1"], epi=ops.EPI_BF16, bias=p["b1"]))
+        else:
+            a = ops.gemm_bf16(h2, p["w1"], epi=ops.EPI_BF16_GELU, bias=p["b1"])
+        return ops.gemm_bf16(a, p["w2"], epi=ops.EPI_F32_RESID, bias=p["b2"], colscale=p["ls2"], residual=x1)
+
     def _apply(self, fn, *a, **k):
         self._prep = None
+        self._prep16 = None
         return super()._apply(fn, *a, **k)
 
     def forward(self, x):
@@ -126,11 +166,18 @@ class VisionTransformer(nn.Module):
         self.norm.weight = nn.Parameter(torch.ones(D), requires_grad=False)
         self.norm.bias = nn.Parameter(torch.zeros(D), requires_grad=False)
         self._pos_cache = {}
+        self._pe16 = None
         self.precision = None
+        self.autocast = False
 
     def set_precision(self, precision):
         """GEMM arithmetic of the frozen teacher: None / "f32" (exact fp32 MFMA), "bf16x3" (split precision) or "bf16"
         (operands rounded to bf16, fp32 accumulate - BASELINE configs[4]'s "bf16 teacher on MFMA")."""
+        self.autocast = precision == "bf16_autocast"
+        if self.autocast:
+            # the teacher's OWN forward follows torch.autocast(bf16) with bf16 activations in HBM (forward_tokens_autocast); the
+            # re-use of its blocks on student tokens (with gradient) keeps the bf16-operand kernels of the "bf16" mode
+            precision = "bf16"
         self.precision = ops.PRECISIONS[precision] if (precision is None or isinstance(precision, str)) else precision
         for blk in self.blocks:
             blk.precision = self.precision
@@ -138,6 +185,7 @@ class VisionTransformer(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._pos_cache = {}
+        self._pe16 = None
         return super()._apply(fn, *a, **k)
 
     def _pos_table(self, ph, pw):
@@ -159,8 +207,35 @@ class VisionTransformer(nn.Module):
             self._pos_cache = {key: table}
         return self._pos_cache[key]
 
+    def forward_tokens_autocast(self, x):
+        """forward_tokens under the reference's default mixed-precision policy (train.py:263: precision=16 == torch autocast),
+        in bf16: patch-embed conv and every Linear on bf16 operands with bf16 results, the token / residual stream, LayerNorm
+        and softmax in fp32 (adding the fp32 position table promotes the embedded patches back to fp32)."""
+        B, _, Himg, Wimg = x.shape
+        ph, pw = Himg // PATCH, Wimg // PATCH
+        n, D = ph * pw, self.embed_dim
+        table = self._pos_table(ph, pw)
+        if self._pe16 is None or self._pe16[0] != self.patch_embed.proj.weight._version:
+            kp = (3 * PATCH * PATCH + 7) // 8 * 8  # 588 -> 592: K padded to whole 16-byte bf16 pieces
+            w16 = torch.zeros((D, kp), dtype=torch.bfloat16, device=x.device)
+            w16[:, :3 * PATCH * PATCH] = self.patch_embed.proj.weight.reshape(D, -1).to(torch.bfloat16)
+            self._pe16 = (self.patch_embed.proj.weight._version, w16, self.patch_embed.proj.bias.to(torch.bfloat16), kp)
+        _, w16, b16, kp = self._pe16
+        rows16 = ops.cast_bf16(ops.patchify_nchw(x.contiguous(), PATCH), kp)
+        tok = torch.empty((B * (n + 1), D), dtype=torch.float32, device=x.device)
+        ops.gemm_bf16(rows16, w16, epi=ops.EPI_F32, bias=b16, residual=table[1:], res_mod=n, row_map=(n, n + 1, 1, B * (n + 1)),
+                      out=tok)
+        ops.set_rows(tok, table[0], B, (n + 1) * D)
+        t = tok
+        for blk in self.blocks:
+            t = blk.forward_autocast(t, B, n + 1)
+        out, _, _ = ops.layernorm_fwd(t, self.norm.weight, self.norm.bias, 1e-6, need_stats=False, in_rows=(n, n + 1, 1, B * n))
+        return out.view(B, n, D)
+
     def forward_tokens(self, x):
         """-> final-norm patch tokens [B, P*P, D], dense (CLS dropped by the norm kernel's row gather)."""
+        if self.autocast and not (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_tokens_autocast(x)
         B, _, Himg, Wimg = x.shape
         ph, pw = Himg // PATCH, Wimg // PATCH
         n, D = ph * pw, self.embed_dim

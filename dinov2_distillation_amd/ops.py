@@ -373,13 +373,15 @@ def _attn_args(q, k, v, o, H, hd, scale, strides):
     return a
 
 
-def attention_forward(q, k, v, H, hd, scale, B, Nq, Nk, q_st, k_st, v_st):
+def attention_forward(q, k, v, H, hd, scale, B, Nq, Nk, q_st, k_st, v_st, round_bf16=False):
+    """round_bf16: logits and probabilities rounded to bf16 as eager attention under torch autocast rounds them (hd 64 only)"""
     lib = _lib.binding()
     D = H * hd
     o = torch.empty((B, Nq, D), dtype=torch.float32, device=k.device)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=k.device)
     a = _attn_args(q, k, v, o, H, hd, scale, (q_st, k_st, v_st, (Nq * D, D)))
     a.B, a.Nq, a.Nk, a.lse = B, Nq, Nk, _p(lse)
+    a.round_bf16 = int(round_bf16)
     check(lib.dkd_attn_fwd_f32(_lib.ref(a), _stream()), f"dkd_attn_fwd_f32[hd={hd}]")
     return o, lse
 
@@ -778,3 +780,74 @@ def winattn_backward(do, qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
     dbias = torch.empty((N * N, H), dtype=torch.float32, device=qkv.device)
     check(lib.dkd_winattn_dbias_f32(_p(part), _p(dbias), parts, H, N, _stream()), "dkd_winattn_dbias_f32")
     return dqkv, dbias
+
+
+# ---- bf16-in-HBM operators of the autocast teacher (train.py:263 precision=16 == torch autocast) --------------------
+BF16 = torch.bfloat16
+EPI_BF16, EPI_BF16_GELU, EPI_F32_RESID, EPI_F32 = 0, 1, 2, 3
+
+
+def _chk16(t, name):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != BF16 or not t.is_contiguous():
+        raise _lib.DkdError(f"{name}: expected a contiguous CUDA(HIP) bfloat16 tensor, got {t.device} {t.dtype} {tuple(t.stride())}")
+
+
+def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, res_mod=0, row_map=None, out=None):
+    """out = epi(a[M,K] @ w[N,K]^T), bf16 operands, fp32 accumulate, the Linear's output rounded to bf16 (see dkd_hip.h).
+    a, w, bias: bfloat16; colscale / residual: float32; out: bfloat16 for EPI_BF16 / EPI_BF16_GELU, float32 otherwise."""
+    _chk16(a, "a"), _chk16(w, "w"), _chk16(bias, "bias"), _chk(colscale, "colscale"), _chk(residual, "residual")
+    a2 = a.reshape(-1, a.shape[-1])
+    M, K = a2.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise _lib.DkdError(f"gemm_bf16: reduction extents differ: {K} vs {w.shape[1]}")
+    g = _lib.args("dkd_gemm_bf16_args")
+    out_rows = M
+    if row_map is not None:
+        g.row_grp, g.row_grp_stride, g.row_off, out_rows = row_map
+    f32_out = epi in (EPI_F32_RESID, EPI_F32)
+    if out is None:
+        out = torch.empty((out_rows, N), dtype=torch.float32 if f32_out else BF16, device=a.device)
+    if out.dtype != (torch.float32 if f32_out else BF16) or not out.is_contiguous():
+        raise _lib.DkdError("gemm_bf16: out has the wrong dtype / layout for this epilogue")
+    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), K, _p(w), K, _p(out), N
+    g.bias, g.colscale, g.residual, g.ldr = _p(bias), _p(colscale), _p(residual), N
+    g.M, g.N, g.K, g.epi, g.res_mod = M, N, K, epi, res_mod
+    check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[{M}x{N}x{K} epi {epi}]")
+    return out
+
+
+def cast_bf16(x, out_cols=None):
+    """fp32 [..., C] -> bf16 [rows, out_cols] (round to nearest even; zero K-padding up to out_cols)"""
+    _chk(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    oc = C if out_cols is None else out_cols
+    out = torch.empty((rows, oc), dtype=BF16, device=x.device)
+    check(_lib.binding().dkd_cast_bf16(_p(x), _p(out), rows, C, oc, _stream()), "dkd_cast_bf16")
+    return out
+
+
+def swiglu_bf16(x12):
+    _chk16(x12, "x12")
+    hidden = x12.shape[-1] // 2
+    rows = x12.numel() // (2 * hidden)
+    out = torch.empty((rows, hidden), dtype=BF16, device=x12.device)
+    check(_lib.binding().dkd_swiglu_bf16(_p(x12), _p(out), rows, hidden, _stream()), "dkd_swiglu_bf16")
+    return out
+
+
+def layernorm_fwd_bf16out(x, gamma, beta, eps, in_rows=None):
+    """LayerNorm in fp32 with a bfloat16 result (the input of the next autocast Linear)"""
+    _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    grp = gst = off = 0
+    if in_rows is not None:
+        grp, gst, off, rows = in_rows
+    y = torch.empty((rows, C), dtype=BF16, device=x.device)
+    check(_lib.binding().dkd_layernorm_fwd_bf16out_f32(_p(x), _p(gamma), _p(beta), _p(y), rows, C, eps, grp, gst, off, _stream()),
+          "dkd_layernorm_fwd_bf16out_f32")
+    return y

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DKD_ABI_VERSION 1
+#define DKD_ABI_VERSION 2
 int dkd_abi_version(void);
 
 /* activation codes for fused epilogues */
@@ -100,6 +100,11 @@ long dkd_layernorm_bwd_f32_workspace_bytes(long rows, int C);
 /* Grouped column reduction  out[g][n] = scale * sum_{r<rows_per_group} f(X[g*rows_per_group+r][n], ...)
  * (bias gradients, BatchNorm batch statistics losses/scalekd.py:200, GRN energies convnext.py:48, pos_embed / query
  * gradients, spatial means for the frequency loss losses/scalekd.py:111-118). */
+/* LayerNorm of the autocast teacher: fp32 in, fp32 statistics, bf16 OUT (what the next nn.Linear would round
+ * its input to anyway under torch autocast). */
+int dkd_layernorm_fwd_bf16out_f32(const float* x, const float* gamma, const float* beta, void* y_bf16, long rows, int C,
+                                  float eps, int in_row_grp, int in_row_grp_stride, int in_row_off, void* stream);
+
 #define DKD_RED_SUM 0    /* x            */
 #define DKD_RED_DOT 1    /* x * y        */
 #define DKD_RED_SUMSQ 2  /* x * x        */
@@ -154,6 +159,37 @@ int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const 
                          const float* gamma, float* dh, int B, long rows_per_img, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * bf16 GEMM with bf16 operands in HBM: the nn.Linear of the reference's default mixed-precision step (train.py:263,
+ * ``precision=16`` == torch autocast; bf16 instead of fp16 on MI355X).  C = epi(A[M,K] . B[N,K]^T), A / B / bias bf16
+ * (void*), fp32 accumulate, the Linear's output rounded to bf16 in every epilogue (autocast's op policy):
+ *   DKD_BF16_EPI_BF16       C bf16 = rnd(acc + bias)
+ *   DKD_BF16_EPI_BF16_GELU  C bf16 = rnd(gelu(rnd(acc + bias)))          DINOv2 MLP fc1 + nn.GELU
+ *   DKD_BF16_EPI_F32_RESID  C f32  = residual + colscale * rnd(acc + bias) LayerScale + fp32 residual stream
+ *   DKD_BF16_EPI_F32        C f32  = rnd(acc + bias) [+ residual]          patch embed + position table (res_mod, row map)
+ * K, lda, ldb multiples of 8; N, ldc, ldr multiples of 4; 16-byte aligned pointers.  Output-row remap and periodic
+ * residual as in dkd_gemm_args. */
+#define DKD_BF16_EPI_BF16 0
+#define DKD_BF16_EPI_BF16_GELU 1
+#define DKD_BF16_EPI_F32_RESID 2
+#define DKD_BF16_EPI_F32 3
+typedef struct dkd_gemm_bf16_args {
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* C; int64_t ldc;
+    const void* bias;
+    const float* colscale;
+    const float* residual; int64_t ldr;
+    int32_t M, N, K;
+    int32_t epi, res_mod, row_grp, row_grp_stride, row_off;
+} dkd_gemm_bf16_args;
+int dkd_gemm_bf16(const dkd_gemm_bf16_args* args, void* stream);
+/* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588
+ * patch rows to a multiple of 8) */
+int dkd_cast_bf16(const float* in, void* out_bf16, long rows, int cols, int out_ld, void* stream);
+/* SwiGLU on bf16 [rows, 2*hidden] -> bf16 [rows, hidden] as autocast rounds it: rnd(rnd(silu(x1)) * x2) */
+int dkd_swiglu_bf16(const void* x12_bf16, void* out_bf16, long rows, int hidden, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * ScaleKD loss tail (losses/scalekd.py:67-92 get_spat_loss, :95-127 get_freq_loss).  S, T: token-major [rows, D].
  * out2[0] = alpha/B * sum |s^ - t^|^2, out2[1] = mean cosine.  mean_s/mean_t: NULL (spatial) or [B, D] spatial
  * means (frequency variant == DCT / zero DC / IDCT).  bwd writes d loss / d (centred) S scaled by *grad_out
@@ -186,6 +222,8 @@ typedef struct dkd_attn_args {
     int64_t do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     int32_t B, H, Nq, Nk, hd;
     float scale;
+    int32_t round_bf16; /* forward only, hd 64: round logits and probabilities to bf16 as eager attention under torch autocast
+                           does (the matmul results / operands of train.py:263's precision=16 policy); 0 = exact fp32 */
 } dkd_attn_args;
 int dkd_attn_fwd_f32(const dkd_attn_args* args, void* stream);
 int dkd_attn_bwd_f32(const dkd_attn_args* args, void* stream);

@@ -163,3 +163,89 @@ def teacher_feature_map(p, x, cfg, depth=None, bf16=False):
     ph, pw = H // PATCH, W // PATCH
     tok = vit_tokens(p, x, cfg, depth, bf16)[:, 1:]
     return tok.reshape(B, ph, pw, tok.shape[-1]).permute(0, 3, 1, 2)
+
+
+# ---- the reference's default mixed-precision policy (train.py:263, precision=16 == torch autocast) for the teacher, in bf16 ------
+def _r16(t):
+    """round to bfloat16 (nearest even), keep the container dtype"""
+    return t.bfloat16().to(t.dtype)
+
+
+def _lin16(x16, w, b):
+    """nn.Linear under autocast: input, weight AND bias cast to the 16-bit type, fp32 accumulation, 16-bit result"""
+    return _r16(F.linear(x16, _r16(w), _r16(b)))
+
+
+def vit_block_autocast(p, prefix, x, num_heads, eps=1e-6):
+    """One block under torch.autocast(bf16)'s op policy: LayerNorm, softmax and the residual adds in fp32; every Linear on
+    bf16 operands with a bf16 result; GELU / SiLU evaluated on the bf16 tensor (fp32 inside, rounded); LayerScale an fp32
+    multiply AFTER the projection's rounding.  Attention is the EAGER form (what the hub model runs without xformers, and
+    what autocast can see): q * hd^-0.5 and q k^T are 16-bit results, softmax is an fp32 op whose output is cast to 16 bit as
+    the operand of P V, the context a 16-bit result.  (test_autocast_oracle_follows_torch_autocast_policy: this emulation
+    agrees with torch.autocast itself to 1e-4, twenty times closer than either is to fp32.)"""
+    B, N, D = x.shape
+    hd = D // num_heads
+    h = _r16(F.layer_norm(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps))
+    qkv = _lin16(h, p[prefix + "attn.qkv.weight"], p[prefix + "attn.qkv.bias"]).view(B, N, 3, num_heads, hd)
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    ctx = _r16(torch.softmax(_r16(_r16(q * hd ** -0.5) @ k.transpose(-1, -2)), dim=-1)) @ v
+    ctx = _r16(ctx.transpose(1, 2).reshape(B, N, D))
+    x = x + p[prefix + "ls1.gamma"] * _lin16(ctx, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"])
+    h = _r16(F.layer_norm(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps))
+    if (prefix + "mlp.w12.weight") in p:
+        x1, x2 = _lin16(h, p[prefix + "mlp.w12.weight"], p[prefix + "mlp.w12.bias"]).chunk(2, dim=-1)
+        m = _lin16(_r16(_r16(F.silu(x1)) * x2), p[prefix + "mlp.w3.weight"], p[prefix + "mlp.w3.bias"])
+    else:
+        m = _r16(F.gelu(_lin16(h, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"])))
+        m = _lin16(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"])
+    return x + p[prefix + "ls2.gamma"] * m
+
+
+def vit_block_upstream_ops(p, prefix, x, num_heads, eps=1e-6):
+    """The block as the SEQUENCE OF TORCH OPS the published module issues (LayerScale a separate multiply, eager attention) -
+    plain fp32 here; run under ``torch.autocast`` it shows where torch's own policy rounds (tests/test_oracle_golden.py)."""
+    B, N, D = x.shape
+    hd = D // num_heads
+    y = F.layer_norm(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps)
+    qkv = F.linear(y, p[prefix + "attn.qkv.weight"], p[prefix + "attn.qkv.bias"]).reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    ctx = (attn @ v).transpose(1, 2).reshape(B, N, D)
+    x = x + p[prefix + "ls1.gamma"] * F.linear(ctx, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"])
+    y = F.layer_norm(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps)
+    if (prefix + "mlp.w12.weight") in p:
+        x1, x2 = F.linear(y, p[prefix + "mlp.w12.weight"], p[prefix + "mlp.w12.bias"]).chunk(2, dim=-1)
+        m = F.linear(F.silu(x1) * x2, p[prefix + "mlp.w3.weight"], p[prefix + "mlp.w3.bias"])
+    else:
+        m = F.linear(F.gelu(F.linear(y, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"])),
+                     p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"])
+    return x + p[prefix + "ls2.gamma"] * m
+
+
+def teacher_feature_map_upstream_ops(p, x, cfg, depth=None):
+    """teacher_feature_map built from vit_block_upstream_ops (same numbers in fp32; the op structure autocast acts on)"""
+    B, _, H, W = x.shape
+    ph, pw = H // PATCH, W // PATCH
+    depth = cfg["depth"] if depth is None else depth
+    t = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=PATCH).flatten(2).transpose(1, 2)
+    t = torch.cat([p["cls_token"].expand(B, -1, -1), t], dim=1) + resize_pos_table(p["pos_embed"], ph, pw)
+    for i in range(depth):
+        t = vit_block_upstream_ops(p, f"blocks.{i}.", t, cfg["num_heads"])
+    t = F.layer_norm(t, (t.shape[-1],), p["norm.weight"], p["norm.bias"], 1e-6)[:, 1:]
+    return t.reshape(B, ph, pw, t.shape[-1]).permute(0, 3, 1, 2)
+
+
+def teacher_feature_map_autocast(p, x, cfg, depth=None):
+    """``DINOv2ViT.forward`` (models/backbones/dinov2.py:27-46) as the reference's DEFAULT trainer configuration runs it
+    (train.py:263 ``precision=16``): patch-embed conv on 16-bit operands with a 16-bit result, the fp32 position table added
+    in fp32 (type promotion), blocks as vit_block_autocast, final LayerNorm in fp32."""
+    B, _, H, W = x.shape
+    ph, pw = H // PATCH, W // PATCH
+    depth = cfg["depth"] if depth is None else depth
+    t = _r16(F.conv2d(_r16(x), _r16(p["patch_embed.proj.weight"]), _r16(p["patch_embed.proj.bias"]), stride=PATCH))
+    t = t.flatten(2).transpose(1, 2)
+    t = torch.cat([p["cls_token"].expand(B, -1, -1), t], dim=1) + resize_pos_table(p["pos_embed"], ph, pw)
+    for i in range(depth):
+        t = vit_block_autocast(p, f"blocks.{i}.", t, cfg["num_heads"])
+    t = F.layer_norm(t, (t.shape[-1],), p["norm.weight"], p["norm.bias"], 1e-6)[:, 1:]
+    return t.reshape(B, ph, pw, t.shape[-1]).permute(0, 3, 1, 2)

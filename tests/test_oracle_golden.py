@@ -364,3 +364,47 @@ def test_mit(golden_dir):
             n += 1
     assert n == len(p)
 
+
+
+def test_autocast_oracle_follows_torch_autocast_policy():
+    """the reference's default step is ``precision=16`` (train.py:263), i.e. torch autocast.  The explicit bf16
+    emulation the GPU teacher is checked against (oracle.vit_oracle.teacher_feature_map_autocast: which op rounds where) must
+    be the policy torch itself applies: run the op-by-op fp32 form of the published block under torch.autocast(cpu, bfloat16)
+    and compare.  (CPU autocast evaluates softmax in bf16 where CUDA autocast uses fp32 and casts its result for the next
+    matmul - the same single rounding of the probabilities.)"""
+    from oracle import vit_oracle as vo
+    cfg = vo.VIT_CONFIGS["dinov2_vits14"]
+    p = vo.init_vit_params(cfg, seed=0, depth=3)
+    gen = torch.Generator().manual_seed(11)
+    for k, v in p.items():  # non-trivial LayerScale / biases so that every rounding site carries signal
+        if k.endswith("gamma"):
+            v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+        elif k.endswith("bias"):
+            v.copy_(0.05 * torch.randn(v.shape, generator=gen))
+        elif v.dim() == 2:
+            v.mul_(3.0)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    emu = vo.teacher_feature_map_autocast(p, x, cfg, depth=3)
+    ref32 = vo.teacher_feature_map(p, x, cfg, depth=3)
+    up32 = vo.teacher_feature_map_upstream_ops(p, x, cfg, depth=3)
+    assert ((up32 - ref32).abs().max() / ref32.abs().max()).item() < 1e-5  # the op-by-op form IS the fp32 restatement
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        auto = vo.teacher_feature_map_upstream_ops(p, x, cfg, depth=3)
+    assert auto.dtype == torch.float32  # the final LayerNorm runs (and returns) fp32 under autocast
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    # one block, on what the block ADDS to the residual stream: the emulation is 4x closer to torch.autocast than torch.autocast
+    # is to fp32 (measured 1.2e-3 vs 4.8e-3).  What is left is bf16's rounding discontinuity: two bf16 implementations whose fp32
+    # accumulation orders differ (here mkldnn's bf16 GEMM vs an fp32 GEMM of the rounded operands) land on different sides of a
+    # rounding boundary in a few elements, and each flip is a 4e-3 step.
+    tok = torch.randn(2, 257, 384, generator=torch.Generator().manual_seed(6))
+    b32 = vo.vit_block_upstream_ops(p, "blocks.0.", tok, 6)
+    bemu = vo.vit_block_autocast(p, "blocks.0.", tok, 6)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        bauto = vo.vit_block_upstream_ops(p, "blocks.0.", tok, 6)
+    be, ba = rel(bemu - tok, bauto - tok), rel(bauto - tok, b32 - tok)
+    print(f"one block (added term): emulation vs torch.autocast {be:.2e}; torch.autocast vs fp32 {ba:.2e}")
+    assert ba > 2e-3 and be < 0.4 * ba
+    d_emu_auto, d_auto_32, d_emu_32 = rel(emu, auto), rel(auto, ref32), rel(emu, ref32)
+    print(f"3 blocks: emulation vs torch.autocast {d_emu_auto:.2e}; torch.autocast vs fp32 {d_auto_32:.2e}; emulation vs fp32 {d_emu_32:.2e}")
+    assert d_auto_32 > 1e-3 and d_emu_32 > 1e-3        # 16-bit rounding is really in play
+    assert d_emu_auto < 0.8 * min(d_auto_32, d_emu_32)  # and after three blocks of that amplification still the closer pair
