@@ -292,6 +292,24 @@ def main():
                 dta = t.item()
             alts[key] = {"gemm_precision": desc, "value": round(args.batch * world * args.steps / dta, 2), "unit": "images/s",
                          "ms_per_step": round(dta / args.steps * 1e3, 3)}
+    if not args.no_alt and ops.GEMM_PRECISION == ops.PREC_F32 and world == 1:
+        # the frozen teacher in the reference's DEFAULT precision policy (train.py:263 precision=16 == autocast; bf16 here) with
+        # bf16 activations in HBM; student, projectors, losses and optimiser exact fp32 as in `value`
+        st16 = DistillationStepper(device=f"cuda:{local}", teacher_precision="bf16_autocast")
+        for _ in range(3):
+            st16.step(batch)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            st16.step(batch)
+        sync()
+        dta = time.perf_counter() - t1
+        alts["alt_bf16_autocast_teacher"] = {
+            "gemm_precision": "teacher forward under the autocast op policy in bf16 (bf16 operands AND activations in HBM, fp32 "
+                              "accumulate / LayerNorm / softmax / residual stream; tests/test_autocast_gpu.py); everything "
+                              "trainable exact fp32", "value": round(args.batch * world * args.steps / dta, 2), "unit": "images/s",
+            "ms_per_step": round(dta / args.steps * 1e3, 3)}
+        del st16
     note(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank != 0:
         if world > 1:
