@@ -22,7 +22,7 @@ _SCALARS = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "int32_t": ctypes.c_int32,
     "int64_t": ctypes.c_int64, "void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "constfloat*": ctypes.c_void_p,
     "constvoid*": ctypes.c_void_p, "int*": ctypes.c_void_p, "constint*": ctypes.c_void_p,
-    "constint32_t*": ctypes.c_void_p, "int32_t*": ctypes.c_void_p,
+    "constint32_t*": ctypes.c_void_p, "int32_t*": ctypes.c_void_p, "constdouble*": ctypes.c_void_p, "double*": ctypes.c_void_p,
 }
 
 

@@ -1,0 +1,286 @@
+"""GPU input pipeline - same surface as /root/reference/datasets/augmentations.py ``DataAugmentationDINO`` (:23-78), batched.
+
+    aug = DataAugmentationDINOGpu(global_crops_scale=(0.08, 1.0), global_crops_size=224)
+    batch = aug(images, generator)      # images: list of uint8 [H, W, 3] tensors (decoded RGB, any sizes) -> float32 [B, 3, S, S] on the GPU
+
+The reference augments one PIL image at a time in DataLoader workers (datasets/CustomDataset.py:53-69, 8 workers per rank); at
+the step rates of this build one MI355X consumes ~1450 images/s, which that pipeline cannot deliver.  Here the host only
+DECODES (Pillow / any decoder) and DECIDES: it draws every random parameter in the order torchvision's transforms draw them
+(RandomResizedCrop.get_params, the flip coin, RandAugment's op / sign draws, RandomErasing.get_params) from an explicit
+``torch.Generator``, and tabulates Pillow's bicubic resize coefficients (double precision, libImaging/Resample.c's formulas).
+All pixel work runs in csrc/augment.hip, bit-exact with the Pillow calls torchvision's PIL branch makes (tests/test_augment_*).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)  # augmentations.py:12-13
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+OP_NAMES = ("Identity", "ShearX", "ShearY", "TranslateX", "TranslateY", "Rotate", "Brightness", "Color", "Contrast", "Sharpness",
+            "Posterize", "Solarize", "AutoContrast", "Equalize")  # torchvision RandAugment._augmentation_space order
+_SIGNED = frozenset(OP_NAMES[1:10])
+(AUG_IDENTITY, AUG_AFFINE, AUG_BRIGHTNESS, AUG_COLOR, AUG_CONTRAST, AUG_SHARPNESS, AUG_POSTERIZE, AUG_SOLARIZE, AUG_AUTOCONTRAST,
+ AUG_EQUALIZE) = range(10)
+_KERNEL_OP = {"Identity": AUG_IDENTITY, "ShearX": AUG_AFFINE, "ShearY": AUG_AFFINE, "TranslateX": AUG_AFFINE, "TranslateY": AUG_AFFINE,
+              "Rotate": AUG_AFFINE, "Brightness": AUG_BRIGHTNESS, "Color": AUG_COLOR, "Contrast": AUG_CONTRAST,
+              "Sharpness": AUG_SHARPNESS, "Posterize": AUG_POSTERIZE, "Solarize": AUG_SOLARIZE, "AutoContrast": AUG_AUTOCONTRAST,
+              "Equalize": AUG_EQUALIZE}
+_NEEDS_STATS = (AUG_CONTRAST, AUG_AUTOCONTRAST, AUG_EQUALIZE)
+PRECISION_BITS = 32 - 8 - 2  # libImaging/Resample.c
+
+
+# ---- random decisions (host; the draw order of torchvision's transforms) ---------------------------------------------------------
+def _uniform(gen, lo, hi):
+    return torch.empty(1).uniform_(lo, hi, generator=gen).item()
+
+
+def _randint(gen, n):
+    return int(torch.randint(n, (1,), generator=gen).item())
+
+
+def _crop_box(gen, height, width, scale, ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    area = height * width
+    log_ratio = torch.log(torch.tensor(ratio))
+    for _ in range(10):
+        target_area = area * _uniform(gen, scale[0], scale[1])
+        aspect = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1], generator=gen)).item()
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if 0 < w <= width and 0 < h <= height:
+            return _randint(gen, height - h + 1), _randint(gen, width - w + 1), h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+_MAG_CACHE = {}
+
+
+def _magnitude(op, bin_, bins, size):
+    key = (op, bin_, bins, size)
+    if key not in _MAG_CACHE:
+        lin = lambda a, b: float(torch.linspace(a, b, bins)[bin_].item())
+        if op in ("ShearX", "ShearY"):
+            v = lin(0.0, 0.3)
+        elif op in ("TranslateX", "TranslateY"):
+            v = lin(0.0, 150.0 / 331.0 * size)
+        elif op == "Rotate":
+            v = lin(0.0, 30.0)
+        elif op in ("Brightness", "Color", "Contrast", "Sharpness"):
+            v = lin(0.0, 0.9)
+        elif op == "Posterize":
+            v = float((8 - (torch.arange(bins) / ((bins - 1) / 4)).round().int())[bin_].item())
+        elif op == "Solarize":
+            v = lin(255.0, 0.0)
+        else:
+            v = 0.0
+        _MAG_CACHE[key] = v
+    return _MAG_CACHE[key]
+
+
+def _inverse_affine(center, angle, translate, scale, shear):
+    rot, sx, sy = math.radians(angle), math.radians(shear[0]), math.radians(shear[1])
+    cx, cy = center
+    tx, ty = translate
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    m = [x / scale for x in (d, -b, 0.0, -c, a, 0.0)]
+    m[2] += m[0] * (-cx - tx) + m[1] * (-cy - ty)
+    m[5] += m[3] * (-cx - tx) + m[4] * (-cy - ty)
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def _rotate_matrix(size, angle):
+    angle = angle % 360.0
+    c = size / 2.0
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    m[2] = m[0] * -c + m[1] * -c + m[2]
+    m[5] = m[3] * -c + m[4] * -c + m[5]
+    m[2] += c
+    m[5] += c
+    return m
+
+
+def _op_params(op, mag, size):
+    """-> (kernel op code, [8 doubles])"""
+    f = [0.0] * 8
+    if op == "ShearX":
+        f[:6] = _inverse_affine([0, 0], 0.0, [0, 0], 1.0, [math.degrees(math.atan(mag)), 0.0])
+    elif op == "ShearY":
+        f[:6] = _inverse_affine([0, 0], 0.0, [0, 0], 1.0, [0.0, math.degrees(math.atan(mag))])
+    elif op == "TranslateX":
+        f[:6] = _inverse_affine([size * 0.5, size * 0.5], 0.0, [int(mag), 0], 1.0, [0.0, 0.0])
+    elif op == "TranslateY":
+        f[:6] = _inverse_affine([size * 0.5, size * 0.5], 0.0, [0, int(mag)], 1.0, [0.0, 0.0])
+    elif op == "Rotate":
+        f[:6] = _rotate_matrix(size, mag)
+    elif op in ("Brightness", "Color", "Contrast", "Sharpness"):
+        f[0] = 1.0 + mag
+    elif op == "Posterize":
+        f[0] = float(int(mag))
+    elif op == "Solarize":
+        f[0] = mag
+    return _KERNEL_OP[op], f
+
+
+def make_plan(gen, height, width, size=224, scale=(0.08, 1.0), num_ops=9, magnitude=9, num_bins=31, erase_p=0.25):
+    """every random decision for ONE image, drawn in the order the reference's transforms draw them"""
+    crop = _crop_box(gen, height, width, scale)
+    flip = bool(torch.rand(1, generator=gen).item() < 0.5)
+    ra = []
+    for _ in range(num_ops):
+        op = OP_NAMES[_randint(gen, len(OP_NAMES))]
+        mag = _magnitude(op, magnitude, num_bins, size)
+        if op in _SIGNED and _randint(gen, 2):
+            mag *= -1.0
+        ra.append((op, mag))
+    erase = None
+    if torch.rand(1, generator=gen).item() < erase_p:
+        area = size * size
+        log_ratio = torch.log(torch.tensor((0.3, 3.3)))
+        for _ in range(10):
+            ea = area * _uniform(gen, 0.02, 1.0 / 3.0)
+            ar = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1], generator=gen)).item()
+            h, w = int(round(math.sqrt(ea * ar))), int(round(math.sqrt(ea / ar)))
+            if not (h < size and w < size):
+                continue
+            erase = (_randint(gen, size - h + 1), _randint(gen, size - w + 1), h, w)
+            break
+    return dict(crop=crop, flip=flip, ops=ra, erase=erase)
+
+
+# ---- Pillow's bicubic resample coefficients (libImaging/Resample.c: precompute_coeffs + normalize_coeffs_8bpc) -----------------
+def _bicubic(x):
+    a = -0.5
+    x = np.abs(x)
+    near = ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    far = (((x - 5) * x + 8) * x - 4) * a
+    return np.where(x < 1.0, near, np.where(x < 2.0, far, 0.0))
+
+
+def resample_coeffs(in_size, out_size):
+    """-> (int32 [out, ksize] coefficients, int32 [out, 2] {first tap, tap count}, ksize); double precision, Pillow's op order"""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xx = np.arange(out_size, dtype=np.float64)
+    center = 0.0 + (xx + 0.5) * scale
+    ss = 1.0 / filterscale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)      # (int) truncation of a value that is > -1 here
+    xmin = np.where(center - support + 0.5 < 0, 0, xmin)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    x = np.arange(ksize, dtype=np.float64)[None, :]
+    w = _bicubic((x + xmin[:, None] - center[:, None] + 0.5) * ss)
+    w = np.where(x < xmax[:, None], w, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for j in range(ksize):  # Pillow accumulates the normaliser tap by tap: keep the summation order
+        ww = ww + w[:, j]
+    k = np.where((ww != 0.0)[:, None], w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    ik = np.where(k < 0, np.trunc(-0.5 + k * (1 << PRECISION_BITS)), np.trunc(0.5 + k * (1 << PRECISION_BITS))).astype(np.int32)
+    return ik, np.stack([xmin, xmax], axis=1).astype(np.int32), ksize
+
+
+# ---- the batched pipeline --------------------------------------------------------------------------------------------------------
+class DataAugmentationDINOGpu:
+    """datasets/augmentations.py:23-78 for a whole batch on the GPU (see the module docstring)"""
+
+    def __init__(self, global_crops_scale=(0.08, 1.0), global_crops_size=224, device="cuda"):
+        self.scale = tuple(global_crops_scale)
+        self.size = int(global_crops_size[0] if isinstance(global_crops_size, (list, tuple)) else global_crops_size)
+        self.device = torch.device(device)
+        self.last_plans = None
+
+    def plan(self, shapes, generator):
+        return [make_plan(generator, h, w, self.size, self.scale) for h, w in shapes]
+
+    def __call__(self, images, generator=None, plans=None, return_stages=False):
+        """images: list of uint8 [H, W, 3] tensors / arrays (CPU).  plans: reuse decisions (tests); default: draw them."""
+        S, dev = self.size, self.device
+        if dev.type != "cuda":
+            raise _lib.DkdError("DataAugmentationDINOGpu needs an MI355X (the pixel pipeline has no CPU path)")
+        imgs = [torch.as_tensor(np.ascontiguousarray(im)) for im in images]
+        for im in imgs:
+            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+                raise _lib.DkdError(f"expected uint8 [H, W, 3] RGB images, got {im.dtype} {tuple(im.shape)}")
+        B = len(imgs)
+        if plans is None:
+            gen = generator if generator is not None else torch.default_generator
+            plans = self.plan([(im.shape[0], im.shape[1]) for im in imgs], gen)
+        self.last_plans = plans
+        # pack the images and the per-image parameter arrays (host), one H2D copy each
+        sizes = [im.numel() for im in imgs]
+        offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
+        packed = torch.empty(int(offs[-1]), dtype=torch.uint8, pin_memory=True)
+        for im, o, n in zip(imgs, offs[:-1], sizes):
+            packed[int(o):int(o) + n] = im.reshape(-1)
+        tabs_h = [resample_coeffs(p["crop"][3], S) for p in plans]
+        tabs_v = [resample_coeffs(p["crop"][2], S) for p in plans]
+        kh_n, kv_n = max(t[2] for t in tabs_h), max(t[2] for t in tabs_v)
+        kh, kv = np.zeros((B, S, kh_n), np.int32), np.zeros((B, S, kv_n), np.int32)
+        bh, bv = np.zeros((B, S, 2), np.int32), np.zeros((B, S, 2), np.int32)
+        meta = np.zeros((B, 10), np.int32)
+        for b, (im, p) in enumerate(zip(imgs, plans)):
+            kh[b, :, :tabs_h[b][2]], bh[b] = tabs_h[b][0], tabs_h[b][1]
+            kv[b, :, :tabs_v[b][2]], bv[b] = tabs_v[b][0], tabs_v[b][1]
+            i, j, h, w = p["crop"]
+            lo = int(offs[b]) & 0xFFFFFFFF
+            meta[b] = [lo - (1 << 32) if lo >= (1 << 31) else lo, int(offs[b]) >> 32, im.shape[0], im.shape[1], i, j, h, w,
+                       int(p["flip"]), 0]
+        max_h = max(p["crop"][2] for p in plans)
+        n_ops = len(plans[0]["ops"])
+        opc = np.zeros((n_ops, B), np.int32)
+        fpar = np.zeros((n_ops, B, 8), np.float64)
+        for b, p in enumerate(plans):
+            for r, (op, mag) in enumerate(p["ops"]):
+                opc[r, b], fpar[r, b] = _op_params(op, mag, S)
+        erase = np.array([p["erase"] if p["erase"] is not None else (0, 0, 0, 0) for p in plans], np.int32)
+        up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+        src = packed.to(dev, non_blocking=True)
+        meta_d, kh_d, bh_d, kv_d, bv_d, opc_d, fpar_d, erase_d = (up(a) for a in (meta, kh, bh, kv, bv, opc, fpar, erase))
+        lib = _lib.binding()
+        P, st = _lib.ptr, _lib.stream
+        u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
+        tmp, cur, nxt = u8(B, max_h, S, 4), u8(B, S, S, 4), u8(B, S, S, 4)
+        _lib.check(lib.dkd_aug_resize(P(src), P(meta_d), P(kh_d), P(bh_d), P(kv_d), P(bv_d), P(tmp), P(cur), B, S, kh_n, kv_n, max_h, st()),
+                   "dkd_aug_resize")
+        stages = [cur.clone()] if return_stages else None
+        hist = torch.empty((B, 768), dtype=torch.int32, device=dev)
+        lsum = torch.empty(B, dtype=torch.int64, device=dev)
+        lut = u8(B, 768)
+        mean_l = torch.empty(B, dtype=torch.int32, device=dev)
+        for r in range(n_ops):
+            if not (opc[r] != AUG_IDENTITY).any():
+                if return_stages:
+                    stages.append(cur.clone())
+                continue
+            need = int(np.isin(opc[r], _NEEDS_STATS).any())
+            _lib.check(lib.dkd_aug_round(P(cur), P(nxt), P(opc_d[r]), P(fpar_d[r]), P(hist), P(lsum), P(lut), P(mean_l), B, S, need, st()),
+                       "dkd_aug_round")
+            cur, nxt = nxt, cur
+            if return_stages:
+                stages.append(cur.clone())
+        out = torch.empty((B, 3, S, S), dtype=torch.float32, device=dev)
+        m, s = IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+        f32 = lambda v: float(np.float32(v))
+        _lib.check(lib.dkd_aug_finish(P(cur), P(erase_d), P(out), B, S, f32(m[0]), f32(m[1]), f32(m[2]), f32(s[0]), f32(s[1]), f32(s[2]), st()),
+                   "dkd_aug_finish")
+        src.record_stream(torch.cuda.current_stream())
+        return (out, stages) if return_stages else out

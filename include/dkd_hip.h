@@ -190,6 +190,37 @@ int dkd_cast_bf16(const float* in, void* out_bf16, long rows, int cols, int out_
 int dkd_swiglu_bf16(const void* x12_bf16, void* out_bf16, long rows, int hidden, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * GPU input pipeline: datasets/augmentations.py:23-78 ``DataAugmentationDINO`` on a batch of decoded uint8 RGB
+ * images - RandomResizedCrop(bicubic) + flip, RandAugment (9 ops), ToTensor + Normalize + RandomErasing - bit-exact with the
+ * Pillow calls torchvision's PIL branch makes.  All random decisions and the resize coefficient tables are made on the host
+ * (dinov2_distillation_amd/data/augment.py) and arrive as small parameter arrays; images are RGBX (4 bytes per pixel).
+ *   dkd_aug_resize: src = packed RGB images; meta int32 [B,10] = {src byte offset lo, hi, H, W, crop top, left, h, w, flip, 0};
+ *     kh / kv int32 [B,S,ksize] = Pillow's 22-bit coefficients of the horizontal / vertical pass, bh / bv int32 [B,S,2] =
+ *     {first tap, tap count}; tmp RGBX [B,max_h,S]; img RGBX [B,S,S].
+ *   dkd_aug_round: one RandAugment op per image: ops int32 [B] (DKD_AUG_*), fparams double [B,8] (affine: the six inverse-map
+ *     coefficients; enhancers: the blend factor; posterize: bits; solarize: threshold); hist int32 [B,768], lsum uint64 [B],
+ *     lut uint8 [B,768], meanL int32 [B] are scratch; need_stats != 0 when any op of the round is contrast / autocontrast /
+ *     equalize.
+ *   dkd_aug_finish: RGBX [B,S,S] -> float32 NCHW [B,3,S,S], (v / 255 - mean) / std, erase int32 [B,4] = {top, left, h, w}
+ *     zeroed (h == 0: none). */
+#define DKD_AUG_IDENTITY 0
+#define DKD_AUG_AFFINE 1
+#define DKD_AUG_BRIGHTNESS 2
+#define DKD_AUG_COLOR 3
+#define DKD_AUG_CONTRAST 4
+#define DKD_AUG_SHARPNESS 5
+#define DKD_AUG_POSTERIZE 6
+#define DKD_AUG_SOLARIZE 7
+#define DKD_AUG_AUTOCONTRAST 8
+#define DKD_AUG_EQUALIZE 9
+int dkd_aug_resize(const void* src, const int* meta, const int* kh, const int* bh, const int* kv, const int* bv, void* tmp, void* img,
+                   int B, int S, int ksize_h, int ksize_v, int max_h, void* stream);
+int dkd_aug_round(const void* in, void* out, const int* ops, const double* fparams, int* hist, void* lsum, void* lut, int* meanL, int B,
+                  int S, int need_stats, void* stream);
+int dkd_aug_finish(const void* img, const int* erase, float* out, int B, int S, float mean0, float mean1, float mean2, float std0,
+                   float std1, float std2, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * ScaleKD loss tail (losses/scalekd.py:67-92 get_spat_loss, :95-127 get_freq_loss).  S, T: token-major [rows, D].
  * out2[0] = alpha/B * sum |s^ - t^|^2, out2[1] = mean cosine.  mean_s/mean_t: NULL (spatial) or [B, D] spatial
  * means (frequency variant == DCT / zero DC / IDCT).  bwd writes d loss / d (centred) S scaled by *grad_out

@@ -1,0 +1,68 @@
+"""GPU input pipeline (csrc/augment.hip) against the Pillow-backed oracle: BIT equality of every intermediate uint8
+image (resized crop + flip, then each of the nine RandAugment ops) and of the final float32 batch, on images of different sizes
+and content, with the reference's random plans and with plans that force every op of the RandAugment space in both signs."""
+import numpy as np
+import pytest
+import torch
+
+from test_augment_cpu import _images
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(images, plans, aug):
+    from oracle import augment_oracle as O
+    out, stages = aug(images, plans=plans, return_stages=True)
+    assert out.shape == (len(images), 3, 224, 224) and out.dtype == torch.float32
+    for b, (img, plan) in enumerate(zip(images, plans)):
+        ref, ref_stages = O.run_plan(img, plan, return_stages=True)
+        assert len(ref_stages) == len(stages)
+        for r, (a, e) in enumerate(zip(stages, ref_stages)):
+            got = a[b, :, :, :3].cpu().numpy()
+            if not np.array_equal(got, e):
+                what = "resize + flip" if r == 0 else f"op {r}: {plan['ops'][r - 1]}"
+                n = int((got != e).sum())
+                raise AssertionError(f"image {b} ({img.shape}), stage {what}: {n} bytes differ, max |diff| "
+                                     f"{int(np.abs(got.astype(int) - e.astype(int)).max())}")
+        assert torch.equal(out[b].cpu(), ref), f"image {b}: float32 result differs ({(out[b].cpu() != ref).sum()} elements)"
+
+
+def test_pipeline_matches_pillow_bit_for_bit_on_random_plans():
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu
+    from oracle import augment_oracle as O
+    aug = DataAugmentationDINOGpu((0.08, 1.0), 224)
+    for seed in range(6):
+        images = _images(seed)
+        gen = torch.Generator().manual_seed(100 + seed)
+        plans = [O.sample_plan(gen, im.shape[0], im.shape[1]) for im in images]
+        _check(images, plans, aug)
+    # drawing inside the product: the same generator state gives the same plans (and the same pixels)
+    g1, g2 = torch.Generator().manual_seed(7), torch.Generator().manual_seed(7)
+    images = _images(9)
+    out = aug(images, generator=g1)
+    plans = [O.sample_plan(g2, im.shape[0], im.shape[1]) for im in images]
+    assert aug.last_plans == plans
+    assert torch.equal(out.cpu(), torch.stack([O.run_plan(im, p) for im, p in zip(images, plans)]))
+
+
+def test_every_randaugment_op_in_both_signs():
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu
+    from dinov2_distillation_amd.data.augment import _magnitude
+    from oracle import augment_oracle as O
+    aug = DataAugmentationDINOGpu((0.08, 1.0), 224)
+    images = _images(21)
+    for op in O.OPS:
+        for sign in ((1.0, -1.0) if op in O.SIGNED else (1.0,)):
+            mag = sign * _magnitude(op, 9, 31, 224)
+            plans = [dict(crop=(3, 5, im.shape[0] - 10, im.shape[1] - 9), flip=bool(k % 2), ops=[(op, mag), ("Identity", 0.0), (op, mag)],
+                          erase=(10, 20, 30, 40) if k == 0 else None) for k, im in enumerate(images)]
+            _check(images, plans, aug)
+
+
+def test_refuses_cpu_and_wrong_layouts():
+    from dinov2_distillation_amd._lib import DkdError
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu
+    with pytest.raises(DkdError):
+        DataAugmentationDINOGpu(device="cpu")([np.zeros((8, 8, 3), np.uint8)])
+    with pytest.raises(DkdError):
+        DataAugmentationDINOGpu()([np.zeros((8, 8), np.uint8)])

