@@ -25,7 +25,9 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INC, "-I" + CSRC, "-Wall", "-Wno-unused-function",
          "-fno-slp-vectorize"]
 # per-file code generation switches (measured)
-FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# augment.hip reproduces Pillow's float / double arithmetic operation by operation: no fused multiply-add contraction there
+# (HIP's __fmul_rn / __dadd_rn are plain operators to the compiler, so a * b + c would still become one fma)
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "augment.hip": ["-ffp-contract=off"]}
 if os.environ.get("DKD_TUNING") == "1":  # also instantiate the timing-only knock-out kernels (scripts/knockout_*.py)
     FLAGS.append("-DDKD_TUNING")
 

@@ -34,6 +34,48 @@ __device__ __forceinline__ ImgMeta load_meta(const int* __restrict__ meta, int b
     return r;
 }
 
+// Pillow's coefficient tables on the device: libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bicubic
+// filter, one thread per (table, output position), the same double-precision operations in the same order (this file is
+// compiled with -ffp-contract=off; IEEE add / mul / div are correctly rounded on both sides, so the integers are identical -
+// tests/test_augment_gpu.py checks them against the host tables).  sizes[t] = input extent of table t (crop width / height).
+__device__ __forceinline__ double bicubic_w(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+__global__ void resample_coeffs_kernel(const int* __restrict__ sizes, int* __restrict__ kk, int* __restrict__ bounds, int T, int S, int ksize) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * S) return;
+    const int t = i / S, xx = i % S;
+    const int in_size = sizes[t];
+    const double scale = (double)in_size / (double)S;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const double center = 0.0 + ((double)xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    int* k = kk + (long)i * ksize;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += bicubic_w(((double)(x + xmin) - center + 0.5) * ss);
+    for (int x = 0; x < ksize; ++x) {
+        int v = 0;
+        if (x < xmax) {
+            double w = bicubic_w(((double)(x + xmin) - center + 0.5) * ss);
+            if (ww != 0.0) w /= ww;
+            v = w < 0 ? (int)(-0.5 + w * (double)(1 << PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << PRECISION_BITS));
+        }
+        k[x] = v;
+    }
+    bounds[2 * i] = xmin;
+    bounds[2 * i + 1] = xmax;
+}
+
 // horizontal pass: tmp[b][y][xx] (y = crop row) = clip8((2^21 + sum_x src[y][xmin + x] * k[xx][x]) >> 22) per channel
 __global__ void resample_h_kernel(const unsigned char* __restrict__ src, const int* __restrict__ meta, const int* __restrict__ kk,
                                   const int* __restrict__ bounds, uchar4* __restrict__ tmp, int B, int S, int ksize, int max_h) {
@@ -293,6 +335,13 @@ extern "C" int dkd_aug_resize(const void* src, const int* meta, const int* kh, c
     DKD_LAUNCH_CHECK();
     hipLaunchKernelGGL(resample_v_kernel, dim3(grid_1d((long)B * S * S)), dim3(256), 0, st, (const uchar4*)tmp, meta, kv, bv, (uchar4*)img, B,
                        S, ksize_v, max_h);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_aug_coeffs(const int* sizes, int* kk, int* bounds, int T, int S, int ksize, void* stream) {
+    if (!sizes || !kk || !bounds || T <= 0 || S <= 0 || ksize <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(resample_coeffs_kernel, dim3((T * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, sizes, kk, bounds, T, S, ksize);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -198,6 +198,31 @@ def resample_coeffs(in_size, out_size):
     return ik, np.stack([xmin, xmax], axis=1).astype(np.int32), ksize
 
 
+def resample_coeffs_batch(in_sizes, out_size):
+    """resample_coeffs for many input extents at once: int32 [n, out, K] (K = the widest kernel), int32 [n, out, 2], K.
+    Element for element the same double-precision operations as the scalar version (tests/test_augment_cpu.py)."""
+    n = np.asarray(in_sizes, dtype=np.float64)[:, None]
+    scale = n / out_size
+    filterscale = np.maximum(scale, 1.0)
+    support = 2.0 * filterscale
+    K = int((np.ceil(support).astype(np.int64) * 2 + 1).max())
+    xx = np.arange(out_size, dtype=np.float64)[None, :]
+    center = 0.0 + (xx + 0.5) * scale
+    ss = 1.0 / filterscale
+    lo = center - support + 0.5
+    xmin = np.where(lo < 0, 0, lo.astype(np.int64))
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), n.astype(np.int64)) - xmin
+    x = np.arange(K, dtype=np.float64)[None, None, :]
+    w = _bicubic((x + xmin[..., None] - center[..., None] + 0.5) * ss[..., None])
+    w = np.where(x < xmax[..., None], w, 0.0)
+    ww = np.zeros(w.shape[:2], dtype=np.float64)
+    for j in range(K):
+        ww = ww + w[..., j]
+    k = np.where((ww != 0.0)[..., None], w / np.where(ww == 0.0, 1.0, ww)[..., None], w)
+    ik = np.where(k < 0, np.trunc(-0.5 + k * (1 << PRECISION_BITS)), np.trunc(0.5 + k * (1 << PRECISION_BITS))).astype(np.int32)
+    return ik, np.stack([xmin, xmax], axis=-1).astype(np.int32), K
+
+
 # ---- the batched pipeline --------------------------------------------------------------------------------------------------------
 class DataAugmentationDINOGpu:
     """datasets/augmentations.py:23-78 for a whole batch on the GPU (see the module docstring)"""
@@ -207,6 +232,7 @@ class DataAugmentationDINOGpu:
         self.size = int(global_crops_size[0] if isinstance(global_crops_size, (list, tuple)) else global_crops_size)
         self.device = torch.device(device)
         self.last_plans = None
+        self._pinned = None  # grow-only pinned staging buffer for the packed batch (a pinned allocation per call costs milliseconds)
 
     def plan(self, shapes, generator):
         return [make_plan(generator, h, w, self.size, self.scale) for h, w in shapes]
@@ -228,18 +254,18 @@ class DataAugmentationDINOGpu:
         # pack the images and the per-image parameter arrays (host), one H2D copy each
         sizes = [im.numel() for im in imgs]
         offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
-        packed = torch.empty(int(offs[-1]), dtype=torch.uint8, pin_memory=True)
+        if self._pinned is None or self._pinned.numel() < int(offs[-1]):
+            self._pinned = torch.empty(int(offs[-1]) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+        packed = self._pinned[:int(offs[-1])]
         for im, o, n in zip(imgs, offs[:-1], sizes):
             packed[int(o):int(o) + n] = im.reshape(-1)
-        tabs_h = [resample_coeffs(p["crop"][3], S) for p in plans]
-        tabs_v = [resample_coeffs(p["crop"][2], S) for p in plans]
-        kh_n, kv_n = max(t[2] for t in tabs_h), max(t[2] for t in tabs_v)
-        kh, kv = np.zeros((B, S, kh_n), np.int32), np.zeros((B, S, kv_n), np.int32)
-        bh, bv = np.zeros((B, S, 2), np.int32), np.zeros((B, S, 2), np.int32)
+        # Pillow's coefficient tables: tabulated on the device (dkd_aug_coeffs, the same double-precision operations as
+        # resample_coeffs below; the host version costs ~25 ms per batch of 64 in numpy and is kept as the test's reference)
+        crop_w, crop_h = [p["crop"][3] for p in plans], [p["crop"][2] for p in plans]
+        ksz = lambda v: int(math.ceil(2.0 * max(1.0, max(v) / S))) * 2 + 1
+        kh_n, kv_n = ksz(crop_w), ksz(crop_h)
         meta = np.zeros((B, 10), np.int32)
         for b, (im, p) in enumerate(zip(imgs, plans)):
-            kh[b, :, :tabs_h[b][2]], bh[b] = tabs_h[b][0], tabs_h[b][1]
-            kv[b, :, :tabs_v[b][2]], bv[b] = tabs_v[b][0], tabs_v[b][1]
             i, j, h, w = p["crop"]
             lo = int(offs[b]) & 0xFFFFFFFF
             meta[b] = [lo - (1 << 32) if lo >= (1 << 31) else lo, int(offs[b]) >> 32, im.shape[0], im.shape[1], i, j, h, w,
@@ -254,10 +280,16 @@ class DataAugmentationDINOGpu:
         erase = np.array([p["erase"] if p["erase"] is not None else (0, 0, 0, 0) for p in plans], np.int32)
         up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
         src = packed.to(dev, non_blocking=True)
-        meta_d, kh_d, bh_d, kv_d, bv_d, opc_d, fpar_d, erase_d = (up(a) for a in (meta, kh, bh, kv, bv, opc, fpar, erase))
+        meta_d, opc_d, fpar_d, erase_d, sizes_d = (up(a) for a in (meta, opc, fpar, erase, np.array(crop_w + crop_h, np.int32)))
         lib = _lib.binding()
         P, st = _lib.ptr, _lib.stream
         u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        kh_d, bh_d, kv_d, bv_d = i32(B, S, kh_n), i32(B, S, 2), i32(B, S, kv_n), i32(B, S, 2)
+        _lib.check(lib.dkd_aug_coeffs(P(sizes_d[:B]), P(kh_d), P(bh_d), B, S, kh_n, st()), "dkd_aug_coeffs")
+        _lib.check(lib.dkd_aug_coeffs(P(sizes_d[B:]), P(kv_d), P(bv_d), B, S, kv_n, st()), "dkd_aug_coeffs")
+        if return_stages:
+            self._tables = (kh_d, bh_d, kv_d, bv_d)
         tmp, cur, nxt = u8(B, max_h, S, 4), u8(B, S, S, 4), u8(B, S, S, 4)
         _lib.check(lib.dkd_aug_resize(P(src), P(meta_d), P(kh_d), P(bh_d), P(kv_d), P(bv_d), P(tmp), P(cur), B, S, kh_n, kv_n, max_h, st()),
                    "dkd_aug_resize")
@@ -277,6 +309,7 @@ class DataAugmentationDINOGpu:
             cur, nxt = nxt, cur
             if return_stages:
                 stages.append(cur.clone())
+                self._debug = dict(hist=hist.clone(), lut=lut.clone(), mean_l=mean_l.clone(), lsum=lsum.clone())
         out = torch.empty((B, 3, S, S), dtype=torch.float32, device=dev)
         m, s = IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
         f32 = lambda v: float(np.float32(v))

@@ -213,6 +213,10 @@ int dkd_swiglu_bf16(const void* x12_bf16, void* out_bf16, long rows, int hidden,
 #define DKD_AUG_SOLARIZE 7
 #define DKD_AUG_AUTOCONTRAST 8
 #define DKD_AUG_EQUALIZE 9
+/* Pillow's bicubic coefficient tables (libImaging/Resample.c) for T input extents sizes[t] -> S outputs, computed on the device
+ * in double precision, operation for operation as Pillow does: kk int32 [T,S,ksize], bounds int32 [T,S,2];
+ * ksize >= 2 * ceil(2 * max(1, max(sizes) / S)) + 1. */
+int dkd_aug_coeffs(const int* sizes, int* kk, int* bounds, int T, int S, int ksize, void* stream);
 int dkd_aug_resize(const void* src, const int* meta, const int* kh, const int* bh, const int* kv, const int* bv, void* tmp, void* img,
                    int B, int S, int ksize_h, int ksize_v, int max_h, void* stream);
 int dkd_aug_round(const void* in, void* out, const int* ops, const double* fparams, int* hist, void* lsum, void* lut, int* meanL, int B,

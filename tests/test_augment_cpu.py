@@ -54,6 +54,15 @@ def test_resize_coefficient_tables_reproduce_pillow_bit_for_bit():
         assert np.array_equal(out, np.asarray(Image.fromarray(img).resize((S, S), Image.BICUBIC))), (H, W, S)
 
 
+def test_batched_coefficient_tables_equal_the_scalar_ones():
+    from dinov2_distillation_amd.data.augment import resample_coeffs, resample_coeffs_batch
+    sizes = [400, 131, 1000, 224, 37, 500, 97, 3]
+    kb, bb, K = resample_coeffs_batch(sizes, 224)
+    for i, n in enumerate(sizes):
+        k, b, ks = resample_coeffs(n, 224)
+        assert ks <= K and np.array_equal(kb[i, :, :ks], k) and np.array_equal(bb[i], b) and not kb[i, :, ks:].any()
+
+
 def test_oracle_pipeline_runs_every_stage():
     from oracle import augment_oracle as O
     gen = torch.Generator().manual_seed(5)

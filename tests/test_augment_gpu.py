@@ -45,6 +45,24 @@ def test_pipeline_matches_pillow_bit_for_bit_on_random_plans():
     assert torch.equal(out.cpu(), torch.stack([O.run_plan(im, p) for im, p in zip(images, plans)]))
 
 
+def test_device_coefficient_tables_equal_the_host_tables():
+    """dkd_aug_coeffs computes Pillow's tables on the GPU in fp64: every integer must equal the host restatement (which
+    tests/test_augment_cpu.py ties to Pillow's own output)"""
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu
+    from dinov2_distillation_amd.data.augment import resample_coeffs
+    rng = np.random.default_rng(5)
+    sizes = [(37, 41), (224, 224), (900, 1300), (225, 223), (640, 480), (97, 131)]
+    images = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    plans = [dict(crop=(0, 0, h, w), flip=False, ops=[("Identity", 0.0)], erase=None) for h, w in sizes]
+    aug = DataAugmentationDINOGpu()
+    aug(images, plans=plans, return_stages=True)
+    kh, bh, kv, bv = (t.cpu().numpy() for t in aug._tables)
+    for b, (h, w) in enumerate(sizes):
+        for tab, bnd, n in ((kh, bh, w), (kv, bv, h)):
+            k, bd, ks = resample_coeffs(n, 224)
+            assert np.array_equal(tab[b, :, :ks], k) and not tab[b, :, ks:].any() and np.array_equal(bnd[b], bd), (b, n)
+
+
 def test_every_randaugment_op_in_both_signs():
     from dinov2_distillation_amd.data import DataAugmentationDINOGpu
     from dinov2_distillation_amd.data.augment import _magnitude
