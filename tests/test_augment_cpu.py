@@ -28,7 +28,7 @@ def test_planner_draws_what_the_oracle_draws():
                 seen.add(op)
                 code, f = A._op_params(op, mag, 224)
                 if code == A.AUG_AFFINE:
-                    assert f[:6] == O.affine_matrix_of(op, mag, 224, 224)
+                    assert list(f[:6]) == O.affine_matrix_of(op, mag, 224, 224)
     assert seen == set(O.OPS)  # every op of the RandAugment space was drawn at least once
     assert A.OP_NAMES == O.OPS and abs(A._magnitude("ShearX", 9, 31, 224) - 0.09) < 1e-6 and A._magnitude("Posterize", 9, 31, 224) == 7.0
 
