@@ -21,6 +21,10 @@ CONFIGS = {
     "mobilenet_v2": dict(teacher="dinov2_vits14", student="mobilenet_v2", crop=224, batch=64, heads=(16, 24)),
     "darknet_m": dict(teacher="dinov2_vits14", student="darknet_m", crop=224, batch=64, heads=(16, 24)),
     "mit_b2": dict(teacher="dinov2_vits14", student="mit_b2", crop=224, batch=64, heads=(16, 24)),
+    "2a": dict(teacher="dinov2_vits14", student="convnext_tiny", crop=224, batch=64, heads=(16, 24), teacher_precision="bf16_autocast"),
+    "3a": dict(teacher="dinov2_vitb14", student="resnet_50", crop=224, batch=128, heads=(16, 24), teacher_precision="bf16_autocast"),
+    "4a": dict(teacher="dinov2_vitl14", student="swin_tiny", crop=518, batch=16, heads=(16, 32), teacher_precision="bf16_autocast"),
+    "5a": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24), teacher_precision="bf16_autocast"),
     "5f32": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24)),
 }
 

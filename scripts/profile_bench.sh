@@ -4,7 +4,7 @@
 #   2. --kernel-trace --stats with DKD_ASYNC_WGRAD=0 (one stream: un-stretched per-kernel durations)
 #   3. --pmc FETCH_SIZE and 4. --pmc WRITE_SIZE (separate passes, counters only)
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
