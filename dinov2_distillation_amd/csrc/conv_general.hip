@@ -86,11 +86,12 @@ __global__ void im2col_nchw_kernel(const float* __restrict__ img, float* __restr
 
 // depthwise 3x3, dilation d, pad d, stride s, tap-major weights [9][C] (nullptr => all taps 1/9 == AvgPool2d(3, s, 1),
 // count_include_pad).  Output extent (H - 1) / s + 1 for every dilation.
-__global__ void dwconv3_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ wt, float4* __restrict__ out,
+template <int K>
+__global__ void dwconv_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ wt, float4* __restrict__ out,
                                    int B, int H, int W, int C, int s, int Ho, int Wo, int d) {
     const int cq = C >> 2;
     const long total = (long)B * Ho * Wo * cq;
-    const float ninth = 1.f / 9.f;
+    const float ninth = 1.f / (float)(K * K);
     GRID_STRIDE(i, total) {
         long r = i;
         const int c4 = (int)(r % cq); r /= cq;
@@ -99,15 +100,15 @@ __global__ void dwconv3_fwd_kernel(const float4* __restrict__ x, const float4* _
         const int b = (int)(r / Ho);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int y = oy * s + (ky - 1) * d;
+        for (int ky = 0; ky < K; ++ky) {
+            const int y = oy * s + (ky - K / 2) * d;
             if (y < 0 || y >= H) continue;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = ox * s + (kx - 1) * d;
+            for (int kx = 0; kx < K; ++kx) {
+                const int xx = ox * s + (kx - K / 2) * d;
                 if (xx < 0 || xx >= W) continue;
                 const float4 v = x[(((long)b * H + y) * W + xx) * cq + c4];
-                const float4 w = wt ? wt[(ky * 3 + kx) * cq + c4] : make_float4(ninth, ninth, ninth, ninth);
+                const float4 w = wt ? wt[(ky * K + kx) * cq + c4] : make_float4(ninth, ninth, ninth, ninth);
                 acc.x = fmaf(w.x, v.x, acc.x); acc.y = fmaf(w.y, v.y, acc.y); acc.z = fmaf(w.z, v.z, acc.z); acc.w = fmaf(w.w, v.w, acc.w);
             }
         }
@@ -115,11 +116,12 @@ __global__ void dwconv3_fwd_kernel(const float4* __restrict__ x, const float4* _
     }
 }
 
-__global__ void dwconv3_dgrad_kernel(const float4* __restrict__ dout, const float4* __restrict__ wt, float4* __restrict__ dx,
+template <int K>
+__global__ void dwconv_dgrad_kernel(const float4* __restrict__ dout, const float4* __restrict__ wt, float4* __restrict__ dx,
                                      int B, int H, int W, int C, int s, int Ho, int Wo, int d) {
     const int cq = C >> 2;
     const long total = (long)B * H * W * cq;
-    const float ninth = 1.f / 9.f;
+    const float ninth = 1.f / (float)(K * K);
     GRID_STRIDE(i, total) {
         long r = i;
         const int c4 = (int)(r % cq); r /= cq;
@@ -128,19 +130,19 @@ __global__ void dwconv3_dgrad_kernel(const float4* __restrict__ dout, const floa
         const int b = (int)(r / H);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int ty = y + (1 - ky) * d;
+        for (int ky = 0; ky < K; ++ky) {
+            const int ty = y + (K / 2 - ky) * d;
             if (ty < 0 || ty % s) continue;
             const int oy = ty / s;
             if (oy >= Ho) continue;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tx = xx + (1 - kx) * d;
+            for (int kx = 0; kx < K; ++kx) {
+                const int tx = xx + (K / 2 - kx) * d;
                 if (tx < 0 || tx % s) continue;
                 const int ox = tx / s;
                 if (ox >= Wo) continue;
                 const float4 g = dout[(((long)b * Ho + oy) * Wo + ox) * cq + c4];
-                const float4 w = wt ? wt[(ky * 3 + kx) * cq + c4] : make_float4(ninth, ninth, ninth, ninth);
+                const float4 w = wt ? wt[(ky * K + kx) * cq + c4] : make_float4(ninth, ninth, ninth, ninth);
                 acc.x = fmaf(w.x, g.x, acc.x); acc.y = fmaf(w.y, g.y, acc.y); acc.z = fmaf(w.z, g.z, acc.z); acc.w = fmaf(w.w, g.w, acc.w);
             }
         }
@@ -149,7 +151,8 @@ __global__ void dwconv3_dgrad_kernel(const float4* __restrict__ dout, const floa
 }
 
 // partial weight gradients: thread = (channel quad, image, output row); part[(b*Ho + oy)][tap][c]
-__global__ void dwconv3_wgrad_kernel(const float4* __restrict__ x, const float4* __restrict__ dout, float4* __restrict__ part,
+template <int K>
+__global__ void dwconv_wgrad_kernel(const float4* __restrict__ x, const float4* __restrict__ dout, float4* __restrict__ part,
                                      int B, int H, int W, int C, int s, int Ho, int Wo, int d) {
     const int cq = C >> 2;
     const long total = (long)B * Ho * cq;
@@ -157,27 +160,27 @@ __global__ void dwconv3_wgrad_kernel(const float4* __restrict__ x, const float4*
         const int c4 = (int)(i % cq);
         const long r = i / cq;
         const int oy = (int)(r % Ho), b = (int)(r / Ho);
-        float4 acc[9];
+        float4 acc[K * K];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ox = 0; ox < Wo; ++ox) {
             const float4 g = dout[(((long)b * Ho + oy) * Wo + ox) * cq + c4];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int y = oy * s + (ky - 1) * d;
+            for (int ky = 0; ky < K; ++ky) {
+                const int y = oy * s + (ky - K / 2) * d;
                 if (y < 0 || y >= H) continue;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = ox * s + (kx - 1) * d;
+                for (int kx = 0; kx < K; ++kx) {
+                    const int xx = ox * s + (kx - K / 2) * d;
                     if (xx < 0 || xx >= W) continue;
                     const float4 v = x[(((long)b * H + y) * W + xx) * cq + c4];
-                    float4& a = acc[ky * 3 + kx];
+                    float4& a = acc[ky * K + kx];
                     a.x = fmaf(g.x, v.x, a.x); a.y = fmaf(g.y, v.y, a.y); a.z = fmaf(g.z, v.z, a.z); a.w = fmaf(g.w, v.w, a.w);
                 }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) part[(r * 9 + t) * cq + c4] = acc[t];
+        for (int t = 0; t < K * K; ++t) part[(r * K * K + t) * cq + c4] = acc[t];
     }
 }
 
@@ -327,36 +330,54 @@ extern "C" int dkd_im2col_nchw_f32(const float* img, float* rows, int B, int Cin
     return DKD_OK;
 }
 
-extern "C" int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int stride,
+extern "C" int dkd_dwconvk_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int k, int stride,
                                int dilation, int mode, void* stream) {
-    // mode 0: forward (in = x [B,H,W,C], out = y [B,Ho,Wo,C]); mode 1: dgrad (in = dy [B,Ho,Wo,C], out = dx [B,H,W,C])
+    // depthwise k x k (k = 3 or 5), padding (k / 2) * dilation.  mode 0: forward (in = x [B,H,W,C], out = y [B,Ho,Wo,C]);
+    // mode 1: dgrad (in = dy [B,Ho,Wo,C], out = dx [B,H,W,C]).  w_tap_major [k*k, C] (NULL with k = 3: the 1/9 average pool)
     if (!in || !out || B <= 0 || stride <= 0 || dilation <= 0) return DKD_ERR_BAD_ARG;
+    if (k != 3 && k != 5) return DKD_ERR_UNSUPPORTED;
     if (C & 3) return DKD_ERR_ALIGN;
-    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;  // (H + 2p - d(k-1) - 1) / s + 1 with p = (k/2) d
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) {
-        const long total = (long)B * Ho * Wo * (C / 4);
-        hipLaunchKernelGGL(dwconv3_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, st, F4(in), F4(w_tap_major), F4W(out), B,
-                           H, W, C, stride, Ho, Wo, dilation);
-    } else {
-        const long total = (long)B * H * W * (C / 4);
-        hipLaunchKernelGGL(dwconv3_dgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, st, F4(in), F4(w_tap_major), F4W(out),
-                           B, H, W, C, stride, Ho, Wo, dilation);
-    }
+    const long total = mode == 0 ? (long)B * Ho * Wo * (C / 4) : (long)B * H * W * (C / 4);
+#define DKD_DW(KK)                                                                                                             \
+    if (mode == 0)                                                                                                             \
+        hipLaunchKernelGGL(dwconv_fwd_kernel<KK>, dim3(blocks_for(total)), dim3(256), 0, st, F4(in), F4(w_tap_major), F4W(out), \
+                           B, H, W, C, stride, Ho, Wo, dilation);                                                              \
+    else                                                                                                                       \
+        hipLaunchKernelGGL(dwconv_dgrad_kernel<KK>, dim3(blocks_for(total)), dim3(256), 0, st, F4(in), F4(w_tap_major),        \
+                           F4W(out), B, H, W, C, stride, Ho, Wo, dilation)
+    if (k == 3) { DKD_DW(3); } else { DKD_DW(5); }
+#undef DKD_DW
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 
-extern "C" int dkd_dwconv3_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C,
+extern "C" int dkd_dwconvk_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C, int k,
                                      int stride, int dilation, void* stream) {
     if (!x || !dout || !partials || B <= 0 || stride <= 0 || dilation <= 0) return DKD_ERR_BAD_ARG;
+    if (k != 3 && k != 5) return DKD_ERR_UNSUPPORTED;
     if (C & 3) return DKD_ERR_ALIGN;
-    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long total = (long)B * Ho * (C / 4);
-    hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, F4(x), F4(dout),
-                       F4W(partials), B, H, W, C, stride, Ho, Wo, dilation);
+    if (k == 3)
+        hipLaunchKernelGGL(dwconv_wgrad_kernel<3>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, F4(x), F4(dout),
+                           F4W(partials), B, H, W, C, stride, Ho, Wo, dilation);
+    else
+        hipLaunchKernelGGL(dwconv_wgrad_kernel<5>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, F4(x), F4(dout),
+                           F4W(partials), B, H, W, C, stride, Ho, Wo, dilation);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
+}
+
+extern "C" int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int stride,
+                               int dilation, int mode, void* stream) {
+    return dkd_dwconvk_f32(in, w_tap_major, out, B, H, W, C, 3, stride, dilation, mode, stream);
+}
+
+extern "C" int dkd_dwconv3_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C,
+                                     int stride, int dilation, void* stream) {
+    return dkd_dwconvk_wgrad_f32(x, dout, partials, B, H, W, C, 3, stride, dilation, stream);
 }
 
 extern "C" int dkd_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate,

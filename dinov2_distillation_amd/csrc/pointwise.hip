@@ -51,6 +51,29 @@ __global__ void sub_group_vec_kernel(const float4* __restrict__ x, const float4*
     }
 }
 
+// out[r][c] = x[r][c] * mul[g][c] + add[g][c], g = r / rows_per_group (mul / add nullable): squeeze-excitation's channel
+// re-scaling per image and its adjoint (MobileNetV3 SElayer: scale * input; dx = dy * scale + d(pool) / HW)
+__global__ void group_affine_kernel(const float4* __restrict__ x, const float4* __restrict__ mul, const float4* __restrict__ add,
+                                    float4* __restrict__ out, long rows_per_group, int nv, float add_scale, long nvec) {
+    EW_LOOP(i, nvec) {
+        const long r = i / nv;
+        const int c = (int)(i % nv);
+        const long gi = (r / rows_per_group) * nv + c;
+        float4 v = x[i];
+        if (mul) { const float4 m = mul[gi]; v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+        if (add) { const float4 a = add[gi]; v.x = fmaf(a.x, add_scale, v.x); v.y = fmaf(a.y, add_scale, v.y); v.z = fmaf(a.z, add_scale, v.z); v.w = fmaf(a.w, add_scale, v.w); }
+        out[i] = v;
+    }
+}
+
+// nn.Hardsigmoid: relu6(x + 3) / 6; with dy: dy * (|x| < 3 ? 1/6 : 0)
+__global__ void hardsigmoid_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        out[i] = dy ? (v > -3.f && v < 3.f ? dy[i] * (1.f / 6.f) : 0.f) : fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+}
+
 // SwiGLU (DINOv2 ViT-g FFN): x12 [rows, 2*Hd] -> out[rows, Hd] = silu(x1) * x2
 __global__ void swiglu_fwd_kernel(const float4* __restrict__ x12, float4* __restrict__ out, int hv, long nvec) {
     EW_LOOP(i, nvec) {
@@ -101,6 +124,9 @@ __global__ void window_permute_kernel(const float4* __restrict__ in, float4* __r
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// nn.Hardswish: x * relu6(x + 3) / 6; derivative 0 below -3, 1 above 3, (2x + 3) / 6 between (MobileNetV3)
+__device__ __forceinline__ float hswish_f(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+__device__ __forceinline__ float hswish_grad_f(float x) { return x < -3.f ? 0.f : (x > 3.f ? 1.f : fmaf(x, 1.f / 3.f, 0.5f)); }
 __device__ __forceinline__ float silu_grad_f(float y) {
     const float sg = sigmoid_f(y);
     return sg * fmaf(y, 1.f - sg, 1.f);
@@ -130,6 +156,8 @@ __global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4
                                g.z * (x.z - mu.z) * rs.z + b.z, g.w * (x.w - mu.w) * rs.w + b.w);
         if (relu == 3) {  // SiLU (DarkNet's Conv, models/backbones/darknet.py:47)
             o = make_float4(o.x * sigmoid_f(o.x), o.y * sigmoid_f(o.y), o.z * sigmoid_f(o.z), o.w * sigmoid_f(o.w));
+        } else if (relu == 4) {  // Hardswish (MobileNetV3's "HS" blocks)
+            o = make_float4(hswish_f(o.x), hswish_f(o.y), hswish_f(o.z), hswish_f(o.w));
         } else if (relu) {
             o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
             if (relu == 2) o = make_float4(fminf(o.x, 6.f), fminf(o.y, 6.f), fminf(o.z, 6.f), fminf(o.w, 6.f));  // ReLU6
@@ -155,6 +183,9 @@ __global__ void bn_bwd_prep_kernel(const float4* __restrict__ dt, const float4* 
         if (relu == 3) {  // SiLU: d/dy [y s(y)] = s (1 + y (1 - s))
             const float4 y = make_float4(g.x * xh.x + b.x, g.y * xh.y + b.y, g.z * xh.z + b.z, g.w * xh.w + b.w);
             o = make_float4(d.x * silu_grad_f(y.x), d.y * silu_grad_f(y.y), d.z * silu_grad_f(y.z), d.w * silu_grad_f(y.w));
+        } else if (relu == 4) {
+            const float4 y = make_float4(g.x * xh.x + b.x, g.y * xh.y + b.y, g.z * xh.z + b.z, g.w * xh.w + b.w);
+            o = make_float4(d.x * hswish_grad_f(y.x), d.y * hswish_grad_f(y.y), d.z * hswish_grad_f(y.z), d.w * hswish_grad_f(y.w));
         } else if (relu) {  // 1: ReLU, 2: ReLU6 (gradient 1 strictly inside (0, 6), as F.relu6 / hardtanh)
             const float hi = relu == 2 ? 6.f : INFINITY;
             const float4 y = make_float4(g.x * xh.x + b.x, g.y * xh.y + b.y, g.z * xh.z + b.z, g.w * xh.w + b.w);
@@ -306,6 +337,23 @@ extern "C" int dkd_sub_group_vec_f32(const float* x, const float* vec, float* ou
     const long nvec = rows_per_group * groups * (N / 4);
     hipLaunchKernelGGL(sub_group_vec_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(x), F4(vec),
                        F4W(out), rows_per_group, N / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_group_affine_f32(const float* x, const float* mul, const float* add, float* out, long rows_per_group, int groups,
+                                    int N, float add_scale, void* stream) {
+    EW_CHECK(N);
+    if (!x || !out || rows_per_group <= 0 || groups <= 0) return DKD_ERR_BAD_ARG;
+    const long nvec = rows_per_group * groups * (N / 4);
+    hipLaunchKernelGGL(group_affine_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(x), F4(mul), F4(add),
+                       F4W(out), rows_per_group, N / 4, add_scale, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_hardsigmoid_f32(const float* x, const float* dy, float* out, long n, void* stream) {
+    if (!x || !out || n <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(hardsigmoid_kernel, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, x, dy, out, n);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

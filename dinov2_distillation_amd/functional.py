@@ -546,15 +546,16 @@ class ConvBNActFn(Function):
 
 
 class DepthwiseBNFn(Function):
-    """depthwise 3x3 stride-s conv (no bias) + train-mode BatchNorm2d (stdc.py:113-126 ``avd_layer``: no activation;
-    MobileNetV2's depthwise stage: act = 2, ReLU6)."""
+    """depthwise k x k (k = w.shape[-1]: 3 or 5) stride-s conv (no bias) + train-mode BatchNorm2d (stdc.py:113-126
+    ``avd_layer``: no activation; MobileNetV2's depthwise stage: act = 2, ReLU6; MobileNetV3's: 1 ReLU / 4 Hardswish)."""
 
     @staticmethod
     def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training, act=0, dilation=1):
         x = _c(x)
         C = x.shape[3]
-        wt = ops.transpose(w.reshape(C, 9))
-        y = ops.dwconv3(x, wt, stride, dilation=dilation)
+        k = w.shape[-1]
+        wt = ops.transpose(w.reshape(C, k * k))
+        y = ops.dwconv(x, wt, k, stride, dilation=dilation)
         y2 = y.reshape(-1, C)
         mean, rstd = _bn_fwd_stats(y2, bn_state, training)
         ctx.training = training
@@ -575,9 +576,46 @@ class DepthwiseBNFn(Function):
         o_w, o_g, o_b = direct(p_w, p_g, p_b)
         dy, dg, db = ops.bn_bwd(_c(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=act, dgamma_out=o_g, dbeta_out=o_b)
         dy = dy.reshape(yshape)
-        dx = ops.dwconv3(dy, wt, stride, dgrad_shape=x.shape[1:3], dilation=dilation) if ctx.needs_input_grad[0] else None
-        dw = ops.transpose(ops.dwconv3_wgrad(x, dy, stride, dilation), out=None if o_w is None else o_w.view(C, 9)).reshape(wshape)
+        k = wshape[-1]
+        dx = ops.dwconv(dy, wt, k, stride, dgrad_shape=x.shape[1:3], dilation=dilation) if ctx.needs_input_grad[0] else None
+        dw = ops.transpose(ops.dwconv_wgrad(x, dy, k, stride, dilation), out=None if o_w is None else o_w.view(C, k * k)).reshape(wshape)
         return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None
+
+
+class SqueezeExciteFn(Function):
+    """torchvision.ops.SqueezeExcitation as MobileNetV3 builds it (models/backbones/mobilenet_v3.py:10 -> torchvision
+    ``InvertedResidual``): out = x * hardsigmoid(fc2(relu(fc1(mean_hw(x))))), fc1 / fc2 = 1x1 convs with bias on the pooled
+    [B, C] vector.  One node: the pooled branch is a handful of [B, C] rows, the two passes over x (pool, scale) and over dy
+    (d(scale) . x per image, dx) are the HBM traffic."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = _c(x)
+        B, H, W, C = x.shape
+        S = w1.shape[0]
+        pooled = ops.colreduce(x.view(B * H * W, C), groups=B, scale=1.0 / (H * W))
+        h = ops.linear_fwd(pooled, w1.view(S, C), b1, act=ops.ACT_RELU)
+        z = ops.linear_fwd(h, w2.view(C, S), b2)
+        s = ops.hardsigmoid(z)
+        ctx.save_for_backward(x, pooled, h, z, s, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
+        return ops.group_affine(x, B, mul=s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pooled, h, z, s, w1, w2 = ctx.saved_tensors
+        dy = _c(dy)
+        B, H, W, C = x.shape
+        S = w1.shape[0]
+        p_w1, p_b1, p_w2, p_b2 = ctx.params
+        ds = ops.colreduce(dy.view(B * H * W, C), ops.RED_DOT, y=x.view(B * H * W, C), groups=B)
+        dz = ops.hardsigmoid(z, ds)
+        dh = ops.relu_bwd(ops.linear_dgrad(dz, w2.view(C, S)), h)
+        dpool = ops.linear_dgrad(dh, w1.view(S, C))
+        dw2, db2 = wgrad(dz, h, p_w2, p_b2, reshape=lambda t: t.reshape(p_w2.shape))
+        dw1, db1 = wgrad(dh, pooled, p_w1, p_b1, reshape=lambda t: t.reshape(p_w1.shape))
+        dx = ops.group_affine(dy, B, mul=s, add=dpool, add_scale=1.0 / (H * W)) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2
 
 
 class AvgPool3Fn(Function):

@@ -10,6 +10,7 @@ from .darknet import VERSIONS as DARKNET_VERSIONS
 from .darknet import DarkNet
 from .mit import MultiscaleImageTransformer
 from .mobilenet_v2 import D2MobileNetV2
+from .mobilenet_v3 import D2MobileNetV3
 from .presnet import D2Presnet
 from .resnet import BasicStem, ResNet, make_resnet_stages
 from .stdc import STDCNet
@@ -221,6 +222,36 @@ class MobileNetV2Wrapper(nn.Module):
         return self._out_feature_channels
 
 
+MOBILENET_V3_CONFIGS = {  # models/wrappers/mobilenet_v3_wrapper.py:11-16
+    "mobilenet_v3_small": ("small", False), "mobilenet_v3_large": ("large", False),
+    "mobilenet_v3_small_os8": ("small", True), "mobilenet_v3_large_os8": ("large", True),
+}
+
+
+class MobileNetV3Wrapper(nn.Module):
+    """models/wrappers/mobilenet_v3_wrapper.py: D2MobileNetV3(size, width_mult=1.0, dilated, out_features)"""
+
+    def __init__(self, model_name="mobilenet_v3_small", out_features=None):
+        super().__init__()
+        if model_name not in MOBILENET_V3_CONFIGS:
+            raise NotImplementedError(f"There is not a MobileNetV3 config called {model_name}.")
+        size, dilated = MOBILENET_V3_CONFIGS[model_name]
+        self._out_features = out_features or ["res2", "res3", "res4", "res5"]
+        self.ckpt_dir = os.path.join(os.path.dirname(__file__), "..", "..", "checkpoints", f"mobilenet_v3_{size}.pkl")
+        self.model = D2MobileNetV3(size=size, width_mult=1.0, dilated=dilated, out_features=self._out_features)
+        self._out_feature_channels = {f: self.model._out_feature_channels[f] for f in self._out_features}
+
+    def get_features(self, x):
+        return self.model(x)
+
+    def get_features_nhwc(self, x):
+        return self.model.forward_features_nhwc(x)
+
+    @property
+    def feature_channels(self):
+        return self._out_feature_channels
+
+
 MIT_CONFIGS = {"0": ([2, 2, 2, 2], [32, 64, 160, 256]), "1": ([2, 2, 2, 2], [64, 128, 320, 512]),  # mit_wrapper.py:6-13
                "2": ([3, 4, 6, 3], [64, 128, 320, 512]), "3": ([3, 4, 18, 3], [64, 128, 320, 512]),
                "4": ([3, 8, 27, 3], [64, 128, 320, 512]), "5": ([3, 6, 40, 3], [64, 128, 320, 512])}
@@ -256,7 +287,7 @@ class ModelWrapper(nn.Module):
     another one fails loudly (no silent fallback to an ATen implementation)."""
 
     MODEL_MAP = {"convnext": ConvNextWrapper, "stdc": STDCWrapper, "resnet": ResNetWrapper, "swin": D2SwinTransformerWrapper,
-                 "presnet": PResNetWrapper, "mobilenet_v2": MobileNetV2Wrapper, "mit": MITWrapper, "darknet": DarkNetWrapper}
+                 "presnet": PResNetWrapper, "mobilenet_v2": MobileNetV2Wrapper, "mobilenet_v3": MobileNetV3Wrapper, "mit": MITWrapper, "darknet": DarkNetWrapper}
 
     def __init__(self, model_name, n_patches, target_feature=("res5", "res4")):
         super().__init__()

@@ -597,9 +597,10 @@ def im2col_nchw(img, k, stride, pad):
     return rows
 
 
-def dwconv3(x, w_tap, stride, dgrad_shape=None, dilation=1):
-    """forward: x [B,H,W,C] -> [B,Ho,Wo,C]; dgrad (dgrad_shape=(H,W)): x is dy [B,Ho,Wo,C] -> dx [B,H,W,C].
-    w_tap None == AvgPool2d(3, stride, 1).  padding = dilation (the output extent does not depend on it)."""
+def dwconv(x, w_tap, k, stride, dgrad_shape=None, dilation=1):
+    """depthwise k x k (k = 3 or 5).  forward: x [B,H,W,C] -> [B,Ho,Wo,C]; dgrad (dgrad_shape=(H,W)): x is dy [B,Ho,Wo,C] ->
+    dx [B,H,W,C].  w_tap tap-major [k*k, C]; None (k = 3) == AvgPool2d(3, stride, 1).  padding = (k // 2) * dilation (the
+    output extent does not depend on the dilation)."""
     _chk(x, "x"), _chk(w_tap, "w_tap")
     B, C = x.shape[0], x.shape[3]
     if dgrad_shape is None:
@@ -609,21 +610,56 @@ def dwconv3(x, w_tap, stride, dgrad_shape=None, dilation=1):
         mode = 0
     else:
         H, W = dgrad_shape
+        if tuple(x.shape[1:3]) != conv_out_hw(H, W, 3, stride, 1):
+            raise _lib.DkdError(f"dwconv dgrad: dy {tuple(x.shape)} does not belong to a {H}x{W} input at stride {stride}")
         out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
         mode = 1
-    check(_lib.binding().dkd_dwconv3_f32(_p(x), _p(w_tap), _p(out), B, H, W, C, stride, dilation, mode, _stream()),
-          "dkd_dwconv3_f32")
+    if w_tap is not None and tuple(w_tap.shape) != (k * k, C):
+        raise _lib.DkdError(f"dwconv: taps {tuple(w_tap.shape)} for k={k}, C={C}")
+    check(_lib.binding().dkd_dwconvk_f32(_p(x), _p(w_tap), _p(out), B, H, W, C, k, stride, dilation, mode, _stream()),
+          "dkd_dwconvk_f32")
     return out
 
 
-def dwconv3_wgrad(x, dout, stride, dilation=1):
+def dwconv_wgrad(x, dout, k, stride, dilation=1):
     _chk(x, "x"), _chk(dout, "dout")
     B, H, W, C = x.shape
     Ho = dout.shape[1]
-    part = workspace(B * Ho * 9 * C * 4, x.device, slot=1)
-    check(_lib.binding().dkd_dwconv3_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, stride, dilation, _stream()),
-          "dkd_dwconv3_wgrad_f32")
-    return colreduce(part[: B * Ho * 9 * C].view(B * Ho, 9 * C)).view(9, C)
+    kk = k * k
+    part = workspace(B * Ho * kk * C * 4, x.device, slot=1)
+    check(_lib.binding().dkd_dwconvk_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, k, stride, dilation, _stream()),
+          "dkd_dwconvk_wgrad_f32")
+    return colreduce(part[: B * Ho * kk * C].view(B * Ho, kk * C)).view(kk, C)
+
+
+def dwconv3(x, w_tap, stride, dgrad_shape=None, dilation=1):
+    return dwconv(x, w_tap, 3, stride, dgrad_shape, dilation)
+
+
+def dwconv3_wgrad(x, dout, stride, dilation=1):
+    return dwconv_wgrad(x, dout, 3, stride, dilation)
+
+
+def group_affine(x, groups, mul=None, add=None, add_scale=1.0):
+    """x viewed as [groups, rows_per_group, N]: out = x * mul[g] + add_scale * add[g] (mul / add [groups, N] or None)"""
+    _chk(x, "x"), _chk(mul, "mul"), _chk(add, "add")
+    N = x.shape[-1]
+    rpg = x.numel() // N // groups
+    for t in (mul, add):
+        if t is not None and t.numel() != groups * N:
+            raise _lib.DkdError(f"group_affine: a [{groups}, {N}] table is needed, got {tuple(t.shape)}")
+    out = torch.empty_like(x)
+    check(_lib.binding().dkd_group_affine_f32(_p(x), _p(mul), _p(add), _p(out), rpg, groups, N, add_scale, _stream()),
+          "dkd_group_affine_f32")
+    return out
+
+
+def hardsigmoid(x, dy=None):
+    """nn.Hardsigmoid forward; with dy: its backward"""
+    _chk(x, "x"), _chk(dy, "dy")
+    out = torch.empty_like(x)
+    check(_lib.binding().dkd_hardsigmoid_f32(_p(x), _p(dy), _p(out), x.numel(), _stream()), "dkd_hardsigmoid_f32")
+    return out
 
 
 def copy2d(src, lds, dst, ldd, rows, cols, accumulate=False):

@@ -280,6 +280,8 @@ class DistillationModule(_Base):
             checkpoint = {f"model.model.{k.replace('cp.backbone.', '')}": v for k, v in checkpoint.items()}
         elif student_type in ("mit", "darknet", "presnet", "mobilenet_v2"):
             checkpoint = {f"model.model.{k.replace('backbone.', '')}": v for k, v in checkpoint.items()}
+        elif student_type == "mobilenet_v3":  # distillation_module.py:419-421: the classification head is not warm-started
+            checkpoint = {f"model.model.{k.replace('backbone.', '')}": v for k, v in checkpoint.items() if "classifier" not in k}
         else:
             checkpoint = {f"model.model.{k}": v for k, v in checkpoint.items()}
         result = self.student.load_state_dict(checkpoint, strict=False)

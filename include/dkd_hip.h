@@ -322,6 +322,16 @@ int dkd_im2col_nhwc_f32(const float* x, float* rows, int B, int H, int W, int C,
                         void* stream);
 int dkd_im2col_nchw_f32(const float* img, float* rows, int B, int Cin, int H, int W, int k, int stride, int pad, int Kp,
                         void* stream);
+/* depthwise k x k (k = 3 or 5; MobileNetV3 uses both), padding (k/2)*dilation: the k-generic form of dkd_dwconv3_* below */
+int dkd_dwconvk_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int k, int stride,
+                    int dilation, int mode, void* stream);
+int dkd_dwconvk_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C, int k, int stride,
+                          int dilation, void* stream);
+/* squeeze-excitation helpers (torchvision SElayer as MobileNetV3 uses it): out = x * mul[group] + add_scale * add[group]
+ * with one [N] vector per group of rows (mul / add nullable); nn.Hardsigmoid forward (dy NULL) / backward */
+int dkd_group_affine_f32(const float* x, const float* mul, const float* add, float* out, long rows_per_group, int groups, int N,
+                         float add_scale, void* stream);
+int dkd_hardsigmoid_f32(const float* x, const float* dy, float* out, long n, void* stream);
 int dkd_dwconv3_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int stride,
                     int dilation, int mode, void* stream);
 int dkd_dwconv3_wgrad_f32(const float* x, const float* dout, float* partials, int B, int H, int W, int C, int stride,

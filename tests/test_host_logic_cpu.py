@@ -97,6 +97,19 @@ def test_error_behaviour_matches_reference():
     assert ModelWrapper("mobilenet_v2_os8", [16, 16]).model.model.layer4[0].conv[1].dilation == 2   # mobilenet_v2_wrapper.py:13-16
     with pytest.raises(NotImplementedError, match="MobileNet config"):
         ModelWrapper("mobilenet_v2_os4", [16, 16])
+    # MobileNetV3 = torchvision's class (models/backbones/mobilenet_v3.py:10): its PUBLISHED parameter counts, 2 542 856 (small) and
+    # 5 483 032 (large) at 1000 classes, minus 999 rows of the last Linear for the reference's num_classes=1
+    m3s, m3l = ModelWrapper("mobilenet_v3_small", [16, 16]), ModelWrapper("mobilenet_v3_large", [16, 16])
+    assert sum(p.numel() for p in m3s.parameters()) == 2_542_856 - 999 * 1025 and len(m3s.model.model.state_dict()) == 244
+    assert sum(p.numel() for p in m3l.parameters()) == 5_483_032 - 999 * 1281 and len(m3l.model.model.state_dict()) == 312
+    assert m3s.feature_channels == {"res5": 576, "res4": 96} and m3l.feature_channels == {"res5": 960, "res4": 160}  # :31-48
+    sd3 = m3s.state_dict()
+    assert "model.model.features.1.block.1.fc1.bias" in sd3 and "model.model.features.12.1.running_var" in sd3
+    assert "model.model.classifier.3.weight" in sd3 and tuple(sd3["model.model.features.4.block.1.0.weight"].shape) == (96, 1, 5, 5)
+    os8 = ModelWrapper("mobilenet_v3_large_os8", [16, 16]).model.model.features
+    assert os8[13].block[1][0].dilation == (2, 2) and os8[13].block[1][0].stride == (1, 1) and os8[12].block[1][0].dilation == (1, 1)
+    with pytest.raises(NotImplementedError, match="MobileNetV3 config"):
+        ModelWrapper("mobilenet_v3_medium", [16, 16])
     s = ModelWrapper("stdc_2", [16, 16])
     assert abs(sum(p.numel() for p in s.parameters()) / 1e6 - 9.35) < 0.01 and len(s.state_dict()) == 636
 
@@ -266,6 +279,16 @@ def test_student_checkpoint_warm_start_and_export_keys(tmp_path):
         bad = tmp_path / "weights.bin"
         bad.write_bytes(b"x")
         module("convnext_atto", bad)
+    # MobileNetV3: keys prefixed 'backbone.', the classification head is dropped before loading (distillation_module.py:419-421)
+    m3 = ModelWrapper("mobilenet_v3_small", [16, 16])
+    k3, kc = "features.0.0.weight", "classifier.3.bias"
+    before = m3.state_dict()["model.model." + kc].clone()
+    pth3 = tmp_path / "mobilenet_v3_small.pth"
+    torch.save({"backbone." + k3: torch.full_like(m3.state_dict()["model.model." + k3], 0.5),
+                "backbone." + kc: torch.full_like(before, 9.0)}, pth3)
+    mm3 = module("mobilenet_v3_small", pth3)
+    assert float(mm3.student.state_dict()["model.model." + k3].min()) == 0.5
+    assert float(mm3.student.state_dict()["model.model." + kc]) != 9.0
     # export surface (convert_to_anyma.py:23-29): student backbone keys, projector / loss keys filtered out
     w_student = {k: v for k, v in m2.state_dict().items() if "student" in k and "scalekd" not in k and "feature_matchers" not in k}
     exported = {k.replace("student.model.model.", "backbone."): v for k, v in w_student.items()}

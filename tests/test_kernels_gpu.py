@@ -510,3 +510,75 @@ def test_dwconv3(ops, B, H, C, stride, dil):
     dw = ops.dwconv3_wgrad(xn, dyn, stride, dil)
     close(ops.transpose(dw).reshape(C, 1, 3, 3), w.grad, "dwconv3 wgrad", rtol=3e-4)
 
+
+
+@pytest.mark.parametrize("B,H,C,stride,dil", [(2, 12, 96, 1, 1), (2, 13, 72, 2, 1), (1, 7, 960, 1, 1), (3, 14, 240, 2, 1),
+                                               (2, 12, 288, 1, 2), (1, 5, 576, 1, 2), (2, 3, 40, 2, 1)])
+def test_dwconv5(ops, B, H, C, stride, dil):
+    """depthwise 5x5, pad = 2 * dilation, stride 1 | 2 (MobileNetV3's C2 / C3 / C4 stages; dilation 2 in the os8 variants where
+    the map may be SMALLER than the 9-wide dilated footprint): forward, dgrad, wgrad"""
+    g = torch.Generator().manual_seed(H * 5 + stride)
+    x = torch.randn(B, C, H, H, generator=g).requires_grad_(True)
+    w = torch.randn(C, 1, 5, 5, generator=g).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=stride, padding=2 * dil, dilation=dil, groups=C)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xn = dev(x.detach().permute(0, 2, 3, 1).contiguous())
+    wt = ops.transpose(dev(w.detach().reshape(C, 25)))
+    out = ops.dwconv(xn, wt, 5, stride, dilation=dil)
+    close(out.permute(0, 3, 1, 2), y, "dwconv5 fwd")
+    dyn = dev(dy.permute(0, 2, 3, 1).contiguous())
+    dx = ops.dwconv(dyn, wt, 5, stride, dgrad_shape=(H, H), dilation=dil)
+    close(dx.permute(0, 3, 1, 2), x.grad, "dwconv5 dgrad")
+    dw = ops.dwconv_wgrad(xn, dyn, 5, stride, dil)
+    close(ops.transpose(dw).reshape(C, 1, 5, 5), w.grad, "dwconv5 wgrad", rtol=3e-4)
+    with pytest.raises(Exception):
+        ops.dwconv(xn, ops.transpose(dev(torch.zeros(C, 49))), 7, stride)  # only k = 3 and 5 exist: refused, nothing launched
+
+
+def test_bn_hardswish(ops):
+    """BatchNorm(eps 1e-3, momentum 0.01) + Hardswish (torchvision MobileNetV3's "HS" layers): forward, running statistics,
+    backward, with a good share of the pre-activations in each of the three pieces (x < -3, |x| < 3, x > 3)"""
+    g = torch.Generator().manual_seed(18)
+    rows, C = 500, 72
+    z = (3.0 * torch.randn(rows, C, generator=g)).requires_grad_(True)
+    ga = (2.5 + 0.5 * torch.randn(C, generator=g)).requires_grad_(True)
+    be = (0.5 * torch.randn(C, generator=g)).requires_grad_(True)
+    rm, rv = 0.1 * torch.randn(C, generator=g), 1.0 + torch.rand(C, generator=g)
+    rm_d, rv_d = dev(rm), dev(rv)
+    pre = F.batch_norm(z, rm, rv, ga, be, True, 0.01, 1e-3)
+    assert (pre < -3).float().mean() > 0.05 and (pre > 3).float().mean() > 0.05
+    y = F.hardswish(pre)
+    dy = torch.randn(rows, C, generator=g)
+    y.backward(dy)
+    zd = dev(z.detach())
+    mean, rstd = ops.bn_stats(zd, rm_d, rv_d, 0.01, 1e-3)
+    close(rm_d, rm, "running mean (momentum 0.01)")
+    close(rv_d, rv, "running var (momentum 0.01)")
+    out = ops.bn_act_pos_fwd(zd, mean, rstd, dev(ga.detach()), dev(be.detach()), None, relu=4)
+    close(out, y, "bn hardswish fwd")
+    dz, dg, db = ops.bn_bwd(dev(dy), zd, mean, rstd, dev(ga.detach()), dev(be.detach()), relu=4)
+    close(dz, z.grad, "bn hardswish dz", rtol=2e-4)
+    close(dg, ga.grad, "bn hardswish dgamma", rtol=2e-4)
+    close(db, be.grad, "bn hardswish dbeta", rtol=2e-4)
+
+
+def test_group_affine_and_hardsigmoid(ops):
+    """the squeeze-excitation helpers: out = x * mul[image] + a * add[image] (either table optional), nn.Hardsigmoid fwd / bwd"""
+    g = torch.Generator().manual_seed(21)
+    B, HW, C = 3, 49, 88
+    x = torch.randn(B, HW, C, generator=g)
+    mul, add = torch.rand(B, C, generator=g), torch.randn(B, C, generator=g)
+    xd, md, ad = dev(x), dev(mul), dev(add)
+    close(ops.group_affine(xd, B, mul=md), x * mul[:, None], "x * mul")
+    close(ops.group_affine(xd, B, add=ad, add_scale=0.25), x + 0.25 * add[:, None], "x + a add")
+    close(ops.group_affine(xd, B, mul=md, add=ad, add_scale=1.0 / HW), x * mul[:, None] + add[:, None] / HW, "x * mul + add / HW")
+    with pytest.raises(Exception):
+        ops.group_affine(xd, B, mul=md[:2])
+    z = (4.0 * torch.randn(B, C, generator=g)).requires_grad_(True)
+    s = F.hardsigmoid(z)
+    ds = torch.randn(B, C, generator=g)
+    s.backward(ds)
+    assert (s == 0).any() and (s == 1).any()
+    close(ops.hardsigmoid(dev(z.detach())), s, "hardsigmoid fwd")
+    close(ops.hardsigmoid(dev(z.detach()), dev(ds)), z.grad, "hardsigmoid bwd")

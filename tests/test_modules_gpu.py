@@ -649,6 +649,130 @@ def test_mobilenet_v2_student_runs_full_step():
     assert l0 == l0 and l1 == l1 and abs(l1) < 1e6
 
 
+def _mnv3_kink_distance(rec):
+    """smallest distance of any recorded pre-activation to a point where its activation's derivative jumps"""
+    d = 1e9
+    for act, t in rec:
+        kinks = (0.0,) if act == "RE" else (-3.0, 3.0)
+        d = min(d, min((t - k).abs().min().item() for k in kinks))
+    return d
+
+
+@pytest.mark.parametrize("row", [(16, 3, 16, 16, True, "RE", 2, 1), (16, 3, 72, 24, False, "RE", 2, 1), (24, 3, 88, 24, False, "RE", 1, 1),
+                                 (24, 5, 96, 40, True, "HS", 2, 1), (40, 5, 240, 40, True, "HS", 1, 1), (48, 5, 288, 96, True, "HS", 2, 2),
+                                 (96, 5, 576, 96, True, "HS", 1, 2), (80, 3, 184, 80, False, "HS", 1, 1)])
+def test_mobilenet_v3_block_vs_oracle(golden_dir, row):
+    """torchvision's InvertedResidual as MobileNetV3 uses it (1x1 expand / depthwise 3x3 | 5x5, stride 1 | 2 or dilated /
+    squeeze-excitation / linear 1x1 projection, BatchNorm(eps 1e-3) + ReLU | Hardswish, residual add): output, input gradient,
+    EVERY parameter gradient and the running statistics element by element against the oracle.  ReLU, Hardswish and
+    Hardsigmoid have derivative jumps (0; -3 and 3): the comparison is made on a seed whose pre-activations (fp64 oracle) all
+    keep clear of them, as for MobileNetV2 above."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import mobilenet_v3_oracle as mo
+    from dinov2_distillation_amd.models.mobilenet_v3 import InvertedResidual
+    cin, k, exp, cout, use_se, act, stride, dil = row
+    blk = InvertedResidual(cin, k, exp, cout, use_se, act == "HS", stride, dil)
+    shapes = {kk: v.shape for kk, v in blk.state_dict().items()}
+    for seed in range(1, 80):
+        state = pr.seeded_state(shapes, seed)
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(4, cin, 6, 6, generator=gen)
+        rec = []
+        p64 = {kk: (v.double() if v.dtype.is_floating_point else v) for kk, v in state.items()}
+        mo.inverted_residual(p64, "", x.double(), row, record=rec)
+        if _mnv3_kink_distance(rec) > 2e-5:
+            break
+    else:
+        raise AssertionError("no seed keeps every pre-activation away from the activation kinks")
+    p = {kk: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in kk else v.clone())
+         for kk, v in state.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = mo.inverted_residual(p, "", xr, row)
+    ct = torch.randn(ref.shape, generator=gen)
+    (ref * ct).sum().backward()
+    blk.load_state_dict(state, strict=True)
+    blk.cuda().train()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)   # NHWC, as inside the backbone
+    out = blk(xg)
+    close(out.permute(0, 3, 1, 2), ref, "block fwd")
+    (out * ct.permute(0, 2, 3, 1).cuda()).sum().backward()
+    close(xg.grad.permute(0, 3, 1, 2), xr.grad, "block dx", rtol=1e-3)
+    for kk, v in blk.named_parameters():
+        close(v.grad, p[kk].grad, "block d" + kk, rtol=1e-3)
+    for kk, v in blk.state_dict().items():
+        if "running" in kk:
+            close(v, p[kk], kk)
+        if "num_batches_tracked" in kk:
+            assert int(v) == 1
+
+
+@pytest.mark.parametrize("name,size,dilated", [("mobilenet_v3_small", "small", False), ("mobilenet_v3_large", "large", False),
+                                               ("mobilenet_v3_small_os8", "small", True)])
+def test_mobilenet_v3_whole_network_vs_oracle(golden_dir, name, size, dilated):
+    """whole MobileNetV3 (through the reference's wrapper names) vs the oracle at 128 x 128: all four tapped levels and every
+    running statistic to fp32 tolerance; parameter gradients by their norms (dozens of kinked activations at batch statistics:
+    element-wise comparison at this depth measures mask flips - the blocks are compared element-wise above)"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import param_recipe as pr
+    from oracle import mobilenet_v3_oracle as mo
+    from dinov2_distillation_amd.models import ModelWrapper
+    wrap = ModelWrapper(name, [16, 16], target_feature=("res2", "res3", "res4", "res5"))
+    net = wrap.model.model
+    shapes = {k: v.shape for k, v in net.state_dict().items()}
+    assert {k: tuple(v) for k, v in shapes.items()} == {k: tuple(v) for k, v in mo.state_shapes(size).items()}
+    state = pr.seeded_state(shapes, 5)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 128, 128, generator=gen)
+    def oracle(dtype):
+        q = {k: ((v.detach().clone().to(dtype).requires_grad_("running" not in k)) if v.dtype.is_floating_point else v.clone())
+             for k, v in state.items()}
+        out = mo.forward(q, x.to(dtype), size, dilated)
+        sum((out[k] * cts[k].to(dtype)).sum() for k in out).backward()
+        return q, out
+
+    with torch.no_grad():
+        probe = mo.forward({k: v.clone() for k, v in state.items()}, x, size, dilated)
+    cts = {k: torch.randn(v.shape, generator=gen) for k, v in probe.items()}
+    p, ref = oracle(torch.float32)
+    p64, _ = oracle(torch.float64)
+    net.load_state_dict(state, strict=True)
+    net.cuda().train()
+    feats = net(x.cuda())
+    assert set(feats) == set(ref)
+    for k in ref:
+        close(feats[k], ref[k], k)
+    sum((feats[k] * cts[k].cuda()).sum() for k in ref).backward()
+    n_zero = 0
+    for k, v in net.named_parameters():
+        if k.startswith("classifier"):
+            assert v.grad is None and p[k].grad is None   # the head never runs (mobilenet_v3.py:56-63), in either implementation
+            continue
+        # the fp64 oracle arbitrates: a BatchNorm bias in front of a 1x1 conv + train-mode BatchNorm has an exactly zero gradient
+        # (the shift is removed again), and what fp32 computes there - ours or torch's - is round-off of either size
+        n_ours, n_ref, n_64 = (t.grad.double().norm().item() for t in (v, p[k], p64[k]))
+        n_zero += n_64 < 1e-3 * n_ref
+        assert abs(n_ours - n_64) <= 5e-2 * n_64 + 2 * abs(n_ref - n_64) + 1e-6, f"{k}: |grad| {n_ours:.6e} vs {n_ref:.6e} (fp64 {n_64:.6e})"
+    print(f"{name}: {n_zero} parameters with a structurally zero gradient")
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            close(v, p[k], k)
+
+
+def test_mobilenet_v3_student_runs_full_step():
+    """dinov2_vits14 -> mobilenet_v3_small (res4 96 / res5 576 channels): full optimiser steps, finite and reproducible losses"""
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        st = DistillationStepper(student="mobilenet_v3_small")
+        runs.append([float(st.step(x).detach()) for _ in range(2)])
+    assert all(v == v and abs(v) < 1e6 for v in runs[0]) and runs[0] == runs[1], runs
+
+
 def test_mit_b0_against_reference_golden(golden_dir):
     """MiT-b0 (overlapping patch embeddings, spatial-reduction attention with head dims 32 / 40, Mix-FFN with a depthwise conv)
     vs the reference's own MultiscaleImageTransformer: outputs against the fixture, every parameter gradient element by
