@@ -536,11 +536,17 @@ struct DmaStager {
     }
 };
 
-template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0>
+// PEEL (forward layout only): the LAST 64-row tile row is not run as whole tiles but as `peel_blocks` K-slabs of `peel_kchunk`
+// that write partial sums to ws (folded by splitk_reduce_kernel) and come FIRST in the grid.  For the frozen teacher's
+// M = 64 * 257 rows (257 is prime: 257 * nbn tiles never fill whole rounds of the 256 CUs) the 6 .. 24 tiles past the last
+// whole round would each run alone on a CU at the very end - 30-40 us of a lone workgroup's latency on a 160 us launch;
+// as a few dozen short slabs in the first round they cost about one tile's worth of work spread over the chip.
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0, bool PEEL = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda,
                                                                     const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                     int M, int N, int K, int kchunk, Epilogue epi,
-                                                                    float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok) {
+                                                                    float* __restrict__ ws, float* __restrict__ rowsum, int vec_ok,
+                                                                    int peel_blocks, int peel_kchunk) {
     // KNOCK (variants 130-132, timing experiments only - results are wrong): 2 = no DMA at all, 4 = no DMA of B, 8 = no barrier.
     // A template parameter on purpose: as a run-time argument the same three tests cost the production kernel 6 %.
     constexpr int knock = KNOCK;
@@ -552,10 +558,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, nbm * nbn);
-    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
-    const int kbeg = blockIdx.y * kchunk;
-    const int kend = min(K, kbeg + kchunk);
+    int bm0, bn0, kbeg, kend;
+    bool peeled = false;
+    if (PEEL && (int)blockIdx.x < peel_blocks) {  // slab blockIdx.x / nbn of column tile blockIdx.x % nbn of the last tile row
+        peeled = true;
+        bm0 = (nbm - 1) * BM;
+        bn0 = ((int)blockIdx.x % nbn) * BN;
+        kbeg = ((int)blockIdx.x / nbn) * peel_kchunk;
+        kend = min(K, kbeg + peel_kchunk);
+    } else {
+        const int tile = PEEL ? xcd_remap(blockIdx.x - peel_blocks, (nbm - 1) * nbn) : xcd_remap(blockIdx.x, nbm * nbn);
+        bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+        kbeg = blockIdx.y * kchunk;
+        kend = min(K, kbeg + kchunk);
+    }
     const int g = lane >> 4, i16 = lane & 15;
     const int nk = (kend - kbeg) / BK;
 
@@ -609,12 +625,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
         if (!(knock & 8)) __syncthreads();
     }
 
-    const bool partial = ws != nullptr;
+    const bool partial = PEEL ? peeled : ws != nullptr;
     if (do_rowsum && bm0 + tid < M) {
         if (partial) ws[(long)gridDim.y * M * N + (long)blockIdx.y * M + bm0 + tid] = rs;
         else rowsum[bm0 + tid] = rs * epi.alpha;
     }
-    float* out = partial ? ws + (long)blockIdx.y * M * N : C;
+    float* out = PEEL ? (peeled ? ws + ((long)(blockIdx.x / nbn) * BM - bm0) * N : C)  // slab z of the [slabs][BM][N] partials
+                      : (partial ? ws + (long)blockIdx.y * M * N : C);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = bm0 + (wm * TM + i) * 16 + i16;
@@ -1049,7 +1066,7 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     const int vec = epilogue_vec_ok(g);
 #define DKD_GEMM_LAUNCH3(AKC, BKC)                                                                                          \
     hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
-                       g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec)
+                       g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec, 0, 0)
     if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH3(true, true);
     else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH3(true, false);
     else if (g->a_layout == 1 && g->b_layout == 0) DKD_GEMM_LAUNCH3(false, true);
@@ -1058,6 +1075,43 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     DKD_LAUNCH_CHECK();
     if (splits > 1) return launch_splitk_reduce(g, epi, splits, st);
     return DKD_OK;
+}
+
+// Peel plan for the 64 x 64 LDS-DMA kernel in the forward layout (see the PEEL note at the kernel): slabs > 0 when dropping the last
+// tile row leaves whole rounds of the 256 CUs.  The slab depth keeps a slab at <= 1/4 of a tile (>= 4 k-tiles of 32).
+static int peel_slabs(int M, int N, int K, int a_layout, int b_layout) {
+    static const bool off = getenv("DKD_GEMM_NO_PEEL") != nullptr;  // A/B switch
+    if (off || a_layout != 0 || b_layout != 0 || (M % 64) || (K % 32)) return 0;
+    const long nbm = M / 64, nbn = dkd_cdiv(N, 64);
+    if (nbm < 2 || ((nbm - 1) * nbn) % 256 != 0 || (nbm - 1) * nbn < 1024) return 0;
+    int slabs = K / 128;
+    if (slabs > 8) slabs = 8;
+    return slabs < 2 ? 0 : slabs;
+}
+static int peel_kchunk(int K, int slabs) { return ((K + slabs - 1) / slabs + 31) / 32 * 32; }
+
+static int launch_dma_peel(const dkd_gemm_args* g, const Epilogue& epi, int slabs, hipStream_t st) {
+    constexpr int BM = 64, BN = 64;
+    const int nbm = g->M / BM, nbn = dkd_cdiv(g->N, BN);
+    const int kc = peel_kchunk(g->K, slabs);
+    slabs = dkd_cdiv(g->K, kc);
+    const int pb = slabs * nbn;
+    dim3 grid((nbm - 1) * nbn + pb), block(256);
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, 2, 2, 32, true, true, 0, true>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C,
+                       g->ldc, g->M, g->N, g->K, g->K, epi, g->workspace, (float*)nullptr, epilogue_vec_ok(g), pb, kc);
+    DKD_LAUNCH_CHECK();
+    // fold the slabs of the last 64 rows: the same fixed-order fold as a split-K launch, on a [64, N] sub-problem
+    dkd_gemm_args g2 = *g;
+    const long r0 = (long)(nbm - 1) * BM;
+    g2.M = BM;
+    g2.C = g->C + r0 * g->ldc;
+    g2.rowsum = nullptr;
+    Epilogue e2 = epi;
+    if (e2.residual) e2.residual += r0 * e2.ldr;
+    if (e2.preact) e2.preact += r0 * g->ldc;
+    g2.residual = e2.residual;
+    g2.preact = e2.preact;
+    return launch_splitk_reduce(&g2, e2, slabs, st);
 }
 
 }  // namespace
@@ -1130,7 +1184,10 @@ extern "C" int dkd_gemm_f32_splits(int M, int N, int K) { return auto_splits(M, 
 
 extern "C" long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout) {
     const int splits = auto_splits(M, N, K, a_layout, b_layout);
-    return splits > 1 ? (long)splits * ((long)M * N + M) * sizeof(float) : 0;
+    if (splits > 1) return (long)splits * ((long)M * N + M) * sizeof(float);
+    if (pick_cfg(M, N, K, a_layout, b_layout, 0) == DMA_64x64_BK32)  // the peeled last tile row's slabs
+        return (long)peel_slabs(M, N, K, a_layout, b_layout) * 64 * N * sizeof(float);
+    return 0;
 }
 
 extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
@@ -1188,6 +1245,11 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     if (g->variant == 0 && cfg == DMA_64x64_BK32 && !dma_ok<32>(g, kchunk))
         cfg = V2_64x64;  // same tile, register staging: handles the ragged cases
     hipStream_t st = (hipStream_t)stream;
+    if (g->variant == 0 && cfg == DMA_64x64_BK32 && splits == 1 && g->workspace && !g->rowsum && g->row_grp == 0 && g->res_mod == 0 &&
+        dkd_aligned16(g->workspace) && (g->N % 4) == 0) {
+        const int slabs = peel_slabs(g->M, g->N, g->K, g->a_layout, g->b_layout);
+        if (slabs > 0) return launch_dma_peel(g, epi, slabs, st);
+    }
     switch (cfg) {
         case 1: return launch_cfg<2, 2, 2, 2, 16, 1>(g, epi, splits, kchunk, st);               // 128 x 128, 4 waves of 64 x 64
         case CFG_128x128_8W: return launch_cfg<4, 2, 1, 2, 16, 1>(g, epi, splits, kchunk, st);  // 128 x 128, 8 waves of 32 x 64

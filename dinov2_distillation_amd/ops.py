@@ -133,7 +133,7 @@ _grad_listeners = []     # callables(param): told when a parameter's gradient la
 def wgrad_stream(device=None):
     idx = torch.cuda.current_device() if device is None else device.index
     if idx not in _side_streams:
-        _side_streams[idx] = torch.cuda.Stream(device=idx)
+        _side_streams[idx] = torch.cuda.Stream(device=idx, priority=int(os.environ.get("DKD_WGRAD_PRIORITY", "0")))
     return _side_streams[idx]
 
 

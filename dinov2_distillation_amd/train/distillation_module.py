@@ -3,6 +3,7 @@
 If ``lightning`` is importable the class derives from ``L.LightningModule`` and drops into the reference's
 ``train.py``; otherwise it is a plain nn.Module with the same hooks, driven by ``dinov2_distillation_amd.trainer``.
 """
+import contextlib
 import logging
 import os
 import pickle
@@ -39,14 +40,14 @@ _CHAIN_STREAMS = {}
 def _chain_stream(device):
     if device.index not in _CHAIN_STREAMS:
         from .. import ops
-        _CHAIN_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        _CHAIN_STREAMS[device.index] = torch.cuda.Stream(device=device, priority=int(os.environ.get("DKD_CHAIN_PRIORITY", "0")))
         ops.register_producer_stream(_CHAIN_STREAMS[device.index])
     return _CHAIN_STREAMS[device.index]
 
 
 def _teacher_stream(device):
     if device.index not in _TEACHER_STREAMS:
-        _TEACHER_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        _TEACHER_STREAMS[device.index] = torch.cuda.Stream(device=device, priority=int(os.environ.get("DKD_TEACHER_PRIORITY", "0")))
     return _TEACHER_STREAMS[device.index]
 
 
@@ -101,81 +102,56 @@ class DistillationModule(_Base):
         return feat
 
     def _compute_losses(self, features):
-        """train/distillation_module.py:180-246 (sorted level order, res5 ends the loop, intermediate levels use
-        get_spat_loss for both terms, queries are handed on without detaching)."""
+        """train/distillation_module.py:180-246: levels in sorted order, res5 ends the loop; an intermediate level projects the
+        student map with both projectors, runs the teacher's own blocks on the tokens (_forward_specific_stage), uses
+        get_spat_loss for BOTH terms and hands its tokens on as the next level's queries (not detached); res5 is
+        ScaleKD.forward (spatial + DCT-frequency term).
+        ONE implementation for both schedules.  The "spatial" chain (projector_0 -> teacher blocks -> loss, level after level) and
+        the "frequency" chain (projector_1 -> ...) never exchange data (:215-237: each hands its own query to the next level), so
+        on the GPU the frequency chain is issued on a second HIP stream: forward AND backward (autograd replays a node on the
+        stream of its forward) of the two chains overlap, each chain's HBM-bound kernels (BatchNorm, LayerNorm, loss tail,
+        attention soft-max) under the other's GEMMs.  TWO_CHAIN_STREAMS = False (and any CPU tensor) issues the same calls on
+        the current stream."""
         teacher = features["teacher"]
-        if TWO_CHAIN_STREAMS and teacher.is_cuda:
-            return self._compute_losses_two_streams(features)
-        total_loss = 0
-        loss_dict = {}
+        two = TWO_CHAIN_STREAMS and teacher.is_cuda
+        main = side = None
+        if two:
+            main = torch.cuda.current_stream(teacher.device)
+            side = _chain_stream(teacher.device)
+            side.wait_stream(main)
+        on_side = (lambda: torch.cuda.stream(side)) if two else contextlib.nullcontext
+        parts = []
         spatial_query = frequency_query = None
         for name in sorted(self.losses.keys()):
             layer_name = name.split("_")[1]
-            loss_fn, weight = self.losses[name], self.loss_weights[name]
-            if "res5" in name:
-                loss = loss_fn(features["student"][layer_name], features["teacher"], query_s=spatial_query,
-                               query_f=frequency_query)
-                loss_dict[f"{name}_total_loss"] = loss["loss"] * weight
-                loss_dict[f"{name}_frequency_loss"] = loss["frequency_loss"] * weight
-                loss_dict[f"{name}_spatial_loss"] = loss["spatial_loss"] * weight
-                loss_dict[f"{name}_spatial_similarity"] = loss["spatial_similarity"]
-                loss_dict[f"{name}_frequency_similarity"] = loss["frequency_similarity"]
-                total_loss = total_loss + loss["loss"] * weight
-                break
-            feat_S_spat = loss_fn.project_feat_spat(features["student"][layer_name], query=spatial_query)
-            feat_S_freq = loss_fn.project_feat_freq(features["student"][layer_name], query=frequency_query)
-            feat_S_spat = self._forward_specific_stage(feat_S_spat, layer_name)
-            feat_S_freq = self._forward_specific_stage(feat_S_freq, layer_name)
-            spatial_query, frequency_query = feat_S_spat, feat_S_freq
-            spatial_loss, spatial_similarity = loss_fn.get_spat_loss(feat_S_spat, features["teacher"])
-            frequency_loss, frequency_similarity = loss_fn.get_spat_loss(feat_S_freq, features["teacher"])
-            loss_dict[f"{name}_total_loss"] = (spatial_loss + frequency_loss) * weight
-            loss_dict[f"{name}_frequency_loss"] = frequency_loss * weight
-            loss_dict[f"{name}_spatial_loss"] = spatial_loss * weight
-            loss_dict[f"{name}_spatial_similarity"] = spatial_similarity
-            loss_dict[f"{name}_frequency_similarity"] = frequency_similarity
-            total_loss = total_loss + (spatial_loss + frequency_loss) * weight
-        loss_dict["loss"] = total_loss
-        return loss_dict
-
-    def _compute_losses_two_streams(self, features):
-        """Same arithmetic as _compute_losses.  The "spatial" chain (projector_0 -> teacher blocks -> loss, level after level)
-        and the "frequency" chain (projector_1 -> ...) never exchange data (train/distillation_module.py:215-237: each hands its
-        own query to the next level), so the frequency chain is issued on a second HIP stream: forward AND backward (autograd
-        replays a node on the stream of its forward) of the two chains overlap, each chain's HBM-bound kernels (BatchNorm,
-        LayerNorm, loss tail, attention soft-max) under the other's GEMMs."""
-        teacher = features["teacher"]
-        main = torch.cuda.current_stream(teacher.device)
-        side = _chain_stream(teacher.device)
-        side.wait_stream(main)
-        total_loss = 0
-        loss_dict = {}
-        spatial_query = frequency_query = None
-        for name in sorted(self.losses.keys()):
-            layer_name = name.split("_")[1]
-            loss_fn, weight = self.losses[name], self.loss_weights[name]
+            loss_fn = self.losses[name]
             x = features["student"][layer_name]
             last = "res5" in name
             tok_s = loss_fn.project_feat_spat(x, query=spatial_query)
             if not last:
                 tok_s = self._forward_specific_stage(tok_s, layer_name)
             spatial_loss, spatial_similarity = loss_fn.get_spat_loss(tok_s, teacher)
-            with torch.cuda.stream(side):
+            with on_side():
                 tok_f = loss_fn.project_feat_freq(x, query=frequency_query)
                 if not last:
                     tok_f = self._forward_specific_stage(tok_f, layer_name)
                 frequency_loss, frequency_similarity = (loss_fn.get_freq_loss if last else loss_fn.get_spat_loss)(tok_f, teacher)
-            x.record_stream(side)
+            if two:
+                x.record_stream(side)
             spatial_query, frequency_query = tok_s, tok_f
-            loss_dict[f"{name}_parts"] = (spatial_loss, frequency_loss, spatial_similarity, frequency_similarity, weight)
+            parts.append((name, spatial_loss, frequency_loss, spatial_similarity, frequency_similarity))
             if last:
                 break
-        teacher.record_stream(side)
-        main.wait_stream(side)
-        for name in [k[:-6] for k in list(loss_dict) if k.endswith("_parts")]:
-            spatial_loss, frequency_loss, spatial_similarity, frequency_similarity, weight = loss_dict.pop(f"{name}_parts")
-            for t in (frequency_loss, frequency_similarity):
-                t.record_stream(main)
+        if two:
+            teacher.record_stream(side)
+            main.wait_stream(side)
+        total_loss = 0
+        loss_dict = {}
+        for name, spatial_loss, frequency_loss, spatial_similarity, frequency_similarity in parts:
+            weight = self.loss_weights[name]
+            if two:
+                for t in (frequency_loss, frequency_similarity):
+                    t.record_stream(main)
             loss_dict[f"{name}_total_loss"] = (spatial_loss + frequency_loss) * weight
             loss_dict[f"{name}_frequency_loss"] = frequency_loss * weight
             loss_dict[f"{name}_spatial_loss"] = spatial_loss * weight

@@ -68,6 +68,35 @@ def test_gemm_dma_wgrad_with_bias_gradient_and_splitk(ops):
     assert _lib.load().dkd_gemm_f32_splits(200, 136, 16384) > 1
 
 
+@pytest.mark.parametrize("N,K", [(384, 1536), (1536, 384), (1152, 384), (200, 768)])
+def test_gemm_peeled_last_tile_row(ops, N, K):
+    """the frozen teacher's forward GEMMs at bs 64 (M = 64 * 257 rows, models/backbones/dinov2.py): the last 64-row tile row
+    runs as K-slabs folded by the split-K fold (csrc/gemm_f32.hip, PEEL); every epilogue term must land on the right rows,
+    the result must not depend on the path beyond fp32 round-off, and be bit-reproducible.  (N = 200: 4 column tiles, the
+    remaining 1024 tiles are exactly four rounds of the 256 CUs; ragged last column tile.)"""
+    import os
+    from dinov2_distillation_amd import _lib
+    M = 64 * 257
+    g = torch.Generator().manual_seed(N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    cs, res = torch.rand(N, generator=g) + 0.5, torch.randn(M, N, generator=g)
+    assert _lib.load().dkd_gemm_f32_workspace_bytes(M, N, K, 0, 0) > 0     # the peel is planned for this shape ...
+    assert _lib.load().dkd_gemm_f32_workspace_bytes(M - 64, N, K, 0, 0) == 0  # ... and not for whole rounds
+    xd, wd, bd, csd, resd = dev(x), dev(w), dev(b), dev(cs), dev(res)
+    ref_pre = (x.double() @ w.double().t() + b.double())
+    pre = torch.empty(M, N, device="cuda")
+    out = ops.gemm(xd, wd, bias=bd, act=ops.ACT_GELU, colscale=csd, residual=resd, preact=pre)
+    close(pre, ref_pre, "preact", rtol=2e-5)
+    close(out, F.gelu(ref_pre) * cs + res, "bias + gelu + colscale + residual", rtol=2e-5)
+    close(out[-64:], (F.gelu(ref_pre) * cs + res)[-64:], "the peeled rows", rtol=2e-5)
+    out2 = ops.gemm(xd, wd, bias=bd, act=ops.ACT_GELU, colscale=csd, residual=resd)
+    assert torch.equal(out, out2)
+    plain = ops.gemm(xd, wd)
+    whole = ops.gemm(xd[:-64], wd)   # 256 tile rows: no peel
+    assert torch.equal(plain[:-64], whole)
+    close(plain[-64:], (x[-64:].double() @ w.double().t()), "peeled rows, no epilogue", rtol=2e-5)
+
+
 def test_gemm_epilogues(ops):
     g = torch.Generator().manual_seed(7)
     M, N, K = 514, 384, 96
