@@ -99,10 +99,35 @@ class HbmProfiler:
             for k, v in pmc.items():
                 if k.startswith(name):
                     traffic = v.get("traffic_bytes")
-            out.append({"kernel": name + "_kernel (csrc/loss.hip)", "bound": "hbm", "achieved": round(by / us * 1e-3, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(by / us * 1e-3 / 8000.0, 4), "traffic": traffic,
-                        "avg_launch_us": round(us, 2), "bytes_per_launch": int(by), "launches": len(recs)})
+            row = {"kernel": name + "_kernel (csrc/loss.hip)", "bound": "hbm", "achieved": round(by / us * 1e-3, 1), "peak": 8000.0,
+                   "unit": "GB/s", "frac": round(by / us * 1e-3 / 8000.0, 4), "traffic": traffic,
+                   "avg_launch_us": round(us, 2), "bytes_per_launch": int(by), "launches": len(recs),
+                   "note": "avg_launch_us: HIP events around the C-ABI call (the loss kernel" +
+                           (" AND its 4-5 us fold kernel kd_loss_final" if name == "kd_loss_fwd" else "") +
+                           ", plus the event records themselves) on one stream"}
+            kus = profiled_kernel_us(name + "_kernel")
+            if kus:  # the kernel's own duration from the committed rocprofv3 trace of this command (same shapes)
+                row.update({"kernel_us_rocprof": round(kus, 2), "kernel_frac_rocprof": round(by / kus * 1e-3 / 8000.0, 4),
+                            "kernel_us_source": "profiles/" + STATS_FILE})
+            out.append(row)
         return out
+
+
+STATS_FILE = "r02_bench_bs64_serial_kernel_stats.csv"
+
+
+def profiled_kernel_us(prefix):
+    """call-weighted average duration (us) of the kernels whose name contains `prefix` in the committed rocprofv3 --stats summary"""
+    import csv
+    path = os.path.join(ROOT, "profiles", STATS_FILE)
+    if not os.path.exists(path):
+        return None
+    calls = tot = 0
+    for r in csv.DictReader(open(path)):
+        if prefix in r["Name"]:
+            calls += int(r["Calls"])
+            tot += int(r["TotalDurationNs"])
+    return tot / calls * 1e-3 if calls else None
 
 
 def cpu_share():

@@ -42,10 +42,11 @@ for k, v in exposed.most_common(18):
     print("  %7.3f ms  %s" % (v / 1e6, k[:110]))
 # the largest gaps with nothing running at all: what ends before / starts after them
 gaps = []
-cur_end = t0
+cur_end, prev_n = t0, '(step start)'
 for s_, e_, n_, q_ in sorted(step):
     if s_ > cur_end: gaps.append((s_ - cur_end, cur_end - t0, prev_n, n_))
     if e_ > cur_end: cur_end, prev_n = e_, n_
 print("largest idle gaps:")
-for d, at, a, b in sorted(gaps, reverse=True)[:12]:
+print("  %d gaps, %.2f ms in total; %d gaps over 20 us = %.2f ms" % (len(gaps), sum(g[0] for g in gaps) / 1e6, sum(g[0] > 20000 for g in gaps), sum(g[0] for g in gaps if g[0] > 20000) / 1e6))
+for d, at, a, b in sorted(gaps, reverse=True)[:25]:
     print("  %6.1f us at +%.2f ms   after %s   before %s" % (d / 1e3, at / 1e6, a[:50], b[:50]))
