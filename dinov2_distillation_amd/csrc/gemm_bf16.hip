@@ -3,8 +3,9 @@
 // ROUNDS ITS OUTPUT to 16 bit; LayerNorm, softmax and the residual stream stay fp32).  bf16 instead of fp16: native on the
 // MI355X matrix cores at the same rate, fp32's exponent range, no loss scaling.
 //
-//   C = epi(A[M,K] . B[N,K]^T)      A, B: bf16, K-contiguous (activations / nn.Linear weights); fp32 accumulation on
-//                                   v_mfma_f32_32x32x16_bf16
+//   C = epi(Aop[M,K] . Bop[N,K]^T)  A, B: bf16; a_layout / b_layout 0: K-contiguous ([M][K] activations, [N][K] nn.Linear
+//                                   weights), 1: stored [K][M] / [K][N] (dgrad: dx = dy W; weight gradient: dW = dy^T x, with
+//                                   K-slabs folded in a fixed order); fp32 accumulation on v_mfma_f32_32x32x16_bf16
 //   EPI_BF16        C bf16 = rnd(acc + bias)                                    (qkv, w12)
 //   EPI_BF16_GELU   C bf16 = rnd(gelu(rnd(acc + bias)))                         (fc1: F.gelu on a bf16 tensor rounds again)
 //   EPI_F32_RESID   C f32  = residual + colscale * rnd(acc + bias)              (proj / fc2 / w3 + LayerScale + residual; the
@@ -35,8 +36,36 @@ __device__ __forceinline__ int xcd_remap_b(int bid, int nblk) {
 
 __device__ __forceinline__ float rnd_bf16(float v) { return (float)(__bf16)v; }
 
-template <int EPI>
-__global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g) {
+// ---- operands that are NOT contiguous along the reduction (dgrad: W stored [N_out][K_in] is the [K][N] operand; weight
+// gradient: dY [rows][N_out] and X [rows][K_in] are [K][M] and [K][N]) ----------------------------------------------------
+// Their LDS image is the global tile as it lies, [64 k][128 m|n] bf16 in 256-byte rows, and the MFMA fragment (8 consecutive
+// k for the lane's row) is gathered by gfx950's transposing read ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16
+// lanes a 4 (k) x 16 (m) block is delivered column-major, lane 4q+p of the group supplying the address of block row q,
+// elements 4p .. 4p+3, lane i receiving column i.  Two reads (k 8h .. 8h+3, 8h+4 .. 8h+7) make one operand.  The 16-byte
+// chunk index is XOR-ed with ((k&3)<<2 | (k>>2)&3) (T10 image (b)): conflict-free transposed reads AND 16-byte stores.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ int tr_off(int row, int ch) {  // byte offset of 16-byte chunk ch (0..15) of k-row `row`
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+// fragment of the 32 rows starting at column c0 (multiple of 32) of the [64][128] image, k-block ks (16 k): 8 consecutive k
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* __restrict__ S, int c0, int ks, int lane) {
+    const int half = lane >> 5, cb = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const int ch = (c0 >> 3) + 2 * cb + (p >> 1);
+    const char* base = reinterpret_cast<const char*>(S);
+    const int r0 = 16 * ks + 8 * half + q;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + tr_off(r0, ch) + 8 * (p & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + tr_off(r0 + 4, ch) + 8 * (p & 1)));
+    union { s16x4 v[2]; bf16x8 f; } u;
+    u.v[0] = lo;
+    u.v[1] = hi;
+    return u.f;
+}
+
+template <int EPI, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int kchunk) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[(BM + BN) * RS];
     __bf16* As = smem;
     __bf16* Bs = smem + BM * RS;
@@ -47,6 +76,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g) {
     const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
     const int tile = xcd_remap_b(blockIdx.x, nbm * nbn);
     const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+    const int kbeg = blockIdx.y * kchunk, kend = min(g.K, kbeg + kchunk);
 
     f32x16 acc[2];
 #pragma unroll
@@ -54,38 +84,55 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // staging: a tile is 128 rows x 64 bf16 = 1024 16-byte pieces; thread t moves pieces t and t + 512 of A and of B
+    // staging: a tile is 1024 16-byte pieces per operand; thread t moves pieces t and t + 512 of A and of B.
+    // K-contiguous operand: piece = (row t/8 [+64], k (t%8)*8); otherwise piece = (k-row t/16 [+32], chunk t%16)
     uint4 ra[2], rb[2];
-    const int pr = tid >> 3, pk = (tid & 7) * 8;  // row 0..63 (+64 for the second piece), k offset in bf16
+    const int pr = tid >> 3, pk = (tid & 7) * 8;
+    const int tr = tid >> 4, tc = tid & 15;
     auto load = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = pr + 64 * i;
-            const int gm = bm0 + r, gn = bn0 + r, gk = k0 + pk;
-            ra[i] = (gm < g.M && gk < g.K) ? *reinterpret_cast<const uint4*>(A + (long)gm * g.lda + gk) : make_uint4(0, 0, 0, 0);
-            rb[i] = (gn < g.N && gk < g.K) ? *reinterpret_cast<const uint4*>(B + (long)gn * g.ldb + gk) : make_uint4(0, 0, 0, 0);
+            if (A_KC) {
+                const int gm = bm0 + pr + 64 * i, gk = k0 + pk;
+                ra[i] = (gm < g.M && gk < kend) ? *reinterpret_cast<const uint4*>(A + (long)gm * g.lda + gk) : make_uint4(0, 0, 0, 0);
+            } else {
+                const int gk = k0 + tr + 32 * i, gm = bm0 + 8 * tc;
+                ra[i] = (gk < kend && gm < g.M) ? *reinterpret_cast<const uint4*>(A + (long)gk * g.lda + gm) : make_uint4(0, 0, 0, 0);
+            }
+            if (B_KC) {
+                const int gn = bn0 + pr + 64 * i, gk = k0 + pk;
+                rb[i] = (gn < g.N && gk < kend) ? *reinterpret_cast<const uint4*>(B + (long)gn * g.ldb + gk) : make_uint4(0, 0, 0, 0);
+            } else {
+                const int gk = k0 + tr + 32 * i, gn = bn0 + 8 * tc;
+                rb[i] = (gk < kend && gn < g.N) ? *reinterpret_cast<const uint4*>(B + (long)gk * g.ldb + gn) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
     auto store = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = pr + 64 * i;
-            *reinterpret_cast<uint4*>(As + r * RS + pk) = ra[i];
-            *reinterpret_cast<uint4*>(Bs + r * RS + pk) = rb[i];
+            if (A_KC) *reinterpret_cast<uint4*>(As + (pr + 64 * i) * RS + pk) = ra[i];
+            else *reinterpret_cast<uint4*>(reinterpret_cast<char*>(As) + tr_off(tr + 32 * i, tc)) = ra[i];
+            if (B_KC) *reinterpret_cast<uint4*>(Bs + (pr + 64 * i) * RS + pk) = rb[i];
+            else *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Bs) + tr_off(tr + 32 * i, tc)) = rb[i];
         }
     };
-    const int nk = (g.K + BK - 1) / BK;
-    load(0);
-    store();
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load(kbeg);
+        store();
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load((kt + 1) * BK);
+        if (kt + 1 < nk) load(kbeg + (kt + 1) * BK);
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + l31) * RS + ks * 16 + half * 8);
+            const bf16x8 a = A_KC ? *reinterpret_cast<const bf16x8*>(As + (wm * 32 + l31) * RS + ks * 16 + half * 8)
+                                  : tr_frag(As, wm * 32, ks, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + j * 32 + l31) * RS + ks * 16 + half * 8);
+                const bf16x8 b = B_KC ? *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + j * 32 + l31) * RS + ks * 16 + half * 8)
+                                      : tr_frag(Bs, wn * 64 + j * 32, ks, lane);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[j], 0, 0, 0);  // D^T: rows = n, columns (lanes) = m
             }
         }
@@ -96,6 +143,18 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g) {
     // epilogue: lane (l31, half) owns output row m and, per register quad q, the columns n0 + 8q + 4 half + (0..3)
     const int m = bm0 + wm * 32 + l31;
     if (m >= g.M) return;
+    if (EPI == DKD_BF16_EPI_PARTIAL) {  // raw fp32 partial sums of this K-slab: workspace [slab][M][N]
+        float* out = g.workspace + ((long)blockIdx.y * g.M + m) * g.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * half;
+                if (n < g.N)
+                    *reinterpret_cast<float4*>(out + n) = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+            }
+        return;
+    }
     long orow = m;
     if (g.row_grp > 0) orow = (long)(m / g.row_grp) * g.row_grp_stride + (m % g.row_grp) + g.row_off;
     const __bf16* __restrict__ bias = reinterpret_cast<const __bf16*>(g.bias);
@@ -135,6 +194,26 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + orow * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+}
+
+// fold of the K-slab partials: out = rnd_bf16(sum over slabs, fixed order) as bf16 or as fp32 holding the bf16 value (what
+// autocast leaves in an fp32 master gradient: the bf16 result of the backward matmul, cast up)
+template <bool OUT_BF16>
+__global__ void bf16_fold_kernel(const float* __restrict__ ws, int slabs, long total4, void* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const float4* p = reinterpret_cast<const float4*>(ws) + i;
+        float4 s = p[0];
+        for (int z = 1; z < slabs; ++z) {
+            const float4 a = p[(long)z * total4];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        if (OUT_BF16) {
+            const bf16x4 o = {(__bf16)s.x, (__bf16)s.y, (__bf16)s.z, (__bf16)s.w};
+            reinterpret_cast<bf16x4*>(out)[i] = o;
+        } else {
+            reinterpret_cast<float4*>(out)[i] = make_float4(rnd_bf16(s.x), rnd_bf16(s.y), rnd_bf16(s.z), rnd_bf16(s.w));
+        }
+    }
 }
 
 // fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even), columns cols .. out_ld-1 zero-filled (K padding)
@@ -183,24 +262,70 @@ int blocks_1d(long total) {
 }
 }  // namespace
 
+// K-slabs: only when the output grid alone cannot fill the chip (weight gradients: small M x N, reduction over all rows)
+static int bf16_slabs(int M, int N, int K) {
+    const long tiles = (long)dkd_cdiv(M, BM) * dkd_cdiv(N, BN);
+    if (tiles >= 256 || K < 2048) return 1;
+    long want = (512 + tiles - 1) / tiles, maxk = K / 512;  // >= 8 k-tiles of 64 per slab
+    if (maxk < 1) maxk = 1;
+    long sp = want < maxk ? want : maxk;
+    if (sp > 64) sp = 64;
+    return (int)(sp < 1 ? 1 : sp);
+}
+
+extern "C" long dkd_gemm_bf16_workspace_bytes(int M, int N, int K) {
+    const int sp = bf16_slabs(M, N, K);
+    return sp > 1 ? (long)sp * M * N * sizeof(float) : 0;
+}
+
 extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
     if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0) return DKD_ERR_BAD_ARG;
-    if ((g->K & 7) || (g->lda & 7) || (g->ldb & 7) || (g->N & 3) || (g->ldc & 3)) return DKD_ERR_ALIGN;
+    if ((g->a_layout | g->b_layout) & ~1) return DKD_ERR_BAD_ARG;
+    // 16-byte staging pieces: the contiguous extent of each operand and its leading dimension are multiples of 8 bf16
+    const int a_contig = g->a_layout == 0 ? g->K : g->M, b_contig = g->b_layout == 0 ? g->K : g->N;
+    if ((a_contig & 7) || (b_contig & 7) || (g->lda & 7) || (g->ldb & 7) || (g->N & 3) || (g->ldc & 3)) return DKD_ERR_ALIGN;
     if (!dkd_aligned16(g->A) || !dkd_aligned16(g->B) || !dkd_aligned16(g->C)) return DKD_ERR_ALIGN;
     if (g->residual && ((g->ldr & 3) || !dkd_aligned16(g->residual))) return DKD_ERR_ALIGN;
     if (g->colscale && !dkd_aligned16(g->colscale)) return DKD_ERR_ALIGN;
     const bool f32_out = g->epi == DKD_BF16_EPI_F32_RESID || g->epi == DKD_BF16_EPI_F32;
     if (!f32_out && (g->residual || g->colscale)) return DKD_ERR_BAD_ARG;
-    const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN)), block(NT);
     hipStream_t st = (hipStream_t)stream;
-    switch (g->epi) {
-        case DKD_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<DKD_BF16_EPI_BF16>, grid, block, 0, st, *g); break;
-        case DKD_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<DKD_BF16_EPI_BF16_GELU>, grid, block, 0, st, *g); break;
-        case DKD_BF16_EPI_F32_RESID:
-        case DKD_BF16_EPI_F32: hipLaunchKernelGGL(gemm_bf16_kernel<DKD_BF16_EPI_F32>, grid, block, 0, st, *g); break;
+    // K-slabs with a fold: plain outputs only (weight gradients; no bias / residual / row map)
+    int slabs = 1;
+    const bool plain = !g->bias && !g->residual && !g->colscale && g->row_grp == 0 && g->ldc == g->N &&
+                       (g->epi == DKD_BF16_EPI_BF16 || g->epi == DKD_BF16_EPI_F32);
+    if (plain && g->workspace && dkd_aligned16(g->workspace)) slabs = bf16_slabs(g->M, g->N, g->K);
+    int kchunk = g->K;
+    if (slabs > 1) {
+        kchunk = ((g->K + slabs - 1) / slabs + BK - 1) / BK * BK;
+        slabs = dkd_cdiv(g->K, kchunk);
+    }
+    const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), slabs), block(NT);
+    const int epi = slabs > 1 ? DKD_BF16_EPI_PARTIAL : (g->epi == DKD_BF16_EPI_F32_RESID ? DKD_BF16_EPI_F32 : g->epi);
+#define DKD_BF16_LAUNCH(E)                                                                                             \
+    do {                                                                                                               \
+        if (g->a_layout == 0 && g->b_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<E, true, true>), grid, block, 0, st, *g, kchunk); \
+        else if (g->a_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<E, true, false>), grid, block, 0, st, *g, kchunk);               \
+        else if (g->b_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<E, false, true>), grid, block, 0, st, *g, kchunk);               \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<E, false, false>), grid, block, 0, st, *g, kchunk);                                    \
+    } while (0)
+    switch (epi) {
+        case DKD_BF16_EPI_BF16: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16); break;
+        case DKD_BF16_EPI_BF16_GELU: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16_GELU); break;
+        case DKD_BF16_EPI_F32: DKD_BF16_LAUNCH(DKD_BF16_EPI_F32); break;
+        case DKD_BF16_EPI_PARTIAL: DKD_BF16_LAUNCH(DKD_BF16_EPI_PARTIAL); break;
         default: return DKD_ERR_BAD_ARG;
     }
+#undef DKD_BF16_LAUNCH
     DKD_LAUNCH_CHECK();
+    if (slabs > 1) {
+        const long total4 = (long)g->M * g->N / 4;
+        if (g->epi == DKD_BF16_EPI_BF16)
+            hipLaunchKernelGGL(bf16_fold_kernel<true>, dim3(blocks_1d(total4)), dim3(256), 0, st, g->workspace, slabs, total4, g->C);
+        else
+            hipLaunchKernelGGL(bf16_fold_kernel<false>, dim3(blocks_1d(total4)), dim3(256), 0, st, g->workspace, slabs, total4, g->C);
+        DKD_LAUNCH_CHECK();
+    }
     return DKD_OK;
 }
 

@@ -830,15 +830,20 @@ def _chk16(t, name):
         raise _lib.DkdError(f"{name}: expected a contiguous CUDA(HIP) bfloat16 tensor, got {t.device} {t.dtype} {tuple(t.stride())}")
 
 
-def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, res_mod=0, row_map=None, out=None):
-    """out = epi(a[M,K] @ w[N,K]^T), bf16 operands, fp32 accumulate, the Linear's output rounded to bf16 (see dkd_hip.h).
-    a, w, bias: bfloat16; colscale / residual: float32; out: bfloat16 for EPI_BF16 / EPI_BF16_GELU, float32 otherwise."""
+def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, res_mod=0, row_map=None, out=None,
+              a_layout=0, b_layout=0, ws_slot=0):
+    """out = epi(Aop[M,K] @ Bop[N,K]^T), bf16 operands, fp32 accumulate, the result rounded to bf16 (see dkd_hip.h).
+    a_layout 0: a is [M,K]; 1: a is [K,M].  b_layout 0: w is [N,K]; 1: w is [K,N] (dgrad: dx = dy W; weight gradient
+    dW = dy^T x: a_layout = b_layout = 1).  a, w, bias: bfloat16; colscale / residual: float32; out: bfloat16 for
+    EPI_BF16 / EPI_BF16_GELU, float32 otherwise."""
     _chk16(a, "a"), _chk16(w, "w"), _chk16(bias, "bias"), _chk(colscale, "colscale"), _chk(residual, "residual")
     a2 = a.reshape(-1, a.shape[-1])
-    M, K = a2.shape
-    N = w.shape[0]
-    if w.shape[1] != K:
-        raise _lib.DkdError(f"gemm_bf16: reduction extents differ: {K} vs {w.shape[1]}")
+    w2 = w.reshape(-1, w.shape[-1])
+    M, K = (a2.shape[0], a2.shape[1]) if a_layout == 0 else (a2.shape[1], a2.shape[0])
+    N, Kb = (w2.shape[0], w2.shape[1]) if b_layout == 0 else (w2.shape[1], w2.shape[0])
+    if Kb != K:
+        raise _lib.DkdError(f"gemm_bf16: reduction extents differ: {K} vs {Kb}")
+    lib = _lib.binding()
     g = _lib.args("dkd_gemm_bf16_args")
     out_rows = M
     if row_map is not None:
@@ -848,10 +853,12 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
         out = torch.empty((out_rows, N), dtype=torch.float32 if f32_out else BF16, device=a.device)
     if out.dtype != (torch.float32 if f32_out else BF16) or not out.is_contiguous():
         raise _lib.DkdError("gemm_bf16: out has the wrong dtype / layout for this epilogue")
-    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), K, _p(w), K, _p(out), N
-    g.bias, g.colscale, g.residual, g.ldr = _p(bias), _p(colscale), _p(residual), N
-    g.M, g.N, g.K, g.epi, g.res_mod = M, N, K, epi, res_mod
-    check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[{M}x{N}x{K} epi {epi}]")
+    wsb = lib.dkd_gemm_bf16_workspace_bytes(M, N, K)
+    ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
+    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), a2.shape[1], _p(w2), w2.shape[1], _p(out), N
+    g.bias, g.colscale, g.residual, g.ldr, g.workspace = _p(bias), _p(colscale), _p(residual), N, _p(ws)
+    g.M, g.N, g.K, g.epi, g.res_mod, g.a_layout, g.b_layout = M, N, K, epi, res_mod, a_layout, b_layout
+    check(lib.dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[{M}x{N}x{K} a{a_layout} b{b_layout} epi {epi}]")
     return out
 
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DKD_ABI_VERSION 2
+#define DKD_ABI_VERSION 3
 int dkd_abi_version(void);
 
 /* activation codes for fused epilogues */
@@ -172,6 +172,13 @@ int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const 
 #define DKD_BF16_EPI_BF16_GELU 1
 #define DKD_BF16_EPI_F32_RESID 2
 #define DKD_BF16_EPI_F32 3
+#define DKD_BF16_EPI_PARTIAL 4 /* internal: raw fp32 K-slab partial sums into `workspace` */
+/* a_layout / b_layout as in dkd_gemm_args: 0 = [M][K] / [N][K] (reduction contiguous), 1 = [K][M] / [K][N] (the operand as it
+ * lies for dx = dy W and for dW = dy^T x; the contiguous extent then has to be a multiple of 8).  `workspace` (fp32,
+ * dkd_gemm_bf16_workspace_bytes; may be NULL) lets a launch whose output grid cannot fill the chip split the reduction into
+ * K-slabs folded in a fixed order; only for the plain epilogues (DKD_BF16_EPI_BF16 / _F32 without bias, residual, colscale,
+ * row map, ldc == N): the weight gradients.  With DKD_BF16_EPI_F32 the result is the bf16-rounded value held in fp32 - what
+ * autocast leaves in an fp32 master gradient. */
 typedef struct dkd_gemm_bf16_args {
     const void* A; int64_t lda;
     const void* B; int64_t ldb;
@@ -179,10 +186,13 @@ typedef struct dkd_gemm_bf16_args {
     const void* bias;
     const float* colscale;
     const float* residual; int64_t ldr;
+    float* workspace;
     int32_t M, N, K;
     int32_t epi, res_mod, row_grp, row_grp_stride, row_off;
+    int32_t a_layout, b_layout;
 } dkd_gemm_bf16_args;
 int dkd_gemm_bf16(const dkd_gemm_bf16_args* args, void* stream);
+long dkd_gemm_bf16_workspace_bytes(int M, int N, int K);
 /* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588
  * patch rows to a multiple of 8) */
 int dkd_cast_bf16(const float* in, void* out_bf16, long rows, int cols, int out_ld, void* stream);

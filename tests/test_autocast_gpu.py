@@ -51,6 +51,45 @@ def test_gemm_bf16_epilogues(M, N, K):
     assert torch.equal(o3, o3.bfloat16().float())  # every stored value IS a bf16 value
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (8224, 384, 1536), (1000, 1152, 384), (520, 136, 592)])
+def test_gemm_bf16_dgrad_and_wgrad_layouts(M, N, K):
+    """the backward matmuls of a 16-bit Linear y[M,N] = x[M,K] W[N,K]^T with the operands AS THEY LIE: dx = dy W (W is the
+    [K][N] operand of a reduction over N) and dW = dy^T x (both operands [rows][.], reduction over the rows; K-slabs when the
+    small output cannot fill the chip).  Fragments come from transposing LDS reads: the operands are asymmetric on purpose."""
+    from dinov2_distillation_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    w[:, 0] += torch.arange(N).bfloat16() * 0.01
+    dy = torch.randn(M, N, generator=g).bfloat16()
+    dy[:, 1] += (torch.arange(M) % 7).bfloat16() * 0.1
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    dx = ops.gemm_bf16(dyd, wd, b_layout=1)                                   # [M, K] = dy[M, N] . W[N, K]
+    assert dx.dtype == torch.bfloat16 and dx.shape == (M, K)
+    ulp_close(dx, (dy.double() @ w.double()).float().bfloat16(), "dgrad (NN)")
+    dw = ops.gemm_bf16(dyd, xd, a_layout=1, b_layout=1, epi=ops.EPI_F32)     # [N, K] = dy^T x, fp32 holding the bf16 value
+    assert dw.dtype == torch.float32 and dw.shape == (N, K)
+    ref = (dy.double().t() @ x.double()).float()
+    ulp_close(dw, r16(ref), "wgrad (TN), fp32 out holding bf16 values")
+    assert torch.equal(dw, dw.bfloat16().float())
+    dw16 = ops.gemm_bf16(dyd, xd, a_layout=1, b_layout=1)
+    assert torch.equal(dw16.float(), dw) and torch.equal(ops.gemm_bf16(dyd, xd, a_layout=1, b_layout=1).float(), dw)  # reproducible
+    yt = ops.gemm_bf16(xd.t().contiguous(), wd, a_layout=1)                  # A stored [K][M], B [N][K]
+    ulp_close(yt, (x.double() @ w.double().t()).float().bfloat16(), "A km / B nk")
+
+
+def test_gemm_bf16_wgrad_takes_k_slabs_on_step_shapes():
+    from dinov2_distillation_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.dkd_gemm_bf16_workspace_bytes(1536, 384, 12544) > 0 and lib.dkd_gemm_bf16_workspace_bytes(12544, 1536, 384) == 0
+    g = torch.Generator().manual_seed(5)
+    rows, n_out, k_in = 12544, 1536, 384
+    dy, x = (torch.randn(rows, n_out, generator=g) * 0.1).bfloat16(), torch.randn(rows, k_in, generator=g).bfloat16()
+    dw = ops.gemm_bf16(dy.cuda(), x.cuda(), a_layout=1, b_layout=1, epi=ops.EPI_F32)
+    ulp_close(dw, r16((dy.double().t() @ x.double()).float()), "split wgrad")
+    assert torch.equal(dw, ops.gemm_bf16(dy.cuda(), x.cuda(), a_layout=1, b_layout=1, epi=ops.EPI_F32))
+
+
 def test_gemm_bf16_row_map_and_periodic_residual():
     """the patch-embed form: rows scattered past a CLS slot per image, position table added with period n"""
     from dinov2_distillation_amd import ops
