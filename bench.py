@@ -340,6 +340,24 @@ def main():
                               "trainable exact fp32", "value": round(args.batch * world * args.steps / dta, 2), "unit": "images/s",
             "ms_per_step": round(dta / args.steps * 1e3, 3)}
         del st16
+        # ... and with the ConvNeXt student under the same policy too (bf16 activations in HBM, bf16 MFMA GEMMs in all three
+        # roles, functional16.py); the ScaleKD projectors, block re-use, losses and the optimiser stay exact fp32
+        st16 = DistillationStepper(device=f"cuda:{local}", teacher_precision="bf16_autocast", student_precision="bf16_autocast")
+        for _ in range(3):
+            st16.step(batch)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            st16.step(batch)
+        sync()
+        dta = time.perf_counter() - t1
+        alts["alt_bf16_autocast_teacher_student"] = {
+            "gemm_precision": "teacher forward AND student backbone forward / backward under the autocast op policy in bf16 (bf16 "
+                              "activations in HBM, bf16 MFMA GEMMs, fp32 LayerNorm / GRN statistics / master weights; "
+                              "tests/test_autocast_gpu.py: layer by layer against torch.autocast on the oracle); projectors, "
+                              "losses, optimiser exact fp32", "value": round(args.batch * world * args.steps / dta, 2),
+            "unit": "images/s", "ms_per_step": round(dta / args.steps * 1e3, 3)}
+        del st16
     note(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank != 0:
         if world > 1:

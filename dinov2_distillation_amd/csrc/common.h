@@ -21,6 +21,30 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- 4-element accesses for tensors that live in HBM as fp32 or as bf16 (the mixed-precision step keeps the activations that
+// torch autocast keeps in 16 bit as bf16; arithmetic is fp32 everywhere).  Index in units of 4 elements.
+typedef __bf16 dkd_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p, long i) { return reinterpret_cast<const float4*>(p)[i]; }
+__device__ __forceinline__ float4 ld4(const __bf16* p, long i) {
+    const dkd_bf16x4 v = reinterpret_cast<const dkd_bf16x4*>(p)[i];
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(float* p, long i, const float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
+__device__ __forceinline__ void st4(__bf16* p, long i, const float4 v) {
+    const dkd_bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    reinterpret_cast<dkd_bf16x4*>(p)[i] = o;
+}
+__device__ __forceinline__ float rnd16(float v) { return (float)(__bf16)v; }  // round to the nearest bf16 (ties to even)
+__device__ __forceinline__ float4 rnd16(const float4 v) { return make_float4(rnd16(v.x), rnd16(v.y), rnd16(v.z), rnd16(v.w)); }
+template <typename T> struct dkd_is16 { static constexpr bool value = false; };
+template <> struct dkd_is16<__bf16> { static constexpr bool value = true; };
+// host-side dispatch on a "this tensor is bf16" flag: binds the element type to NAME inside the block
+#define DKD_IO_TYPE(flag, NAME, ...)              \
+    do {                                          \
+        if (flag) { using NAME = __bf16; __VA_ARGS__; } \
+        else { using NAME = float; __VA_ARGS__; } \
+    } while (0)
+
 static inline int dkd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool dkd_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

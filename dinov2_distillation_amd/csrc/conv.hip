@@ -20,13 +20,15 @@ __device__ __forceinline__ void fma4(float4& a, const float4 w, const float4 x) 
 // addresses are 32-bit float4 indices off the wave-uniform tensor base (one add per load instead of a 64-bit multiply-add
 // chain; the launcher checks the tensor has < 2^32 float4), out-of-range columns are loaded from the clamped column and
 // zeroed afterwards only in the threads of the first / last strip of a row.
-template <bool FLIP>
-__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ wt,
-                                                      const float* __restrict__ bias, const float* __restrict__ add,
-                                                      float* __restrict__ out, int B, int H, int W, int C) {
+// TI / TA / TO: element types of the input, of the optional addend and of the output (float or __bf16, common.h).  A bf16
+// output is rounded once after the taps (the convolution's own 16-bit result) and again after the addend (the 16-bit sum
+// autograd forms when it accumulates the two gradients), as the autocast step does.
+template <bool FLIP, typename TI = float, typename TA = float, typename TO = float>
+__global__ __launch_bounds__(256) void dwconv7_kernel(const TI* __restrict__ in, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias, const TA* __restrict__ add,
+                                                      TO* __restrict__ out, int B, int H, int W, int C) {
     const unsigned cq = C >> 2, xt = (W + 6) / 7;
     const unsigned total = (unsigned)B * H * xt * cq;  // < 2^32 (launcher): the index split below stays in 32-bit division
-    const float4* in4 = reinterpret_cast<const float4*>(in);
     const float4* w4 = reinterpret_cast<const float4*>(wt);
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const unsigned c4 = idx % cq;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
             const unsigned rowb = (unsigned)((b * H + yy) * W) * (unsigned)cq;
             float4 v[13];
 #pragma unroll
-            for (int k = 0; k < 13; ++k) v[k] = in4[rowb + xo[k]];
+            for (int k = 0; k < 13; ++k) v[k] = ld4(in, rowb + xo[k]);
             if (edge) {
 #pragma unroll
                 for (int k = 0; k < 13; ++k)
@@ -64,17 +66,16 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
             }
         }
         const unsigned ob = (unsigned)((b * H + y) * W + x0) * (unsigned)cq + c4;
-        float4* o4 = reinterpret_cast<float4*>(out);
-        const float4* a4 = reinterpret_cast<const float4*>(add);
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             if (x0 + k >= W) break;
             float4 o = acc[k];
             if (add) {
-                const float4 a = a4[ob + (unsigned)k * cq];
+                if (dkd_is16<TI>::value) o = rnd16(o);
+                const float4 a = ld4(add, ob + (unsigned)k * cq);
                 o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
             }
-            o4[ob + (unsigned)k * cq] = o;
+            st4(out, ob + (unsigned)k * cq, o);
         }
     }
 }
@@ -86,14 +87,13 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
 //   * a thread produces RY output rows x 7 columns: an input row is loaded once and feeds up to RY tap rows (vertical
 //     reuse: (RY + 6) / RY input rows per output row instead of 7).
 // block = CB channel quads x SP spatial tiles (CB * SP <= 256), grid.y = channel chunks, grid.x strides over the tiles.
-template <bool FLIP, int RY, int XW>
-__global__ __launch_bounds__(256) void dwconv7_lds_kernel(const float* __restrict__ in, const float* __restrict__ wt,
-                                                          const float* __restrict__ bias, const float* __restrict__ add,
-                                                          float* __restrict__ out, int B, int H, int W, int C, int CB, int SP) {
+template <bool FLIP, int RY, int XW, typename TI = float, typename TA = float, typename TO = float>
+__global__ __launch_bounds__(256) void dwconv7_lds_kernel(const TI* __restrict__ in, const float* __restrict__ wt,
+                                                          const float* __restrict__ bias, const TA* __restrict__ add,
+                                                          TO* __restrict__ out, int B, int H, int W, int C, int CB, int SP) {
     extern __shared__ float4 wl[];  // [49][CB], already flipped for the dgrad form
     const unsigned cq = C >> 2, xt = (W + XW - 1) / XW, nyb = (H + RY - 1) / RY;
     const unsigned c40 = blockIdx.y * CB;
-    const float4* in4 = reinterpret_cast<const float4*>(in);
     const float4* w4 = reinterpret_cast<const float4*>(wt);
     for (unsigned t = threadIdx.x; t < 49u * CB; t += 256) {
         const unsigned tap = t / CB, cc = t % CB;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void dwconv7_lds_kernel(const float* __restric
             const unsigned rowb = (unsigned)((b * H + yy) * W) * cq;
             float4 v[XW + 6];
 #pragma unroll
-            for (int k = 0; k < XW + 6; ++k) v[k] = in4[rowb + xo[k]];
+            for (int k = 0; k < XW + 6; ++k) v[k] = ld4(in, rowb + xo[k]);
             if (edge) {
 #pragma unroll
                 for (int k = 0; k < XW + 6; ++k)
@@ -144,8 +144,6 @@ __global__ __launch_bounds__(256) void dwconv7_lds_kernel(const float* __restric
                 }
             }
         }
-        float4* o4 = reinterpret_cast<float4*>(out);
-        const float4* a4 = reinterpret_cast<const float4*>(add);
 #pragma unroll
         for (int ro = 0; ro < RY; ++ro) {
             if (y0 + ro >= H) break;
@@ -155,10 +153,11 @@ __global__ __launch_bounds__(256) void dwconv7_lds_kernel(const float* __restric
                 if (x0 + k >= W) break;
                 float4 o = acc[ro][k];
                 if (add) {
-                    const float4 a = a4[ob + (unsigned)k * cq];
+                    if (dkd_is16<TI>::value) o = rnd16(o);
+                    const float4 a = ld4(add, ob + (unsigned)k * cq);
                     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
                 }
-                o4[ob + (unsigned)k * cq] = o;
+                st4(out, ob + (unsigned)k * cq, o);
             }
         }
     }
@@ -166,7 +165,8 @@ __global__ __launch_bounds__(256) void dwconv7_lds_kernel(const float* __restric
 
 // wgrad partials: thread = (channel quad, tap row i, image, RY consecutive output rows); 7 float4 running sums, the input
 // row slides through a 7-wide register window.  part[(b*ny + yc)][tap][c]
-__global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+template <typename TI = float, typename TD = float>
+__global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const TI* __restrict__ in, const TD* __restrict__ dout,
                                                             float* __restrict__ part, int B, int H, int W, int C,
                                                             int RY) {
     const int ny = (H + RY - 1) / RY, cq = C >> 2;
@@ -181,22 +181,21 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restr
         float4 acc[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc[j] = zero;
-        const float4* inb = reinterpret_cast<const float4*>(in) + (long)b * H * W * cq + c4;
-        const float4* db = reinterpret_cast<const float4*>(dout) + (long)b * H * W * cq + c4;
+        const long inb = (long)b * H * W * cq + c4, db = inb;  // 4-element index of (b, 0, 0, c4) in x and in dout
         const int y1 = min(H, (yc + 1) * RY);
         for (int y = yc * RY; y < y1; ++y) {
             const int yy = y + i - 3;
             if (yy < 0 || yy >= H) continue;
-            const float4* irow = inb + (long)yy * W * cq;
-            const float4* drow = db + (long)y * W * cq;
+            const long irow = inb + (long)yy * W * cq;
+            const long drow = db + (long)y * W * cq;
             float4 win[7];  // in[yy][x-3 .. x+3]
 #pragma unroll
-            for (int j = 0; j < 6; ++j) win[j + 1] = (j - 3 >= 0 && j - 3 < W) ? irow[(long)(j - 3) * cq] : zero;
+            for (int j = 0; j < 6; ++j) win[j + 1] = (j - 3 >= 0 && j - 3 < W) ? ld4(in, irow + (long)(j - 3) * cq) : zero;
             for (int x = 0; x < W; ++x) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) win[j] = win[j + 1];
-                win[6] = (x + 3 < W) ? irow[(long)(x + 3) * cq] : zero;
-                const float4 d = drow[(long)x * cq];
+                win[6] = (x + 3 < W) ? ld4(in, irow + (long)(x + 3) * cq) : zero;
+                const float4 d = ld4(dout, drow + (long)x * cq);
 #pragma unroll
                 for (int j = 0; j < 7; ++j) fma4(acc[j], d, win[j]);
             }
@@ -334,8 +333,9 @@ inline int blocks_for(long n) {
 }
 }  // namespace
 
-extern "C" int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, const float* bias, const float* add,
-                                   float* out, int B, int H, int W, int C, int flip, void* stream) {
+template <typename TI, typename TA, typename TO>
+static int launch_dwconv7(const TI* in, const float* w_tap_major, const float* bias, const TA* add, TO* out, int B, int H, int W,
+                          int C, int flip, void* stream) {
     if (!in || !w_tap_major || !out || B <= 0 || H <= 0 || W <= 0) return DKD_ERR_BAD_ARG;
     if (C & 3) return DKD_ERR_UNSUPPORTED;
     const long total = (long)B * H * ((W + 6) / 7) * (C / 4);
@@ -360,7 +360,7 @@ extern "C" int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, co
         const dim3 grid((unsigned)gx, chunks), block(256);
         const size_t lds = (size_t)49 * CB * sizeof(float4);
         hipStream_t st = (hipStream_t)stream;
-#define DKD_DW(FL, R, X) hipLaunchKernelGGL((dwconv7_lds_kernel<FL, R, X>), grid, block, lds, st, in, w_tap_major, bias, add, out, B, H, W, C, CB, SP)
+#define DKD_DW(FL, R, X) hipLaunchKernelGGL((dwconv7_lds_kernel<FL, R, X, TI, TA, TO>), grid, block, lds, st, in, w_tap_major, bias, add, out, B, H, W, C, CB, SP)
 #define DKD_DW2(FL, R) DKD_DW(FL, R, 7)
         if (flip) { if (ry >= 4) { DKD_DW2(true, 4); } else if (ry == 3) { DKD_DW2(true, 3); } else { DKD_DW2(true, 2); } }
         else { if (ry >= 4) { DKD_DW2(false, 4); } else if (ry == 3) { DKD_DW2(false, 3); } else { DKD_DW2(false, 2); } }
@@ -370,13 +370,28 @@ extern "C" int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, co
         return DKD_OK;
     }
     if (flip)
-        hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, w_tap_major,
-                           bias, add, out, B, H, W, C);
+        hipLaunchKernelGGL((dwconv7_kernel<true, TI, TA, TO>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                           w_tap_major, bias, add, out, B, H, W, C);
     else
-        hipLaunchKernelGGL(dwconv7_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+        hipLaunchKernelGGL((dwconv7_kernel<false, TI, TA, TO>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in,
                            w_tap_major, bias, add, out, B, H, W, C);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
+}
+
+extern "C" int dkd_dwconv7_fwd_f32(const float* in, const float* w_tap_major, const float* bias, const float* add,
+                                   float* out, int B, int H, int W, int C, int flip, void* stream) {
+    return launch_dwconv7(in, w_tap_major, bias, add, out, B, H, W, C, flip, stream);
+}
+
+// mixed-precision step: bf16 input; addend and output fp32 or bf16 (add16 / out16); taps and bias fp32 (pre-rounded by the caller)
+extern "C" int dkd_dwconv7_fwd_io(const void* in_bf16, const float* w_tap_major, const float* bias, const void* add, int add16,
+                                  void* out, int out16, int B, int H, int W, int C, int flip, void* stream) {
+    const __bf16* in = reinterpret_cast<const __bf16*>(in_bf16);
+    int rc = DKD_ERR_BAD_ARG;
+    DKD_IO_TYPE(add16, TA, DKD_IO_TYPE(out16, TO, rc = launch_dwconv7(in, w_tap_major, bias, reinterpret_cast<const TA*>(add),
+                                                                          reinterpret_cast<TO*>(out), B, H, W, C, flip, stream)));
+    return rc;
 }
 
 static int dw_ry(int H) { return H >= 28 ? 4 : (H >= 14 ? 2 : 1); }
@@ -388,8 +403,19 @@ extern "C" int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* 
     const int RY = dw_ry(H);
     if (C & 3) return DKD_ERR_ALIGN;
     const long total = (long)B * ((H + RY - 1) / RY) * 7 * (C / 4);
-    hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, dout, partials,
-                       B, H, W, C, RY);
+    hipLaunchKernelGGL((dwconv7_wgrad_kernel<float, float>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, dout,
+                       partials, B, H, W, C, RY);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_dwconv7_wgrad_bf16(const void* in, const void* dout, float* partials, int B, int H, int W, int C, void* stream) {
+    if (!in || !dout || !partials || B <= 0) return DKD_ERR_BAD_ARG;
+    const int RY = dw_ry(H);
+    if (C & 3) return DKD_ERR_ALIGN;
+    const long total = (long)B * ((H + RY - 1) / RY) * 7 * (C / 4);
+    hipLaunchKernelGGL((dwconv7_wgrad_kernel<__bf16, __bf16>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(in), reinterpret_cast<const __bf16*>(dout), partials, B, H, W, C, RY);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

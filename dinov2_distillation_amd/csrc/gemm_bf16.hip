@@ -179,6 +179,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
                 }
+                if (g.residual16) {  // a 16-bit residual stream: rnd(x + rnd(acc + bias)), x bf16 (ConvNeXt block, stages 1-3)
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g.residual16) + orow * g.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                }
                 const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + orow * g.ldc + n) = o;
             } else {
@@ -292,7 +297,8 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // K-slabs with a fold: plain outputs only (weight gradients; no bias / residual / row map)
     int slabs = 1;
-    const bool plain = !g->bias && !g->residual && !g->colscale && g->row_grp == 0 && g->ldc == g->N &&
+    if (g->residual16 && (f32_out || g->epi != DKD_BF16_EPI_BF16 || (g->ldr & 3) || (((uintptr_t)g->residual16) & 7))) return DKD_ERR_BAD_ARG;
+    const bool plain = !g->bias && !g->residual && !g->residual16 && !g->colscale && g->row_grp == 0 && g->ldc == g->N &&
                        (g->epi == DKD_BF16_EPI_BF16 || g->epi == DKD_BF16_EPI_F32);
     if (plain && g->workspace && dkd_aligned16(g->workspace)) slabs = bf16_slabs(g->M, g->N, g->K);
     int kchunk = g->K;

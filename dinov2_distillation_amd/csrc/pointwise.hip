@@ -236,18 +236,21 @@ __global__ __launch_bounds__(256) void grn_stats_kernel(const float* __restrict_
 
 // y = g * (gamma * nx[b] + 1) + beta;  PREACT: the input is the pre-activation h and g = gelu(h) is recomputed here (the
 // block then never stores g: one [M,4C] write less in the producing GEMM, one read less in the backward)
-template <bool PREACT>
-__global__ void grn_apply_kernel(const float4* __restrict__ g, const float4* __restrict__ nx,
+// T: element type of g / y (float, or __bf16 in the mixed-precision step: gelu(h) is then rounded to bf16 as the 16-bit GELU
+// output it stands for, the GRN arithmetic is fp32 as under autocast, y is rounded by its store - the cast of the next Linear)
+template <bool PREACT, typename T = float>
+__global__ void grn_apply_kernel(const T* __restrict__ g, const float4* __restrict__ nx,
                                  const float4* __restrict__ gamma, const float4* __restrict__ beta,
-                                 float4* __restrict__ y, long rows_per_img, int nv, long nvec) {
+                                 T* __restrict__ y, long rows_per_img, int nv, long nvec) {
     EW_LOOP(i, nvec) {
         const long r = i / nv;
         const int c = (int)(i % nv);
-        float4 v = g[i];
+        float4 v = ld4(g, i);
         if (PREACT) v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+        if (PREACT && dkd_is16<T>::value) v = rnd16(v);
         const float4 n = nx[(r / rows_per_img) * nv + c], ga = gamma[c], be = beta[c];
-        y[i] = make_float4(v.x * (ga.x * n.x + 1.f) + be.x, v.y * (ga.y * n.y + 1.f) + be.y,
-                           v.z * (ga.z * n.z + 1.f) + be.z, v.w * (ga.w * n.w + 1.f) + be.w);
+        st4(y, i, make_float4(v.x * (ga.x * n.x + 1.f) + be.x, v.y * (ga.y * n.y + 1.f) + be.y,
+                              v.z * (ga.z * n.z + 1.f) + be.z, v.w * (ga.w * n.w + 1.f) + be.w));
     }
 }
 
@@ -277,24 +280,53 @@ __global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restr
 }
 
 // dh = (dy * (gamma*nx + 1) + coef * g) * gelu'(h);  g == nullptr: g = gelu(h) comes out of the same erf as gelu'(h)
-template <bool HAVE_G>
-__global__ void grn_gelu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ g,
-                                    const float4* __restrict__ h, const float4* __restrict__ nx,
+// T (mixed-precision step, __bf16): g = rnd(gelu(h)); the gradient of the 16-bit g is rounded before the GELU derivative
+// multiplies it, and dh is rounded by its store
+template <bool HAVE_G, typename T = float>
+__global__ void grn_gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ g,
+                                    const T* __restrict__ h, const float4* __restrict__ nx,
                                     const float4* __restrict__ coef, const float4* __restrict__ gamma,
-                                    float4* __restrict__ dh, long rows_per_img, int nv, long nvec) {
+                                    T* __restrict__ dh, long rows_per_img, int nv, long nvec) {
     EW_LOOP(i, nvec) {
         const long r = i / nv;
         const int c = (int)(i % nv);
         const long bi = (r / rows_per_img) * nv + c;
-        const float4 d = dy[i], hv = h[i], n = nx[bi], cf = coef[bi], ga = gamma[c];
+        const float4 d = ld4(dy, i), hv = ld4(h, i), n = nx[bi], cf = coef[bi], ga = gamma[c];
         float4 gv, gp;
         gelu_both_f(hv.x, gv.x, gp.x);
         gelu_both_f(hv.y, gv.y, gp.y);
         gelu_both_f(hv.z, gv.z, gp.z);
         gelu_both_f(hv.w, gv.w, gp.w);
-        if (HAVE_G) gv = g[i];
-        dh[i] = make_float4((d.x * (ga.x * n.x + 1.f) + cf.x * gv.x) * gp.x, (d.y * (ga.y * n.y + 1.f) + cf.y * gv.y) * gp.y,
-                            (d.z * (ga.z * n.z + 1.f) + cf.z * gv.z) * gp.z, (d.w * (ga.w * n.w + 1.f) + cf.w * gv.w) * gp.w);
+        if (HAVE_G) gv = ld4(g, i);
+        else if (dkd_is16<T>::value) gv = rnd16(gv);
+        float4 dg;
+        if (dkd_is16<T>::value) {
+            // autograd hands the 16-bit g three 16-bit gradients - from "+ x", from "x * Nx" and through the norm - and adds them
+            // as they arrive, rounding each sum: rnd(rnd(d + rnd((d gamma) Nx)) + rnd(coef g))
+            const float4 b = rnd16(make_float4((d.x * ga.x) * n.x, (d.y * ga.y) * n.y, (d.z * ga.z) * n.z, (d.w * ga.w) * n.w));
+            const float4 s1 = rnd16(make_float4(d.x + b.x, d.y + b.y, d.z + b.z, d.w + b.w));
+            const float4 c3 = rnd16(make_float4(cf.x * gv.x, cf.y * gv.y, cf.z * gv.z, cf.w * gv.w));
+            dg = rnd16(make_float4(s1.x + c3.x, s1.y + c3.y, s1.z + c3.z, s1.w + c3.w));
+        } else {
+            dg = make_float4(d.x * (ga.x * n.x + 1.f) + cf.x * gv.x, d.y * (ga.y * n.y + 1.f) + cf.y * gv.y,
+                             d.z * (ga.z * n.z + 1.f) + cf.z * gv.z, d.w * (ga.w * n.w + 1.f) + cf.w * gv.w);
+        }
+        st4(dh, i, make_float4(dg.x * gp.x, dg.y * gp.y, dg.z * gp.z, dg.w * gp.w));
+    }
+}
+
+// bf16 <-> fp32 plumbing of the mixed-precision step
+__global__ void cast_f32_kernel(const __bf16* __restrict__ in, float* __restrict__ out, long nvec) {
+    EW_LOOP(i, nvec) st4(out, i, ld4(in, i));
+}
+__global__ void round_bf16_kernel(float* __restrict__ x, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = rnd16(x[i]);
+}
+// out = rnd(a + b) on bf16 tensors (autograd's accumulation of two 16-bit gradients)
+__global__ void add_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ out, long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 u = ld4(a, i), v = ld4(b, i);
+        st4(out, i, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
     }
 }
 
@@ -407,11 +439,11 @@ extern "C" int dkd_grn_apply_f32(const float* g, const float* nx, const float* g
     if (!g || !nx || !gamma || !beta || !y || B <= 0 || rows_per_img <= 0) return DKD_ERR_BAD_ARG;
     const long nvec = (long)B * rows_per_img * (C / 4);
     if (input_is_preact)
-        hipLaunchKernelGGL(grn_apply_kernel<true>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(g), F4(nx),
-                           F4(gamma), F4(beta), F4W(y), rows_per_img, C / 4, nvec);
+        hipLaunchKernelGGL((grn_apply_kernel<true, float>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, g, F4(nx),
+                           F4(gamma), F4(beta), y, rows_per_img, C / 4, nvec);
     else
-        hipLaunchKernelGGL(grn_apply_kernel<false>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(g), F4(nx),
-                           F4(gamma), F4(beta), F4W(y), rows_per_img, C / 4, nvec);
+        hipLaunchKernelGGL((grn_apply_kernel<false, float>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, g, F4(nx),
+                           F4(gamma), F4(beta), y, rows_per_img, C / 4, nvec);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
@@ -429,11 +461,57 @@ extern "C" int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float
     if (!dy || !h || !nx || !coef || !gamma || !dh || B <= 0 || rows_per_img <= 0) return DKD_ERR_BAD_ARG;
     const long nvec = (long)B * rows_per_img * (C / 4);
     if (g)
-        hipLaunchKernelGGL(grn_gelu_bwd_kernel<true>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(dy), F4(g),
-                           F4(h), F4(nx), F4(coef), F4(gamma), F4W(dh), rows_per_img, C / 4, nvec);
+        hipLaunchKernelGGL((grn_gelu_bwd_kernel<true, float>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, dy, g, h,
+                           F4(nx), F4(coef), F4(gamma), dh, rows_per_img, C / 4, nvec);
     else
-        hipLaunchKernelGGL(grn_gelu_bwd_kernel<false>, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, F4(dy), F4(g),
-                           F4(h), F4(nx), F4(coef), F4(gamma), F4W(dh), rows_per_img, C / 4, nvec);
+        hipLaunchKernelGGL((grn_gelu_bwd_kernel<false, float>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, dy, g, h,
+                           F4(nx), F4(coef), F4(gamma), dh, rows_per_img, C / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+// ---- the same two on bf16 activations (mixed-precision step): h, y, dy, dh bf16; statistics / parameters fp32 ----------------
+extern "C" int dkd_grn_apply_bf16(const void* h, const float* nx, const float* gamma, const float* beta, void* y, int B,
+                                  long rows_per_img, int C, void* stream) {
+    EW_CHECK(C);
+    if (!h || !nx || !gamma || !beta || !y || B <= 0 || rows_per_img <= 0) return DKD_ERR_BAD_ARG;
+    const long nvec = (long)B * rows_per_img * (C / 4);
+    hipLaunchKernelGGL((grn_apply_kernel<true, __bf16>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(h), F4(nx), F4(gamma), F4(beta), reinterpret_cast<__bf16*>(y), rows_per_img,
+                       C / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_grn_gelu_bwd_bf16(const void* dy, const void* h, const float* nx, const float* coef, const float* gamma, void* dh,
+                                     int B, long rows_per_img, int C, void* stream) {
+    EW_CHECK(C);
+    if (!dy || !h || !nx || !coef || !gamma || !dh || B <= 0 || rows_per_img <= 0) return DKD_ERR_BAD_ARG;
+    const long nvec = (long)B * rows_per_img * (C / 4);
+    hipLaunchKernelGGL((grn_gelu_bwd_kernel<false, __bf16>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(dy), (const __bf16*)nullptr, reinterpret_cast<const __bf16*>(h), F4(nx),
+                       F4(coef), F4(gamma), reinterpret_cast<__bf16*>(dh), rows_per_img, C / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_cast_f32_from_bf16(const void* in, float* out, long n, void* stream) {
+    EW_CHECK(n);
+    if (!in || !out) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(in),
+                       out, n / 4);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_round_bf16_f32(float* x, long n, void* stream) {
+    if (!x || n <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(round_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream) {
+    EW_CHECK(n);
+    if (!a || !b || !out) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(a),
+                       reinterpret_cast<const __bf16*>(b), reinterpret_cast<__bf16*>(out), n / 4);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -21,8 +21,11 @@ typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
 
 // OUT_BF16: y is bf16 (the autocast teacher: LayerNorm computes in fp32 and its only consumer, an nn.Linear, rounds its input
 // to 16 bit - the rounding is done here and the [rows, C] tensor costs half the bytes)
-template <int LPR, int VPL, bool WRITE_STATS, bool OUT_BF16 = false>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// CF16 (bf16 input only): the reference's channels-first LayerNorm (convnext.py:31-36) as torch autocast runs it op by op on a
+// 16-bit tensor: u = x.mean() and d = x - u are 16-bit results (rounded), pow / mean / sqrt / the affine part fp32.  `mean` then
+// holds the rounded u and the variance is that of the rounded d about zero.
+template <int LPR, int VPL, bool WRITE_STATS, bool OUT_BF16 = false, typename TI = float, bool CF16 = false>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             long rows, int C, float eps, int in_grp, int in_grp_stride,
@@ -40,22 +43,27 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
     for (long row = ((long)blockIdx.x * 4 + wid) * RPW + sub; row < rows; row += (long)gridDim.x * 4 * RPW) {
         const long irow = in_grp > 0 ? (row / in_grp) * in_grp_stride + row % in_grp + in_off : row;
-        const float4* xr = reinterpret_cast<const float4*>(x + irow * C);
+        const long xr = irow * nv;  // 4-element index of the row
         float4 v[VPL];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = lir + i * LPR;
-            v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = c < nv ? ld4(x, xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
-        const float mu = group_sum<LPR>(s) * invC;
+        float mu = group_sum<LPR>(s) * invC;
+        if (CF16) mu = rnd16(mu);
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = lir + i * LPR;
             if (c < nv) {
-                const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+                float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+                if (CF16) {  // keep the rounded differences: the output below is built from them
+                    a = rnd16(a), b = rnd16(b), cc = rnd16(cc), d = rnd16(d);
+                    v[i] = make_float4(a, b, cc, d);
+                }
                 q += (a * a + b * b) + (cc * cc + d * d);
             }
         }
@@ -66,11 +74,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         for (int i = 0; i < VPL; ++i) {
             const int c = lir + i * LPR;
             if (c < nv) {
+                const float sub = CF16 ? 0.f : mu;
                 float4 o;
-                o.x = (v[i].x - mu) * rs * gm[i].x + bt[i].x;
-                o.y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
-                o.z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
-                o.w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
+                o.x = (v[i].x - sub) * rs * gm[i].x + bt[i].x;
+                o.y = (v[i].y - sub) * rs * gm[i].y + bt[i].y;
+                o.z = (v[i].z - sub) * rs * gm[i].z + bt[i].z;
+                o.w = (v[i].w - sub) * rs * gm[i].w + bt[i].w;
                 if (OUT_BF16) yb[c] = ln_bf16x4{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
                 else yr[c] = o;
             }
@@ -84,12 +93,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Per-block partial sums of
 // dgamma = sum dy*xhat and dbeta = sum dy go to ws[block][2][C] (AFFINE) and are folded by reduce_partials.
-template <int LPR, int VPL, bool AFFINE>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// CF16 (bf16 x): the adjoint of the CF16 forward as autograd forms it - d's two 16-bit gradients (through d / sqrt(s) and through
+// the variance) are added and rounded, the mean's gradient is the rounded negative channel sum, and x receives
+// rnd(dd + rnd(du / C)); the statistics are those of the rounded d (xhat = rnd(x - u) * rstd)
+template <int LPR, int VPL, bool AFFINE, typename TD = float, typename TI = float, typename TO = float, bool CF16 = false>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict__ dy, const TI* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
-                                                            const float* __restrict__ add, float* __restrict__ dx,
+                                                            const float* __restrict__ add, TO* __restrict__ dx,
                                                             float* __restrict__ ws, long rows, int C) {
     constexpr int RPW = 64 / LPR, SLOTS = 4 * RPW, CMAX = 4 * LPR * VPL;
     __shared__ float red[AFFINE ? SLOTS * CMAX : 4];  // [wave x sub-row][C]
@@ -104,8 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         gm[i] = c < nv ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (long row = ((long)blockIdx.x * 4 + wid) * RPW + sub; row < rows; row += (long)gridDim.x * 4 * RPW) {
-        const float4* xr = reinterpret_cast<const float4*>(x + row * C);
-        const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
+        const long r4 = row * nv;  // 4-element index of the row
         const float mu = mean[row], rs = rstd[row];
         float4 xh[VPL], g[VPL];
         float s1 = 0.f, s2 = 0.f;
@@ -113,8 +124,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int i = 0; i < VPL; ++i) {
             const int c = lir + i * LPR;
             if (c < nv) {
-                const float4 xv = xr[c], dv = dr[c];
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                const float4 xv = ld4(x, r4 + c), dv = ld4(dy, r4 + c);
+                xh[i] = CF16 ? make_float4(rnd16(xv.x - mu) * rs, rnd16(xv.y - mu) * rs, rnd16(xv.z - mu) * rs, rnd16(xv.w - mu) * rs)
+                             : make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 g[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
                 s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
                 s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
@@ -128,7 +140,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
         s1 = group_sum<LPR>(s1) * invC;
         s2 = group_sum<LPR>(s2) * invC;
-        float4* oxr = reinterpret_cast<float4*>(dx + row * C);
+        if (CF16) {
+            float4 dd[VPL];
+            float sd = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = lir + i * LPR;
+                dd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < nv) {
+                    const float4 t1 = rnd16(make_float4(g[i].x * rs, g[i].y * rs, g[i].z * rs, g[i].w * rs));
+                    const float4 t2 = rnd16(make_float4(-xh[i].x * s2 * rs, -xh[i].y * s2 * rs, -xh[i].z * s2 * rs, -xh[i].w * s2 * rs));
+                    dd[i] = rnd16(make_float4(t1.x + t2.x, t1.y + t2.y, t1.z + t2.z, t1.w + t2.w));
+                    sd += (dd[i].x + dd[i].y) + (dd[i].z + dd[i].w);
+                }
+            }
+            const float du = rnd16(rnd16(-group_sum<LPR>(sd)) * invC);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = lir + i * LPR;
+                if (c < nv) st4(dx, r4 + c, make_float4(dd[i].x + du, dd[i].y + du, dd[i].z + du, dd[i].w + du));
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = lir + i * LPR;
@@ -142,7 +175,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     const float4 a = reinterpret_cast<const float4*>(add + row * C)[c];
                     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
                 }
-                oxr[c] = o;
+                st4(dx, r4 + c, o);
             }
         }
     }
@@ -232,8 +265,10 @@ __device__ __forceinline__ float4 colop(const float4 x, const float4 y, const fl
 }
 
 // OP == DKD_RED_DOT_SUM: two results per column, sum x*y -> out[.], sum x -> out[groups*nsplit*N + .]
-template <int OP>
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+// T: element type of X and Y (float or __bf16).  R16 (the mixed-precision step): the GELU inside the gelu variants is rounded to
+// bf16 first - the value the 16-bit GELU output tensor of the autocast step holds.
+template <int OP, typename T = float, bool R16 = false>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X, const T* __restrict__ Y,
                                                         const float* __restrict__ aux, float* __restrict__ out,
                                                         long rows_per_group, int N, long ldx, int CL, int rows_per_split,
                                                         float scale, int nsplit) {
@@ -252,8 +287,16 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
         // Kahan-compensated accumulation: a column of B*H*W gradients summed in plain fp32 carries an error that grows with the
         // number of rows a thread folds; the BatchNorm / bias gradients of a 50-layer student amplify it (the PResNet-50 case of
         // round 1).  The kernel is HBM-bound, the three extra VALU ops per element are free (scripts/bench_colreduce.py).
-        auto fold = [&](const float4 x, float4 y) {
-            if (OP == DKD_RED_DOTGELU_SUM) y = make_float4(gelu_f(y.x), gelu_f(y.y), gelu_f(y.z), gelu_f(y.w));
+        auto fold = [&](float4 x, float4 y) {
+            if (OP == DKD_RED_DOTGELU_SUM) {
+                y = make_float4(gelu_f(y.x), gelu_f(y.y), gelu_f(y.z), gelu_f(y.w));
+                if (R16) y = rnd16(y);
+            }
+            if (OP == DKD_RED_GELUSQ && R16) {  // (gelu rounded, then squared: colop's own gelu is bypassed)
+                const float4 g = rnd16(make_float4(gelu_f(x.x), gelu_f(x.y), gelu_f(x.z), gelu_f(x.w)));
+                kahan4(acc, cmp, make_float4(g.x * g.x, g.y * g.y, g.z * g.z, g.w * g.w));
+                return;
+            }
             const float4 v = colop<TWO ? DKD_RED_DOT : OP>(x, y, a);
             kahan4(acc, cmp, v);
             if (TWO) kahan4(acc2, cmp2, x);
@@ -263,17 +306,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
         // keep several rows' loads in flight ahead of the (for the gelu variants VALU-heavy) arithmetic: four rows for the
         // one-operand reductions, the plain loop for the two-operand ones (eight float4 in flight cost occupancy: +12 %)
         if (!HAS_Y) {
+            const long l4 = ldx >> 2;
             for (; r + 3 * RL < r1; r += 4 * RL) {
-                const float* px = X + (base + r) * ldx + 4 * c4;
-                const float4 x0 = *reinterpret_cast<const float4*>(px), x1 = *reinterpret_cast<const float4*>(px + RL * ldx);
-                const float4 x2 = *reinterpret_cast<const float4*>(px + 2 * RL * ldx), x3 = *reinterpret_cast<const float4*>(px + 3 * RL * ldx);
+                const long px = (base + r) * l4 + c4;  // 4-element index
+                const float4 x0 = ld4(X, px), x1 = ld4(X, px + RL * l4);
+                const float4 x2 = ld4(X, px + 2 * RL * l4), x3 = ld4(X, px + 3 * RL * l4);
                 fold(x0, x0); fold(x1, x1); fold(x2, x2); fold(x3, x3);
             }
         }
         for (; r < r1; r += RL) {
-            const float4 x = *reinterpret_cast<const float4*>(X + (base + r) * ldx + 4 * c4);
+            const float4 x = ld4(X, (base + r) * (ldx >> 2) + c4);
             float4 y = x;
-            if (HAS_Y) y = *reinterpret_cast<const float4*>(Y + (base + r) * ldx + 4 * c4);
+            if (HAS_Y) y = ld4(Y, (base + r) * (ldx >> 2) + c4);
             fold(x, y);
         }
     }
@@ -414,6 +458,43 @@ extern "C" int dkd_layernorm_fwd_bf16out_f32(const float* x, const float* gamma,
     return DKD_OK;
 }
 
+// mixed-precision step: x fp32 or bf16 (x16), y fp32 or bf16 (y16); the arithmetic and the statistics are fp32 either way
+// (torch autocast runs layer_norm in fp32; a bf16 y is the rounding its only consumer, a 16-bit Linear / conv, applies)
+extern "C" int dkd_layernorm_fwd_io(const void* x, int x16, const float* gamma, const float* beta, void* y, int y16, float* mean,
+                                    float* rstd, long rows, int C, float eps, int cf16, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    if (cf16 && !x16) return DKD_ERR_BAD_ARG;
+    if ((C & 3) || C > LN_MAXV * 256) return DKD_ERR_UNSUPPORTED;
+    const int nv = C / 4, rpb = ln_rows_per_block(nv);
+    const int blocks = (int)((rows + rpb - 1) / rpb < 4096 ? (rows + rpb - 1) / rpb : 4096);
+    hipStream_t st = (hipStream_t)stream;
+#define DKD_LN_FWD_CF(L, V)                                                                                                  \
+    if (y16) hipLaunchKernelGGL((layernorm_fwd_kernel<L, V, true, true, __bf16, true>), dim3(blocks), dim3(256), 0, st,      \
+                                reinterpret_cast<const __bf16*>(x), gamma, beta, reinterpret_cast<float*>(y), mean, rstd,    \
+                                rows, C, eps, 0, 0, 0);                                                                      \
+    else hipLaunchKernelGGL((layernorm_fwd_kernel<L, V, true, false, __bf16, true>), dim3(blocks), dim3(256), 0, st,         \
+                            reinterpret_cast<const __bf16*>(x), gamma, beta, reinterpret_cast<float*>(y), mean, rstd, rows,  \
+                            C, eps, 0, 0, 0)
+    if (cf16) {
+        DKD_LN_DISPATCH(nv, DKD_LN_FWD_CF);
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
+#undef DKD_LN_FWD_CF
+#define DKD_LN_FWD_IO(L, V)                                                                                                  \
+    DKD_IO_TYPE(x16, TI,                                                                                                     \
+                if (y16) hipLaunchKernelGGL((layernorm_fwd_kernel<L, V, true, true, TI>), dim3(blocks), dim3(256), 0, st,   \
+                                            reinterpret_cast<const TI*>(x), gamma, beta, reinterpret_cast<float*>(y), mean,  \
+                                            rstd, rows, C, eps, 0, 0, 0);                                                    \
+                else hipLaunchKernelGGL((layernorm_fwd_kernel<L, V, true, false, TI>), dim3(blocks), dim3(256), 0, st,      \
+                                        reinterpret_cast<const TI*>(x), gamma, beta, reinterpret_cast<float*>(y), mean,      \
+                                        rstd, rows, C, eps, 0, 0, 0))
+    DKD_LN_DISPATCH(nv, DKD_LN_FWD_IO);
+#undef DKD_LN_FWD_IO
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
 // 4 workgroups per CU: enough waves in flight to cover the HBM latency of the two row reads; partials stay tiny
 static int ln_bwd_blocks(long rows, int C) {
     const int rpb = ln_rows_per_block(C / 4);
@@ -451,6 +532,50 @@ extern "C" int dkd_layernorm_bwd_f32(const float* dy, const float* x, const floa
     return DKD_OK;
 }
 
+// dy / x / dx each fp32 or bf16; dgamma / dbeta (both or neither) fp32; ws as dkd_layernorm_bwd_f32
+extern "C" int dkd_layernorm_bwd_io(const void* dy, int dy16, const void* x, int x16, const float* mean, const float* rstd,
+                                    const float* gamma, void* dx, int dx16, float* dgamma, float* dbeta, float* ws, long rows,
+                                    int C, int cf16, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || rows <= 0) return DKD_ERR_BAD_ARG;
+    if (cf16 && !(x16 && dx16 && dgamma)) return DKD_ERR_BAD_ARG;  // (bf16 x and dx, with parameter gradients)
+    if ((C & 3) || C > LN_MAXV * 256) return DKD_ERR_UNSUPPORTED;
+    if ((dgamma == nullptr) != (dbeta == nullptr) || (dgamma && !ws)) return DKD_ERR_BAD_ARG;
+    const int blocks = ln_bwd_blocks(rows, C), nv = C / 4;
+    hipStream_t st = (hipStream_t)stream;
+    const bool affine = dgamma != nullptr;
+#define DKD_LN_BWD_CF(L, V)                                                                                                    \
+    DKD_IO_TYPE(dy16, TD,                                                                                                      \
+        hipLaunchKernelGGL((layernorm_bwd_kernel<L, V, true, TD, __bf16, __bf16, true>), dim3(blocks), dim3(256), 0, st,       \
+                           reinterpret_cast<const TD*>(dy), reinterpret_cast<const __bf16*>(x), mean, rstd, gamma,             \
+                           (const float*)nullptr, reinterpret_cast<__bf16*>(dx), ws, rows, C))
+    if (cf16) {
+        DKD_LN_DISPATCH(nv, DKD_LN_BWD_CF);
+        DKD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C / 4 + 15) / 16), dim3(256), 0, st, ws, blocks, 2 * C, dgamma, dbeta, C,
+                           1.0f);
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
+#undef DKD_LN_BWD_CF
+#define DKD_LN_BWD_IO(L, V)                                                                                                    \
+    DKD_IO_TYPE(dy16, TD, DKD_IO_TYPE(x16, TI, DKD_IO_TYPE(dx16, TO,                                                           \
+        if (affine) hipLaunchKernelGGL((layernorm_bwd_kernel<L, V, true, TD, TI, TO>), dim3(blocks), dim3(256), 0, st,         \
+                                       reinterpret_cast<const TD*>(dy), reinterpret_cast<const TI*>(x), mean, rstd, gamma,     \
+                                       (const float*)nullptr, reinterpret_cast<TO*>(dx), ws, rows, C);                         \
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<L, V, false, TD, TI, TO>), dim3(blocks), dim3(256), 0, st,               \
+                                reinterpret_cast<const TD*>(dy), reinterpret_cast<const TI*>(x), mean, rstd, gamma,            \
+                                (const float*)nullptr, reinterpret_cast<TO*>(dx), ws, rows, C))))
+    DKD_LN_DISPATCH(nv, DKD_LN_BWD_IO);
+#undef DKD_LN_BWD_IO
+    DKD_LAUNCH_CHECK();
+    if (affine) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C / 4 + 15) / 16), dim3(256), 0, st, ws, blocks, 2 * C, dgamma, dbeta, C,
+                           1.0f);
+        DKD_LAUNCH_CHECK();
+    }
+    return DKD_OK;
+}
+
 extern "C" long dkd_colreduce_f32_workspace_bytes(long rows_per_group, int groups, int N) {
     int cl, ns, rps, cb;
     colreduce_plan(rows_per_group, groups, N, &cl, &ns, &rps, &cb);
@@ -484,6 +609,42 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
         default: return DKD_ERR_BAD_ARG;
     }
 #undef DKD_CR
+    DKD_LAUNCH_CHECK();
+    if (ns > 1) {
+        const dim3 fgrid((N + 31) / 32, groups, two ? 2 : 1);
+        hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale);
+        DKD_LAUNCH_CHECK();
+    }
+    return DKD_OK;
+}
+
+// bf16 X (and Y): the column sums of the mixed-precision step (bias gradients; GRN energies and GRN-backward sums with the
+// GELU rounded to bf16 when round_gelu != 0).  Ops: DKD_RED_SUM, DKD_RED_DOT, DKD_RED_GELUSQ, DKD_RED_DOTGELU_SUM; fp32 results
+extern "C" int dkd_colreduce_bf16(const void* X, const void* Y, float* out, float* ws, long rows_per_group, int groups, int N,
+                                  int op, int round_gelu, float scale, void* stream) {
+    if (!X || !out || rows_per_group <= 0 || groups <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
+    if (N & 3) return DKD_ERR_ALIGN;
+    const bool two = op == DKD_RED_DOTGELU_SUM;
+    if ((op == DKD_RED_DOT || two) && !Y) return DKD_ERR_BAD_ARG;
+    int cl, ns, rps, cb;
+    colreduce_plan(rows_per_group, groups, N, &cl, &ns, &rps, &cb);
+    if (ns > 1 && !ws) return DKD_ERR_BAD_ARG;
+    float* dst = ns > 1 ? ws : out;
+    dim3 grid(cb, ns, groups), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* x = reinterpret_cast<const __bf16*>(X);
+    const __bf16* y = reinterpret_cast<const __bf16*>(Y);
+#define DKD_CR16(OPV, R)                                                                                                     \
+    hipLaunchKernelGGL((colreduce_kernel<OPV, __bf16, R>), grid, block, 0, st, x, y, (const float*)nullptr, dst, rows_per_group, N, \
+                       (long)N, cl, rps, scale, ns)
+    switch (op) {
+        case DKD_RED_SUM: DKD_CR16(DKD_RED_SUM, false); break;
+        case DKD_RED_DOT: DKD_CR16(DKD_RED_DOT, false); break;
+        case DKD_RED_GELUSQ: if (round_gelu) DKD_CR16(DKD_RED_GELUSQ, true); else DKD_CR16(DKD_RED_GELUSQ, false); break;
+        case DKD_RED_DOTGELU_SUM: if (round_gelu) DKD_CR16(DKD_RED_DOTGELU_SUM, true); else DKD_CR16(DKD_RED_DOTGELU_SUM, false); break;
+        default: return DKD_ERR_UNSUPPORTED;
+    }
+#undef DKD_CR16
     DKD_LAUNCH_CHECK();
     if (ns > 1) {
         const dim3 fgrid((N + 31) / 32, groups, two ? 2 : 1);

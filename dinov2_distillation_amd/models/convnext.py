@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 
 class _P(nn.Module):
@@ -39,10 +40,11 @@ class Block(nn.Module):
         self.grn.beta = nn.Parameter(torch.zeros(1, 1, 1, 4 * dim))
         self.pwconv2.weight, self.pwconv2.bias = _tn(dim, 4 * dim), nn.Parameter(torch.zeros(dim))
 
-    def forward(self, x):  # x NHWC
-        return Fn.ConvNeXtBlockFn.apply(x, self.dwconv.weight, self.dwconv.bias, self.norm.weight, self.norm.bias,
-                                        self.pwconv1.weight, self.pwconv1.bias, self.grn.gamma, self.grn.beta,
-                                        self.pwconv2.weight, self.pwconv2.bias)
+    def forward(self, x, autocast=False):  # x NHWC
+        fn = Fn16.ConvNeXtBlock16Fn if autocast else Fn.ConvNeXtBlockFn
+        return fn.apply(x, self.dwconv.weight, self.dwconv.bias, self.norm.weight, self.norm.bias,
+                        self.pwconv1.weight, self.pwconv1.bias, self.grn.gamma, self.grn.beta,
+                        self.pwconv2.weight, self.pwconv2.bias)
 
 
 class ConvNeXtV2(nn.Module):
@@ -54,8 +56,34 @@ class ConvNeXtV2(nn.Module):
         for i in range(3):
             self.downsample_layers.append(nn.ModuleList([_ln(dims[i]), _conv(dims[i + 1], dims[i], 2)]))  # :121-126
         self.stages = nn.ModuleList(nn.ModuleList(Block(dims[i]) for _ in range(depths[i])) for i in range(4))
+        self.precision = "fp32"
+
+    def set_precision(self, precision):
+        """"fp32": exact fp32 (every parity claim and bench.py's `value`); "bf16_autocast": the reference's default precision=16
+        policy (train.py:263) in bf16 with bf16 activations in HBM (functional16.py); the features are handed on as fp32"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        return self
+
+    def _forward_features_nhwc_autocast(self, x):
+        outs = {}
+        for i in range(4):
+            ds = self.downsample_layers[i]
+            if i == 0:  # stem conv -> 16 bit; its channels-first LayerNorm returns fp32: stage 0 keeps an fp32 residual stream
+                x = Fn16.PatchConv16Fn.apply(x, ds[0].weight, ds[0].bias, 4, True)
+                x = Fn16.LayerNorm16Fn.apply(x, ds[1].weight, ds[1].bias, 1e-6, False)
+            else:       # LayerNorm (fp32 arithmetic) -> the conv's 16-bit input -> 16-bit output
+                x = Fn16.LayerNorm16Fn.apply(x, ds[0].weight, ds[0].bias, 1e-6, True)
+                x = Fn16.PatchConv16Fn.apply(x, ds[1].weight, ds[1].bias, 2, False)
+            for blk in self.stages[i]:
+                x = blk(x, autocast=True)
+            outs[f"res{i + 2}"] = x if x.dtype == torch.float32 else Fn16.ToFloatFn.apply(x)
+        return outs
 
     def forward_features_nhwc(self, x):
+        if self.precision == "bf16_autocast":
+            return self._forward_features_nhwc_autocast(x)
         outs = {}
         for i in range(4):
             ds = self.downsample_layers[i]

@@ -302,6 +302,17 @@ class ModelWrapper(nn.Module):
         self.target_features = list(target_feature)
         self.patch_size = n_patches
 
+    def set_precision(self, precision):
+        """"fp32" (default, exact) or "bf16_autocast": the backbone under the reference's default precision=16 policy with bf16
+        activations in HBM (ConvNeXt-V2 students; functional16.py).  Other families have no mixed-precision path yet."""
+        backbone = self.model.model
+        if not hasattr(backbone, "set_precision"):
+            if precision in (None, "fp32"):
+                return self
+            raise NotImplementedError(f"{type(backbone).__name__} has no mixed-precision path (ConvNeXt-V2 students only)")
+        backbone.set_precision(precision or "fp32")
+        return self
+
     def forward(self, x):
         """every target feature bilinearly resized (align_corners=False) to the teacher grid (model_zoo.py:116-129);
         returned as [B,C,P,P] views of NHWC memory."""

@@ -894,3 +894,151 @@ def layernorm_fwd_bf16out(x, gamma, beta, eps, in_rows=None):
     check(_lib.binding().dkd_layernorm_fwd_bf16out_f32(_p(x), _p(gamma), _p(beta), _p(y), rows, C, eps, grp, gst, off, _stream()),
           "dkd_layernorm_fwd_bf16out_f32")
     return y
+
+
+# ---- HBM-bound kernels of the mixed-precision student (bf16 activations in HBM, fp32 arithmetic; dkd_hip.h) -------------------
+def _chk_io(t, name):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype not in (torch.float32, BF16) or not t.is_contiguous():
+        raise _lib.DkdError(f"{name}: expected a contiguous CUDA(HIP) float32 / bfloat16 tensor, got {t.device} {t.dtype} "
+                            f"{tuple(t.stride())}")
+
+
+def _is16(t):
+    return int(t is not None and t.dtype == BF16)
+
+
+def gemm_bf16_resid16(a, w, bias, residual16, out=None):
+    """rnd(residual16 + rnd(a @ w^T + bias)) on bf16 tensors: a 16-bit Linear + a 16-bit residual add"""
+    _chk16(a, "a"), _chk16(w, "w"), _chk16(bias, "bias"), _chk16(residual16, "residual16")
+    a2 = a.reshape(-1, a.shape[-1])
+    M, K = a2.shape
+    N = w.shape[0]
+    g = _lib.args("dkd_gemm_bf16_args")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), K, _p(w), K, _p(out), N
+    g.bias, g.residual16, g.ldr = _p(bias), _p(residual16), N
+    g.M, g.N, g.K, g.epi = M, N, K, EPI_BF16
+    check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[{M}x{N}x{K} bf16 residual]")
+    return out
+
+
+def dwconv7_io(x16, w_tap, bias=None, add=None, flip=False, out_dtype=BF16):
+    """depthwise 7x7 on a bf16 NHWC tensor; taps / bias fp32 (pre-rounded by the caller); add (fp32 or bf16) and the output
+    dtype free.  flip + add = the dgrad form dx = rnd(rnd(conv^T(dy)) + add)."""
+    _chk16(x16, "x16"), _chk(w_tap, "w_tap"), _chk(bias, "bias"), _chk_io(add, "add")
+    B, H, W, C = x16.shape
+    out = torch.empty((B, H, W, C), dtype=out_dtype, device=x16.device)
+    check(_lib.binding().dkd_dwconv7_fwd_io(_p(x16), _p(w_tap), _p(bias), _p(add), _is16(add), _p(out), int(out_dtype == BF16), B, H,
+                                            W, C, int(flip), _stream()), "dkd_dwconv7_fwd_io")
+    return out
+
+
+def dwconv7_wgrad16(x16, dout16):
+    """-> dW tap-major [49, C] fp32 (not yet rounded) from bf16 x and dout"""
+    lib = _lib.binding()
+    _chk16(x16, "x16"), _chk16(dout16, "dout16")
+    B, H, W, C = x16.shape
+    parts = lib.dkd_dwconv7_wgrad_f32_parts(B, H)
+    part = workspace(parts * 49 * C * 4, x16.device, slot=1)
+    check(lib.dkd_dwconv7_wgrad_bf16(_p(x16), _p(dout16), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_bf16")
+    return colreduce(part[: parts * 49 * C].view(parts, 49 * C)).view(49, C)
+
+
+def layernorm_fwd_io(x, gamma, beta, eps, out_dtype, cf16=False):
+    """LayerNorm over the last dim in fp32, x fp32 or bf16, y fp32 or bf16 -> y, mean, rstd.  cf16 (bf16 x): the reference's
+    op-by-op channels-first form under autocast (16-bit mean and centred values, dkd_hip.h)"""
+    _chk_io(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.binding().dkd_layernorm_fwd_io(_p(x), _is16(x), _p(gamma), _p(beta), _p(y), int(out_dtype == BF16), _p(mean), _p(rstd),
+                                              rows, C, eps, int(cf16), _stream()), "dkd_layernorm_fwd_io")
+    return y, mean, rstd
+
+
+def layernorm_bwd_io(dy, x, mean, rstd, gamma, out_dtype, dg_out=None, db_out=None, cf16=False):
+    lib = _lib.binding()
+    _chk_io(dy, "dy"), _chk_io(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device) if dg_out is None else dg_out
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if db_out is None else db_out
+    ws = workspace(lib.dkd_layernorm_bwd_f32_workspace_bytes(rows, C), x.device)
+    check(lib.dkd_layernorm_bwd_io(_p(dy), _is16(dy), _p(x), _is16(x), _p(mean), _p(rstd), _p(gamma), _p(dx), int(out_dtype == BF16),
+                                   _p(dg), _p(db), _p(ws), rows, C, int(cf16), _stream()), "dkd_layernorm_bwd_io")
+    return dx, dg, db
+
+
+def colreduce16(x, op=RED_SUM, y=None, groups=1, round_gelu=False, scale=1.0, out=None):
+    """column sums of bf16 rows [groups, rows_per_group, N] -> fp32 [groups, N] ([2, groups, N] for RED_DOTGELU_SUM)"""
+    lib = _lib.binding()
+    _chk16(x, "x"), _chk16(y, "y")
+    N = x.shape[-1]
+    rpg = x.numel() // N // groups
+    if out is None:
+        out = torch.empty((2, groups, N) if op == RED_DOTGELU_SUM else (groups, N), dtype=torch.float32, device=x.device)
+    wsb = lib.dkd_colreduce_f32_workspace_bytes(rpg, groups, N)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.dkd_colreduce_bf16(_p(x), _p(y), _p(out), _p(ws), rpg, groups, N, op, int(round_gelu), scale, _stream()),
+          "dkd_colreduce_bf16")
+    return out
+
+
+def grn_fwd16(h16, gamma, beta, B):
+    """GRN on g = rnd(gelu(h16)) (h16 [B*HW, C] bf16, the 16-bit pre-activation) -> y16, (gx, nx, denom)"""
+    lib = _lib.binding()
+    C = h16.shape[-1]
+    rpi = h16.numel() // C // B
+    sumsq = colreduce16(h16, RED_GELUSQ, groups=B, round_gelu=True)
+    gx, nx = torch.empty_like(sumsq), torch.empty_like(sumsq)
+    denom = torch.empty(B, dtype=torch.float32, device=h16.device)
+    check(lib.dkd_grn_stats_f32(_p(sumsq), _p(gx), _p(nx), _p(denom), B, C, _stream()), "dkd_grn_stats_f32")
+    y = torch.empty_like(h16)
+    check(lib.dkd_grn_apply_bf16(_p(h16), _p(nx), _p(gamma), _p(beta), _p(y), B, rpi, C, _stream()), "dkd_grn_apply_bf16")
+    return y, (gx, nx, denom)
+
+
+def grn_gelu_bwd16(dy16, h16, stats, gamma, B, dgamma_out=None, dbeta_out=None):
+    """-> dh16 (through GRN and GELU), dgamma, dbeta (fp32)"""
+    lib = _lib.binding()
+    gx, nx, denom = stats
+    C = h16.shape[-1]
+    rpi = h16.numel() // C // B
+    both = colreduce16(dy16, RED_DOTGELU_SUM, y=h16, groups=B, round_gelu=True)  # [0] = sum dy*g, [1] = sum dy, per image
+    A = both[0]
+    dbeta = colreduce(both[1], RED_SUM, out=None if dbeta_out is None else dbeta_out.view(1, C)).reshape(C)
+    coef, dgp = torch.empty_like(A), torch.empty_like(A)
+    check(lib.dkd_grn_bwd_stats_f32(_p(A), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgp), B, C, _stream()),
+          "dkd_grn_bwd_stats_f32")
+    dgamma = colreduce(dgp, RED_SUM, out=None if dgamma_out is None else dgamma_out.view(1, C)).reshape(C)
+    dh = torch.empty_like(h16)
+    check(lib.dkd_grn_gelu_bwd_bf16(_p(dy16), _p(h16), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
+          "dkd_grn_gelu_bwd_bf16")
+    return dh, dgamma, dbeta
+
+
+def cast_f32(x16):
+    _chk16(x16, "x16")
+    out = torch.empty(x16.shape, dtype=torch.float32, device=x16.device)
+    check(_lib.binding().dkd_cast_f32_from_bf16(_p(x16), _p(out), x16.numel(), _stream()), "dkd_cast_f32_from_bf16")
+    return out
+
+
+def round_bf16_(x):
+    """in place: every fp32 value to the nearest bf16"""
+    _chk(x, "x")
+    check(_lib.binding().dkd_round_bf16_f32(_p(x), x.numel(), _stream()), "dkd_round_bf16_f32")
+    return x
+
+
+def add16(a, b):
+    _chk16(a, "a"), _chk16(b, "b")
+    out = torch.empty_like(a)
+    check(_lib.binding().dkd_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "dkd_add_bf16")
+    return out

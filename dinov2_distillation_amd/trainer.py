@@ -11,10 +11,13 @@ from .train import DistillationModule
 
 class DistillationStepper:
     def __init__(self, teacher="dinov2_vits14", student="convnext_tiny", crop=224, device="cuda", heads=(16, 24),
-                 clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None, accumulate_grad_batches=1):
+                 clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None, accumulate_grad_batches=1,
+                 student_precision=None):
         self.cfg = make_config(teacher, student, crop, heads=heads, lr=lr)
         torch.manual_seed(seed)  # student seed 1, ScaleKD follows; identical on every rank
         self.student = ModelWrapper(student, self.cfg.teacher.n_patches, self.cfg.student.student_keys)
+        if student_precision is not None:
+            self.student.set_precision(student_precision)
         set_student_dims(self.cfg, self.student)
         self.teacher = DINOv2ViT(teacher, seed=0, precision=teacher_precision)
         self.module = DistillationModule(self.student, self.teacher, self.cfg).to(device).train()

@@ -186,6 +186,7 @@ typedef struct dkd_gemm_bf16_args {
     const void* bias;
     const float* colscale;
     const float* residual; int64_t ldr;
+    const void* residual16; /* DKD_BF16_EPI_BF16 only: bf16 residual [.., ldr], C = rnd(residual16 + rnd(acc + bias)) */
     float* workspace;
     int32_t M, N, K;
     int32_t epi, res_mod, row_grp, row_grp_stride, row_off;
@@ -193,6 +194,31 @@ typedef struct dkd_gemm_bf16_args {
 } dkd_gemm_bf16_args;
 int dkd_gemm_bf16(const dkd_gemm_bf16_args* args, void* stream);
 long dkd_gemm_bf16_workspace_bytes(int M, int N, int K);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * HBM-bound kernels of the mixed-precision student (ConvNeXt-V2 block, models/backbones/convnext.py:75-87, under the
+ * reference's default precision=16 policy, train.py:263): the tensors torch autocast keeps in 16 bit live in HBM as bf16,
+ * the arithmetic is fp32, parameters and statistics stay fp32.  `x16`-style flags: 1 = that tensor is bf16, 0 = fp32. */
+int dkd_dwconv7_fwd_io(const void* in_bf16, const float* w_tap_major, const float* bias, const void* add, int add16, void* out,
+                       int out16, int B, int H, int W, int C, int flip, void* stream);
+int dkd_dwconv7_wgrad_bf16(const void* in, const void* dout, float* partials, int B, int H, int W, int C, void* stream);
+/* cf16 != 0 (bf16 x): the reference's hand-written channels-first LayerNorm (convnext.py:31-36) as autocast runs it op by op
+ * on a 16-bit tensor - the mean and x - mean are 16-bit results; backward: bf16 dx, the matching adjoint */
+int dkd_layernorm_fwd_io(const void* x, int x16, const float* gamma, const float* beta, void* y, int y16, float* mean, float* rstd,
+                         long rows, int C, float eps, int cf16, void* stream);
+int dkd_layernorm_bwd_io(const void* dy, int dy16, const void* x, int x16, const float* mean, const float* rstd, const float* gamma,
+                         void* dx, int dx16, float* dgamma, float* dbeta, float* ws, long rows, int C, int cf16, void* stream);
+/* column sums over bf16 rows (ops DKD_RED_SUM / _DOT / _GELUSQ / _DOTGELU_SUM; round_gelu: gelu rounded to bf16 first);
+ * ws sized by dkd_colreduce_f32_workspace_bytes */
+int dkd_colreduce_bf16(const void* X, const void* Y, float* out, float* ws, long rows_per_group, int groups, int N, int op,
+                       int round_gelu, float scale, void* stream);
+int dkd_grn_apply_bf16(const void* h, const float* nx, const float* gamma, const float* beta, void* y, int B, long rows_per_img,
+                       int C, void* stream);
+int dkd_grn_gelu_bwd_bf16(const void* dy, const void* h, const float* nx, const float* coef, const float* gamma, void* dh, int B,
+                          long rows_per_img, int C, void* stream);
+int dkd_cast_f32_from_bf16(const void* in, float* out, long n, void* stream);
+int dkd_round_bf16_f32(float* x, long n, void* stream); /* in place: every value to the nearest bf16 */
+int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
 /* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588
  * patch rows to a multiple of 8) */
 int dkd_cast_bf16(const float* in, void* out_bf16, long rows, int cols, int out_ld, void* stream);

@@ -103,3 +103,59 @@ def student_features(p, x, depths, n_patches, targets=("res5", "res4")):
     feats = forward_features(p, x, depths)
     return {k: F.interpolate(feats[k], size=tuple(n_patches), mode="bilinear", align_corners=False)
             for k in targets if k in feats}
+
+
+# ---- the same backbone under the reference's DEFAULT trainer precision (train.py:263 precision=16 == torch autocast) --------------
+# torch.autocast itself decides what conv2d / linear do (every tensor argument cast to 16 bit, 16-bit result) and autograd replays
+# the backward in the dtypes of the forward; run on the CPU in bfloat16.  CUDA's autocast additionally runs layer_norm, pow and norm
+# in fp32 (torch/csrc/autocast_mode.cpp, the `fp32` cast-policy list), which the CPU policy does not: those three call sites are
+# forced to fp32 here with explicit casts, so that the op policy is the one the reference's GPU run applies.  PARITY UNPINNED for
+# that policy (no CUDA device to run the reference's autocast on); the ops themselves are the pinned fp32 restatement above.
+def _fp32(fn, *args, **kw):
+    with torch.autocast("cpu", enabled=False):
+        return fn(*[a.float() if torch.is_tensor(a) and a.is_floating_point() else a for a in args], **kw)
+
+
+def _ln_channels_first_autocast(x, w, b, eps=1e-6):
+    """convnext.py:31-36 op by op: mean and (x - u) in the dtype of x, pow (an fp32 op under CUDA autocast) and everything after
+    it in fp32"""
+    u = x.mean(1, keepdim=True)
+    d = x - u
+    s = _fp32(lambda t: t.pow(2), d).mean(1, keepdim=True)
+    xn = d / torch.sqrt(s + eps)
+    return w[None, :, None, None] * xn + b[None, :, None, None]
+
+
+def grn_autocast(x, gamma, beta):
+    gx = _fp32(lambda t: torch.linalg.vector_norm(t, ord=2, dim=(1, 2), keepdim=True), x)  # torch.norm: fp32 under CUDA autocast
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    return gamma * (x * nx) + beta + x
+
+
+def block_autocast(p, pre, x):
+    C = x.shape[1]
+    y = F.conv2d(x, p[pre + "dwconv.weight"], p[pre + "dwconv.bias"], padding=3, groups=C)
+    y = y.permute(0, 2, 3, 1)
+    y = _fp32(F.layer_norm, y, (C,), p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-6)
+    y = F.gelu(F.linear(y, p[pre + "pwconv1.weight"], p[pre + "pwconv1.bias"]))
+    y = grn_autocast(y, p[pre + "grn.gamma"], p[pre + "grn.beta"])
+    y = F.linear(y, p[pre + "pwconv2.weight"], p[pre + "pwconv2.bias"])
+    return x + y.permute(0, 3, 1, 2)
+
+
+def forward_features_autocast(p, x, depths):
+    """forward_features under torch.autocast(bfloat16) with CUDA's op policy; fp32 parameters, the dtypes of the results are
+    autocast's (res2 fp32: the stem LayerNorm returns fp32 and stage 0 adds 16-bit branches to it; res3..res5 bfloat16)"""
+    outs = {}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        for i in range(4):
+            if i == 0:
+                x = F.conv2d(x, p["downsample_layers.0.0.weight"], p["downsample_layers.0.0.bias"], stride=4)
+                x = _ln_channels_first_autocast(x, p["downsample_layers.0.1.weight"], p["downsample_layers.0.1.bias"])
+            else:
+                x = _ln_channels_first_autocast(x, p[f"downsample_layers.{i}.0.weight"], p[f"downsample_layers.{i}.0.bias"])
+                x = F.conv2d(x, p[f"downsample_layers.{i}.1.weight"], p[f"downsample_layers.{i}.1.bias"], stride=2)
+            for j in range(depths[i]):
+                x = block_autocast(p, f"stages.{i}.{j}.", x)
+            outs[f"res{i+2}"] = x
+    return outs

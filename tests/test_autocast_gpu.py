@@ -208,3 +208,200 @@ def test_step_with_autocast_teacher_stays_close_to_the_fp32_step():
     l16b = float(st.step(x).detach())
     print(f"step loss: fp32 teacher {l32:.5f}, autocast-bf16 teacher {l16:.5f}")
     assert abs(l16 - l32) <= 2e-2 * abs(l32) and l16 != l32 and l16b == l16b
+
+
+# ---- the mixed-precision STUDENT (functional16.py): bf16 activations in HBM, fp32 arithmetic ------------------------------------
+def test_io_kernels_equal_the_fp32_kernels_on_16_bit_data():
+    """every bf16-I/O kernel of the student computes in fp32 exactly what its fp32 twin computes on the same (bf16-representable)
+    values, and differs only by the roundings the mixed-precision step defines: bit-equal after rounding the fp32 result"""
+    from dinov2_distillation_amd import ops
+    g = torch.Generator().manual_seed(17)
+    B, H, W, C = 3, 14, 14, 96
+    x16 = torch.randn(B, H, W, C, generator=g).bfloat16().cuda()
+    wt = r16(torch.randn(49, C, generator=g) * 0.1).cuda()
+    bias = r16(torch.randn(C, generator=g)).cuda()
+    add16 = torch.randn(B, H, W, C, generator=g).bfloat16().cuda()
+    x32 = x16.float()
+    # depthwise 7x7: forward, and the dgrad form with a 16-bit / an fp32 addend
+    assert torch.equal(ops.dwconv7_io(x16, wt, bias), ops.dwconv7(x32, wt, bias).bfloat16())
+    conv_t = ops.dwconv7(x32, wt, None, flip=True).bfloat16().float()
+    assert torch.equal(ops.dwconv7_io(x16, wt, None, add=add16, flip=True), (conv_t + add16.float()).bfloat16())
+    a32 = torch.randn(B, H, W, C, generator=g).cuda()
+    assert torch.equal(ops.dwconv7_io(x16, wt, None, add=a32, flip=True, out_dtype=torch.float32), conv_t + a32)
+    dw_ref = ops.dwconv7_wgrad(x32, add16.float())
+    close_rel = lambda a, b, tol: ((a - b).abs().max() / b.abs().max()).item() < tol
+    assert close_rel(ops.dwconv7_wgrad16(x16, add16), dw_ref, 1e-6)
+    # LayerNorm, all four dtype combinations; backward
+    gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    y_ref, m_ref, r_ref = ops.layernorm_fwd(x32.reshape(-1, C), gm, bt, 1e-6)
+    for src in (x16, x32):
+        for od in (torch.bfloat16, torch.float32):
+            y, m, r = ops.layernorm_fwd_io(src.reshape(-1, C), gm, bt, 1e-6, od)
+            assert torch.equal(y, y_ref.to(od)) and torch.equal(m, m_ref) and torch.equal(r, r_ref)
+    dy16 = torch.randn(B * H * W, C, generator=g).bfloat16().cuda()
+    dx_ref, dg_ref, db_ref = ops.layernorm_bwd(dy16.float(), x32.reshape(-1, C), m_ref, r_ref, gm)
+    dx, dg, db = ops.layernorm_bwd_io(dy16, x16.reshape(-1, C), m_ref, r_ref, gm, torch.bfloat16)
+    assert torch.equal(dx, dx_ref.bfloat16()) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    dx32, _, _ = ops.layernorm_bwd_io(dy16.float(), x32.reshape(-1, C), m_ref, r_ref, gm, torch.float32)
+    assert torch.equal(dx32, dx_ref)
+    # column sums
+    h16 = (2 * torch.randn(B * H * W, 4 * C, generator=g)).bfloat16().cuda()
+    assert torch.equal(ops.colreduce16(h16), ops.colreduce(h16.float()))
+    assert torch.equal(ops.colreduce16(h16, ops.RED_GELUSQ, groups=B), ops.colreduce(h16.float(), ops.RED_GELUSQ, groups=B))
+    g16 = F.gelu(h16.float()).bfloat16().float()   # the 16-bit GELU output the step never stores
+    e_ref = (g16.double() ** 2).view(B, H * W, 4 * C).sum(1).float()
+    assert close_rel(ops.colreduce16(h16, ops.RED_GELUSQ, groups=B, round_gelu=True), e_ref, 2e-3)   # (gelu_f vs erf: 1 ulp flips)
+    # GRN forward / backward on the 16-bit pre-activation vs the fp32 kernels fed the rounded GELU
+    gg, gb = (0.5 * torch.randn(4 * C, generator=g)).cuda(), (0.1 * torch.randn(4 * C, generator=g)).cuda()
+    y16, st16 = ops.grn_fwd16(h16, gg, gb, B)
+    y_ref, st_ref = ops.grn_fwd(g16, gg, gb, B)
+    assert y16.dtype == torch.bfloat16 and ((y16.float() - y_ref).abs().max() / y_ref.abs().max()).item() < 1e-2
+    assert ((y16.float() - y_ref).abs() > 2.0 ** -7 * y_ref.abs() + 1e-6).float().mean().item() < 5e-3
+    dyy = torch.randn(B * H * W, 4 * C, generator=g).bfloat16().cuda()
+    dh16, dgg, dgb = ops.grn_gelu_bwd16(dyy, h16, st16, gg, B)
+    dh_ref, dgg_ref, dgb_ref = ops.grn_gelu_bwd(dyy.float(), None, h16.float(), st_ref, gg, B)
+    assert dh16.dtype == torch.bfloat16
+    assert ((dh16.float() - dh_ref).norm() / dh_ref.norm()).item() < 6e-3 and close_rel(dgb, dgb_ref, 1e-5) and close_rel(dgg, dgg_ref, 2e-2)
+    # plumbing
+    assert torch.equal(ops.cast_f32(x16), x32) and torch.equal(ops.add16(x16, add16), (x32 + add16.float()).bfloat16())
+    t = torch.randn(1000, generator=g).cuda()
+    assert torch.equal(ops.round_bf16_(t.clone()), t.bfloat16().float())
+    o = ops.gemm_bf16_resid16(x16.reshape(-1, C), (torch.randn(C, C, generator=g) * 0.1).bfloat16().cuda(), bias.bfloat16(), add16.reshape(-1, C))
+    assert o.dtype == torch.bfloat16 and o.shape == (B * H * W, C)
+
+
+def _autocast_backbone_case(depths, dims, hw, batch, seed):
+    from oracle import convnext_oracle as co
+    p = co.init_convnext_params(depths, dims, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    for k, v in p.items():  # the reference's zero-initialised GRN / biases would hide those paths
+        if "grn" in k:
+            v.copy_(0.5 * torch.randn(v.shape, generator=g))
+        elif k.endswith("bias"):
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+    x = torch.randn(batch, 3, hw, hw, generator=g)
+    return co, p, x, g
+
+
+def test_autocast_convnext_vs_autocast_oracle():
+    """The whole ConvNeXt-V2 backbone under the reference's default precision policy (train.py:263) with bf16 activations in HBM,
+    against the oracle that RUNS torch.autocast(bfloat16) on the CPU restatement (CUDA's fp32 op list forced where the CPU policy
+    differs): features of all four levels and every parameter gradient.  bf16 rounding is discontinuous - two exact
+    implementations of the same policy differ by a fraction of the policy's own distance from fp32 - so the yardstick is that
+    distance ("noise"), measured on the oracle."""
+    from dinov2_distillation_amd.models.convnext import ConvNeXtV2
+    depths, dims = [2, 2, 3, 2], [96, 192, 384, 768]
+    co, p, x, g = _autocast_backbone_case(depths, dims, 128, 4, 7)
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().norm()).item()
+
+    def run_oracle(fn):
+        q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        out = fn(q, x, depths)
+        return q, out
+
+    q16, o16 = run_oracle(co.forward_features_autocast)
+    q32, o32 = run_oracle(co.forward_features)
+    cts = {k: torch.randn(v.shape, generator=g) for k, v in o32.items()}
+    sum((o16[k].float() * cts[k]).sum() for k in o16).backward()
+    sum((o32[k] * cts[k]).sum() for k in o32).backward()
+
+    net = ConvNeXtV2(depths, dims).set_precision("bf16_autocast")
+    net.load_state_dict(p, strict=True)
+    net.cuda().train()
+    feats = net.forward_features(x.cuda())
+    for k in o32:
+        assert feats[k].dtype == torch.float32 and feats[k].shape == o32[k].shape
+        e, noise = rel(feats[k], o16[k]), rel(o16[k], o32[k])
+        print(f"{k}: ours vs autocast oracle {e:.2e}; autocast oracle vs fp32 oracle {noise:.2e}")
+        # (one block agrees to ~0.3 of the noise, test below; over 9 blocks the 1-ulp flips of two fp32 summation orders decorrelate:
+        # fully independent realisations of the same policy would sit at sqrt(2) x noise)
+        assert noise > 1e-3 and e < 1.0 * noise, (k, e, noise)
+    sum((feats[k] * cts[k].cuda()).sum() for k in feats).backward()
+    worst = 0.0
+    for k, v in net.named_parameters():
+        assert v.grad is not None and torch.isfinite(v.grad).all(), k
+        e, noise = rel(v.grad, q16[k].grad), rel(q16[k].grad, q32[k].grad)
+        worst = max(worst, e / max(noise, 1e-9))
+        assert e < max(1.25 * noise, 5e-3), f"d{k}: ours vs autocast oracle {e:.2e}, autocast vs fp32 {noise:.2e}"
+    tot = lambda grads: torch.cat([t.float().reshape(-1).cpu() for t in grads])
+    names = [k for k, _ in net.named_parameters()]
+    ours, a16, a32 = tot([dict(net.named_parameters())[k].grad for k in names]), tot([q16[k].grad for k in names]), tot([q32[k].grad for k in names])
+    e, noise = ((ours - a16).norm() / a16.norm()).item(), ((a16 - a32).norm() / a32.norm()).item()
+    print(f"all parameter gradients: ours vs autocast oracle {e:.2e}; autocast oracle vs fp32 oracle {noise:.2e}; worst tensor ratio {worst:.2f}")
+    assert e < 1.0 * noise
+    # weight gradients ARE 16-bit values held in fp32 (autocast's backward matmul result, cast up)
+    wg = dict(net.named_parameters())["stages.2.1.pwconv1.weight"].grad
+    assert torch.equal(wg, wg.bfloat16().float())
+
+
+@pytest.mark.parametrize("stream16", [True, False])
+def test_autocast_convnext_block_vs_autocast_oracle(stream16):
+    """ONE block, where the two implementations' roundings are still strongly correlated: output, input gradient and every
+    parameter gradient against torch.autocast on the oracle's block, for a 16-bit residual stream (stages 1-3) and an fp32 one
+    (stage 0)"""
+    from oracle import convnext_oracle as co
+    from dinov2_distillation_amd.models.convnext import Block
+    C, B, H = 192, 4, 28
+    g = torch.Generator().manual_seed(31 + stream16)
+    p = {k[len("stages.0.0."):]: v for k, v in co.init_convnext_params([1, 0, 0, 0], [C, C, C, C], seed=5).items() if k.startswith("stages.0.0.")}
+    for k, v in p.items():
+        if "grn" in k:
+            v.copy_(0.5 * torch.randn(v.shape, generator=g))
+        elif k.endswith("bias"):
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+        elif k.startswith("pwconv") or k.startswith("dwconv"):
+            v.mul_(8.0)   # (the trunc-normal 0.02 init makes the branch ~1e-2 of the residual: scale it up to O(1))
+    x = torch.randn(B, C, H, H, generator=g)
+    if stream16:
+        x = x.bfloat16().float()
+    ct = torch.randn(B, C, H, H, generator=g)
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().norm()).item()
+
+    def oracle(autocast):
+        q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        xin = (x.bfloat16() if (autocast and stream16) else x.clone()).requires_grad_(True)
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = co.block_autocast(q, "", xin)
+        else:
+            out = co.block(q, "", xin)
+        (out.float() * ct).sum().backward()
+        return q, xin, out
+
+    q16, x16, o16 = oracle(True)
+    q32, x32, o32 = oracle(False)
+    assert o16.dtype == (torch.bfloat16 if stream16 else torch.float32)
+    blk = Block(C)
+    blk.load_state_dict(p, strict=True)
+    blk.cuda().train()
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    xin = (xin.bfloat16() if stream16 else xin).requires_grad_(True)
+    out = blk(xin, autocast=True)
+    assert out.dtype == o16.dtype
+    # compare the branch (what the block adds to its input): the residual itself is common to all three
+    br = lambda o, xi: o.float().cpu() - xi.detach().float().cpu()
+    e, noise = rel(br(out.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2)), br(o16, x16)), rel(br(o16, x16), br(o32, x32))
+    print(f"block branch: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
+    assert noise > 1e-3 and e < 0.5 * noise
+    (out.float() * ct.permute(0, 2, 3, 1).cuda()).sum().backward()
+    e, noise = rel(xin.grad.permute(0, 3, 1, 2), x16.grad), rel(x16.grad, x32.grad)
+    print(f"block dx: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
+    assert xin.grad.dtype == x16.grad.dtype and e < 0.7 * noise
+    bad = []
+    for k, v in blk.named_parameters():
+        e, noise = rel(v.grad, q16[k].grad), rel(q16[k].grad, q32[k].grad)
+        print(f"block d{k}: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
+        bad.append(k) if e >= max(0.7 * noise, 2e-3) else None
+    assert not bad, bad
+
+
+def test_step_with_autocast_student_and_teacher():
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(77)).cuda()
+    l32 = float(DistillationStepper(device="cuda:0").step(x).detach())
+    st = DistillationStepper(device="cuda:0", teacher_precision="bf16_autocast", student_precision="bf16_autocast")
+    l16 = [float(st.step(x).detach()) for _ in range(3)]
+    st2 = DistillationStepper(device="cuda:0", teacher_precision="bf16_autocast", student_precision="bf16_autocast")
+    l16b = [float(st2.step(x).detach()) for _ in range(3)]
+    print(f"step loss: fp32 {l32:.5f}; autocast teacher + student {l16}")
+    assert abs(l16[0] - l32) <= 3e-2 * abs(l32) and l16[0] != l32 and l16 == l16b and l16[2] < l16[0]
