@@ -334,6 +334,59 @@ def test_autocast_convnext_vs_autocast_oracle():
     assert torch.equal(wg, wg.bfloat16().float())
 
 
+def test_autocast_convnext_layer_by_layer_on_the_same_input():
+    """The sharp form of the comparison above: every layer of the backbone (stem conv, the channels-first LayerNorms on fp32 and
+    on 16-bit inputs, the downsample convs, every block) is fed the SAME input as torch.autocast on the oracle's layer and has to
+    land within a few 1-ulp flips of it - 1e-6 ... 5e-4 of the tensor against the 3e-3 ... 6e-3 by which the policy itself moves
+    the result (measured).  Whatever separates the two whole networks beyond that is the cascade of those flips."""
+    from dinov2_distillation_amd import functional16 as Fn16
+    from dinov2_distillation_amd.models.convnext import ConvNeXtV2
+    depths, dims = [2, 2, 3, 2], [96, 192, 384, 768]
+    co, p, x, g = _autocast_backbone_case(depths, dims, 128, 4, 7)
+    net = ConvNeXtV2(depths, dims).set_precision("bf16_autocast")
+    net.load_state_dict(p, strict=True)
+    net.cuda().train()
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm()).item()
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    worst = 0.0
+
+    def check(what, ours, ref, tol):
+        nonlocal worst
+        assert ours.dtype == ref.dtype, (what, ours.dtype, ref.dtype)
+        e = rel(ours, ref)
+        worst = max(worst, e)
+        assert e < tol, f"{what}: {e:.2e}"
+
+    with torch.no_grad():
+        cur = None
+        for i in range(4):
+            ds = net.downsample_layers[i]
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                if i == 0:
+                    o_conv = F.conv2d(x, p["downsample_layers.0.0.weight"], p["downsample_layers.0.0.bias"], stride=4)
+                    o = co._ln_channels_first_autocast(o_conv, p["downsample_layers.0.1.weight"], p["downsample_layers.0.1.bias"])
+                else:
+                    o_ln = co._ln_channels_first_autocast(nchw(cur).cpu(), p[f"downsample_layers.{i}.0.weight"],
+                                                          p[f"downsample_layers.{i}.0.bias"])
+                    o = F.conv2d(o_ln, p[f"downsample_layers.{i}.1.weight"], p[f"downsample_layers.{i}.1.bias"], stride=2)
+            if i == 0:
+                m = Fn16.PatchConv16Fn.apply(x.cuda(), ds[0].weight, ds[0].bias, 4, True)
+                check("stem conv", nchw(m), o_conv, 2e-5)
+                m = Fn16.LayerNorm16Fn.apply(m, ds[1].weight, ds[1].bias, 1e-6, False)   # 16-bit input: the cf16 form, fp32 result
+            else:
+                mln = Fn16.LayerNorm16Fn.apply(cur, ds[0].weight, ds[0].bias, 1e-6, True)
+                check(f"downsample {i} LayerNorm", nchw(mln), o_ln.bfloat16(), 1e-4)
+                m = Fn16.PatchConv16Fn.apply(mln, ds[1].weight, ds[1].bias, 2, False)
+            check(f"stage {i} input", nchw(m), o, 3e-4)
+            for j, blk in enumerate(net.stages[i]):
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    o = co.block_autocast(p, f"stages.{i}.{j}.", nchw(m).cpu())   # the oracle's block on OUR input
+                m = blk(m, autocast=True)
+                check(f"stage {i} block {j}", nchw(m), o, 1e-3)
+            cur = m
+    print(f"layer by layer: worst distance from torch.autocast on the same input {worst:.2e}")
+
+
 @pytest.mark.parametrize("stream16", [True, False])
 def test_autocast_convnext_block_vs_autocast_oracle(stream16):
     """ONE block, where the two implementations' roundings are still strongly correlated: output, input gradient and every
@@ -382,16 +435,16 @@ def test_autocast_convnext_block_vs_autocast_oracle(stream16):
     br = lambda o, xi: o.float().cpu() - xi.detach().float().cpu()
     e, noise = rel(br(out.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2)), br(o16, x16)), rel(br(o16, x16), br(o32, x32))
     print(f"block branch: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
-    assert noise > 1e-3 and e < 0.5 * noise
+    assert noise > 1e-3 and e < 0.1 * noise
     (out.float() * ct.permute(0, 2, 3, 1).cuda()).sum().backward()
     e, noise = rel(xin.grad.permute(0, 3, 1, 2), x16.grad), rel(x16.grad, x32.grad)
     print(f"block dx: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
-    assert xin.grad.dtype == x16.grad.dtype and e < 0.7 * noise
+    assert xin.grad.dtype == x16.grad.dtype and e < 0.25 * noise
     bad = []
     for k, v in blk.named_parameters():
         e, noise = rel(v.grad, q16[k].grad), rel(q16[k].grad, q32[k].grad)
         print(f"block d{k}: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
-        bad.append(k) if e >= max(0.7 * noise, 2e-3) else None
+        bad.append(k) if e >= 0.25 * noise else None
     assert not bad, bad
 
 
