@@ -1035,6 +1035,23 @@ def _rccl_one_rank_worker(port, q):
     ops.wgrad_join()
     torch.cuda.synchronize()
     err = ((st.optimizer.flat_g - expect).abs().max() / expect.abs().max()).item()
+    # the mixed-precision student writes its weight gradients through its own path (functional16.wgrad16): the reducer has to be
+    # told about every one of them too (a gradient it never hears of would leave its bucket unreduced until finish())
+    st16 = DistillationStepper(device="cuda:0", bucket_bytes=8 << 20, student_precision="bf16_autocast", teacher_precision="bf16_autocast")
+    st16.reducer.remove()
+    st16.optimizer.zero_grad()
+    st16.module.training_step(x, 0).backward()
+    ops.wgrad_join()
+    expect16 = st16.optimizer.flat_g.clone()
+    st16.reducer = GradBucketReducer(st16.optimizer, 8 << 20, force=True)
+    st16.optimizer.zero_grad()
+    st16.module.training_step(x, 0).backward()
+    launched16 = sum(st16.reducer.launched)
+    st16.reducer.finish()
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    err = max(err, ((st16.optimizer.flat_g - expect16).abs().max() / expect16.abs().max()).item())
+    launched = min(launched, launched16)
     t = torch.ones(4, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
