@@ -7,9 +7,12 @@ RESNET_BLOCKS = {"resnet_50": [3, 4, 6, 3], "resnet_101": [3, 4, 23, 3]}
 STDC_LAYERS = {"stdc_1": [2, 2, 2], "stdc_2": [4, 5, 3]}
 
 
-def oracle_step(mod, cfg, x, dtype=torch.float32, teacher_bf16=False):
+def oracle_step(mod, cfg, x, dtype=torch.float32, teacher_bf16=False, autocast=False):
     """-> (logged-scalar dict, {student key: grad}, {loss-module key: grad}) of the oracle run with ``mod``'s weights.
-    teacher_bf16: the frozen teacher (forward and block re-use) in the "bf16 operands, fp32 accumulate" arithmetic."""
+    teacher_bf16: the frozen teacher (forward and block re-use) in the "bf16 operands, fp32 accumulate" arithmetic.
+    autocast: the mixed-precision step as the build runs it - teacher forward and ConvNeXt backbone under torch's autocast policy
+    in bfloat16 (oracle/vit_oracle.py, oracle/convnext_oracle.py), the features handed on as fp32, block re-use in the bf16-operand
+    arithmetic, projectors / losses fp32."""
     from oracle import convnext_oracle as cno, resnet_oracle as ro, stdc_oracle as sto, step_oracle as so, swin_oracle as swo
     from oracle import vit_oracle as vo
 
@@ -27,10 +30,14 @@ def oracle_step(mod, cfg, x, dtype=torch.float32, teacher_bf16=False):
     tcfg = vo.VIT_CONFIGS[cfg.teacher.model_name]
     xd = x.to(dtype)
     with torch.no_grad():
-        feat_t = vo.teacher_feature_map(tp, xd, tcfg, bf16=teacher_bf16)
+        feat_t = vo.teacher_feature_map_autocast(tp, xd, tcfg) if autocast else vo.teacher_feature_map(tp, xd, tcfg, bf16=teacher_bf16)
+    teacher_bf16 = teacher_bf16 or autocast
     name, grid, keys = cfg.student.model_name, tuple(cfg.teacher.n_patches), cfg.student.student_keys
     if name.startswith("swin"):
         feats = swo.student_features(sp, xd, swo.SWIN_CONFIGS[name], grid, keys)
+    elif name.startswith("convnext") and autocast:
+        f = cno.forward_features_autocast(sp, xd, cno.CONVNEXT_CONFIGS[name]["depths"])
+        feats = {k: F.interpolate(f[k].float(), size=grid, mode="bilinear", align_corners=False) for k in keys}
     elif name.startswith("convnext"):
         feats = cno.student_features(sp, xd, cno.CONVNEXT_CONFIGS[name]["depths"], grid, keys)
     elif name.startswith("resnet"):

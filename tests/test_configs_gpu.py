@@ -95,6 +95,43 @@ def test_config1_vits14_convnext_tiny_fp64_arbiter():
     _check_step(mod, cfg, x, "configs[1] vits14->convnext_tiny B=2")
 
 
+def test_config1_mixed_precision_step_vs_autocast_oracle():
+    """configs[1] with the reference's DEFAULT trainer precision (train.py:263) on the teacher forward and the ConvNeXt backbone
+    (bf16 activations in HBM, bf16 MFMA GEMMs; projectors / losses fp32) against the oracle run in the same modes - torch.autocast
+    itself on the backbone restatement.  Yardstick as for every 16-bit mode: the distance between the mixed-precision and the fp32
+    oracle runs (two exact implementations of one rounding policy separate by a fraction of it over 18 blocks; layer-level
+    agreement is pinned in tests/test_autocast_gpu.py)."""
+    from dinov2_distillation_amd import ops
+    mod, cfg = _build("dinov2_vits14", "convnext_tiny", 224, (16, 24), seed=1, teacher_precision="bf16_autocast")
+    mod.student.set_precision("bf16_autocast")
+    with torch.no_grad():
+        for n_, p_ in mod.student.named_parameters():
+            if "grn" in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+            elif p_.dim() > 1:
+                p_.mul_(4.0)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    ref16, gs16, gl16 = oracle_step(mod, cfg, x, torch.float32, autocast=True)
+    ref32, gs32, gl32 = oracle_step(mod, cfg, x, torch.float32)
+    mod.cuda().train()
+    loss = mod.training_step(x.cuda(), 0)
+    loss.backward()
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    lk = [k for k in ref32 if "loss" in k]
+    noise = max(abs(float(ref16[k]) - float(ref32[k])) / abs(float(ref32[k])) for k in lk)
+    dev = max(abs(float(mod.logged["train_" + k]) - float(ref16[k])) / abs(float(ref16[k])) for k in lk)
+    print(f"configs[1] mixed precision: logged losses vs autocast oracle {dev:.2e}; autocast oracle vs fp32 oracle {noise:.2e}")
+    assert dev <= max(1e-3, 1.0 * noise), (dev, noise)
+    gs, gl = module_grads(mod)
+    for tag, ours, g16, g32 in (("student", gs, gs16, gs32), ("projectors", gl, gl16, gl32)):
+        gmax = max(v.abs().max().item() for v in g16.values())
+        names = [k for k in sorted(g16) if g16[k].abs().max().item() >= 1e-6 * gmax]
+        e16, o = rel_l2(flat(ours, names), flat(g16, names)), rel_l2(flat(g16, names), flat(g32, names))
+        print(f"configs[1] mixed precision: {tag} gradient relL2: ours vs autocast oracle {e16:.2e}; autocast oracle vs fp32 oracle {o:.2e}")
+        assert e16 <= max(3e-3, 1.0 * o), (tag, e16, o)
+
+
 # ---- configs[2]: dinov2_vitb14 -> resnet_50, 224x224 -------------------------------------------------------------------------
 def test_config2_vitb14_resnet50_step_vs_oracle():
     """D = 768, 12 teacher heads, ScaleKD heads 16 / 24 (head dims 48 / 32), ResNet-50 with live BatchNorm over B = 2"""
