@@ -25,13 +25,18 @@ CONFIGS = {
     "3a": dict(teacher="dinov2_vitb14", student="resnet_50", crop=224, batch=128, heads=(16, 24), teacher_precision="bf16_autocast"),
     "4a": dict(teacher="dinov2_vitl14", student="swin_tiny", crop=518, batch=16, heads=(16, 32), teacher_precision="bf16_autocast"),
     "5a": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24), teacher_precision="bf16_autocast"),
+    "2as": dict(teacher="dinov2_vits14", student="convnext_tiny", crop=224, batch=64, heads=(16, 24), teacher_precision="bf16_autocast",
+                student_precision="bf16_autocast"),
+    "5as": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24), teacher_precision="bf16_autocast",
+                student_precision="bf16_autocast"),
+    "mobilenet_v3_large": dict(teacher="dinov2_vits14", student="mobilenet_v3_large", crop=224, batch=64, heads=(16, 24)),
     "5f32": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24)),
 }
 
 for name in sys.argv[1:] or ["3", "4", "5"]:
     c = CONFIGS[name]
     st = DistillationStepper(teacher=c["teacher"], student=c["student"], crop=c["crop"], heads=c["heads"], device="cuda:0",
-                             teacher_precision=c.get("teacher_precision"))
+                             teacher_precision=c.get("teacher_precision"), student_precision=c.get("student_precision"))
     x = torch.randn(c["batch"], 3, c["crop"], c["crop"], generator=torch.Generator().manual_seed(1234)).cuda()
     for _ in range(2):
         loss = st.step(x)
