@@ -313,22 +313,23 @@ def test_autocast_convnext_vs_autocast_oracle():
         assert feats[k].dtype == torch.float32 and feats[k].shape == o32[k].shape
         e, noise = rel(feats[k], o16[k]), rel(o16[k], o32[k])
         print(f"{k}: ours vs autocast oracle {e:.2e}; autocast oracle vs fp32 oracle {noise:.2e}")
-        # (one block agrees to ~0.3 of the noise, test below; over 9 blocks the 1-ulp flips of two fp32 summation orders decorrelate:
-        # fully independent realisations of the same policy would sit at sqrt(2) x noise)
-        assert noise > 1e-3 and e < 1.0 * noise, (k, e, noise)
+        # (a layer agrees to 1e-6 ... 5e-4 on the same input, tests below; over 9 blocks the 1-ulp flips of two fp32 summation orders
+        # decorrelate: measured 0.02 (res2) ... 0.97 (res5) of the noise; fully independent realisations of the same policy would
+        # sit at sqrt(2) x noise, which bounds the assertion)
+        assert noise > 1e-3 and e < 1.3 * noise, (k, e, noise)
     sum((feats[k] * cts[k].cuda()).sum() for k in feats).backward()
     worst = 0.0
     for k, v in net.named_parameters():
         assert v.grad is not None and torch.isfinite(v.grad).all(), k
         e, noise = rel(v.grad, q16[k].grad), rel(q16[k].grad, q32[k].grad)
         worst = max(worst, e / max(noise, 1e-9))
-        assert e < max(1.25 * noise, 5e-3), f"d{k}: ours vs autocast oracle {e:.2e}, autocast vs fp32 {noise:.2e}"
+        assert e < max(1.5 * noise, 5e-3), f"d{k}: ours vs autocast oracle {e:.2e}, autocast vs fp32 {noise:.2e}"
     tot = lambda grads: torch.cat([t.float().reshape(-1).cpu() for t in grads])
     names = [k for k, _ in net.named_parameters()]
     ours, a16, a32 = tot([dict(net.named_parameters())[k].grad for k in names]), tot([q16[k].grad for k in names]), tot([q32[k].grad for k in names])
     e, noise = ((ours - a16).norm() / a16.norm()).item(), ((a16 - a32).norm() / a32.norm()).item()
     print(f"all parameter gradients: ours vs autocast oracle {e:.2e}; autocast oracle vs fp32 oracle {noise:.2e}; worst tensor ratio {worst:.2f}")
-    assert e < 1.0 * noise
+    assert e < 1.3 * noise
     # weight gradients ARE 16-bit values held in fp32 (autocast's backward matmul result, cast up)
     wg = dict(net.named_parameters())["stages.2.1.pwconv1.weight"].grad
     assert torch.equal(wg, wg.bfloat16().float())

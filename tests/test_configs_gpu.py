@@ -122,14 +122,14 @@ def test_config1_mixed_precision_step_vs_autocast_oracle():
     noise = max(abs(float(ref16[k]) - float(ref32[k])) / abs(float(ref32[k])) for k in lk)
     dev = max(abs(float(mod.logged["train_" + k]) - float(ref16[k])) / abs(float(ref16[k])) for k in lk)
     print(f"configs[1] mixed precision: logged losses vs autocast oracle {dev:.2e}; autocast oracle vs fp32 oracle {noise:.2e}")
-    assert dev <= max(1e-3, 1.0 * noise), (dev, noise)
+    assert dev <= max(1e-3, 1.3 * noise), (dev, noise)
     gs, gl = module_grads(mod)
     for tag, ours, g16, g32 in (("student", gs, gs16, gs32), ("projectors", gl, gl16, gl32)):
         gmax = max(v.abs().max().item() for v in g16.values())
         names = [k for k in sorted(g16) if g16[k].abs().max().item() >= 1e-6 * gmax]
         e16, o = rel_l2(flat(ours, names), flat(g16, names)), rel_l2(flat(g16, names), flat(g32, names))
         print(f"configs[1] mixed precision: {tag} gradient relL2: ours vs autocast oracle {e16:.2e}; autocast oracle vs fp32 oracle {o:.2e}")
-        assert e16 <= max(3e-3, 1.0 * o), (tag, e16, o)
+        assert e16 <= max(3e-3, 1.3 * o), (tag, e16, o)   # (sqrt(2) o: two independent realisations of one rounding policy)
 
 
 # ---- configs[2]: dinov2_vitb14 -> resnet_50, 224x224 -------------------------------------------------------------------------
