@@ -170,3 +170,38 @@ def test_torch_ddp_wrapper_sees_every_gradient():
     for rank, err, views_kept, same_params in res:
         assert err < 1e-5, (rank, err)
         assert views_kept and same_params, (rank, views_kept, same_params)
+
+
+@pytest.mark.parametrize("student_precision", [None, "bf16_autocast"])
+def test_torch_gradscaler_drives_the_fused_optimizer(student_precision):
+    """Lightning's precision="16-mixed" (train.py:263 ``precision=16``) wraps the step in torch.amp.GradScaler: scale(loss) ->
+    backward -> on_after_backward -> unscale_ (a foreach kernel over every p.grad) -> inf check -> optimizer.step() -> update().
+    FusedAdamW's arena views are ordinary .grad tensors, so the scaler works on them as they are: a scaled step equals the
+    unscaled one (scaling by a power of two commutes with fp32 AND bf16 rounding), an overflowing step is skipped and backs the
+    scale off."""
+    from dinov2_distillation_amd import ops
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(5)).cuda()
+    kw = dict(device="cuda:0", student_precision=student_precision, teacher_precision="bf16_autocast" if student_precision else None, clip=None)
+    a, b = DistillationStepper(**kw), DistillationStepper(**kw)
+    a.step(x)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=1)
+    b.optimizer.zero_grad()
+    scaler.scale(b.module.training_step(x, 0)).backward()
+    b.module.on_after_backward()             # (Lightning's hook: joins the weight-gradient stream before anything reads .grad)
+    scaler.step(b.optimizer)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert scaler.get_scale() == 2048.0      # no overflow: the step ran and the scale grew
+    pa, pb = a.optimizer.flat_p, b.optimizer.flat_p
+    assert ((pa - pb).abs().max() / pa.abs().max()).item() < 1e-6
+    # an overflow: the step must be skipped (parameters untouched) and the scale halved
+    before = b.optimizer.flat_p.clone()
+    b.optimizer.zero_grad()
+    scaler.scale(b.module.training_step(x, 1)).backward()
+    b.module.on_after_backward()
+    b.optimizer.flat_g[7] = float("inf")
+    scaler.step(b.optimizer)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert torch.equal(b.optimizer.flat_p, before) and scaler.get_scale() == 1024.0
