@@ -71,6 +71,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
     __bf16* Bs = smem + BM * RS;
     const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(g.A);
     const __bf16* __restrict__ B = reinterpret_cast<const __bf16*>(g.B);
+    long coff = 0;  // element offset of this batch's output
+    if (g.batch > 1) {
+        const long zo = blockIdx.z / g.batch_inner, zi = blockIdx.z % g.batch_inner;
+        A += zo * g.sAo + zi * g.sAi;
+        B += zo * g.sBo + zi * g.sBi;
+        coff = zo * g.sCo + zi * g.sCi;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;  // 4 (m) x 2 (n) waves
     const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
                     for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
                 }
                 const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + orow * g.ldc + n) = o;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + coff + orow * g.ldc + n) = o;
             } else {
                 if (g.colscale) {
                     const float4 c = *reinterpret_cast<const float4*>(g.colscale + n);
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
                     const float4 r = *reinterpret_cast<const float4*>(g.residual + rr * g.ldr + n);
                     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                 }
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + orow * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + coff + orow * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
 }
@@ -300,13 +307,19 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
     if (g->residual16 && (f32_out || g->epi != DKD_BF16_EPI_BF16 || (g->ldr & 3) || (((uintptr_t)g->residual16) & 7))) return DKD_ERR_BAD_ARG;
     const bool plain = !g->bias && !g->residual && !g->residual16 && !g->colscale && g->row_grp == 0 && g->ldc == g->N &&
                        (g->epi == DKD_BF16_EPI_BF16 || g->epi == DKD_BF16_EPI_F32);
-    if (plain && g->workspace && dkd_aligned16(g->workspace)) slabs = bf16_slabs(g->M, g->N, g->K);
+    const int batch = g->batch > 1 ? g->batch : 1;
+    if (batch > 1) {
+        if (g->batch_inner <= 0 || batch > 65535 || g->residual || g->residual16 || g->row_grp) return DKD_ERR_BAD_ARG;
+        if ((g->sAo | g->sAi | g->sBo | g->sBi) & 7) return DKD_ERR_ALIGN;  // 16-byte staging pieces off every batch base
+        if ((g->sCo | g->sCi) & 3) return DKD_ERR_ALIGN;
+    }
+    if (plain && batch == 1 && g->workspace && dkd_aligned16(g->workspace)) slabs = bf16_slabs(g->M, g->N, g->K);
     int kchunk = g->K;
     if (slabs > 1) {
         kchunk = ((g->K + slabs - 1) / slabs + BK - 1) / BK * BK;
         slabs = dkd_cdiv(g->K, kchunk);
     }
-    const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), slabs), block(NT);
+    const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), slabs, batch), block(NT);
     const int epi = slabs > 1 ? DKD_BF16_EPI_PARTIAL : (g->epi == DKD_BF16_EPI_F32_RESID ? DKD_BF16_EPI_F32 : g->epi);
 #define DKD_BF16_LAUNCH(E)                                                                                             \
     do {                                                                                                               \

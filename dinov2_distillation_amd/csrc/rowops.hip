@@ -404,6 +404,74 @@ void colreduce_plan(long rows_per_group, int groups, int N, int* CL, int* nsplit
     *CL = cl; *nsplit = (int)ns; *rows_per_split = (int)rps; *colblocks = cb;
 }
 
+// ---- eager attention under the 16-bit policy: the softmax between the two bf16 matmuls (include/dkd_hip.h) ---------------------
+// one wave per row of N logits (N % 4 == 0, N <= 64 * 4 * VPL), everything between the bf16 load and the bf16 store in fp32
+template <int VPL, bool BWD>
+__global__ __launch_bounds__(256) void attn16_softmax_kernel(const __bf16* __restrict__ S, const __bf16* __restrict__ dP,
+                                                             __bf16* __restrict__ out, long rows, int N, long ld, float c1, float c2) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nv = N >> 2;
+    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
+        const long r4 = row * (ld >> 2);
+        float4 t[VPL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                t[i] = rnd16(ld4(S, r4 + c));  // (bf16 already; rnd16 is the identity here)
+                t[i] = rnd16(make_float4(t[i].x * c1, t[i].y * c1, t[i].z * c1, t[i].w * c1));
+                t[i] = rnd16(make_float4(t[i].x * c2, t[i].y * c2, t[i].z * c2, t[i].w * c2));
+                mx = fmaxf(mx, fmaxf(fmaxf(t[i].x, t[i].y), fmaxf(t[i].z, t[i].w)));
+            } else {
+                t[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            t[i] = make_float4(__expf(t[i].x - mx), __expf(t[i].y - mx), __expf(t[i].z - mx), __expf(t[i].w - mx));
+            sum += (t[i].x + t[i].y) + (t[i].z + t[i].w);
+        }
+        const float inv = 1.f / wave_sum(sum);
+        if (!BWD) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) st4(out, r4 + c, make_float4(t[i].x * inv, t[i].y * inv, t[i].z * inv, t[i].w * inv));
+            }
+            continue;
+        }
+        float4 d[VPL];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            t[i] = make_float4(t[i].x * inv, t[i].y * inv, t[i].z * inv, t[i].w * inv);  // P32
+            d[i] = c < nv ? ld4(dP, r4 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dot += (d[i].x * t[i].x + d[i].y * t[i].y) + (d[i].z * t[i].z + d[i].w * t[i].w);
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 v = rnd16(make_float4(t[i].x * (d[i].x - dot), t[i].y * (d[i].y - dot), t[i].z * (d[i].z - dot), t[i].w * (d[i].w - dot)));
+                v = rnd16(make_float4(v.x * c2, v.y * c2, v.z * c2, v.w * c2));
+                v = rnd16(make_float4(v.x * c1, v.y * c1, v.z * c1, v.w * c1));
+                st4(out, r4 + c, v);
+            }
+        }
+    }
+}
+
+__global__ void scale_bf16_kernel(const __bf16* __restrict__ x, float s, __bf16* __restrict__ out, long nvec) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = ld4(x, i);
+        st4(out, i, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+    }
+}
+
 }  // namespace
 
 // (LPR, VPL) for a row of nv float4: the narrowest lane group that holds it
@@ -659,6 +727,38 @@ extern "C" int dkd_transpose_f32(const float* in, float* out, int rows, int cols
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols,
                        (long)rows * cols, (long)rows * cols);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+template <bool BWD>
+static int launch_attn16_softmax(const void* S, const void* dP, void* out, long rows, int N, long ld, float c1, float c2, void* stream) {
+    if (!S || !out || (BWD && !dP) || rows <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
+    if ((N & 3) || (ld & 3) || ld < N) return DKD_ERR_ALIGN;
+    if (N > 64 * 4 * 8) return DKD_ERR_UNSUPPORTED;
+    const int nv = N / 4, vpl = (nv + 63) / 64;
+    const int blocks = (int)((rows + 3) / 4 < 16384 ? (rows + 3) / 4 : 16384);
+    const __bf16* s = reinterpret_cast<const __bf16*>(S);
+    const __bf16* d = reinterpret_cast<const __bf16*>(dP);
+    __bf16* o = reinterpret_cast<__bf16*>(out);
+#define DKD_SM16(V) hipLaunchKernelGGL((attn16_softmax_kernel<V, BWD>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, d, o, rows, N, ld, c1, c2)
+    if (vpl <= 1) DKD_SM16(1); else if (vpl <= 2) DKD_SM16(2); else if (vpl <= 4) DKD_SM16(4); else if (vpl <= 6) DKD_SM16(6); else DKD_SM16(8);
+#undef DKD_SM16
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, void* stream) {
+    return launch_attn16_softmax<false>(S, nullptr, P, rows, N, ld, c1, c2, stream);
+}
+extern "C" int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, void* stream) {
+    return launch_attn16_softmax<true>(S, dP, dS, rows, N, ld, c1, c2, stream);
+}
+extern "C" int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream) {
+    if (!x || !out || n <= 0) return DKD_ERR_BAD_ARG;
+    if (n & 3) return DKD_ERR_ALIGN;
+    const long nvec = n / 4;
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3((int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const __bf16*>(x), s, reinterpret_cast<__bf16*>(out), nvec);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -1042,3 +1042,54 @@ def add16(a, b):
     out = torch.empty_like(a)
     check(_lib.binding().dkd_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "dkd_add_bf16")
     return out
+
+
+# ---- eager attention under the 16-bit policy (dkd_hip.h): two batched bf16 matmuls around an fp32 softmax ----------------------
+def _gemm16_batched(a, lda, sA, b, ldb, sB, c, ldc, sC, M, N, K, batch, inner, a_layout=0, b_layout=0, epi=EPI_BF16):
+    g = _lib.args("dkd_gemm_bf16_args")
+    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a), lda, _p(b), ldb, _p(c), ldc
+    g.M, g.N, g.K, g.epi, g.a_layout, g.b_layout = M, N, K, epi, a_layout, b_layout
+    g.batch, g.batch_inner = batch, inner
+    (g.sAo, g.sAi), (g.sBo, g.sBi), (g.sCo, g.sCi) = sA, sB, sC
+    check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[batched {batch} x {M}x{N}x{K} a{a_layout} b{b_layout}]")
+
+
+def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0):
+    """q [B*Nq, H*hd], k / v [B*Nk, H*hd] bf16 (token-major, heads side by side) -> O [B*Nq, H*hd] bf16 and the saved logits /
+    probabilities S, P [B*H, Nq, Nk] bf16:  S = rnd(q k^T), P = rnd(softmax_fp32(rnd(rnd(S c1) c2))), O = rnd(P v)"""
+    _chk16(q, "q"), _chk16(k, "k"), _chk16(v, "v")
+    D = H * hd
+    if (Nk % 8) or (Nq % 8) or (hd % 8):
+        raise _lib.DkdError(f"attention16: token counts and head dim must be multiples of 8 (got {Nq}, {Nk}, {hd})")
+    S = torch.empty((B * H, Nq, Nk), dtype=BF16, device=q.device)
+    _gemm16_batched(q, D, (Nq * D, hd), k, D, (Nk * D, hd), S, Nk, (H * Nq * Nk, Nq * Nk), Nq, Nk, hd, B * H, H)
+    P = torch.empty_like(S)
+    check(_lib.binding().dkd_attn16_softmax_fwd(_p(S), _p(P), B * H * Nq, Nk, Nk, c1, c2, _stream()), "dkd_attn16_softmax_fwd")
+    O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
+    _gemm16_batched(P, Nk, (H * Nq * Nk, Nq * Nk), v, D, (Nk * D, hd), O, D, (Nq * D, hd), Nq, hd, Nk, B * H, H, b_layout=1)
+    return O, S, P
+
+
+def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0):
+    """-> dq, dk, dv (bf16), every matmul result and every scalar product rounded as autograd's 16-bit backward does"""
+    _chk16(dO, "dO")
+    D = H * hd
+    pz, oz_q, oz_k = (H * Nq * Nk, Nq * Nk), (Nq * D, hd), (Nk * D, hd)
+    dP = torch.empty_like(S)
+    _gemm16_batched(dO, D, oz_q, v, D, oz_k, dP, Nk, pz, Nq, Nk, hd, B * H, H)                                  # dP = dO v^T
+    dv = torch.empty((B * Nk, D), dtype=BF16, device=q.device)
+    _gemm16_batched(P, Nk, pz, dO, D, oz_q, dv, D, oz_k, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)          # dv = P^T dO
+    dS = dP  # in place: row r of dS depends on row r of S and dP only
+    check(_lib.binding().dkd_attn16_softmax_bwd(_p(S), _p(dP), _p(dS), B * H * Nq, Nk, Nk, c1, c2, _stream()), "dkd_attn16_softmax_bwd")
+    dq = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
+    _gemm16_batched(dS, Nk, pz, k, D, oz_k, dq, D, oz_q, Nq, hd, Nk, B * H, H, b_layout=1)                      # dq = dS k
+    dk = torch.empty((B * Nk, D), dtype=BF16, device=q.device)
+    _gemm16_batched(dS, Nk, pz, q, D, oz_q, dk, D, oz_k, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)          # dk = dS^T q
+    return dq, dk, dv
+
+
+def scale16(x, s):
+    _chk16(x, "x")
+    out = torch.empty_like(x)
+    check(_lib.binding().dkd_scale_bf16(_p(x), float(s), _p(out), x.numel(), _stream()), "dkd_scale_bf16")
+    return out

@@ -191,6 +191,10 @@ typedef struct dkd_gemm_bf16_args {
     int32_t M, N, K;
     int32_t epi, res_mod, row_grp, row_grp_stride, row_off;
     int32_t a_layout, b_layout;
+    /* batched launch (attention under the 16-bit policy: one product per (image, head)): batch z = zo * batch_inner + zi adds
+     * zo * s?o + zi * s?i ELEMENTS to A / B / C (0 / 0 / 0 ... = one product; batch <= 1 = not batched; no K-slabs, no residual) */
+    int32_t batch, batch_inner;
+    int64_t sAo, sAi, sBo, sBi, sCo, sCi;
 } dkd_gemm_bf16_args;
 int dkd_gemm_bf16(const dkd_gemm_bf16_args* args, void* stream);
 long dkd_gemm_bf16_workspace_bytes(int M, int N, int K);
@@ -219,6 +223,14 @@ int dkd_grn_gelu_bwd_bf16(const void* dy, const void* h, const float* nx, const 
 int dkd_cast_f32_from_bf16(const void* in, float* out, long n, void* stream);
 int dkd_round_bf16_f32(float* x, long n, void* stream); /* in place: every value to the nearest bf16 */
 int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
+/* Eager attention under the 16-bit policy (what torch autocast makes of `softmax((q @ k^T) * c1 * c2) @ v`, losses/scalekd.py:
+ * 308-313 and the DINOv2 block): the logits S are a bf16 matmul result (dkd_gemm_bf16, batched), each scalar factor rounds
+ * again, softmax runs in fp32 and its result is rounded to bf16 for the second matmul.  rows x N logits with row pitch ld
+ * (multiples of 4).  fwd: P = rnd(softmax(rnd(rnd(S c1) c2))).  bwd: dS = rnd(rnd(rnd(dT) c2) c1) with
+ * dT = P32 (dP - sum(dP P32)), P32 recomputed from S.  out = rnd(x * s) on n bf16 values (the DINOv2 block's q * scale). */
+int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, void* stream);
+int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, void* stream);
+int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
 /* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588
  * patch rows to a multiple of 8) */
 int dkd_cast_bf16(const float* in, void* out_bf16, long rows, int cols, int out_ld, void* stream);

@@ -459,3 +459,39 @@ def test_step_with_autocast_student_and_teacher():
     l16b = [float(st2.step(x).detach()) for _ in range(3)]
     print(f"step loss: fp32 {l32:.5f}; autocast teacher + student {l16}")
     assert abs(l16[0] - l32) <= 3e-2 * abs(l32) and l16[0] != l32 and l16 == l16b and l16[2] < l16[0]
+
+
+@pytest.mark.parametrize("H,hd,c2", [(16, 24, 5.0), (24, 16, 5.0), (6, 64, 1.0)])
+def test_attention_under_the_16_bit_policy_vs_torch_autocast(H, hd, c2):
+    """`softmax((q @ k^T) * scale * softmax_scale) @ v` (losses/scalekd.py:308-313; head dims 24 / 16 of the ScaleKD projectors, 64 of
+    the re-used teacher blocks) as torch autocast runs it - bf16 matmuls, each scalar factor a 16-bit multiply, softmax in fp32,
+    its result cast down for the second matmul - forward and backward against torch itself (CPU autocast; softmax forced to
+    fp32 as on CUDA).  Both sides round at the same places, so they agree to a few 1-ulp flips."""
+    from dinov2_distillation_amd import ops
+    B, N = 3, 256
+    D = H * hd
+    g = torch.Generator().manual_seed(H)
+    q, k, v = (torch.randn(B, N, D, generator=g).bfloat16() for _ in range(3))
+    do = torch.randn(B, N, D, generator=g).bfloat16()
+    c1 = hd ** -0.5
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        qh, kh, vh = (t.reshape(B, N, H, hd).permute(0, 2, 1, 3) for t in (qr, kr, vr))
+        attn = (qh @ kh.transpose(-2, -1)) * c1 * c2
+        with torch.autocast("cpu", enabled=False):
+            attn = attn.float().softmax(dim=-1)
+        ref = (attn @ vh).transpose(1, 2).reshape(B, N, D)
+    assert ref.dtype == torch.bfloat16
+    ref.backward(do)
+    qd, kd, vd = (t.reshape(B * N, D).cuda() for t in (q, k, v))
+    O, S, P = ops.attention16_forward(qd, kd, vd, B, H, N, N, hd, c1, c2)
+    dq, dk, dv = ops.attention16_backward(do.reshape(B * N, D).cuda(), qd, kd, vd, S, P, B, H, N, N, hd, c1, c2)
+    rel = lambda a, b: ((a.float().cpu().reshape(b.shape) - b.float()).norm() / b.float().norm()).item()
+    exact = (torch.softmax((q.double().reshape(B, N, H, hd).permute(0, 2, 1, 3) @ k.double().reshape(B, N, H, hd).permute(0, 2, 3, 1)) * c1 * c2, -1)
+             @ v.double().reshape(B, N, H, hd).permute(0, 2, 1, 3)).transpose(1, 2).reshape(B, N, D)
+    e, noise = rel(O, ref), rel(ref, exact)
+    print(f"attention16 (H {H}, hd {hd}): O ours vs torch autocast {e:.2e}; torch autocast vs exact {noise:.2e}; "
+          f"dq {rel(dq, qr.grad):.2e} dk {rel(dk, kr.grad):.2e} dv {rel(dv, vr.grad):.2e}")
+    assert e < 0.15 * noise and noise > 1e-3
+    assert rel(dq, qr.grad) < 2e-3 and rel(dk, kr.grad) < 2e-3 and rel(dv, vr.grad) < 1e-3
+    assert torch.equal(ops.scale16(qd, c1), (qd.float() * c1).bfloat16())
