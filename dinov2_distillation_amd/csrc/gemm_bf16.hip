@@ -181,10 +181,14 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = rnd_bf16(v[e]);  // the Linear's 16-bit output
-            if (EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU) {
+            if (EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU || EPI == DKD_BF16_EPI_BF16_RELU) {
                 if (EPI == DKD_BF16_EPI_BF16_GELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                }
+                if (EPI == DKD_BF16_EPI_BF16_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (g.residual16) {  // a 16-bit residual stream: rnd(x + rnd(acc + bias)), x bf16 (ConvNeXt block, stages 1-3)
                     const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g.residual16) + orow * g.ldr + n);
@@ -331,6 +335,7 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
     switch (epi) {
         case DKD_BF16_EPI_BF16: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16); break;
         case DKD_BF16_EPI_BF16_GELU: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16_GELU); break;
+        case DKD_BF16_EPI_BF16_RELU: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16_RELU); break;
         case DKD_BF16_EPI_F32: DKD_BF16_LAUNCH(DKD_BF16_EPI_F32); break;
         case DKD_BF16_EPI_PARTIAL: DKD_BF16_LAUNCH(DKD_BF16_EPI_PARTIAL); break;
         default: return DKD_ERR_BAD_ARG;

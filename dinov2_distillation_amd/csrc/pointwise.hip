@@ -148,12 +148,17 @@ __global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4
                                       const float4* __restrict__ rstd, const float4* __restrict__ gamma,
                                       const float4* __restrict__ beta, const float4* __restrict__ pos,
                                       float4* __restrict__ out, int nv, int period, int relu, long nvec) {
+    // (relu & 16, the mixed-precision projector: BatchNorm and the activation produce 16-bit tensors - rounded after each - before
+    // the fp32 position table is added)
+    const bool r16 = (relu & 16) != 0;
+    relu &= 15;
     EW_LOOP(i, nvec) {
         const long r = i / nv;
         const int c = (int)(i % nv);
         const float4 x = z[i], mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
         float4 o = make_float4(g.x * (x.x - mu.x) * rs.x + b.x, g.y * (x.y - mu.y) * rs.y + b.y,
                                g.z * (x.z - mu.z) * rs.z + b.z, g.w * (x.w - mu.w) * rs.w + b.w);
+        if (r16) o = rnd16(o);
         if (relu == 3) {  // SiLU (DarkNet's Conv, models/backbones/darknet.py:47)
             o = make_float4(o.x * sigmoid_f(o.x), o.y * sigmoid_f(o.y), o.z * sigmoid_f(o.z), o.w * sigmoid_f(o.w));
         } else if (relu == 4) {  // Hardswish (MobileNetV3's "HS" blocks)
@@ -321,6 +326,12 @@ __global__ void cast_f32_kernel(const __bf16* __restrict__ in, float* __restrict
 }
 __global__ void round_bf16_kernel(float* __restrict__ x, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = rnd16(x[i]);
+}
+__global__ void relu_bwd_bf16_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y, __bf16* __restrict__ dx, long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 v = ld4(y, i), g = ld4(dy, i);
+        st4(dx, i, make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f));
+    }
 }
 // out = rnd(a + b) on bf16 tensors (autograd's accumulation of two 16-bit gradients)
 __global__ void add_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ out, long nvec) {
@@ -504,6 +515,14 @@ extern "C" int dkd_cast_f32_from_bf16(const void* in, float* out, long n, void* 
 extern "C" int dkd_round_bf16_f32(float* x, long n, void* stream) {
     if (!x || n <= 0) return DKD_ERR_BAD_ARG;
     hipLaunchKernelGGL(round_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_relu_bwd_bf16(const void* dy, const void* y, void* dx, long n, void* stream) {
+    EW_CHECK(n);
+    if (!dy || !y || !dx) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(relu_bwd_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(dy),
+                       reinterpret_cast<const __bf16*>(y), reinterpret_cast<__bf16*>(dx), n / 4);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -189,3 +189,99 @@ class ConvNeXtBlock16Fn(Function):
         return (dx, ret(o_dww, ddw.reshape(dw_shape), p_dww), ret(o_dwb, ddb.reshape(-1), p_dwb), ret(o_lnw, dln_w, p_lnw),
                 ret(o_lnb, dln_b, p_lnb), dw1, db1, ret(o_gg, dgrn_g.reshape(grn_shape), p_gg),
                 ret(o_gb, dgrn_b.reshape(grn_shape), p_gb), dw2, db2)
+
+
+class AttentionProjector16Fn(Function):
+    """The ScaleKD projector (losses/scalekd.py:228-245) under the autocast policy.  What autocast makes of it: the 1x1 conv, q / k /
+    v / proj and the two FFN Linears are 16-bit matmuls with 16-bit results; BatchNorm and ReLU act on (and return) 16-bit
+    tensors; adding the fp32 position table, the attention and FFN residuals, both LayerNorms and the output are fp32; the
+    attention core is ops.attention16 (logits and probabilities 16-bit, softmax fp32).  GEMMs and attention read bf16 from HBM;
+    the small element-wise tensors in between are kept as fp32 HOLDING the 16-bit values (rounded where the policy rounds).
+    x NHWC [B,P,P,Cs] fp32; ext_query [B,N,D] fp32 or None (then self_query [N,D], repeated over the batch as :234 does)."""
+
+    @staticmethod
+    def forward(ctx, x, ext_query, self_query, bn_state, num_heads, softmax_scale, training, window, *params):
+        (pos_embed, wc, bc, bn_w, bn_b, wq, bq, wk, bk, wv, bv, wp, bp, w1, b1, w2, b2, n1w, n1b, n2w, n2b) = params
+        if window[0] * window[1] != 1:
+            raise NotImplementedError("windowed projector attention has no mixed-precision path yet")
+        from .functional import _bn_fwd_stats
+        x = _c(x)
+        B, Ph, Pw, Cs = x.shape
+        N, D = Ph * Pw, wc.shape[0]
+        M, hd = B * N, D // num_heads
+        x16 = ops.cast_bf16(x.reshape(M, Cs))
+        wc16 = ops.cast_bf16(wc.reshape(D, Cs))
+        z = ops.cast_f32(ops.gemm_bf16(x16, wc16, bias=_w16(bc)))                      # conv output: 16-bit values
+        mean, rstd = _bn_fwd_stats(z, bn_state, training)
+        pos_t = ops.transpose(pos_embed.reshape(D, N))                                  # [N, D]
+        tok = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, pos_t, relu=1 | 16)         # rnd(bn) -> relu -> + pos (fp32)
+        shared = ext_query is None
+        ctx.sq = self_query if shared else None
+        qin16 = ops.cast_bf16(_c(self_query) if shared else _c(ext_query).reshape(M, D))
+        tok16 = ops.cast_bf16(tok)
+        wq16, wk16, wv16, wp16, w1h, w2h = (ops.cast_bf16(t) for t in (wq, wk, wv, wp, w1, w2))
+        q16 = ops.gemm_bf16(qin16, wq16, bias=_w16(bq))                                # [N, D] (shared) or [M, D]
+        k16 = ops.gemm_bf16(tok16, wk16, bias=_w16(bk))
+        v16 = ops.gemm_bf16(tok16, wv16, bias=_w16(bv))
+        c1 = hd ** -0.5
+        o16, S, P = ops.attention16_forward(q16, k16, v16, B, num_heads, N, N, hd, c1, float(softmax_scale), q_shared=shared)
+        y = ops.gemm_bf16(o16, wp16, epi=ops.EPI_F32_RESID, bias=_w16(bp), residual=tok)      # tok + rnd(proj)
+        zn, m1, r1 = ops.layernorm_fwd(y, n1w, n1b, 1e-5)
+        zn16 = ops.cast_bf16(zn)
+        f1 = ops.gemm_bf16(zn16, w1h, epi=ops.EPI_BF16_RELU, bias=_w16(b1))
+        f2 = ops.gemm_bf16(f1, w2h, epi=ops.EPI_F32_RESID, bias=_w16(b2), residual=zn)        # zn + rnd(ffn)
+        out, m2, r2 = ops.layernorm_fwd(f2, n2w, n2b, 1e-5)
+        ctx.save_for_backward(x16, z, mean, rstd, tok16, qin16, q16, k16, v16, o16, S, P, y, m1, r1, zn16, f1, f2, m2, r2,
+                              wc16, wq16, wk16, wv16, wp16, w1h, w2h, bn_w, bn_b, n1w, n2w)
+        ctx.meta = (B, N, D, Cs, num_heads, hd, c1, float(softmax_scale), shared, tuple(pos_embed.shape), tuple(wc.shape), tuple(x.shape))
+        ctx.training = training
+        ctx.params = params
+        return out.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x16, z, mean, rstd, tok16, qin16, q16, k16, v16, o16, S, P, y, m1, r1, zn16, f1, f2, m2, r2,
+         wc16, wq16, wk16, wv16, wp16, w1h, w2h, bn_w, bn_b, n1w, n2w) = ctx.saved_tensors
+        B, N, D, Cs, H, hd, c1, c2, shared, pos_shape, wc_shape, xshape = ctx.meta
+        (P_pos, P_wc, P_bc, P_bnw, P_bnb, P_wq, P_bq, P_wk, P_bk, P_wv, P_bv, P_wp, P_bp, P_w1, P_b1, P_w2, P_b2,
+         P_n1w, P_n1b, P_n2w, P_n2b) = ctx.params
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
+        o_pos, o_bnw, o_bnb, o_n1w, o_n1b, o_n2w, o_n2b = direct(P_pos, P_bnw, P_bnb, P_n1w, P_n1b, P_n2w, P_n2b)
+        M = B * N
+        df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w, dg_out=o_n2w, db_out=o_n2b)
+        df2h = ops.cast_bf16(df2)                                                       # gradient of the 16-bit FFN output
+        dh = ops.relu_bwd16(ops.gemm_bf16(df2h, w2h, b_layout=1), f1)
+        dw2, db2 = wgrad16(df2h, f1, P_w2, P_b2)
+        dw1, db1 = wgrad16(dh, zn16, P_w1, P_b1)
+        dzn = ops.gemm_bf16(dh, w1h, b_layout=1, epi=ops.EPI_F32_RESID, residual=df2)   # + the FFN residual branch (fp32 add)
+        dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w, dg_out=o_n1w, db_out=o_n1b)
+        dyh = ops.cast_bf16(dy)                                                         # gradient of the 16-bit proj output
+        do16 = ops.gemm_bf16(dyh, wp16, b_layout=1)
+        dwp, dbp = wgrad16(dyh, o16, P_wp, P_bp)
+        dq16, dk16, dv16 = ops.attention16_backward(do16, q16, k16, v16, S, P, B, H, N, N, hd, c1, c2, q_shared=shared)
+        dwk, dbk = wgrad16(dk16, tok16, P_wk, P_bk)
+        dwv, dbv = wgrad16(dv16, tok16, P_wv, P_bv)
+        # tok feeds the k and the v Linear through two separate casts: their 16-bit input gradients are added in fp32
+        dtok = ops.gemm_bf16(dk16, wk16, b_layout=1, epi=ops.EPI_F32_RESID, residual=dy)
+        dtok = ops.gemm_bf16(dv16, wv16, b_layout=1, epi=ops.EPI_F32_RESID, residual=dtok, out=dtok)
+        dqin = ops.gemm_bf16(dq16, wq16, b_layout=1, epi=ops.EPI_F32)                   # [M, D] fp32 holding 16-bit values
+        if shared:   # the embedding was repeated over the batch (:234): its gradient is the fp32 sum of the per-image gradients
+            o_sq = ops.grad_out(ctx.sq)
+            dself = ops.colreduce(dqin.reshape(B, N * D), ops.RED_SUM, out=None if o_sq is None else o_sq.view(1, N * D)).reshape(N, D)
+            dwq, dbq = wgrad16(dq16, qin16.reshape(1, N, D).expand(B, N, D).reshape(M, D).contiguous(), P_wq, P_bq)
+            dext, dself = None, ret(o_sq, dself, ctx.sq)
+        else:
+            dwq, dbq = wgrad16(dq16, qin16, P_wq, P_bq)
+            dext, dself = dqin.reshape(B, N, D), None
+        dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D),
+                             out=None if o_pos is None else o_pos.view(D, N)).reshape(pos_shape)
+        # BatchNorm + ReLU on 16-bit tensors: the incoming gradient is rounded (it belongs to a 16-bit tensor), the arithmetic is fp32
+        dz, dbn_w, dbn_b = ops.bn_bwd(ops.round_bf16_(dtok), z, mean, rstd, bn_w, bn_b, relu=True, dgamma_out=o_bnw, dbeta_out=o_bnb)
+        dz16 = ops.cast_bf16(dz)
+        dwc, dbc = wgrad16(dz16, x16, P_wc, P_bc, reshape=lambda t: t.reshape(wc_shape))
+        dx = ops.gemm_bf16(dz16, wc16, b_layout=1, epi=ops.EPI_F32).reshape(xshape) if ctx.needs_input_grad[0] else None
+        return (dx, dext, dself, None, None, None, None, None,
+                ret(o_pos, dpos, P_pos), dwc, dbc, ret(o_bnw, dbn_w, P_bnw), ret(o_bnb, dbn_b, P_bnb), dwq, dbq, dwk, dbk,
+                dwv, dbv, dwp, dbp, dw1, db1, dw2, db2, ret(o_n1w, dn1w, P_n1w), ret(o_n1b, dn1b, P_n1b),
+                ret(o_n2w, dn2w, P_n2w), ret(o_n2b, dn2b, P_n2b))

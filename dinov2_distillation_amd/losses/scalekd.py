@@ -10,6 +10,7 @@ import torch.nn as nn
 from torch.nn.init import trunc_normal_
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 
 def _tokens_of_map(feat):
@@ -56,6 +57,7 @@ class AttentionProjector(nn.Module):
         self.norm_2 = nn.LayerNorm([teacher_dims])
         self.query = nn.Embedding(hw_dims[0] * hw_dims[1], teacher_dims) if self_query else None
         trunc_normal_(self.pos_embed, std=0.02)
+        self.precision = "fp32"  # "bf16_autocast": the reference's default precision=16 policy (functional16.AttentionProjector16Fn)
 
     def _params(self):
         sd = dict(self.named_parameters())
@@ -69,9 +71,10 @@ class AttentionProjector(nn.Module):
         x_nhwc = x.permute(0, 2, 3, 1)
         if self.training:
             bn.num_batches_tracked += 1
-        return Fn.AttentionProjectorFn.apply(x_nhwc, query, None if query is not None else self.query.weight,
-                                             (bn.running_mean, bn.running_var), self.num_heads, self.softmax_scale,
-                                             self.training, self.window_shapes, *self._params())
+        fn = Fn16.AttentionProjector16Fn if self.precision == "bf16_autocast" else Fn.AttentionProjectorFn
+        return fn.apply(x_nhwc, query, None if query is not None else self.query.weight,
+                        (bn.running_mean, bn.running_var), self.num_heads, self.softmax_scale,
+                        self.training, self.window_shapes, *self._params())
 
 
 class ScaleKD(nn.Module):
@@ -85,6 +88,14 @@ class ScaleKD(nn.Module):
         kw = dict(window_shapes=tuple(window_shapes), self_query=self_query, num_heads=num_heads)
         self.projector_0 = AttentionProjector(student_dims, teacher_dims, query_hw, pos_dims, softmax_scale=softmax_scale[0], **kw)
         self.projector_1 = AttentionProjector(student_dims, teacher_dims, query_hw, pos_dims, softmax_scale=softmax_scale[1], **kw)
+
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast" (both projectors under the reference's default precision=16 policy; the loss tails
+        are fp32 under that policy too)"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown precision {precision!r}")
+        self.projector_0.precision = self.projector_1.precision = precision
+        return self
 
     def project_feat_spat(self, preds_S, query=None):
         return self.projector_0(preds_S, query=query)

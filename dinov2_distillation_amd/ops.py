@@ -820,7 +820,7 @@ def winattn_backward(do, qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
 
 # ---- bf16-in-HBM operators of the autocast teacher (train.py:263 precision=16 == torch autocast) --------------------
 BF16 = torch.bfloat16
-EPI_BF16, EPI_BF16_GELU, EPI_F32_RESID, EPI_F32 = 0, 1, 2, 3
+EPI_BF16, EPI_BF16_GELU, EPI_F32_RESID, EPI_F32, EPI_BF16_RELU = 0, 1, 2, 3, 5
 
 
 def _chk16(t, name):
@@ -1054,7 +1054,7 @@ def _gemm16_batched(a, lda, sA, b, ldb, sB, c, ldc, sC, M, N, K, batch, inner, a
     check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[batched {batch} x {M}x{N}x{K} a{a_layout} b{b_layout}]")
 
 
-def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0):
+def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False):
     """q [B*Nq, H*hd], k / v [B*Nk, H*hd] bf16 (token-major, heads side by side) -> O [B*Nq, H*hd] bf16 and the saved logits /
     probabilities S, P [B*H, Nq, Nk] bf16:  S = rnd(q k^T), P = rnd(softmax_fp32(rnd(rnd(S c1) c2))), O = rnd(P v)"""
     _chk16(q, "q"), _chk16(k, "k"), _chk16(v, "v")
@@ -1062,7 +1062,8 @@ def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0):
     if (Nk % 8) or (Nq % 8) or (hd % 8):
         raise _lib.DkdError(f"attention16: token counts and head dim must be multiples of 8 (got {Nq}, {Nk}, {hd})")
     S = torch.empty((B * H, Nq, Nk), dtype=BF16, device=q.device)
-    _gemm16_batched(q, D, (Nq * D, hd), k, D, (Nk * D, hd), S, Nk, (H * Nq * Nk, Nq * Nk), Nq, Nk, hd, B * H, H)
+    qz = (0 if q_shared else Nq * D, hd)  # q_shared: one [Nq, D] query block for every image
+    _gemm16_batched(q, D, qz, k, D, (Nk * D, hd), S, Nk, (H * Nq * Nk, Nq * Nk), Nq, Nk, hd, B * H, H)
     P = torch.empty_like(S)
     check(_lib.binding().dkd_attn16_softmax_fwd(_p(S), _p(P), B * H * Nq, Nk, Nk, c1, c2, _stream()), "dkd_attn16_softmax_fwd")
     O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
@@ -1070,7 +1071,7 @@ def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0):
     return O, S, P
 
 
-def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0):
+def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False):
     """-> dq, dk, dv (bf16), every matmul result and every scalar product rounded as autograd's 16-bit backward does"""
     _chk16(dO, "dO")
     D = H * hd
@@ -1084,7 +1085,7 @@ def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0):
     dq = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
     _gemm16_batched(dS, Nk, pz, k, D, oz_k, dq, D, oz_q, Nq, hd, Nk, B * H, H, b_layout=1)                      # dq = dS k
     dk = torch.empty((B * Nk, D), dtype=BF16, device=q.device)
-    _gemm16_batched(dS, Nk, pz, q, D, oz_q, dk, D, oz_k, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)          # dk = dS^T q
+    _gemm16_batched(dS, Nk, pz, q, D, (0, hd) if q_shared else oz_q, dk, D, oz_k, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)  # dk = dS^T q
     return dq, dk, dv
 
 
@@ -1093,3 +1094,10 @@ def scale16(x, s):
     out = torch.empty_like(x)
     check(_lib.binding().dkd_scale_bf16(_p(x), float(s), _p(out), x.numel(), _stream()), "dkd_scale_bf16")
     return out
+
+
+def relu_bwd16(dy, y):
+    _chk16(dy, "dy"), _chk16(y, "y")
+    dx = torch.empty_like(dy)
+    check(_lib.binding().dkd_relu_bwd_bf16(_p(dy), _p(y), _p(dx), dy.numel(), _stream()), "dkd_relu_bwd_bf16")
+    return dx

@@ -173,6 +173,7 @@ int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const 
 #define DKD_BF16_EPI_F32_RESID 2
 #define DKD_BF16_EPI_F32 3
 #define DKD_BF16_EPI_PARTIAL 4 /* internal: raw fp32 K-slab partial sums into `workspace` */
+#define DKD_BF16_EPI_BF16_RELU 5 /* C bf16 = relu(rnd(acc + bias))   the FFN's Linear + ReLU (losses/scalekd.py:448) */
 /* a_layout / b_layout as in dkd_gemm_args: 0 = [M][K] / [N][K] (reduction contiguous), 1 = [K][M] / [K][N] (the operand as it
  * lies for dx = dy W and for dW = dy^T x; the contiguous extent then has to be a multiple of 8).  `workspace` (fp32,
  * dkd_gemm_bf16_workspace_bytes; may be NULL) lets a launch whose output grid cannot fill the chip split the reduction into
@@ -231,6 +232,7 @@ int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
 int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, void* stream);
 int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, void* stream);
 int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
+int dkd_relu_bwd_bf16(const void* dy, const void* y, void* dx, long n, void* stream); /* dx = y > 0 ? dy : 0 on bf16 tensors */
 /* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588
  * patch rows to a multiple of 8) */
 int dkd_cast_bf16(const float* in, void* out_bf16, long rows, int cols, int out_ld, void* stream);

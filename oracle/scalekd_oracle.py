@@ -22,10 +22,18 @@ def _window_major(t, wh, ww):
     return t.reshape(B, h * wh * ww, -1, hd)
 
 
-def pos_attention(p, pre, x, pos, num_heads, softmax_scale, window_shapes=(1, 1)):
+def _fp32(fn, *args, **kw):
+    """an op of CUDA autocast's fp32 list (layer_norm, softmax, ...) when the oracle runs under torch.autocast on the CPU, whose
+    own policy leaves those ops in the input dtype: inputs cast up, autocast off inside"""
+    with torch.autocast("cpu", enabled=False):
+        return fn(*[a.float() if torch.is_tensor(a) and a.is_floating_point() else a for a in args], **kw)
+
+
+def pos_attention(p, pre, x, pos, num_heads, softmax_scale, window_shapes=(1, 1), policy=False):
     """``WindowMultiheadPosAttention.forward`` (losses/scalekd.py:293-324).
     q from the positional/query stream, k and v from the student tokens; logits scaled by
-    head_dim^-0.5 * softmax_scale (:308); dropouts are p=0 and gamma1 is Identity (:288-291)."""
+    head_dim^-0.5 * softmax_scale (:308); dropouts are p=0 and gamma1 is Identity (:288-291).
+    policy: the caller runs this under torch.autocast(bfloat16); softmax is then forced to fp32 as CUDA's policy does."""
     B, N, D = x.shape
     n_out = pos.shape[1]
     hd = D // num_heads
@@ -39,14 +47,15 @@ def pos_attention(p, pre, x, pos, num_heads, softmax_scale, window_shapes=(1, 1)
     v = heads(F.linear(x, p[pre + "v.weight"], p[pre + "v.bias"]), N)
     if nwin > 1:
         q, k, v = (_window_major(t, *window_shapes) for t in (q, k, v))
-    w = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5) * softmax_scale, dim=-1)
+    logits = (q @ k.transpose(-1, -2)) * (hd ** -0.5) * softmax_scale
+    w = _fp32(torch.softmax, logits, dim=-1) if policy else torch.softmax(logits, dim=-1)
     # :313-314 - the windowed result is only *viewed* back; tokens stay window-major (no inverse permute)
     o = (w @ v).reshape(B, num_heads, n_out, hd).transpose(1, 2).reshape(B, n_out, D)
     return F.linear(o, p[pre + "proj.weight"], p[pre + "proj.bias"])
 
 
 def attention_projector(p, pre, x, query, hw, num_heads, softmax_scale, window_shapes=(1, 1),
-                        training=True, bn_momentum=0.1):
+                        training=True, bn_momentum=0.1, policy=False):
     """``AttentionProjector.forward`` (losses/scalekd.py:228-245).
 
     x: student feature [B,Cs,H,W]; query: None (use the learned ``query.weight``) or tokens [B,HW,D].
@@ -64,18 +73,21 @@ def attention_projector(p, pre, x, query, hw, num_heads, softmax_scale, window_s
         p[pre + "proj_student.1.num_batches_tracked"] += 1
     z = torch.relu(z) + p[pre + "pos_embed"]
     tok = z.flatten(2).transpose(1, 2)  # [B,HW,D]   (:241)
+    if policy:  # torch's CPU bf16 Linear on a strided (transposed) input takes a path that loses 3e-3 against fp32 accumulation
+        tok = tok.contiguous()  # (measured: tests/diag/diag_projector16.py); dense, it accumulates in fp32 like the GPU kernels
     if query is not None:
         pos = query  # :232 + :240 are a net identity on [B,HW,D]
     elif (pre + "query.weight") in p:
         pos = p[pre + "query.weight"].unsqueeze(0).expand(B, -1, -1)  # :234
     else:
         raise NotImplementedError("There is no query!")  # :236
-    a = pos_attention(p, pre + "pos_attention.", tok, pos, num_heads, softmax_scale, window_shapes)
+    a = pos_attention(p, pre + "pos_attention.", tok, pos, num_heads, softmax_scale, window_shapes, policy)
     y = a + tok  # :243
-    zn = F.layer_norm(y, (D,), p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-5)
+    ln = (lambda *a_: _fp32(F.layer_norm, *a_)) if policy else F.layer_norm   # (policy: see pos_attention)
+    zn = ln(y, (D,), p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-5)
     f = F.linear(torch.relu(F.linear(zn, p[pre + "ffn.layers.0.0.weight"], p[pre + "ffn.layers.0.0.bias"])),
                  p[pre + "ffn.layers.1.weight"], p[pre + "ffn.layers.1.bias"])
-    return F.layer_norm(zn + f, (D,), p[pre + "norm_2.weight"], p[pre + "norm_2.bias"], 1e-5)
+    return ln(zn + f, (D,), p[pre + "norm_2.weight"], p[pre + "norm_2.bias"], 1e-5)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -495,3 +495,66 @@ def test_attention_under_the_16_bit_policy_vs_torch_autocast(H, hd, c2):
     assert e < 0.15 * noise and noise > 1e-3
     assert rel(dq, qr.grad) < 2e-3 and rel(dk, kr.grad) < 2e-3 and rel(dv, vr.grad) < 1e-3
     assert torch.equal(ops.scale16(qd, c1), (qd.float() * c1).bfloat16())
+
+
+@pytest.mark.parametrize("self_query,cs,heads", [(True, 768, 24), (False, 384, 16)])
+def test_projector_under_the_policy_vs_torch_autocast(self_query, cs, heads):
+    """The ScaleKD projector (losses/scalekd.py:228-245: 1x1 conv + BatchNorm + ReLU + position table, cross attention with
+    softmax_scale 5, LayerNorm, FFN, LayerNorm) under the autocast policy, forward and every gradient, against torch.autocast on
+    the oracle's projector (softmax and layer_norm forced to fp32 as CUDA's policy does).  Yardstick: the distance of that oracle
+    from its own fp32 run."""
+    from oracle import scalekd_oracle as so
+    from dinov2_distillation_amd.losses.scalekd import AttentionProjector
+    D, P, B = 384, 16, 4
+    g = torch.Generator().manual_seed(cs + heads)
+    m = AttentionProjector(cs, D, (P, P), D, self_query=self_query, softmax_scale=5.0, num_heads=heads)
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith("bias"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif "norm" in k or k.startswith("proj_student.1"):
+                v.copy_(1 + 0.1 * torch.randn(v.shape, generator=g))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(B, cs, P, P, generator=g).bfloat16().float()     # a 16-bit student feature, as the policy's backbone delivers
+    query = None if self_query else torch.randn(B, P * P, D, generator=g)
+    ct = torch.randn(B, P * P, D, generator=g)
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().norm()).item()
+
+    def oracle(policy):
+        p = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        qr = None if query is None else query.clone().requires_grad_(True)
+        if policy:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = so.attention_projector(p, "", xr, qr, (P, P), heads, 5.0, policy=True)
+        else:
+            out = so.attention_projector(p, "", xr, qr, (P, P), heads, 5.0)
+        assert out.dtype == torch.float32
+        (out * ct).sum().backward()
+        return p, xr, qr, out
+
+    p16, x16, q16, o16 = oracle(True)
+    p32, x32, q32, o32 = oracle(False)
+    m.precision = "bf16_autocast"
+    m.cuda().train()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().permute(0, 3, 1, 2).requires_grad_(True)   # NHWC memory, as on the path
+    qg = None if query is None else query.cuda().requires_grad_(True)
+    out = m(xg, query=qg)
+    e, noise = rel(out, o16), rel(o16, o32)
+    print(f"projector (self_query {self_query}): tokens ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
+    assert out.dtype == torch.float32 and noise > 1e-3 and e < 0.3 * noise
+    (out * ct.cuda()).sum().backward()
+    bad = []
+    pairs = [("x", xg.grad, x16.grad, x32.grad)] + ([] if query is None else [("query", qg.grad, q16.grad, q32.grad)])
+    pairs += [(k, v.grad, p16[k].grad, p32[k].grad) for k, v in m.named_parameters()]
+    for k, ours, a16, a32 in pairs:
+        e, noise = rel(ours, a16), rel(a16, a32)
+        print(f"  d{k}: ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
+        # (every op of the node agrees with torch to a few flips on the same input - GEMMs, attention, LayerNorm, BatchNorm are
+        # tested one by one; through the softmax with scale 5 a forward flip moves the gradients by more than itself: measured
+        # 0.15 ... 0.5 of the policy's own distance from fp32, sqrt(2) would be two unrelated realisations)
+        if e >= max(0.75 * noise, 1e-4):
+            bad.append((k, e, noise))
+    assert not bad, bad
+    for k in ("proj_student.1.running_mean", "proj_student.1.running_var"):
+        assert rel(m.state_dict()[k], p16[k]) < 1e-4
