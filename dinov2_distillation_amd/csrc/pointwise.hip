@@ -333,6 +333,18 @@ __global__ void relu_bwd_bf16_kernel(const __bf16* __restrict__ dy, const __bf16
         st4(dx, i, make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f));
     }
 }
+// F.gelu on a 16-bit tensor and its backward (fp32 inside, 16-bit results): the DINOv2 MLP under the policy
+__global__ void gelu_bf16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, __bf16* __restrict__ out, long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 v = ld4(x, i);
+        if (dy) {
+            const float4 g = ld4(dy, i);
+            st4(out, i, make_float4(g.x * gelu_grad_f(v.x), g.y * gelu_grad_f(v.y), g.z * gelu_grad_f(v.z), g.w * gelu_grad_f(v.w)));
+        } else {
+            st4(out, i, make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w)));
+        }
+    }
+}
 // out = rnd(a + b) on bf16 tensors (autograd's accumulation of two 16-bit gradients)
 __global__ void add_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ out, long nvec) {
     EW_LOOP(i, nvec) {
@@ -515,6 +527,14 @@ extern "C" int dkd_cast_f32_from_bf16(const void* in, float* out, long n, void* 
 extern "C" int dkd_round_bf16_f32(float* x, long n, void* stream) {
     if (!x || n <= 0) return DKD_ERR_BAD_ARG;
     hipLaunchKernelGGL(round_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_gelu_bf16(const void* x, const void* dy, void* out, long n, void* stream) {
+    EW_CHECK(n);
+    if (!x || !out) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gelu_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(x),
+                       reinterpret_cast<const __bf16*>(dy), reinterpret_cast<__bf16*>(out), n / 4);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

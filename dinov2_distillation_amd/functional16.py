@@ -285,3 +285,54 @@ class AttentionProjector16Fn(Function):
                 ret(o_pos, dpos, P_pos), dwc, dbc, ret(o_bnw, dbn_w, P_bnw), ret(o_bnb, dbn_b, P_bnb), dwq, dbq, dwk, dbk,
                 dwv, dbv, dwp, dbp, dw1, db1, dw2, db2, ret(o_n1w, dn1w, P_n1w), ret(o_n1b, dn1b, P_n1b),
                 ret(o_n2w, dn2w, P_n2w), ret(o_n2b, dn2b, P_n2b))
+
+
+class ViTBlockFrozen16Fn(Function):
+    """A frozen DINOv2 block applied to student tokens (train/distillation_module.py:176-177) under the autocast policy, with the
+    gradient to its INPUT: LayerNorm and both residual adds fp32; the fused qkv Linear, proj, fc1, fc2 16-bit matmuls (fp32
+    LayerScale multiplies AFTER the Linear's rounding); attention = ops.attention16 (q * hd^-0.5 is a 16-bit multiply - exact for
+    the 64-wide heads of every DINOv2 model, so it rides in the softmax kernel's first factor); GELU on the 16-bit tensor.
+    x [B,N,D] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, blk):
+        x = _c(x)
+        p, H = blk.prepared16(), blk.num_heads
+        if p["swiglu"]:
+            raise NotImplementedError("SwiGLU blocks have no mixed-precision backward yet")
+        B, N, D = x.shape
+        M, hd = B * N, D // H
+        c1 = hd ** -0.5
+        if abs(c1 - 2.0 ** round(torch.log2(torch.tensor(c1)).item())) > 0:
+            raise NotImplementedError("head dims other than a power of four need the q scaling as its own rounding step")
+        x2 = x.reshape(M, D)
+        h1, m1, r1 = ops.layernorm_fwd_io(x2, p["n1w"], p["n1b"], 1e-6, BF16)
+        qkv = ops.gemm_bf16(h1, p["wqkv"], bias=p["bqkv"])                                  # [M, 3D] packed (3, H, hd)
+        o16, S, P = ops.attention16_forward(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, hd, c1, ld=3 * D)
+        x1 = ops.gemm_bf16(o16, p["wproj"], epi=ops.EPI_F32_RESID, bias=p["bproj"], colscale=p["ls1"], residual=x2)
+        h2, m2, r2 = ops.layernorm_fwd_io(x1, p["n2w"], p["n2b"], 1e-6, BF16)
+        u = ops.gemm_bf16(h2, p["w1"], bias=p["b1"])
+        out = ops.gemm_bf16(ops.gelu16(u), p["w2"], epi=ops.EPI_F32_RESID, bias=p["b2"], colscale=p["ls2"], residual=x1)
+        ctx.blk = blk
+        ctx.save_for_backward(x2, m1, r1, qkv, S, P, x1, m2, r2, u)
+        ctx.shape = (B, N, D)
+        return out.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, m1, r1, qkv, S, P, x1, m2, r2, u = ctx.saved_tensors
+        p, H = ctx.blk.prepared16(), ctx.blk.num_heads
+        B, N, D = ctx.shape
+        M, hd = B * N, D // H
+        d2 = _c(dout).reshape(M, D)
+        scaled16 = lambda g, ls: ops.cast_bf16(ops.group_affine(g, 1, mul=ls.reshape(1, -1)))   # the 16-bit Linear output's gradient
+        da = ops.gemm_bf16(scaled16(d2, p["ls2"]), p["w2"], b_layout=1)
+        dh2 = ops.gemm_bf16(ops.gelu16(u, da), p["w1"], b_layout=1)
+        dx1, _, _ = ops.layernorm_bwd(ops.cast_f32(dh2), x1, m2, r2, p["n2w"], affine=False, add=d2)
+        do16 = ops.gemm_bf16(scaled16(dx1, p["ls1"]), p["wproj"], b_layout=1)
+        dqkv = torch.empty_like(qkv)
+        ops.attention16_backward(do16, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], S, P, B, H, N, N, hd, hd ** -0.5, ld=3 * D,
+                                 out=(dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]))
+        dh1 = ops.gemm_bf16(dqkv, p["wqkv"], b_layout=1)
+        dx, _, _ = ops.layernorm_bwd(ops.cast_f32(dh1), x2, m1, r1, p["n1w"], affine=False, add=dx1)
+        return dx.reshape(B, N, D), None

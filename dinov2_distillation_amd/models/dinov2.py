@@ -144,6 +144,9 @@ class Block(nn.Module):
 
     def forward(self, x):
         if torch.is_grad_enabled() and x.requires_grad:
+            if getattr(self, "policy16", False):  # block re-use under the autocast policy (functional16.ViTBlockFrozen16Fn)
+                from .. import functional16 as Fn16
+                return Fn16.ViTBlockFrozen16Fn.apply(x, self)
             return Fn.ViTBlockFrozenFn.apply(x, self)
         return Fn.vit_block_forward(x.contiguous(), self.prepared(), self.num_heads, save=False, prec=self.precision)[0]
 

@@ -1054,38 +1054,57 @@ def _gemm16_batched(a, lda, sA, b, ldb, sB, c, ldc, sC, M, N, K, batch, inner, a
     check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[batched {batch} x {M}x{N}x{K} a{a_layout} b{b_layout}]")
 
 
-def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False):
-    """q [B*Nq, H*hd], k / v [B*Nk, H*hd] bf16 (token-major, heads side by side) -> O [B*Nq, H*hd] bf16 and the saved logits /
-    probabilities S, P [B*H, Nq, Nk] bf16:  S = rnd(q k^T), P = rnd(softmax_fp32(rnd(rnd(S c1) c2))), O = rnd(P v)"""
-    _chk16(q, "q"), _chk16(k, "k"), _chk16(v, "v")
+def _chk16v(t, name, ld):
+    """bf16 operand of the batched attention matmuls: dense, or (ld given) a column slice of a dense [rows, ld] buffer"""
+    if ld is None:
+        return _chk16(t, name)
+    if not t.is_cuda or t.dtype != BF16 or t.stride(-1) != 1 or t.stride(-2) != ld or (t.storage_offset() % 8):
+        raise _lib.DkdError(f"{name}: expected a bfloat16 column slice with row pitch {ld}, got strides {tuple(t.stride())}")
+
+
+def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, ld=None):
+    """q [B*Nq, H*hd], k / v [B*Nk, H*hd] bf16 (token-major, heads side by side; ld: they are column slices of one [rows, ld]
+    buffer - a fused qkv Linear's output) -> O [B*Nq, H*hd] bf16 and the saved logits / probabilities S, P [B*H, Nq, Nk] bf16:
+    S = rnd(q k^T), P = rnd(softmax_fp32(rnd(rnd(S c1) c2))), O = rnd(P v)"""
+    _chk16v(q, "q", ld), _chk16v(k, "k", ld), _chk16v(v, "v", ld)
     D = H * hd
+    L = D if ld is None else ld
     if (Nk % 8) or (Nq % 8) or (hd % 8):
         raise _lib.DkdError(f"attention16: token counts and head dim must be multiples of 8 (got {Nq}, {Nk}, {hd})")
     S = torch.empty((B * H, Nq, Nk), dtype=BF16, device=q.device)
-    qz = (0 if q_shared else Nq * D, hd)  # q_shared: one [Nq, D] query block for every image
-    _gemm16_batched(q, D, qz, k, D, (Nk * D, hd), S, Nk, (H * Nq * Nk, Nq * Nk), Nq, Nk, hd, B * H, H)
+    qz = (0 if q_shared else Nq * L, hd)  # q_shared: one [Nq, D] query block for every image
+    _gemm16_batched(q, L, qz, k, L, (Nk * L, hd), S, Nk, (H * Nq * Nk, Nq * Nk), Nq, Nk, hd, B * H, H)
     P = torch.empty_like(S)
     check(_lib.binding().dkd_attn16_softmax_fwd(_p(S), _p(P), B * H * Nq, Nk, Nk, c1, c2, _stream()), "dkd_attn16_softmax_fwd")
     O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
-    _gemm16_batched(P, Nk, (H * Nq * Nk, Nq * Nk), v, D, (Nk * D, hd), O, D, (Nq * D, hd), Nq, hd, Nk, B * H, H, b_layout=1)
+    _gemm16_batched(P, Nk, (H * Nq * Nk, Nq * Nk), v, L, (Nk * L, hd), O, D, (Nq * D, hd), Nq, hd, Nk, B * H, H, b_layout=1)
     return O, S, P
 
 
-def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False):
-    """-> dq, dk, dv (bf16), every matmul result and every scalar product rounded as autograd's 16-bit backward does"""
+def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, ld=None, out=None):
+    """-> dq, dk, dv (bf16), every matmul result and every scalar product rounded as autograd's 16-bit backward does.
+    ld: q / k / v are column slices with that row pitch; out = (dq, dk, dv) column slices (same pitch) to write into."""
     _chk16(dO, "dO")
     D = H * hd
-    pz, oz_q, oz_k = (H * Nq * Nk, Nq * Nk), (Nq * D, hd), (Nk * D, hd)
+    L = D if ld is None else ld
+    pz, oz_q, oz_k = (H * Nq * Nk, Nq * Nk), (Nq * D, hd), (Nk * D, hd)   # S / P planes, dense [rows, D] tensors
+    lz_q, lz_k = (0 if q_shared else Nq * L, hd), (Nk * L, hd)            # q / k / v (and dq / dk / dv when `out` is given)
     dP = torch.empty_like(S)
-    _gemm16_batched(dO, D, oz_q, v, D, oz_k, dP, Nk, pz, Nq, Nk, hd, B * H, H)                                  # dP = dO v^T
-    dv = torch.empty((B * Nk, D), dtype=BF16, device=q.device)
-    _gemm16_batched(P, Nk, pz, dO, D, oz_q, dv, D, oz_k, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)          # dv = P^T dO
+    _gemm16_batched(dO, D, oz_q, v, L, lz_k, dP, Nk, pz, Nq, Nk, hd, B * H, H)                                  # dP = dO v^T
+    if out is None:
+        dq = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
+        dk, dv = torch.empty((B * Nk, D), dtype=BF16, device=q.device), torch.empty((B * Nk, D), dtype=BF16, device=q.device)
+        Lo, zq, zk = D, oz_q, oz_k
+    else:
+        dq, dk, dv = out
+        for t, n in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+            _chk16v(t, n, L)
+        Lo, zq, zk = L, (Nq * L, hd), (Nk * L, hd)
+    _gemm16_batched(P, Nk, pz, dO, D, oz_q, dv, Lo, zk, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)           # dv = P^T dO
     dS = dP  # in place: row r of dS depends on row r of S and dP only
     check(_lib.binding().dkd_attn16_softmax_bwd(_p(S), _p(dP), _p(dS), B * H * Nq, Nk, Nk, c1, c2, _stream()), "dkd_attn16_softmax_bwd")
-    dq = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
-    _gemm16_batched(dS, Nk, pz, k, D, oz_k, dq, D, oz_q, Nq, hd, Nk, B * H, H, b_layout=1)                      # dq = dS k
-    dk = torch.empty((B * Nk, D), dtype=BF16, device=q.device)
-    _gemm16_batched(dS, Nk, pz, q, D, (0, hd) if q_shared else oz_q, dk, D, oz_k, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)  # dk = dS^T q
+    _gemm16_batched(dS, Nk, pz, k, L, lz_k, dq, Lo, zq, Nq, hd, Nk, B * H, H, b_layout=1)                       # dq = dS k
+    _gemm16_batched(dS, Nk, pz, q, L, lz_q, dk, Lo, zk, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)           # dk = dS^T q
     return dq, dk, dv
 
 
@@ -1101,3 +1120,11 @@ def relu_bwd16(dy, y):
     dx = torch.empty_like(dy)
     check(_lib.binding().dkd_relu_bwd_bf16(_p(dy), _p(y), _p(dx), dy.numel(), _stream()), "dkd_relu_bwd_bf16")
     return dx
+
+
+def gelu16(x, dy=None):
+    """F.gelu on a bf16 tensor (dy None) or its backward dy * gelu'(x); fp32 inside, bf16 result"""
+    _chk16(x, "x"), _chk16(dy, "dy")
+    out = torch.empty_like(x)
+    check(_lib.binding().dkd_gelu_bf16(_p(x), _p(dy), _p(out), x.numel(), _stream()), "dkd_gelu_bf16")
+    return out

@@ -12,7 +12,7 @@ from .train import DistillationModule
 class DistillationStepper:
     def __init__(self, teacher="dinov2_vits14", student="convnext_tiny", crop=224, device="cuda", heads=(16, 24),
                  clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None, accumulate_grad_batches=1,
-                 student_precision=None):
+                 student_precision=None, projector_precision=None):
         self.cfg = make_config(teacher, student, crop, heads=heads, lr=lr)
         torch.manual_seed(seed)  # student seed 1, ScaleKD follows; identical on every rank
         self.student = ModelWrapper(student, self.cfg.teacher.n_patches, self.cfg.student.student_keys)
@@ -21,6 +21,11 @@ class DistillationStepper:
         set_student_dims(self.cfg, self.student)
         self.teacher = DINOv2ViT(teacher, seed=0, precision=teacher_precision)
         self.module = DistillationModule(self.student, self.teacher, self.cfg).to(device).train()
+        if projector_precision is not None:  # the whole loss chain: both projectors of every level AND the teacher blocks re-used on
+            for loss in self.module.losses.values():   # the student tokens (train/distillation_module.py:139-178)
+                loss.set_precision(projector_precision)
+            for blk in self.teacher.model.blocks:
+                blk.policy16 = projector_precision == "bf16_autocast"
         self.optimizer = self.module.configure_optimizers()
         if isinstance(self.optimizer, dict):
             self.optimizer = self.optimizer["optimizer"]

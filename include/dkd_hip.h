@@ -232,6 +232,7 @@ int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
 int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, void* stream);
 int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, void* stream);
 int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
+int dkd_gelu_bf16(const void* x, const void* dy, void* out, long n, void* stream); /* dy NULL: gelu(x); else dy * gelu'(x); bf16 */
 int dkd_relu_bwd_bf16(const void* dy, const void* y, void* dx, long n, void* stream); /* dx = y > 0 ? dy : 0 on bf16 tensors */
 /* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588
  * patch rows to a multiple of 8) */

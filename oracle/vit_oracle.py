@@ -201,18 +201,31 @@ def vit_block_autocast(p, prefix, x, num_heads, eps=1e-6):
     return x + p[prefix + "ls2.gamma"] * m
 
 
-def vit_block_upstream_ops(p, prefix, x, num_heads, eps=1e-6):
+def _cuda_fp32_op(fn, *args, **kw):
+    """an op of CUDA autocast's fp32 list (layer_norm, softmax) while the block runs under torch.autocast on the CPU, whose policy
+    leaves those ops in the input dtype (values agree either way; the BACKWARD does not: fp32 softmax saves fp32 probabilities)"""
+    with torch.autocast("cpu", enabled=False):
+        return fn(*[a.float() if torch.is_tensor(a) and a.is_floating_point() else a for a in args], **kw)
+
+
+def vit_block_upstream_ops(p, prefix, x, num_heads, eps=1e-6, cuda_policy=False):
     """The block as the SEQUENCE OF TORCH OPS the published module issues (LayerScale a separate multiply, eager attention) -
-    plain fp32 here; run under ``torch.autocast`` it shows where torch's own policy rounds (tests/test_oracle_golden.py)."""
+    plain fp32 here; run under ``torch.autocast`` it shows where torch's own policy rounds (tests/test_oracle_golden.py).
+    cuda_policy (with autocast on): layer_norm and softmax forced to fp32 as CUDA's autocast does - the form whose autograd
+    backward the mixed-precision block re-use is compared with."""
     B, N, D = x.shape
     hd = D // num_heads
-    y = F.layer_norm(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps)
+    ln = (lambda *a: _cuda_fp32_op(F.layer_norm, *a)) if cuda_policy else F.layer_norm
+    sm = (lambda t: _cuda_fp32_op(torch.softmax, t, dim=-1)) if cuda_policy else (lambda t: t.softmax(dim=-1))
+    y = ln(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps)
     qkv = F.linear(y, p[prefix + "attn.qkv.weight"], p[prefix + "attn.qkv.bias"]).reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
-    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    if cuda_policy:  # dense operands: torch's CPU bf16 matmuls lose accuracy on some strided layouts (tests/diag/diag_projector16.py)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    attn = sm(q @ k.transpose(-2, -1))
     ctx = (attn @ v).transpose(1, 2).reshape(B, N, D)
     x = x + p[prefix + "ls1.gamma"] * F.linear(ctx, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"])
-    y = F.layer_norm(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps)
+    y = ln(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps)
     if (prefix + "mlp.w12.weight") in p:
         x1, x2 = F.linear(y, p[prefix + "mlp.w12.weight"], p[prefix + "mlp.w12.bias"]).chunk(2, dim=-1)
         m = F.linear(F.silu(x1) * x2, p[prefix + "mlp.w3.weight"], p[prefix + "mlp.w3.bias"])

@@ -7,7 +7,8 @@ import torch
 from dinov2_distillation_amd.trainer import DistillationStepper
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-st = DistillationStepper(teacher_precision="bf16_autocast", student_precision=os.environ.get("STUDENT", "bf16_autocast"))
+st = DistillationStepper(teacher_precision="bf16_autocast", student_precision=os.environ.get("STUDENT", "bf16_autocast"),
+                         projector_precision=os.environ.get("PROJECTOR", "bf16_autocast"))
 x = torch.randn(64, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
 st.step(x)
 torch.cuda.synchronize()

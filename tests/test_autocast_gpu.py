@@ -558,3 +558,42 @@ def test_projector_under_the_policy_vs_torch_autocast(self_query, cs, heads):
     assert not bad, bad
     for k in ("proj_student.1.running_mean", "proj_student.1.running_var"):
         assert rel(m.state_dict()[k], p16[k]) < 1e-4
+
+
+def test_frozen_block_reuse_under_the_policy_vs_torch_autocast():
+    """train/distillation_module.py:176-177: a frozen teacher block applied to student tokens, gradient to the tokens, under the
+    autocast policy (functional16.ViTBlockFrozen16Fn) against torch.autocast on the published block's op sequence (layer_norm /
+    softmax forced to fp32 as on CUDA), forward and input gradient"""
+    from oracle import vit_oracle as vo
+    t = _teacher("bf16_autocast")
+    p = {k: v.clone() for k, v in t.model.state_dict().items()}
+    blk = t.model.blocks[9]
+    blk.policy16 = True
+    t.cuda()
+    g = torch.Generator().manual_seed(12)
+    B, N, D, H = 4, 256, 384, 6
+    tok = torch.randn(B, N, D, generator=g)
+    ct = torch.randn(B, N, D, generator=g)
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().norm()).item()
+
+    def oracle(policy):
+        xr = tok.clone().requires_grad_(True)
+        if policy:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = vo.vit_block_upstream_ops(p, "blocks.9.", xr, H, cuda_policy=True)
+        else:
+            out = vo.vit_block_upstream_ops(p, "blocks.9.", xr, H)
+        (out * ct).sum().backward()
+        return xr, out
+
+    x16, o16 = oracle(True)
+    x32, o32 = oracle(False)
+    xg = tok.cuda().requires_grad_(True)
+    out = blk(xg)
+    e, noise = rel(out - xg.detach(), o16 - tok), rel(o16 - tok, o32 - tok)
+    print(f"frozen block (added term): ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
+    assert o16.dtype == torch.float32 and noise > 1e-3 and e < 0.35 * noise   # (stage by stage 1e-5 ... 2e-4: tests/diag/diag_block16.py)
+    (out * ct.cuda()).sum().backward()
+    e, noise = rel(xg.grad - ct.cuda(), x16.grad - ct), rel(x16.grad - ct, x32.grad - ct)
+    print(f"frozen block d(tokens) minus the residual path: ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
+    assert e < 0.5 * noise
