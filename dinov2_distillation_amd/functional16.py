@@ -336,3 +336,35 @@ class ViTBlockFrozen16Fn(Function):
         dh1 = ops.gemm_bf16(dqkv, p["wqkv"], b_layout=1)
         dx, _, _ = ops.layernorm_bwd(ops.cast_f32(dh1), x2, m1, r1, p["n1w"], affine=False, add=dx1)
         return dx.reshape(B, N, D), None
+
+
+class DctRoundtrip16Fn(Function):
+    """inverse_dct(zero_dc(dct(map))) of the frequency loss (losses/scalekd.py:107-118) under the autocast policy: the reference
+    builds both transforms from nn.Linear layers (:337-428), so they are four 16-bit matmuls with 16-bit matrices - NOT the exact
+    mean removal the fp32 path uses.  tok [B, 256, C] fp32 (a 16 x 16 token grid) -> the same layout, fp32 holding the 16-bit
+    result.  Fw / Gw: forward / inverse Linear weights [16, 16] (fp32 holding their 16-bit values)."""
+
+    @staticmethod
+    def forward(ctx, tok, Fw, Gw):
+        tok = _c(tok)
+        B, N, C = tok.shape
+        if N != 256:
+            raise NotImplementedError("the mixed-precision frequency loss is written for the 16 x 16 grid (224 / 14)")
+        x = tok.reshape(B, 16, 16, C)
+        x = ops.dct16_step(x, Fw, 0)                       # forward_transform along W
+        x = ops.dct16_step(x, Fw, 1, zero_out=True)        # ... along H; [:, :, 0, 0] = 0
+        x = ops.dct16_step(x, Gw, 0)                       # inverse_transform along the last axis
+        x = ops.dct16_step(x, Gw, 1, out_dtype=F32)        # ... and along H
+        ctx.save_for_backward(Fw, Gw)
+        return x.reshape(B, N, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Fw, Gw = ctx.saved_tensors
+        dy = _c(dy)
+        B, N, C = dy.shape
+        d = ops.dct16_step(dy.reshape(B, 16, 16, C), Gw, 1, transposed=True)
+        d = ops.dct16_step(d, Gw, 0, transposed=True)
+        d = ops.dct16_step(d, Fw, 1, transposed=True, zero_in=True)
+        d = ops.dct16_step(d, Fw, 0, transposed=True, out_dtype=F32)
+        return d.reshape(B, N, C), None, None

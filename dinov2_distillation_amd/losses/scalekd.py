@@ -20,6 +20,26 @@ def _tokens_of_map(feat):
     return feat.permute(0, 2, 3, 1).reshape(B, H * W, C)
 
 
+_DCT16 = {}
+
+
+def _dct16_weights(device):
+    """weights of the reference's DCT(resolution=16) Linear layers (losses/scalekd.py:343-350: ``_dct(I).t()`` / ``_idct(I).t()``,
+    norm=None) as the 16-bit values autocast multiplies with, held in fp32: forward W[k][w] = 2 cos(pi (2w+1) k / 32), inverse
+    W[w][k] = cos(pi (2w+1) k / 32) / 16 (k = 0: / 32)"""
+    key = str(device)
+    if key not in _DCT16:
+        import math
+        j = torch.arange(16, dtype=torch.float64)
+        ang = math.pi * (2 * j[:, None] + 1) * j[None, :] / 32          # [w, k]
+        fw = (2 * torch.cos(ang)).t()                                     # [k, w]
+        gw = torch.cos(ang) / 16                                          # [w, k]
+        gw[:, 0] = gw[:, 0] / 2
+        rnd = lambda m: m.float().bfloat16().float().contiguous().to(device)
+        _DCT16[key] = (rnd(fw), rnd(gw))
+    return _DCT16[key]
+
+
 class _PosAttentionParams(nn.Module):  # WindowMultiheadPosAttention parameters (losses/scalekd.py:277-282)
     def __init__(self, dims, pos_dims):
         super().__init__()
@@ -110,6 +130,13 @@ class ScaleKD(nn.Module):
     def get_freq_loss(self, preds_S, preds_T):
         if preds_T.shape[-1] != preds_T.shape[-2]:
             raise ValueError("frequency loss needs a square grid (DCT(resolution=H) on both axes, scalekd.py:107)")
+        if self.projector_0.precision == "bf16_autocast":
+            # under autocast the reference's DCT (nn.Linear layers, scalekd.py:337-428) is four 16-bit matmuls per map: reproduce
+            # THAT rather than the exact mean removal; the normalise / MSE / cosine tail is fp32 either way
+            Fw, Gw = _dct16_weights(preds_S.device)
+            with torch.no_grad():
+                t = Fn16.DctRoundtrip16Fn.apply(_tokens_of_map(preds_T), Fw, Gw)
+            return Fn.KDLossFn.apply(Fn16.DctRoundtrip16Fn.apply(preds_S, Fw, Gw), t, self.alpha[1], False)
         return Fn.KDLossFn.apply(preds_S, _tokens_of_map(preds_T), self.alpha[1], True)
 
     def forward(self, preds_S, preds_T, query_s=None, query_f=None):

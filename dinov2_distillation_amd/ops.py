@@ -1128,3 +1128,15 @@ def gelu16(x, dy=None):
     out = torch.empty_like(x)
     check(_lib.binding().dkd_gelu_bf16(_p(x), _p(dy), _p(out), x.numel(), _stream()), "dkd_gelu_bf16")
     return out
+
+
+def dct16_step(x, Mx, axis, out_dtype=BF16, transposed=False, zero_in=False, zero_out=False):
+    """one 16 x 16 Linear of the DCT pipeline along W (axis 0) or H (axis 1) of an NHWC map [B, 16, 16, C] (dkd_hip.h)"""
+    _chk_io(x, "x"), _chk(Mx, "Mx")
+    B, H, W, C = x.shape
+    if H != 16 or W != 16 or tuple(Mx.shape) != (16, 16):
+        raise _lib.DkdError(f"dct16_step: a 16 x 16 grid is needed (got {H} x {W})")
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(_lib.binding().dkd_dct16_step(_p(x), _is16(x), _p(out), int(out_dtype == BF16), _p(Mx), B, C, axis, int(transposed),
+                                        int(zero_in), int(zero_out), _stream()), "dkd_dct16_step")
+    return out

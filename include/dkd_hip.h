@@ -232,6 +232,11 @@ int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
 int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, void* stream);
 int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, void* stream);
 int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
+/* one Linear of the frequency loss's DCT / inverse DCT (losses/scalekd.py:337-428: 16 x 16 matrices applied along one spatial
+ * axis) under the 16-bit policy on an NHWC map [n_maps, 16, 16, C]: out = rnd(Mx . in) along axis 0 (W) or 1 (H); Mx[16][16] the
+ * 16-bit matrix values in fp32; transposed: the adjoint; zero_in / zero_out: the DC coefficient is zero (:114-115) */
+int dkd_dct16_step(const void* in, int in16, void* out, int out16, const float* Mx, long n_maps, int C, int axis, int transposed,
+                   int zero_in, int zero_out, void* stream);
 int dkd_gelu_bf16(const void* x, const void* dy, void* out, long n, void* stream); /* dy NULL: gelu(x); else dy * gelu'(x); bf16 */
 int dkd_relu_bwd_bf16(const void* dy, const void* y, void* dx, long n, void* stream); /* dx = y > 0 ? dy : 0 on bf16 tensors */
 /* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588

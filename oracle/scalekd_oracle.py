@@ -137,23 +137,30 @@ def drop_dc(m):
     return r.transpose(-1, -2)
 
 
-def freq_loss(tok_s, feat_t, alpha1):
-    """``ScaleKD.get_freq_loss`` (losses/scalekd.py:95-127)."""
-    s = drop_dc(tokens_to_map(tok_s, feat_t.shape))
+def freq_loss(tok_s, feat_t, alpha1, policy=False):
+    """``ScaleKD.get_freq_loss`` (losses/scalekd.py:95-127).  policy (the caller runs under torch.autocast(bfloat16)): the
+    reference's DCT is built from nn.Linear layers (:337-428), i.e. four 16-bit matmuls per map with 16-bit matrices - the four
+    ``@`` of drop_dc are cast down by autocast exactly like those Linears; the normalise / MSE / cosine tail is fp32 on CUDA."""
+    m = tokens_to_map(tok_s, feat_t.shape)
+    if policy:
+        m, feat_t = m.contiguous(), feat_t.contiguous()  # (dense matmul operands: see attention_projector)
+    s = drop_dc(m)
     t = drop_dc(feat_t)
+    if policy:
+        s, t = s.float(), t.float()
     return _normalised_mse_and_cos(s, t, alpha1, feat_t.shape[0])
 
 
 # --------------------------------------------------------------------------------------------------
 # ScaleKD.forward                                                        losses/scalekd.py:31-54
 # --------------------------------------------------------------------------------------------------
-def scalekd_forward(p, pre, feat_s, feat_t, cfg, query_s=None, query_f=None, training=True):
+def scalekd_forward(p, pre, feat_s, feat_t, cfg, query_s=None, query_f=None, training=True, policy=False):
     """cfg: dict(alpha, hw, num_heads, softmax_scale, window_shapes)."""
     kw = dict(hw=cfg["hw"], num_heads=cfg["num_heads"], window_shapes=tuple(cfg.get("window_shapes", (1, 1))),
-              training=training)
+              training=training, policy=policy)
     ts = attention_projector(p, pre + "projector_0.", feat_s, query_s, softmax_scale=cfg["softmax_scale"][0], **kw)
     tf = attention_projector(p, pre + "projector_1.", feat_s, query_f, softmax_scale=cfg["softmax_scale"][1], **kw)
     ls, ss = spat_loss(ts, feat_t, cfg["alpha"][0])
-    lf, sf = freq_loss(tf, feat_t, cfg["alpha"][1])
+    lf, sf = freq_loss(tf, feat_t, cfg["alpha"][1], policy)
     return {"spatial_loss": ls, "frequency_loss": lf, "spatial_similarity": ss,
             "frequency_similarity": sf, "loss": ls + lf}
