@@ -358,6 +358,24 @@ def main():
                               "losses, optimiser exact fp32", "value": round(args.batch * world * args.steps / dta, 2),
             "unit": "images/s", "ms_per_step": round(dta / args.steps * 1e3, 3)}
         del st16
+        # ... and the whole step under the policy: ScaleKD projectors, the re-use of teacher blocks on the student tokens (forward and
+        # input gradient) and the frequency loss's Linear-built DCT as well (functional16.py); optimiser and master weights fp32
+        st16 = DistillationStepper(device=f"cuda:{local}", precision="bf16_autocast")
+        for _ in range(3):
+            st16.step(batch)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            st16.step(batch)
+        sync()
+        dta = time.perf_counter() - t1
+        alts["alt_bf16_autocast_step"] = {
+            "gemm_precision": "the WHOLE step under the reference's default precision=16 policy (train.py:263, torch autocast) in bf16: "
+                              "every conv / Linear / attention matmul on bf16 operands from HBM with bf16 results, LayerNorm / softmax / "
+                              "GRN statistics / loss tails / residual streams that autocast keeps fp32 in fp32, fp32 master weights and "
+                              "optimiser; every node tested against torch.autocast on the oracle (tests/test_autocast_gpu.py)",
+            "value": round(args.batch * world * args.steps / dta, 2), "unit": "images/s", "ms_per_step": round(dta / args.steps * 1e3, 3)}
+        del st16
     note(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank != 0:
         if world > 1:

@@ -12,7 +12,11 @@ from .train import DistillationModule
 class DistillationStepper:
     def __init__(self, teacher="dinov2_vits14", student="convnext_tiny", crop=224, device="cuda", heads=(16, 24),
                  clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None, accumulate_grad_batches=1,
-                 student_precision=None, projector_precision=None):
+                 student_precision=None, projector_precision=None, precision=None):
+        if precision is not None:  # one switch for the whole step: "bf16_autocast" = the reference's default precision=16 policy
+            teacher_precision = teacher_precision or precision
+            student_precision = student_precision or precision
+            projector_precision = projector_precision or precision
         self.cfg = make_config(teacher, student, crop, heads=heads, lr=lr)
         torch.manual_seed(seed)  # student seed 1, ScaleKD follows; identical on every rank
         self.student = ModelWrapper(student, self.cfg.teacher.n_patches, self.cfg.student.student_keys)

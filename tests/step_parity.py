@@ -10,9 +10,10 @@ STDC_LAYERS = {"stdc_1": [2, 2, 2], "stdc_2": [4, 5, 3]}
 def oracle_step(mod, cfg, x, dtype=torch.float32, teacher_bf16=False, autocast=False):
     """-> (logged-scalar dict, {student key: grad}, {loss-module key: grad}) of the oracle run with ``mod``'s weights.
     teacher_bf16: the frozen teacher (forward and block re-use) in the "bf16 operands, fp32 accumulate" arithmetic.
-    autocast: the mixed-precision step as the build runs it - teacher forward and ConvNeXt backbone under torch's autocast policy
-    in bfloat16 (oracle/vit_oracle.py, oracle/convnext_oracle.py), the features handed on as fp32, block re-use in the bf16-operand
-    arithmetic, projectors / losses fp32."""
+    autocast: the whole step under torch's autocast policy in bfloat16, as the reference's default precision=16 runs it - teacher
+    forward (oracle/vit_oracle.py), ConvNeXt backbone and feature resize, ScaleKD projectors, re-used teacher blocks and the
+    Linear-built DCT of the frequency loss: torch.autocast itself on the oracle's op sequences, CUDA's fp32 op list forced where
+    the CPU policy differs."""
     from oracle import convnext_oracle as cno, resnet_oracle as ro, stdc_oracle as sto, step_oracle as so, swin_oracle as swo
     from oracle import vit_oracle as vo
 
@@ -31,13 +32,12 @@ def oracle_step(mod, cfg, x, dtype=torch.float32, teacher_bf16=False, autocast=F
     xd = x.to(dtype)
     with torch.no_grad():
         feat_t = vo.teacher_feature_map_autocast(tp, xd, tcfg) if autocast else vo.teacher_feature_map(tp, xd, tcfg, bf16=teacher_bf16)
-    teacher_bf16 = teacher_bf16 or autocast
     name, grid, keys = cfg.student.model_name, tuple(cfg.teacher.n_patches), cfg.student.student_keys
     if name.startswith("swin"):
         feats = swo.student_features(sp, xd, swo.SWIN_CONFIGS[name], grid, keys)
     elif name.startswith("convnext") and autocast:
         f = cno.forward_features_autocast(sp, xd, cno.CONVNEXT_CONFIGS[name]["depths"])
-        feats = {k: F.interpolate(f[k].float(), size=grid, mode="bilinear", align_corners=False) for k in keys}
+        feats = {k: F.interpolate(f[k], size=grid, mode="bilinear", align_corners=False) for k in keys}   # 16-bit in, 16-bit out
     elif name.startswith("convnext"):
         feats = cno.student_features(sp, xd, cno.CONVNEXT_CONFIGS[name]["depths"], grid, keys)
     elif name.startswith("resnet"):
@@ -53,7 +53,11 @@ def oracle_step(mod, cfg, x, dtype=torch.float32, teacher_bf16=False, autocast=F
         kw = spec.kwargs
         cfgs[kw.name] = dict(alpha=kw.alpha, hw=tuple(kw.pos_hw), num_heads=kw.num_heads, softmax_scale=kw.softmax_scale)
         w[kw.name] = spec.weight
-    out = so.compute_losses(lp, cfgs, w, feats, feat_t, tp, tcfg["depth"], tcfg["num_heads"], teacher_bf16=teacher_bf16)
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = so.compute_losses(lp, cfgs, w, feats, feat_t, tp, tcfg["depth"], tcfg["num_heads"], policy=True)
+    else:
+        out = so.compute_losses(lp, cfgs, w, feats, feat_t, tp, tcfg["depth"], tcfg["num_heads"], teacher_bf16=teacher_bf16)
     out["loss"].backward()
     gs = {k: v.grad for k, v in sp.items() if v.dtype.is_floating_point and v.requires_grad and v.grad is not None}
     gl = {k: v.grad for k, v in lp.items() if v.dtype.is_floating_point and v.requires_grad and v.grad is not None}

@@ -96,20 +96,22 @@ def test_config1_vits14_convnext_tiny_fp64_arbiter():
 
 
 def test_config1_mixed_precision_step_vs_autocast_oracle():
-    """configs[1] with the reference's DEFAULT trainer precision (train.py:263) on the teacher forward and the ConvNeXt backbone
-    (bf16 activations in HBM, bf16 MFMA GEMMs; projectors / losses fp32) against the oracle run in the same modes - torch.autocast
-    itself on the backbone restatement.  Yardstick as for every 16-bit mode: the distance between the mixed-precision and the fp32
+    """configs[1] with the reference's DEFAULT trainer precision (train.py:263) on the WHOLE step - teacher forward, ConvNeXt
+    backbone, ScaleKD projectors, re-used teacher blocks, the frequency loss's Linear-built DCT (bf16 operands in HBM, bf16 MFMA
+    GEMMs, fp32 where autocast keeps fp32) - against torch.autocast itself on the oracle's op sequences.  Yardstick as for every 16-bit mode: the distance between the mixed-precision and the fp32
     oracle runs (two exact implementations of one rounding policy separate by a fraction of it over 18 blocks; layer-level
     agreement is pinned in tests/test_autocast_gpu.py)."""
     from dinov2_distillation_amd import ops
     mod, cfg = _build("dinov2_vits14", "convnext_tiny", 224, (16, 24), seed=1, teacher_precision="bf16_autocast")
     mod.student.set_precision("bf16_autocast")
+    for loss_mod in mod.losses.values():
+        loss_mod.set_precision("bf16_autocast")
+    for blk in mod.teacher.model.blocks:
+        blk.policy16 = True
     with torch.no_grad():
         for n_, p_ in mod.student.named_parameters():
             if "grn" in n_:
                 p_.add_(0.1 * torch.randn_like(p_))
-            elif p_.dim() > 1:
-                p_.mul_(4.0)
     x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
     ref16, gs16, gl16 = oracle_step(mod, cfg, x, torch.float32, autocast=True)
     ref32, gs32, gl32 = oracle_step(mod, cfg, x, torch.float32)
