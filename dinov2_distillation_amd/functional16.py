@@ -14,6 +14,8 @@ block (models/backbones/convnext.py:75-87 under autocast):
 
 and the mirror image in the backward pass (every gradient of a 16-bit tensor is a 16-bit tensor; weight gradients are the 16-bit
 results of the backward matmuls, cast up into the fp32 master gradients).  All arithmetic inside the kernels is fp32."""
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -23,14 +25,42 @@ from .functional import _c, direct, ret
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+# 16-bit copies of the fp32 master parameters, made once per optimiser step instead of once per use (~200 tiny launches per
+# step otherwise, and the mixed-precision step is as host-bound as it is GPU-bound).  A copy is valid while the parameter object,
+# its storage, its autograd version (in-place edits through torch) and ops.WEIGHT_EPOCH (bumped by FusedAdamW.step(), whose
+# kernel writes the arena behind torch's back) are unchanged; never used while a hipGraph is being captured (the casts have to be
+# part of the graph: the weights change at every replay).
+_CASTS = {}  # id(parameter) -> (weak reference to it, {kind: (stamp, copy)})   (tensors hash by identity but compare element-wise:
+             # no WeakKeyDictionary)
+
+
+def _cached(w, kind, make):
+    if w.is_cuda and torch.cuda.is_current_stream_capturing():
+        return make()
+    stamp = (w._version, ops.WEIGHT_EPOCH, w.data_ptr())
+    key = id(w)
+    ent = _CASTS.get(key)
+    if ent is None or ent[0]() is not w:
+        ent = _CASTS[key] = (weakref.ref(w, lambda _r, k=key: _CASTS.pop(k, None)), {})
+    hit = ent[1].get(kind)
+    if hit is None or hit[0] != stamp:
+        hit = ent[1][kind] = (stamp, make())
+    return hit[1]
+
+
 def _w16(w):
     """a parameter as the 16-bit operand autocast makes of it"""
-    return ops.cast_bf16(w.reshape(-1, w.shape[-1]) if w.dim() > 1 else w.reshape(1, -1)).reshape(w.shape)
+    return _cached(w, "bf16", lambda: ops.cast_bf16(w.detach().reshape(-1, w.shape[-1]) if w.dim() > 1 else w.detach().reshape(1, -1)).reshape(w.shape))
+
+
+def _w16_2d(w, rows, cols):
+    """_w16 of a parameter viewed as [rows, cols] (conv weights)"""
+    return _cached(w, ("bf16", rows, cols), lambda: ops.cast_bf16(w.detach().reshape(rows, cols)))
 
 
 def _rounded(t):
     """fp32 copy holding bf16 values (taps / biases that a kernel consumes as fp32)"""
-    return ops.round_bf16_(t.detach().clone())
+    return _cached(t, "rounded", lambda: ops.round_bf16_(t.detach().clone()))
 
 
 def wgrad16(dy16, x16, w, b, transform=None, reshape=None):
@@ -105,12 +135,12 @@ class PatchConv16Fn(Function):
         if src_nchw:
             B, _, H, W = x.shape
             rows = ops.cast_bf16(ops.patchify_nchw(x, k))
-            w2 = ops.cast_bf16(w.reshape(O, -1))
+            w2 = _w16_2d(w, O, w.numel() // O)
         else:
             B, H, W, C = x.shape
             # pure data movement: a bf16 [.., C] tensor is an fp32 [.., C / 2] tensor to the patchify kernel
             rows = ops.patchify_nhwc(x.view(F32), k).view(BF16)
-            w2 = ops.cast_bf16(ops.transpose(w.reshape(O, C, k * k)).reshape(O, k * k * C))  # [O][ky][kx][c]
+            w2 = _cached(w, "patch16", lambda: ops.cast_bf16(ops.transpose(w.detach().reshape(O, C, k * k)).reshape(O, k * k * C)))  # [O][ky][kx][c]
         y = ops.gemm_bf16(rows, w2, bias=_w16(b))
         ctx.save_for_backward(rows, w2)
         ctx.meta = (k, src_nchw, tuple(x.shape), tuple(w.shape))
@@ -148,10 +178,10 @@ class ConvNeXtBlock16Fn(Function):
         B, H, W, C = x.shape
         M = B * H * W
         x16 = x if x.dtype == BF16 else ops.cast_bf16(x).reshape(x.shape)
-        wt = ops.round_bf16_(ops.transpose(dw_w.reshape(C, 49)))  # tap-major [49, C], 16-bit values
+        wt = _cached(dw_w, "taps16", lambda: ops.round_bf16_(ops.transpose(dw_w.detach().reshape(C, 49))))  # tap-major [49, C], 16-bit values
         d16 = ops.dwconv7_io(x16, wt, _rounded(dw_b))
         n16, mean, rstd = ops.layernorm_fwd_io(d16, ln_w, ln_b, 1e-6, BF16)
-        w1h, w2h = ops.cast_bf16(w1), ops.cast_bf16(w2)
+        w1h, w2h = _w16(w1), _w16(w2)
         h16 = ops.gemm_bf16(n16.reshape(M, C), w1h, bias=_w16(b1))
         gg, gb = grn_g.reshape(-1), grn_b.reshape(-1)
         y16, stats = ops.grn_fwd16(h16, gg, gb, B)
@@ -210,7 +240,7 @@ class AttentionProjector16Fn(Function):
         N, D = Ph * Pw, wc.shape[0]
         M, hd = B * N, D // num_heads
         x16 = ops.cast_bf16(x.reshape(M, Cs))
-        wc16 = ops.cast_bf16(wc.reshape(D, Cs))
+        wc16 = _w16_2d(wc, D, Cs)
         z = ops.cast_f32(ops.gemm_bf16(x16, wc16, bias=_w16(bc)))                      # conv output: 16-bit values
         mean, rstd = _bn_fwd_stats(z, bn_state, training)
         pos_t = ops.transpose(pos_embed.reshape(D, N))                                  # [N, D]
@@ -219,7 +249,7 @@ class AttentionProjector16Fn(Function):
         ctx.sq = self_query if shared else None
         qin16 = ops.cast_bf16(_c(self_query) if shared else _c(ext_query).reshape(M, D))
         tok16 = ops.cast_bf16(tok)
-        wq16, wk16, wv16, wp16, w1h, w2h = (ops.cast_bf16(t) for t in (wq, wk, wv, wp, w1, w2))
+        wq16, wk16, wv16, wp16, w1h, w2h = (_w16(t) for t in (wq, wk, wv, wp, w1, w2))
         q16 = ops.gemm_bf16(qin16, wq16, bias=_w16(bq))                                # [N, D] (shared) or [M, D]
         k16 = ops.gemm_bf16(tok16, wk16, bias=_w16(bk))
         v16 = ops.gemm_bf16(tok16, wv16, bias=_w16(bv))

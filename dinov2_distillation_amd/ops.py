@@ -125,6 +125,7 @@ def linear_wgrad(dy, x, with_bias_grad=False):
 # dW = dy^T x never feeds the rest of the backward pass: it is only needed by the optimiser.  With arena-backed gradients
 # (FusedAdamW) those GEMMs are launched on a side HIP stream straight into the parameter's .grad view, so the MFMA-bound
 # wgrad launches overlap the HBM-bound element-wise kernels (and fill the tail rounds) of the main dgrad chain.
+WEIGHT_EPOCH = 0         # bumped by FusedAdamW.step(): its kernel rewrites the parameter arena without touching torch's version counters
 ASYNC_WGRAD = False      # switched on by optim.FusedAdamW (every parameter owns a persistent .grad view, used once per backward)
 _side_streams = {}
 _grad_listeners = []     # callables(param): told when a parameter's gradient launch has been enqueued on the side stream

