@@ -271,7 +271,7 @@ template <int OP, typename T = float, bool R16 = false>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X, const T* __restrict__ Y,
                                                         const float* __restrict__ aux, float* __restrict__ out,
                                                         long rows_per_group, int N, long ldx, int CL, int rows_per_split,
-                                                        float scale, int nsplit) {
+                                                        float scale, int nsplit, int round_out = 0) {
     __shared__ float4 red[256];
     const int RL = 256 / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X,
             acc.x -= cmp.x; acc.y -= cmp.y; acc.z -= cmp.z; acc.w -= cmp.w;
             // partial layout [g][split][N]; with nsplit == 1 this IS the output
             float4* o = reinterpret_cast<float4*>(out + pass * second + ((long)g * nsplit + sp) * N) + c4;
-            if (nsplit == 1) { acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale; }
+            if (nsplit == 1) {
+                acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+                if (round_out) acc = rnd16(acc);  // (a 16-bit reduction result held in fp32: the mixed-precision step's bias gradients)
+            }
             *o = acc;
         }
     }
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X,
 // out[g][n] = scale * sum_p ws[g][p][n]: 32 column lanes x 8 split lanes per block (grid: column chunks x groups)
 // (grid.z = result planes: the two planes of DKD_RED_DOT_SUM / DOTGELU_SUM are folded by ONE launch)
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int groups,
-                                                              int nsplit, int N, float scale) {
+                                                              int nsplit, int N, float scale, int round_out = 0) {
     __shared__ float red[256];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + cl, g = blockIdx.y;
@@ -365,7 +368,8 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
         float s = 0.f, c = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) kahan1(s, c, red[k * 32 + cl]);
-        out[(long)g * N + n] = (s - c) * scale;
+        const float r = (s - c) * scale;
+        out[(long)g * N + n] = round_out ? rnd16(r) : r;
     }
 }
 
@@ -689,7 +693,7 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
 // bf16 X (and Y): the column sums of the mixed-precision step (bias gradients; GRN energies and GRN-backward sums with the
 // GELU rounded to bf16 when round_gelu != 0).  Ops: DKD_RED_SUM, DKD_RED_DOT, DKD_RED_GELUSQ, DKD_RED_DOTGELU_SUM; fp32 results
 extern "C" int dkd_colreduce_bf16(const void* X, const void* Y, float* out, float* ws, long rows_per_group, int groups, int N,
-                                  int op, int round_gelu, float scale, void* stream) {
+                                  int op, int round_gelu, int round_out, float scale, void* stream) {
     if (!X || !out || rows_per_group <= 0 || groups <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
     if (N & 3) return DKD_ERR_ALIGN;
     const bool two = op == DKD_RED_DOTGELU_SUM;
@@ -704,7 +708,7 @@ extern "C" int dkd_colreduce_bf16(const void* X, const void* Y, float* out, floa
     const __bf16* y = reinterpret_cast<const __bf16*>(Y);
 #define DKD_CR16(OPV, R)                                                                                                     \
     hipLaunchKernelGGL((colreduce_kernel<OPV, __bf16, R>), grid, block, 0, st, x, y, (const float*)nullptr, dst, rows_per_group, N, \
-                       (long)N, cl, rps, scale, ns)
+                       (long)N, cl, rps, scale, ns, round_out)
     switch (op) {
         case DKD_RED_SUM: DKD_CR16(DKD_RED_SUM, false); break;
         case DKD_RED_DOT: DKD_CR16(DKD_RED_DOT, false); break;
@@ -716,7 +720,7 @@ extern "C" int dkd_colreduce_bf16(const void* X, const void* Y, float* out, floa
     DKD_LAUNCH_CHECK();
     if (ns > 1) {
         const dim3 fgrid((N + 31) / 32, groups, two ? 2 : 1);
-        hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale);
+        hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale, round_out);
         DKD_LAUNCH_CHECK();
     }
     return DKD_OK;

@@ -77,7 +77,7 @@ def wgrad16(dy16, x16, w, b, transform=None, reshape=None):
             else:
                 transform(ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, ws_slot=3))
             if b is not None:
-                ops.round_bf16_(ops.colreduce16(dy16, ops.RED_SUM, out=b.grad.view(1, -1)))
+                ops.colreduce16(dy16, ops.RED_SUM, out=b.grad.view(1, -1), round_out=True)
         dy16.record_stream(side)
         x16.record_stream(side)
         ops.grad_done(w, b)
@@ -85,7 +85,7 @@ def wgrad16(dy16, x16, w, b, transform=None, reshape=None):
     dw = ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32)
     if reshape is not None:
         dw = reshape(dw)
-    db = None if b is None else ops.round_bf16_(ops.colreduce16(dy16, ops.RED_SUM)).reshape(-1)
+    db = None if b is None else ops.colreduce16(dy16, ops.RED_SUM, round_out=True).reshape(-1)
     return dw, db
 
 
@@ -215,7 +215,7 @@ class ConvNeXtBlock16Fn(Function):
         dd16 = dd16.reshape(B, H, W, C)
         dx = ops.dwconv7_io(dd16, wt, None, add=dout.reshape(B, H, W, C), flip=True, out_dtype=dout.dtype)
         ddw = ops.round_bf16_(ops.transpose(ops.dwconv7_wgrad16(x16, dd16), out=None if o_dww is None else o_dww.view(C, 49)))
-        ddb = ops.round_bf16_(ops.colreduce16(dd16.reshape(M, C), ops.RED_SUM, out=None if o_dwb is None else o_dwb.view(1, C)))
+        ddb = ops.colreduce16(dd16.reshape(M, C), ops.RED_SUM, out=None if o_dwb is None else o_dwb.view(1, C), round_out=True)
         return (dx, ret(o_dww, ddw.reshape(dw_shape), p_dww), ret(o_dwb, ddb.reshape(-1), p_dwb), ret(o_lnw, dln_w, p_lnw),
                 ret(o_lnb, dln_b, p_lnb), dw1, db1, ret(o_gg, dgrn_g.reshape(grn_shape), p_gg),
                 ret(o_gb, dgrn_b.reshape(grn_shape), p_gb), dw2, db2)

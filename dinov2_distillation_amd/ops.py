@@ -976,7 +976,7 @@ def layernorm_bwd_io(dy, x, mean, rstd, gamma, out_dtype, dg_out=None, db_out=No
     return dx, dg, db
 
 
-def colreduce16(x, op=RED_SUM, y=None, groups=1, round_gelu=False, scale=1.0, out=None):
+def colreduce16(x, op=RED_SUM, y=None, groups=1, round_gelu=False, scale=1.0, out=None, round_out=False):
     """column sums of bf16 rows [groups, rows_per_group, N] -> fp32 [groups, N] ([2, groups, N] for RED_DOTGELU_SUM)"""
     lib = _lib.binding()
     _chk16(x, "x"), _chk16(y, "y")
@@ -986,7 +986,7 @@ def colreduce16(x, op=RED_SUM, y=None, groups=1, round_gelu=False, scale=1.0, ou
         out = torch.empty((2, groups, N) if op == RED_DOTGELU_SUM else (groups, N), dtype=torch.float32, device=x.device)
     wsb = lib.dkd_colreduce_f32_workspace_bytes(rpg, groups, N)
     ws = workspace(wsb, x.device) if wsb else None
-    check(lib.dkd_colreduce_bf16(_p(x), _p(y), _p(out), _p(ws), rpg, groups, N, op, int(round_gelu), scale, _stream()),
+    check(lib.dkd_colreduce_bf16(_p(x), _p(y), _p(out), _p(ws), rpg, groups, N, op, int(round_gelu), int(round_out), scale, _stream()),
           "dkd_colreduce_bf16")
     return out
 

@@ -213,10 +213,10 @@ int dkd_layernorm_fwd_io(const void* x, int x16, const float* gamma, const float
                          long rows, int C, float eps, int cf16, void* stream);
 int dkd_layernorm_bwd_io(const void* dy, int dy16, const void* x, int x16, const float* mean, const float* rstd, const float* gamma,
                          void* dx, int dx16, float* dgamma, float* dbeta, float* ws, long rows, int C, int cf16, void* stream);
-/* column sums over bf16 rows (ops DKD_RED_SUM / _DOT / _GELUSQ / _DOTGELU_SUM; round_gelu: gelu rounded to bf16 first);
- * ws sized by dkd_colreduce_f32_workspace_bytes */
+/* column sums over bf16 rows (ops DKD_RED_SUM / _DOT / _GELUSQ / _DOTGELU_SUM; round_gelu: gelu rounded to bf16 first;
+ * round_out: the fp32 results hold bf16 values - a 16-bit bias gradient); ws sized by dkd_colreduce_f32_workspace_bytes */
 int dkd_colreduce_bf16(const void* X, const void* Y, float* out, float* ws, long rows_per_group, int groups, int N, int op,
-                       int round_gelu, float scale, void* stream);
+                       int round_gelu, int round_out, float scale, void* stream);
 int dkd_grn_apply_bf16(const void* h, const float* nx, const float* gamma, const float* beta, void* y, int B, long rows_per_img,
                        int C, void* stream);
 int dkd_grn_gelu_bwd_bf16(const void* dy, const void* h, const float* nx, const float* coef, const float* gamma, void* dh, int B,

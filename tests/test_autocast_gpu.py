@@ -463,12 +463,10 @@ def test_step_with_autocast_student_and_teacher():
     from dinov2_distillation_amd import functional16 as Fn16
     blk = st.student.model.model.stages[2][0]
     for w in (blk.pwconv1.weight, blk.pwconv2.bias):
-        before = Fn16._w16(w).clone()
-        assert torch.equal(before, w.detach().bfloat16())
+        assert torch.equal(Fn16._w16(w), w.detach().bfloat16())
     st.step(x)
     for w in (blk.pwconv1.weight, blk.pwconv2.bias):
         assert torch.equal(Fn16._w16(w), w.detach().bfloat16())
-    assert not torch.equal(Fn16._w16(blk.pwconv1.weight), before) or True
 
 
 @pytest.mark.parametrize("H,hd,c2", [(16, 24, 5.0), (24, 16, 5.0), (6, 64, 1.0)])
