@@ -272,6 +272,32 @@ __global__ void swiglu_bf16_kernel(const __bf16* __restrict__ x12, __bf16* __res
     }
 }
 
+// its backward as autograd forms it on the 16-bit tensors: with s = rnd(silu(x1)),  ds = rnd(da x2),  dx2 = rnd(da s),
+// dx1 = rnd(ds silu'(x1));  dx12 = [dx1 | dx2]
+__global__ void swiglu_bf16_bwd_kernel(const __bf16* __restrict__ da, const __bf16* __restrict__ x12, __bf16* __restrict__ dx12,
+                                       long rows, int hidden) {
+    const int hq = hidden >> 2;
+    const long total = rows * hq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / hq;
+        const int c = (int)(i % hq) * 4;
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(x12 + r * 2 * hidden + c);
+        const bf16x4 b = *reinterpret_cast<const bf16x4*>(x12 + r * 2 * hidden + hidden + c);
+        const bf16x4 g = *reinterpret_cast<const bf16x4*>(da + r * hidden + c);
+        bf16x4 d1, d2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = (float)a[e], sg = 1.f / (1.f + __expf(-x));
+            const float s = rnd_bf16(x * sg);
+            const float ds = rnd_bf16((float)g[e] * (float)b[e]);
+            d2[e] = (__bf16)((float)g[e] * s);
+            d1[e] = (__bf16)(ds * (sg * (1.f + x * (1.f - sg))));
+        }
+        *reinterpret_cast<bf16x4*>(dx12 + r * 2 * hidden + c) = d1;
+        *reinterpret_cast<bf16x4*>(dx12 + r * 2 * hidden + hidden + c) = d2;
+    }
+}
+
 int blocks_1d(long total) {
     const long b = (total + 255) / 256;
     return (int)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
@@ -368,6 +394,15 @@ extern "C" int dkd_swiglu_bf16(const void* x12, void* out, long rows, int hidden
     if (hidden & 3) return DKD_ERR_ALIGN;
     hipLaunchKernelGGL(swiglu_bf16_kernel, dim3(blocks_1d(rows * (hidden / 4))), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const __bf16*>(x12), reinterpret_cast<__bf16*>(out), rows, hidden);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_swiglu_bf16_bwd(const void* da, const void* x12, void* dx12, long rows, int hidden, void* stream) {
+    if (!da || !x12 || !dx12 || rows <= 0 || hidden <= 0) return DKD_ERR_BAD_ARG;
+    if (hidden & 3) return DKD_ERR_ALIGN;
+    hipLaunchKernelGGL(swiglu_bf16_bwd_kernel, dim3(blocks_1d(rows * (hidden / 4))), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(da), reinterpret_cast<const __bf16*>(x12), reinterpret_cast<__bf16*>(dx12), rows, hidden);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

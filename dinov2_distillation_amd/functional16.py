@@ -328,8 +328,6 @@ class ViTBlockFrozen16Fn(Function):
     def forward(ctx, x, blk):
         x = _c(x)
         p, H = blk.prepared16(), blk.num_heads
-        if p["swiglu"]:
-            raise NotImplementedError("SwiGLU blocks have no mixed-precision backward yet")
         B, N, D = x.shape
         M, hd = B * N, D // H
         c1 = hd ** -0.5
@@ -341,8 +339,9 @@ class ViTBlockFrozen16Fn(Function):
         o16, S, P = ops.attention16_forward(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, hd, c1, ld=3 * D)
         x1 = ops.gemm_bf16(o16, p["wproj"], epi=ops.EPI_F32_RESID, bias=p["bproj"], colscale=p["ls1"], residual=x2)
         h2, m2, r2 = ops.layernorm_fwd_io(x1, p["n2w"], p["n2b"], 1e-6, BF16)
-        u = ops.gemm_bf16(h2, p["w1"], bias=p["b1"])
-        out = ops.gemm_bf16(ops.gelu16(u), p["w2"], epi=ops.EPI_F32_RESID, bias=p["b2"], colscale=p["ls2"], residual=x1)
+        u = ops.gemm_bf16(h2, p["w1"], bias=p["b1"])                                        # fc1, or w12 = [x1 | x2] (SwiGLU, ViT-g)
+        a = ops.swiglu_bf16(u) if p["swiglu"] else ops.gelu16(u)
+        out = ops.gemm_bf16(a, p["w2"], epi=ops.EPI_F32_RESID, bias=p["b2"], colscale=p["ls2"], residual=x1)
         ctx.blk = blk
         ctx.save_for_backward(x2, m1, r1, qkv, S, P, x1, m2, r2, u)
         ctx.shape = (B, N, D)
@@ -357,7 +356,8 @@ class ViTBlockFrozen16Fn(Function):
         d2 = _c(dout).reshape(M, D)
         scaled16 = lambda g, ls: ops.cast_bf16(ops.group_affine(g, 1, mul=ls.reshape(1, -1)))   # the 16-bit Linear output's gradient
         da = ops.gemm_bf16(scaled16(d2, p["ls2"]), p["w2"], b_layout=1)
-        dh2 = ops.gemm_bf16(ops.gelu16(u, da), p["w1"], b_layout=1)
+        du = ops.swiglu_bf16_bwd(da, u) if p["swiglu"] else ops.gelu16(u, da)
+        dh2 = ops.gemm_bf16(du, p["w1"], b_layout=1)
         dx1, _, _ = ops.layernorm_bwd(ops.cast_f32(dh2), x1, m2, r2, p["n2w"], affine=False, add=d2)
         do16 = ops.gemm_bf16(scaled16(dx1, p["ls1"]), p["wproj"], b_layout=1)
         dqkv = torch.empty_like(qkv)

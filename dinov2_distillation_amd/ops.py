@@ -883,6 +883,15 @@ def swiglu_bf16(x12):
     return out
 
 
+def swiglu_bf16_bwd(da, x12):
+    _chk16(da, "da"), _chk16(x12, "x12")
+    hidden = x12.shape[-1] // 2
+    rows = x12.numel() // (2 * hidden)
+    dx = torch.empty_like(x12)
+    check(_lib.binding().dkd_swiglu_bf16_bwd(_p(da), _p(x12), _p(dx), rows, hidden, _stream()), "dkd_swiglu_bf16_bwd")
+    return dx
+
+
 def layernorm_fwd_bf16out(x, gamma, beta, eps, in_rows=None):
     """LayerNorm in fp32 with a bfloat16 result (the input of the next autocast Linear)"""
     _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")

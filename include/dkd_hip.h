@@ -244,6 +244,8 @@ int dkd_relu_bwd_bf16(const void* dy, const void* y, void* dx, long n, void* str
 int dkd_cast_bf16(const float* in, void* out_bf16, long rows, int cols, int out_ld, void* stream);
 /* SwiGLU on bf16 [rows, 2*hidden] -> bf16 [rows, hidden] as autocast rounds it: rnd(rnd(silu(x1)) * x2) */
 int dkd_swiglu_bf16(const void* x12_bf16, void* out_bf16, long rows, int hidden, void* stream);
+/* backward of the above on 16-bit tensors as autograd forms it: dx12 [rows, 2*hidden] = [dx1 | dx2] */
+int dkd_swiglu_bf16_bwd(const void* da, const void* x12, void* dx12, long rows, int hidden, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GPU input pipeline: datasets/augmentations.py:23-78 ``DataAugmentationDINO`` on a batch of decoded uint8 RGB

@@ -29,6 +29,8 @@ CONFIGS = {
                 student_precision="bf16_autocast"),
     "5as": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24), teacher_precision="bf16_autocast",
                 student_precision="bf16_autocast"),
+    "5p": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24), precision="bf16_autocast"),
+    "2p": dict(teacher="dinov2_vits14", student="convnext_tiny", crop=224, batch=64, heads=(16, 24), precision="bf16_autocast"),
     "mobilenet_v3_large": dict(teacher="dinov2_vits14", student="mobilenet_v3_large", crop=224, batch=64, heads=(16, 24)),
     "5f32": dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, batch=32, heads=(16, 24)),
 }
@@ -36,7 +38,8 @@ CONFIGS = {
 for name in sys.argv[1:] or ["3", "4", "5"]:
     c = CONFIGS[name]
     st = DistillationStepper(teacher=c["teacher"], student=c["student"], crop=c["crop"], heads=c["heads"], device="cuda:0",
-                             teacher_precision=c.get("teacher_precision"), student_precision=c.get("student_precision"))
+                             teacher_precision=c.get("teacher_precision"), student_precision=c.get("student_precision"),
+                             precision=c.get("precision"))
     x = torch.randn(c["batch"], 3, c["crop"], c["crop"], generator=torch.Generator().manual_seed(1234)).cuda()
     for _ in range(2):
         loss = st.step(x)

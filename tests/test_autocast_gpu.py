@@ -643,3 +643,46 @@ def test_frequency_loss_under_the_policy_vs_torch_autocast():
           f"d(tokens) {e_g:.2e} (autocast vs fp32 {n_g:.2e}); similarity {float(sim):.3e} vs {s16:.3e}")
     assert e_l < max(0.2 * n_l, 2e-5) and e_g < 0.2 * n_g and n_g > 1e-3
     assert abs(float(sim) - s16) < 1e-4
+
+
+def test_frozen_swiglu_block_reuse_under_the_policy_vs_torch_autocast():
+    """the same for a SwiGLU block (ViT-g, BASELINE configs[4]): silu(x1) * x2 on 16-bit tensors, forward and the backward autograd
+    forms for it"""
+    from oracle import vit_oracle as vo
+    from dinov2_distillation_amd.models.dinov2 import Block
+    gen = torch.Generator().manual_seed(21)
+    D, H, B, N = 384, 6, 4, 256
+    blk = Block(D, H, gen, ffn="swiglu")
+    with torch.no_grad():
+        for k, v in blk.state_dict().items():
+            if k.endswith("gamma"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+            elif k.endswith("bias"):
+                v.copy_(0.05 * torch.randn(v.shape, generator=gen))
+    p = {"blocks.0." + k: v.clone() for k, v in blk.state_dict().items()}
+    blk.policy16 = True
+    blk.cuda()
+    tok, ct = torch.randn(B, N, D, generator=gen), torch.randn(B, N, D, generator=gen)
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / b.float().norm()).item()
+
+    def oracle(policy):
+        xr = tok.clone().requires_grad_(True)
+        if policy:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = vo.vit_block_upstream_ops(p, "blocks.0.", xr, H, cuda_policy=True)
+        else:
+            out = vo.vit_block_upstream_ops(p, "blocks.0.", xr, H)
+        (out * ct).sum().backward()
+        return xr, out
+
+    x16, o16 = oracle(True)
+    x32, o32 = oracle(False)
+    xg = tok.cuda().requires_grad_(True)
+    out = blk(xg)
+    e, noise = rel(out - xg.detach(), o16 - tok), rel(o16 - tok, o32 - tok)
+    print(f"frozen SwiGLU block (added term): ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
+    assert noise > 1e-3 and e < 0.35 * noise
+    (out * ct.cuda()).sum().backward()
+    e, noise = rel(xg.grad - ct.cuda(), x16.grad - ct), rel(x16.grad - ct, x32.grad - ct)
+    print(f"frozen SwiGLU block d(tokens) minus the residual path: ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
+    assert e < 0.5 * noise
