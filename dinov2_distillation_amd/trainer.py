@@ -3,6 +3,8 @@ zero_grad -> training_step -> backward (+ DDP exchange) -> clip -> optimizer.ste
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 from .config import make_config, set_student_dims
 from .ddp import GradBucketReducer
 from .models import DINOv2ViT, ModelWrapper
@@ -69,6 +71,7 @@ class DistillationStepper:
         if batch.data_ptr() != self.static_batch.data_ptr():
             self.static_batch.copy_(batch, non_blocking=True)
         self.graph.replay()
+        ops.WEIGHT_EPOCH += 1  # the replayed optimiser kernel rewrote the parameters: cached 16-bit copies (functional16) are stale
         self.step_idx += 1
         return self.static_loss
 
