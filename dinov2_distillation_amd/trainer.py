@@ -4,7 +4,6 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-
 from .config import make_config, set_student_dims
 from .ddp import GradBucketReducer
 from .models import DINOv2ViT, ModelWrapper
