@@ -686,3 +686,20 @@ def test_frozen_swiglu_block_reuse_under_the_policy_vs_torch_autocast():
     e, noise = rel(xg.grad - ct.cuda(), x16.grad - ct), rel(x16.grad - ct, x32.grad - ct)
     print(f"frozen SwiGLU block d(tokens) minus the residual path: ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
     assert e < 0.5 * noise
+
+
+def test_validation_step_under_the_policy():
+    """validation_step (train/distillation_module.py:278-309) with the whole step under the policy: eval-mode BatchNorm in the
+    projectors (running statistics), no autograd; the logged losses stay within the policy's noise of the fp32 run"""
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()
+    out = {}
+    for prec in (None, "bf16_autocast"):
+        st = DistillationStepper(device="cuda:0", precision=prec)
+        st.step(x)                      # one training step first: the running statistics move off their initial values
+        st.module.eval()
+        with torch.no_grad():
+            out[prec] = float(st.module.validation_step(x, 0))
+        assert any(k.startswith("val_") for k in st.module.logged)
+    print(f"validation loss: fp32 {out[None]:.5f}, policy {out['bf16_autocast']:.5f}")
+    assert out["bf16_autocast"] == out["bf16_autocast"] and abs(out["bf16_autocast"] - out[None]) <= 3e-2 * abs(out[None])
