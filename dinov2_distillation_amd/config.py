@@ -27,7 +27,8 @@ TEACHER_DIMS = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 102
 
 def make_config(teacher="dinov2_vits14", student="convnext_tiny", crop=224, student_keys=("res5", "res4"),
                 heads=(16, 24), lr=1e-3):
-    """config/config.yaml defaults for the chosen pair, with ``_handle_config`` (train.py:86-122) applied."""
+    """config/config.yaml defaults for the chosen pair, with ``_handle_config`` (train.py:86-122) applied.  Synthetic runs have
+    no checkpoint files (the reference's are git-ignored): ``allow_missing_checkpoint`` is set, a real config leaves it out."""
     n = crop // 14
     d = TEACHER_DIMS[teacher]
 
@@ -37,7 +38,7 @@ def make_config(teacher="dinov2_vits14", student="convnext_tiny", crop=224, stud
                                                            teacher_dims=d, pos_dims=d, pos_hw=[n, n], query_hw=[n, n]))
 
     return to_cfg(dict(
-        student=dict(model_name=student, student_keys=list(student_keys), checkpoint_path=None),
+        student=dict(model_name=student, student_keys=list(student_keys), checkpoint_path=None, allow_missing_checkpoint=True),
         teacher=dict(model_name=teacher, out_dim=d, teacher_key="feature_map", n_patches=[n, n]),
         data_transform=dict(global_crops_size=[crop, crop]),
         optimizer=dict(type="AdamW", kwargs=dict(lr=lr, betas=[0.9, 0.999], weight_decay=0.01)),

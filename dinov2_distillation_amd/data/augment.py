@@ -238,12 +238,30 @@ def resample_coeffs_batch(in_sizes, out_size):
 class DataAugmentationDINOGpu:
     """datasets/augmentations.py:23-78 for a whole batch on the GPU (see the module docstring)"""
 
+    PINNED_SLOTS = 3
+
     def __init__(self, global_crops_scale=(0.08, 1.0), global_crops_size=224, device="cuda"):
         self.scale = tuple(global_crops_scale)
         self.size = int(global_crops_size[0] if isinstance(global_crops_size, (list, tuple)) else global_crops_size)
         self.device = torch.device(device)
         self.last_plans = None
-        self._pinned = None  # grow-only pinned staging buffer for the packed batch (a pinned allocation per call costs milliseconds)
+        # Pinned staging for the packed batch (a pinned allocation per call costs milliseconds): a ring of grow-only buffers,
+        # each guarded by a HIP event recorded right after its H2D copy.  The copy is asynchronous and sits behind whatever the
+        # stream still has queued (a 40 ms training step), so the host must not repack a buffer until ITS copy has executed.
+        self._ring = [None] * self.PINNED_SLOTS   # [buffer, event of its last H2D copy]
+        self._slot = 0
+
+    def _staging(self, nbytes):
+        """-> (pinned uint8 view of nbytes, the event to record after its H2D copy).  Waits (host side) for the previous copy out
+        of this slot: with PINNED_SLOTS buffers in rotation that copy was enqueued PINNED_SLOTS calls ago."""
+        i = self._slot
+        self._slot = (i + 1) % self.PINNED_SLOTS
+        ent = self._ring[i]
+        if ent is not None:
+            ent[1].synchronize()
+        if ent is None or ent[0].numel() < nbytes:
+            ent = self._ring[i] = [torch.empty(nbytes * 5 // 4, dtype=torch.uint8, pin_memory=True), torch.cuda.Event()]
+        return ent[0][:nbytes], ent[1]
 
     def plan(self, shapes, generator):
         return [make_plan(generator, h, w, self.size, self.scale) for h, w in shapes]
@@ -265,9 +283,7 @@ class DataAugmentationDINOGpu:
         # pack the images and the per-image parameter arrays (host), one H2D copy each
         sizes = [im.numel() for im in imgs]
         offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
-        if self._pinned is None or self._pinned.numel() < int(offs[-1]):
-            self._pinned = torch.empty(int(offs[-1]) * 5 // 4, dtype=torch.uint8, pin_memory=True)
-        packed = self._pinned[:int(offs[-1])]
+        packed, copied = self._staging(int(offs[-1]))
         packed_np = packed.numpy()  # (numpy's memcpy into the pinned pages: 10x faster than 64 torch slice assignments)
         for im, o, n in zip(imgs, offs[:-1], sizes):
             packed_np[int(o):int(o) + n] = im.numpy().reshape(-1)
@@ -292,6 +308,7 @@ class DataAugmentationDINOGpu:
         erase = np.array([p["erase"] if p["erase"] is not None else (0, 0, 0, 0) for p in plans], np.int32)
         up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
         src = packed.to(dev, non_blocking=True)
+        copied.record(torch.cuda.current_stream(dev))  # the host may rewrite this slot once the DMA above has run
         meta_d, opc_d, fpar_d, erase_d, sizes_d = (up(a) for a in (meta, opc, fpar, erase, np.array(crop_w + crop_h, np.int32)))
         lib = _lib.binding()
         P, st = _lib.ptr, _lib.stream

@@ -174,12 +174,59 @@ def broadcast_tensors(tensors, src=0, process_group=None, chunk_bytes=256 << 20)
                 i = j
 
 
-def allreduce_metrics(values, process_group=None):
-    """C5: the step's scalar metrics packed in ONE vector, ONE all-reduce (mean) instead of 12 sync_dist logs."""
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
-        return values
+class PackedMetrics:
+    """The step's scalar metrics as ONE vector in ONE all-reduce (rank mean), issued on a side stream so that it never sits
+    between two kernels of the compute stream.  ``values()`` (after ``wait()``) -> {name: 0-d tensor}."""
+
+    def __init__(self, keys, vec, handle, side):
+        self.keys, self.vec, self.handle, self.side = keys, vec, handle, side
+
+    def wait(self):
+        """make the CURRENT stream (and, for gloo, the host) wait for the exchange; idempotent"""
+        if self.handle is not None:
+            self.handle.wait()
+            self.handle = None
+            if self.side is not None:
+                torch.cuda.current_stream().wait_stream(self.side)
+        return self
+
+    def values(self):
+        self.wait()
+        return {k: self.vec[i] for i, k in enumerate(self.keys)}
+
+
+_METRIC_STREAMS = {}
+
+
+def allreduce_metrics_async(values, process_group=None, side=None):
+    """C5 (train/distillation_module.py:353-358 logs every scalar with sync_dist=True: 12 collectives per step): pack the scalars,
+    average them over the ranks with one collective on ``side`` (default: a stream of this module's own).  Returns PackedMetrics,
+    or None when there is nothing to exchange (no process group / one rank)."""
+    if not values or not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return None
     keys = sorted(values)
-    vec = torch.stack([values[k].detach().float().reshape(()) for k in keys])
-    vec /= dist.get_world_size(process_group)
-    dist.all_reduce(vec, group=process_group)
-    return {k: vec[i] for i, k in enumerate(keys)}
+    first = next(v for v in values.values() if torch.is_tensor(v))
+    vec = torch.stack([(values[k].detach().float() if torch.is_tensor(values[k])
+                        else torch.tensor(float(values[k]), device=first.device)).reshape(()) for k in keys])
+    world = dist.get_world_size(process_group)
+    if vec.is_cuda:
+        if side is None:
+            side = _METRIC_STREAMS.get(vec.device.index)
+            if side is None:
+                side = _METRIC_STREAMS[vec.device.index] = torch.cuda.Stream(device=vec.device)
+        side.wait_stream(torch.cuda.current_stream(vec.device))
+        with torch.cuda.stream(side):
+            vec.div_(world)  # SUM of pre-divided values == mean (no ReduceOp.AVG on gloo)
+            handle = dist.all_reduce(vec, group=process_group, async_op=True)
+        vec.record_stream(side)
+    else:
+        side = None
+        vec.div_(world)
+        handle = dist.all_reduce(vec, group=process_group, async_op=True)
+    return PackedMetrics(keys, vec, handle, side)
+
+
+def allreduce_metrics(values, process_group=None):
+    """blocking form: {name: scalar} -> {name: rank mean}, one collective"""
+    packed = allreduce_metrics_async(values, process_group)
+    return values if packed is None else packed.values()

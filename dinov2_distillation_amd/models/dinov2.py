@@ -101,7 +101,10 @@ class Block(nn.Module):
 
     def prepared16(self):
         """bf16 copies of the frozen weights / biases for the autocast forward (made once): torch autocast casts weight AND
-        bias of every nn.Linear to the 16-bit type; LayerScale stays a separate fp32 multiply after the Linear's rounding"""
+        bias of every nn.Linear to the 16-bit type; LayerScale stays a separate fp32 multiply after the Linear's rounding.
+        The copies are enqueued on whichever stream asks first and then handed to EVERY stream (teacher stream, main loss chain,
+        frequency-loss chain), which share no dependency for them: the host waits once for the casts, exactly as transposed()
+        does (once per block and weight change; during hipGraph capture the copies exist already from the warm-up steps)."""
         w = self.attn.qkv.weight
         if self._prep16 is None or self._prep16["_ptr"] != w.data_ptr() or self._prep16["_ver"] != w._version:
             with torch.no_grad():
@@ -112,6 +115,8 @@ class Block(nn.Module):
                                 "wqkv": b(w), "bqkv": b(self.attn.qkv.bias), "wproj": b(self.attn.proj.weight),
                                 "bproj": b(self.attn.proj.bias), "ls1": self.ls1.gamma, "ls2": self.ls2.gamma,
                                 "w1": b(fin.weight), "b1": b(fin.bias), "w2": b(fout.weight), "b2": b(fout.bias)}
+            if w.is_cuda and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
         return self._prep16
 
     def forward_autocast(self, x2, B, N):
@@ -223,6 +228,8 @@ class VisionTransformer(nn.Module):
             w16 = torch.zeros((D, kp), dtype=torch.bfloat16, device=x.device)
             w16[:, :3 * PATCH * PATCH] = self.patch_embed.proj.weight.reshape(D, -1).to(torch.bfloat16)
             self._pe16 = (self.patch_embed.proj.weight._version, w16, self.patch_embed.proj.bias.to(torch.bfloat16), kp)
+            if not torch.cuda.is_current_stream_capturing():  # (same reason as Block.prepared16: built once, read from any stream)
+                torch.cuda.current_stream().synchronize()
         _, w16, b16, kp = self._pe16
         rows16 = ops.cast_bf16(ops.patchify_nchw(x.contiguous(), PATCH), kp)
         tok = torch.empty((B * (n + 1), D), dtype=torch.float32, device=x.device)

@@ -187,8 +187,7 @@ class DistillationModule(_Base):
 
     def validation_step(self, batch, batch_idx):
         losses = self._compute_losses(self._extract_features(batch))
-        for k, v in losses.items():
-            self.log(f"val_{k}", v, sync_dist=True)
+        self._log_metrics("val_", losses)
         return losses["loss"]
 
     def on_after_backward(self):
@@ -203,16 +202,49 @@ class DistillationModule(_Base):
             return super().log(name, value, **kwargs)
         self.logged[name] = value  # kept on the device: no host sync inside the step
 
+    def _log_metrics(self, prefix, losses):
+        """train/distillation_module.py:353-358,376-377 log every scalar with sync_dist=True - one collective per scalar, 11 per
+        step.  In a multi-rank job the scalars are packed into ONE vector and averaged by ONE all-reduce on a side stream
+        (ddp.allreduce_metrics_async) and logged with sync_dist=False (they already are the rank mean); with one rank (or no
+        process group) the calls are the reference's.  Plain-module branch: the exchange stays in flight behind the backward pass
+        and ``sync_logged()`` (called by trainer.DistillationStepper after the gradient exchange) joins it; under Lightning, which
+        reads the logged tensors on its own schedule, the current stream waits for the one collective right here."""
+        from ..ddp import allreduce_metrics_async
+        packed = allreduce_metrics_async({prefix + k: v for k, v in losses.items()}, getattr(self, "metric_group", None))
+        if packed is None:
+            for k, v in losses.items():
+                self.log(prefix + k, v, sync_dist=True)
+            return
+        if _Base is not nn.Module:
+            for k, v in packed.values().items():
+                self.log(k, v, sync_dist=False)
+            return
+        self.sync_logged()          # (a previous step's exchange nobody joined)
+        self._packed_metrics = packed
+        for i, k in enumerate(packed.keys):
+            self.log(k, packed.vec[i], sync_dist=False)   # views of the vector the collective fills in
+
+    def sync_logged(self):
+        """join the packed metric all-reduce of the last step: after this ``self.logged`` holds rank means that the current
+        stream may read"""
+        packed = getattr(self, "_packed_metrics", None)
+        if packed is not None:
+            packed.wait()
+            self._packed_metrics = None
+        return self.logged
+
     def _log_training_metrics(self, losses):
-        for k, v in losses.items():
-            self.log(f"train_{k}", v, sync_dist=True)
+        self._log_metrics("train_", losses)
         if _Base is not nn.Module:
             try:  # (the module may also be stepped without a Trainer attached: dinov2_distillation_amd.trainer)
                 opt = self.optimizers()
             except (RuntimeError, AttributeError):
                 opt = None
             if opt is not None:
-                self.log("lr", opt.param_groups[0]["lr"], sync_dist=True, prog_bar=True)
+                # (identical on every rank: no collective for it in a multi-rank job)
+                import torch.distributed as dist
+                multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                self.log("lr", opt.param_groups[0]["lr"], sync_dist=not multi, prog_bar=True)
 
     # ---- optimiser (train/distillation_module.py:440-502) ------------------------------------------------------------
     def configure_optimizers(self):
@@ -239,8 +271,15 @@ class DistillationModule(_Base):
     # ---- student warm start (train/distillation_module.py:381-438) ---------------------------------------------------
     def _load_student_checkpoint(self, checkpoint_path):
         if not checkpoint_path or not os.path.exists(checkpoint_path):
-            logger.warning("student checkpoint %s not found - keeping the initialised weights", checkpoint_path)
-            return
+            # The reference loads unconditionally at construction (:90-93) and a missing file ends the run there (open() /
+            # torch.load raise).  Synthetic runs (bench, tests, make_config) opt out explicitly.
+            if _get(self.cfg["student"], "allow_missing_checkpoint", False):
+                logger.warning("student checkpoint %s not found - keeping the initialised weights "
+                               "(cfg.student.allow_missing_checkpoint)", checkpoint_path)
+                return
+            raise FileNotFoundError(f"student checkpoint {checkpoint_path!r} not found (cfg.student.checkpoint_path, else the "
+                                    "wrapper's ckpt_dir); set cfg.student.allow_missing_checkpoint: true to train from the "
+                                    "initialised weights")
         if checkpoint_path.endswith(".pkl"):
             with open(checkpoint_path, "rb") as f:
                 checkpoint = pickle.load(f)["model"]

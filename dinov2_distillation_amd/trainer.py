@@ -100,4 +100,5 @@ class DistillationStepper:
                 self.reducer.finish()
             self.optimizer.step(clip_grad_norm=self.clip)
             self.step_idx += 1
+        self.module.sync_logged()  # the packed metric all-reduce (one per micro-batch) has long finished: join it
         return loss

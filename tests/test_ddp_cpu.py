@@ -1,0 +1,194 @@
+"""Multi-rank host logic on CPU (gloo): the packed metric all-reduce as the step module uses it, and the bucketed gradient
+exchange at world size 4 with unused parameters, gradient accumulation and buckets that cut through parameter groups."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(target, world, *extra):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def _init(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from dinov2_distillation_amd.ddp import init_process_group_from_env
+    init_process_group_from_env("gloo")
+
+
+# ---- packed metrics (/root/reference/train/distillation_module.py:353-358 logs each scalar with sync_dist=True) ----
+def _metrics_worker(rank, world, port, q):
+    _init(rank, world, port)
+    import torch.distributed as dist
+    from dinov2_distillation_amd.config import to_cfg
+    from dinov2_distillation_amd.train import DistillationModule
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = torch.nn.Linear(2, 2)
+
+    cfg = to_cfg(dict(student=dict(model_name="convnext_tiny", checkpoint_path=None, allow_missing_checkpoint=True),
+                      teacher=dict(model_name="dinov2_vits14", teacher_key="feature_map"), loss=dict(losses=[]),
+                      optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3))))
+    mod = DistillationModule(Net(), Net(), cfg)
+    calls = []
+    inner = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    losses = {"loss": torch.tensor(1.0 + rank, requires_grad=True) * 2.0, "scalekd_res4_spatial_loss": torch.tensor(float(rank * rank)),
+              "scalekd_res5_frequency_similarity": torch.tensor(0.25)}
+    mod._log_training_metrics(losses)
+    assert len(calls) == 1, "one packed collective per step, not one per scalar"
+    logged = mod.sync_logged()
+    mod._log_metrics("val_", {"loss": torch.tensor(float(rank))})
+    logged = mod.sync_logged()
+    assert len(calls) == 2
+    q.put((rank, {k: float(v) for k, v in logged.items()}))
+    dist.destroy_process_group()
+
+
+def test_logged_metrics_are_the_rank_mean_from_one_packed_allreduce_gloo_world2():
+    res = _spawn(_metrics_worker, 2)
+    for rank, logged in res:
+        assert logged == {"train_loss": 3.0, "train_scalekd_res4_spatial_loss": 0.5, "train_scalekd_res5_frequency_similarity": 0.25,
+                          "val_loss": 0.5}, (rank, logged)
+
+
+def test_one_rank_logs_like_the_reference():
+    """no process group: every scalar is logged as the reference logs it (sync_dist=True is the caller's flag), no collective"""
+    from dinov2_distillation_amd.config import to_cfg
+    from dinov2_distillation_amd.train import DistillationModule
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = torch.nn.Linear(2, 2)
+
+    cfg = to_cfg(dict(student=dict(model_name="convnext_tiny", checkpoint_path=None, allow_missing_checkpoint=True),
+                      teacher=dict(model_name="dinov2_vits14", teacher_key="feature_map"), loss=dict(losses=[]),
+                      optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3))))
+    mod = DistillationModule(Net(), Net(), cfg)
+    seen = []
+    mod.log = lambda name, value, **kw: seen.append((name, float(value), kw))
+    mod._log_training_metrics({"loss": torch.tensor(3.0), "a": torch.tensor(1.0)})
+    assert seen == [("train_loss", 3.0, {"sync_dist": True}), ("train_a", 1.0, {"sync_dist": True})]
+    assert mod.sync_logged() == {}
+
+
+# ---- bucketed exchange, world 4 ---------------------------------------------------------------------------------------------
+def _make_net():
+    """integer-valued weights and inputs: every product and partial sum below is an integer far below 2^24, so fp32 sums are
+    exact in ANY order and 'equal to the single-process full-batch mean' can be asserted bit for bit"""
+    g = torch.Generator().manual_seed(7)
+    ri = lambda *s: torch.randint(-2, 3, s, generator=g).float()
+    net = torch.nn.ModuleDict(dict(
+        stem=torch.nn.Linear(12, 40), norm0=torch.nn.LayerNorm(40),   # norm0 / norm1: registered, never used (the Swin wrapper's
+        body=torch.nn.Linear(40, 24), norm1=torch.nn.LayerNorm(24),   # unused output norms): no gradient ever arrives for them
+        head=torch.nn.Linear(24, 4)))
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "norm" not in n:
+                p.copy_(ri(*p.shape))
+    return net
+
+
+def _forward(net, x):
+    return net["head"](torch.relu(net["body"](torch.relu(net["stem"](x)))))
+
+
+def _batch(rank, micro):
+    g = torch.Generator().manual_seed(1000 + 10 * rank + micro)
+    return torch.randint(-2, 3, (4, 12), generator=g).float()
+
+
+def _world4_worker(rank, world, port, q):
+    _init(rank, world, port)
+    import torch.distributed as dist
+    from dinov2_distillation_amd.ddp import GradBucketReducer
+
+    class FlatOpt:  # FusedAdamW's arena layout on CPU tensors, two parameter groups (student | loss module) back to back
+        def __init__(self, groups):
+            self.layout, tot = [], 0
+            ps = [p for g in groups for p in g]
+            offs = []
+            for p in ps:
+                offs.append(tot)
+                tot += (p.numel() + 63) // 64 * 64
+            self.flat_p, self.flat_g = torch.zeros(tot), torch.zeros(tot)
+            for p, o in zip(ps, offs):
+                self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+                self.layout.append((p, o, p.numel()))
+
+    net = _make_net()
+    names = [n for n, _ in net.named_parameters()]
+    student = [p for n, p in net.named_parameters() if not n.startswith("head")]
+    loss_mod = [p for n, p in net.named_parameters() if n.startswith("head")]
+    opt = FlatOpt([student, loss_mod])
+    # 600 elements per bucket: [stem.w 480->512 | stem.b 64] [norm0 x2 | body.w 960->...] ... boundaries fall INSIDE the student
+    # group and the last student tensors share a bucket with the loss module's
+    red = GradBucketReducer(opt, bucket_bytes=1100 * 4)
+    sizes = [b[2] for b in red.buckets]
+    assert len(red.buckets) >= 3 and sum(sizes) == len(opt.layout), sizes
+    head_bucket = red.param_bucket[id(loss_mod[0])]
+    assert any(red.param_bucket[id(p)] == head_bucket for p in student), "a bucket must straddle the two parameter groups"
+    red.broadcast_parameters(0)
+    n_acc = 2
+    for step in range(2):  # two optimiser steps: hooks and counters re-arm
+        opt.flat_g.zero_()
+        for micro in range(n_acc):
+            loss = _forward(net, _batch(rank, micro)).sum() / n_acc
+            if micro < n_acc - 1:
+                with red.no_sync():
+                    loss.backward()
+                assert not any(red.launched), "nothing is exchanged inside no_sync()"
+            else:
+                loss.backward()
+        unused = [red.param_bucket[id(p)] for n, p in net.named_parameters() if "norm" in n]
+        assert not all(red.launched[b] for b in unused), "a bucket holding never-used parameters cannot complete from hooks"
+        red.finish()  # launches what the hooks could not
+    out = {n: p.grad.clone() for n, p in zip(names, [p for p, _, _ in opt.layout])}
+    q.put((rank, {k: v.numpy() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_world4_unused_params_accumulation_and_split_groups_bit_equal():
+    res = _spawn(_world4_worker, 4)
+    # single process, full batch: mean over ranks of the accumulated (sum of micro-batch losses / n_acc) gradients
+    net = _make_net()
+    world, n_acc = 4, 2
+    for r in range(world):
+        for micro in range(n_acc):
+            (_forward(net, _batch(r, micro)).sum() / n_acc / world).backward()
+    ref = {n: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for n, p in net.named_parameters()}
+    import numpy as np
+    for rank, grads in res:
+        for n, g in grads.items():
+            assert np.array_equal(g, ref[n]), (rank, n, float(np.abs(g - ref[n]).max()))
+        assert not grads["norm0.weight"].any() and not grads["norm1.bias"].any()
+    assert any(np.abs(v).max() > 0 for v in res[0][1].values())

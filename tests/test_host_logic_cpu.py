@@ -279,6 +279,19 @@ def test_student_checkpoint_warm_start_and_export_keys(tmp_path):
         bad = tmp_path / "weights.bin"
         bad.write_bytes(b"x")
         module("convnext_atto", bad)
+    # a missing file ends construction as in the reference (:90-93 loads unconditionally, open() / torch.load raise) unless the
+    # config opts out (make_config does, for synthetic runs)
+    cfg_strict = make_config(student="convnext_atto")
+    cfg_strict.student.allow_missing_checkpoint = False
+    st_ = ModelWrapper("convnext_atto", cfg_strict.teacher.n_patches, cfg_strict.student.student_keys)
+    set_student_dims(cfg_strict, st_)
+    t_ = DINOv2ViT("dinov2_vits14", seed=0)
+    t_.model.blocks = t_.model.blocks[:1]
+    with pytest.raises(FileNotFoundError, match="student checkpoint"):
+        DistillationModule(st_, t_, cfg_strict)              # falls back to the wrapper's ckpt_dir, which does not exist here
+    cfg_strict.student.checkpoint_path = str(tmp_path / "nope.pth")
+    with pytest.raises(FileNotFoundError, match="nope.pth"):
+        DistillationModule(st_, t_, cfg_strict)
     # MobileNetV3: keys prefixed 'backbone.', the classification head is dropped before loading (distillation_module.py:419-421)
     m3 = ModelWrapper("mobilenet_v3_small", [16, 16])
     k3, kc = "features.0.0.weight", "classifier.3.bias"

@@ -124,7 +124,7 @@ def test_training_step_against_reference_golden(golden_dir):
                                                          softmax_scale=[5.0, 5.0], num_heads=h, name=name, teacher_dims=D,
                                                          pos_dims=D, pos_hw=[P, P], query_hw=[P, P], student_dims=cs))
 
-    cfg = to_cfg(dict(student=dict(model_name="convnext_tiny", checkpoint_path=None),
+    cfg = to_cfg(dict(student=dict(model_name="convnext_tiny", checkpoint_path=None, allow_missing_checkpoint=True),
                       teacher=dict(model_name="dinov2_vits14", teacher_key="feature_map"),
                       loss=dict(losses=[spec("scalekd_res4", 6, True, c4, 0.7), spec("scalekd_res5", 3, False, c5, 1.0)]),
                       optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3))))
