@@ -22,19 +22,10 @@
 // barriers per 64-deep k-tile, 8 MFMAs per wave between them).
 #include "common.h"
 #include "dkd_hip.h"
+#include "gemm_bf16_common.h"
 
 namespace {
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 constexpr int BM = 128, BN = 128, BK = 64, RS = 72, NT = 512;  // RS: bf16 per LDS row
-
-__device__ __forceinline__ int xcd_remap_b(int bid, int nblk) {
-    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
-
-__device__ __forceinline__ float rnd_bf16(float v) { return (float)(__bf16)v; }
 
 // ---- operands that are NOT contiguous along the reduction (dgrad: W stored [N_out][K_in] is the [K][N] operand; weight
 // gradient: dY [rows][N_out] and X [rows][K_in] are [K][M] and [K][N]) ----------------------------------------------------
@@ -43,9 +34,6 @@ __device__ __forceinline__ float rnd_bf16(float v) { return (float)(__bf16)v; }
 // lanes a 4 (k) x 16 (m) block is delivered column-major, lane 4q+p of the group supplying the address of block row q,
 // elements 4p .. 4p+3, lane i receiving column i.  Two reads (k 8h .. 8h+3, 8h+4 .. 8h+7) make one operand.  The 16-byte
 // chunk index is XOR-ed with ((k&3)<<2 | (k>>2)&3) (T10 image (b)): conflict-free transposed reads AND 16-byte stores.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
 __device__ __forceinline__ int tr_off(int row, int ch) {  // byte offset of 16-byte chunk ch (0..15) of k-row `row`
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
@@ -164,7 +152,6 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
     }
     long orow = m;
     if (g.row_grp > 0) orow = (long)(m / g.row_grp) * g.row_grp_stride + (m % g.row_grp) + g.row_off;
-    const __bf16* __restrict__ bias = reinterpret_cast<const __bf16*>(g.bias);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -174,49 +161,23 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * q + e];
-            if (bias) {
-                const bf16x4 bq = *reinterpret_cast<const bf16x4*>(bias + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)bq[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rnd_bf16(v[e]);  // the Linear's 16-bit output
-            if (EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU || EPI == DKD_BF16_EPI_BF16_RELU) {
-                if (EPI == DKD_BF16_EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-                }
-                if (EPI == DKD_BF16_EPI_BF16_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (g.residual16) {  // a 16-bit residual stream: rnd(x + rnd(acc + bias)), x bf16 (ConvNeXt block, stages 1-3)
-                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g.residual16) + orow * g.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-                }
-                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + coff + orow * g.ldc + n) = o;
-            } else {
-                if (g.colscale) {
-                    const float4 c = *reinterpret_cast<const float4*>(g.colscale + n);
-                    v[0] *= c.x; v[1] *= c.y; v[2] *= c.z; v[3] *= c.w;
-                }
-                if (g.residual) {
-                    const long rr = g.res_mod > 0 ? (long)(m % g.res_mod) : orow;
-                    const float4 r = *reinterpret_cast<const float4*>(g.residual + rr * g.ldr + n);
-                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-                }
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + coff + orow * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            bf16_epilogue_quad<EPI>(g, v, m, orow, n, coff);
         }
 }
 
 // fold of the K-slab partials: out = rnd_bf16(sum over slabs, fixed order) as bf16 or as fp32 holding the bf16 value (what
 // autocast leaves in an fp32 master gradient: the bf16 result of the backward matmul, cast up)
 template <bool OUT_BF16>
-__global__ void bf16_fold_kernel(const float* __restrict__ ws, int slabs, long total4, void* __restrict__ out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+__global__ void bf16_fold_kernel(const float* __restrict__ ws, int slabs, long total4, void* __restrict__ out, int M, float* __restrict__ rowsum) {
+    const long items = total4 + (rowsum ? M : 0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        if (i >= total4) {  // the fused bias gradient: slab partials [slabs][M] behind the [slabs][M][N] block
+            const float* r = ws + (long)slabs * total4 * 4 + (i - total4);
+            float a = r[0];
+            for (int z = 1; z < slabs; ++z) a += r[(long)z * M];
+            rowsum[i - total4] = rnd_bf16(a);
+            continue;
+        }
         const float4* p = reinterpret_cast<const float4*>(ws) + i;
         float4 s = p[0];
         for (int z = 1; z < slabs; ++z) {
@@ -315,9 +276,21 @@ static int bf16_slabs(int M, int N, int K) {
     return (int)(sp < 1 ? 1 : sp);
 }
 
-extern "C" long dkd_gemm_bf16_workspace_bytes(int M, int N, int K) {
+extern "C" long dkd_gemm_bf16_workspace_bytes(int M, int N, int K, int with_rowsum) {
     const int sp = bf16_slabs(M, N, K);
+    if (with_rowsum) return (long)sp * ((long)M * N + M) * sizeof(float);  // (always through the partial-sum path)
     return sp > 1 ? (long)sp * M * N * sizeof(float) : 0;
+}
+
+// which kernel: 1 = the register-staged kernel above, 10 + c = ring configuration c (gemm_bf16_ring.hip).  DKD_BF16_CFG
+// overrides the automatic choice (A/B runs), args.variant overrides both.
+static int bf16_auto_cfg(const dkd_gemm_bf16_args* g) {
+    static const int forced = getenv("DKD_BF16_CFG") ? atoi(getenv("DKD_BF16_CFG")) : 0;
+    if (g->variant > 0) return g->variant;
+    if (forced > 0) return forced;
+    // the LDS-DMA ring on 128 x 128 tiles, two workgroups per CU, the next tile's pieces issued between the k-blocks' MFMAs
+    // (measured ahead of the un-spread order on every shape of the step, scripts/tune_bf16_ring.py)
+    return 20;
 }
 
 extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
@@ -343,14 +316,33 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
         if ((g->sAo | g->sAi | g->sBo | g->sBi) & 7) return DKD_ERR_ALIGN;  // 16-byte staging pieces off every batch base
         if ((g->sCo | g->sCi) & 3) return DKD_ERR_ALIGN;
     }
+    // the fused bias gradient: weight-gradient layout, plain output, through the partial sums (even with one slab)
+    const bool rowsum = g->rowsum != nullptr;
+    if (rowsum && (!plain || batch > 1 || g->a_layout != 1 || g->b_layout != 1 || !g->workspace || !dkd_aligned16(g->workspace)))
+        return DKD_ERR_BAD_ARG;
     if (plain && batch == 1 && g->workspace && dkd_aligned16(g->workspace)) slabs = bf16_slabs(g->M, g->N, g->K);
     int kchunk = g->K;
     if (slabs > 1) {
         kchunk = ((g->K + slabs - 1) / slabs + BK - 1) / BK * BK;
         slabs = dkd_cdiv(g->K, kchunk);
     }
-    const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), slabs, batch), block(NT);
-    const int epi = slabs > 1 ? DKD_BF16_EPI_PARTIAL : (g->epi == DKD_BF16_EPI_F32_RESID ? DKD_BF16_EPI_F32 : g->epi);
+    const bool partial = slabs > 1 || rowsum;
+    const int epi = partial ? DKD_BF16_EPI_PARTIAL : (g->epi == DKD_BF16_EPI_F32_RESID ? DKD_BF16_EPI_F32 : g->epi);
+    int cfg = bf16_auto_cfg(g);
+    if (cfg >= 10) {
+        int bm, bn, bk;
+        if (dkd_bf16_ring_tile(cfg % 100 - 10, &bm, &bn, &bk) != 0) return DKD_ERR_BAD_ARG;
+        if (!dkd_bf16_ring_ok(g, kchunk, bk)) {
+            if (g->variant > 0) return DKD_ERR_UNSUPPORTED;  // a pinned configuration that cannot run this shape
+            cfg = dkd_bf16_ring_ok(g, kchunk, 32) ? 16 : 1;  // K = 96: the BK 32 ring; ragged reductions: the register-staged kernel
+        }
+    }
+    if (cfg >= 10) {
+        const int rc = dkd_bf16_ring_launch(g, epi, cfg - 10, slabs, kchunk, rowsum, st);
+        if (rc != DKD_OK) return rc;
+    } else {
+        if (rowsum) return DKD_ERR_UNSUPPORTED;  // (callers fall back to a column reduction when the ring kernel cannot run)
+        const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), slabs, batch), block(NT);
 #define DKD_BF16_LAUNCH(E)                                                                                             \
     do {                                                                                                               \
         if (g->a_layout == 0 && g->b_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<E, true, true>), grid, block, 0, st, *g, kchunk); \
@@ -358,22 +350,24 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
         else if (g->b_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<E, false, true>), grid, block, 0, st, *g, kchunk);               \
         else hipLaunchKernelGGL((gemm_bf16_kernel<E, false, false>), grid, block, 0, st, *g, kchunk);                                    \
     } while (0)
-    switch (epi) {
-        case DKD_BF16_EPI_BF16: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16); break;
-        case DKD_BF16_EPI_BF16_GELU: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16_GELU); break;
-        case DKD_BF16_EPI_BF16_RELU: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16_RELU); break;
-        case DKD_BF16_EPI_F32: DKD_BF16_LAUNCH(DKD_BF16_EPI_F32); break;
-        case DKD_BF16_EPI_PARTIAL: DKD_BF16_LAUNCH(DKD_BF16_EPI_PARTIAL); break;
-        default: return DKD_ERR_BAD_ARG;
-    }
+        switch (epi) {
+            case DKD_BF16_EPI_BF16: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16); break;
+            case DKD_BF16_EPI_BF16_GELU: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16_GELU); break;
+            case DKD_BF16_EPI_BF16_RELU: DKD_BF16_LAUNCH(DKD_BF16_EPI_BF16_RELU); break;
+            case DKD_BF16_EPI_F32: DKD_BF16_LAUNCH(DKD_BF16_EPI_F32); break;
+            case DKD_BF16_EPI_PARTIAL: DKD_BF16_LAUNCH(DKD_BF16_EPI_PARTIAL); break;
+            default: return DKD_ERR_BAD_ARG;
+        }
 #undef DKD_BF16_LAUNCH
-    DKD_LAUNCH_CHECK();
-    if (slabs > 1) {
+        DKD_LAUNCH_CHECK();
+    }
+    if (partial) {
         const long total4 = (long)g->M * g->N / 4;
+        const int blocks = blocks_1d(total4 + (rowsum ? g->M : 0));
         if (g->epi == DKD_BF16_EPI_BF16)
-            hipLaunchKernelGGL(bf16_fold_kernel<true>, dim3(blocks_1d(total4)), dim3(256), 0, st, g->workspace, slabs, total4, g->C);
+            hipLaunchKernelGGL(bf16_fold_kernel<true>, dim3(blocks), dim3(256), 0, st, g->workspace, slabs, total4, g->C, g->M, g->rowsum);
         else
-            hipLaunchKernelGGL(bf16_fold_kernel<false>, dim3(blocks_1d(total4)), dim3(256), 0, st, g->workspace, slabs, total4, g->C);
+            hipLaunchKernelGGL(bf16_fold_kernel<false>, dim3(blocks), dim3(256), 0, st, g->workspace, slabs, total4, g->C, g->M, g->rowsum);
         DKD_LAUNCH_CHECK();
     }
     return DKD_OK;

@@ -1,0 +1,170 @@
+// Shared by the two bf16 GEMM kernels (gemm_bf16.hip: register-staged, any K; gemm_bf16_ring.hip: LDS-DMA ring): vector
+// types, the XCD tile order and the output epilogue of dkd_gemm_bf16 (include/dkd_hip.h).
+#pragma once
+#include "common.h"
+#include "dkd_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous run of tiles (bijective for any count)
+__device__ __forceinline__ int xcd_remap_b(int bid, int nblk) {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+__device__ __forceinline__ float rnd_bf16(float v) { return (float)(__bf16)v; }
+
+// four consecutive outputs (row m -> output row orow, columns n .. n+3) of a non-partial epilogue: v = the fp32 accumulators
+template <int EPI>
+__device__ __forceinline__ void bf16_epilogue_quad(const dkd_gemm_bf16_args& g, float (&v)[4], int m, long orow, int n, long coff) {
+    const __bf16* __restrict__ bias = reinterpret_cast<const __bf16*>(g.bias);
+    if (bias) {
+        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)bq[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = rnd_bf16(v[e]);  // the Linear's 16-bit output
+    if (EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU || EPI == DKD_BF16_EPI_BF16_RELU) {
+        if (EPI == DKD_BF16_EPI_BF16_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (EPI == DKD_BF16_EPI_BF16_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (g.residual16) {  // a 16-bit residual stream: rnd(x + rnd(acc + bias)), x bf16 (ConvNeXt block, stages 1-3)
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g.residual16) + orow * g.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        }
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + coff + orow * g.ldc + n) = o;
+    } else {
+        if (g.colscale) {
+            const float4 c = *reinterpret_cast<const float4*>(g.colscale + n);
+            v[0] *= c.x; v[1] *= c.y; v[2] *= c.z; v[3] *= c.w;
+        }
+        if (g.residual) {
+            const long rr = g.res_mod > 0 ? (long)(m % g.res_mod) : orow;
+            const float4 r = *reinterpret_cast<const float4*>(g.residual + rr * g.ldr + n);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + coff + orow * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// eight consecutive outputs of a 16-bit epilogue (row m -> output row orow, columns n .. n+7; 16-byte loads and stores): the
+// row-contiguous form the LDS-transposed epilogue of the ring kernel uses
+template <int EPI>
+__device__ __forceinline__ void bf16_epilogue_oct(const dkd_gemm_bf16_args& g, float (&v)[8], long orow, int n, long coff) {
+    static_assert(EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU || EPI == DKD_BF16_EPI_BF16_RELU, "16-bit outputs");
+    const __bf16* __restrict__ bias = reinterpret_cast<const __bf16*>(g.bias);
+    if (bias) {
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(bias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)bq[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rnd_bf16(v[e]);  // the Linear's 16-bit output
+    if (EPI == DKD_BF16_EPI_BF16_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (EPI == DKD_BF16_EPI_BF16_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (g.residual16) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(g.residual16) + orow * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(g.C) + coff + orow * g.ldc + n) = o;
+}
+
+// One output row of a wave's 64-column slab under the D^T accumulator layout: acc[j][4q + e] = column n0 + 32 j + 8 q + e, q = 0..3
+// (n0 already includes the lane half's +4).  Loads first (bias / colscale / residuals of all eight quads in flight together, tail
+// columns clamped instead of branched around), then arithmetic and stores: a K = 384 tile spends as long here as in its k-loop
+// when every quad waits for its own bias load.
+template <int EPI>
+__device__ __forceinline__ void bf16_epilogue_row(const dkd_gemm_bf16_args& g, const f32x16 (&acc)[2], int m, long orow, int n0, long coff) {
+    constexpr bool OUT16 = EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU || EPI == DKD_BF16_EPI_BF16_RELU;
+    int n[8], nc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        n[t] = n0 + 32 * (t >> 2) + 8 * (t & 3);
+        nc[t] = min(n[t], g.N - 4);
+    }
+    bf16x4 bq[8], r16[8];
+    float4 cs[8], rr[8];
+    const __bf16* __restrict__ bias = reinterpret_cast<const __bf16*>(g.bias);
+    if (bias) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bq[t] = *reinterpret_cast<const bf16x4*>(bias + nc[t]);
+    }
+    if (OUT16) {
+        if (g.residual16) {
+            const __bf16* __restrict__ r = reinterpret_cast<const __bf16*>(g.residual16) + orow * g.ldr;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) r16[t] = *reinterpret_cast<const bf16x4*>(r + nc[t]);
+        }
+    } else {
+        if (g.colscale) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cs[t] = *reinterpret_cast<const float4*>(g.colscale + nc[t]);
+        }
+        if (g.residual) {
+            const float* __restrict__ r = g.residual + (g.res_mod > 0 ? (long)(m % g.res_mod) : orow) * g.ldr;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rr[t] = *reinterpret_cast<const float4*>(r + nc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[t >> 2][4 * (t & 3) + e];
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)bq[t][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rnd_bf16(v[e]);  // the Linear's 16-bit output
+        if (OUT16) {
+            if (EPI == DKD_BF16_EPI_BF16_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            }
+            if (EPI == DKD_BF16_EPI_BF16_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (g.residual16) {  // a 16-bit residual stream: rnd(x + rnd(acc + bias)), x bf16 (ConvNeXt block, stages 1-3)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)r16[t][e];
+            }
+            if (n[t] < g.N) {
+                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + coff + orow * g.ldc + n[t]) = o;
+            }
+        } else {
+            if (g.colscale) { v[0] *= cs[t].x; v[1] *= cs[t].y; v[2] *= cs[t].z; v[3] *= cs[t].w; }
+            if (g.residual) { v[0] += rr[t].x; v[1] += rr[t].y; v[2] += rr[t].z; v[3] += rr[t].w; }
+            if (n[t] < g.N)
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + coff + orow * g.ldc + n[t]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// gemm_bf16_ring.hip
+bool dkd_bf16_ring_ok(const dkd_gemm_bf16_args* g, int kchunk, int bk);
+int dkd_bf16_ring_launch(const dkd_gemm_bf16_args* g, int epi, int cfg, int slabs, int kchunk, bool rowsum, hipStream_t st);
+int dkd_bf16_ring_tile(int cfg, int* bm, int* bn, int* bk);

@@ -1,0 +1,365 @@
+// bf16 GEMM, LDS-DMA ring: the main kernel of the mixed-precision step (the reference's default precision=16,
+// /root/reference/train.py:263).  Same contract and epilogues as gemm_bf16.hip's register-staged kernel (which stays for the
+// ragged cases: K or a K-slab not a multiple of the k-tile), different pipeline:
+//
+//   * operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip, no
+//     ds_write) into a ring of NS stages; the loads of tile t + NS - 1 are issued while tile t is multiplied, a counted
+//     s_waitcnt vmcnt(n) retires exactly the tile that is read next and ONE raw s_barrier per k-tile both publishes it and
+//     frees the stage that is overwritten next (cdna_hip_programming.md 5, "Pipelining across barriers");
+//   * an LDS-DMA image is lane-linear (wave base + lane * 16 B), so the bank swizzle goes on the SOURCE address: a K-contiguous
+//     operand keeps [rows][BK] bf16 rows whose 16-byte chunk index is XOR-ed with (row / rows-per-256-B) - conflict-free for the
+//     ds_read_b128 fragment of v_mfma_f32_32x32x16_bf16 under gfx950's 16-lane service groups; an operand that is contiguous
+//     along M / N (dgrad's weight, both operands of a weight gradient) keeps the global tile as it lies, [BK k][128] with the
+//     chunk XOR of gemm_bf16.hip's tr_off, and is read through the transposing ds_read_b64_tr_b16;
+//   * 4 waves of 64 x 64 (or 8 of 64 x 64 on a 256-row tile): 16 fragment reads per 16 MFMAs and k-tile instead of 12 per 8;
+//   * the bias gradient of a weight-gradient launch (column sums of dy = row sums of the [K][M] operand) rides on the matrix
+//     cores: one more MFMA per k-block against a fragment of ones in the waves that own the first column tile.
+#include "common.h"
+#include "dkd_hip.h"
+#include "gemm_bf16_common.h"
+
+namespace {
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One operand's share of the ring.  BX rows (m or n) x BK k per stage.
+template <int BX, int BK, bool KC, int NW>
+struct Ring {
+    static constexpr int BYTES = BX * BK * 2, PIECES = BYTES / 1024, PPW = PIECES / NW;
+    static_assert(PIECES % NW == 0 && PPW >= 1, "an operand tile must split into whole 1 KiB pieces per wave");
+    static_assert(KC || BX % 128 == 0, "the transposed image needs 256-byte k-rows");
+    // K-contiguous image: CPR 16-byte chunks per row, RP rows per 256-byte bank period
+    static constexpr int CPR = BK / 8, RP = 256 / (BK * 2);
+    // M / N-contiguous image: CPK chunks per k-row
+    static constexpr int CPK = BX / 8;
+    // source of piece p = base (wave-uniform: the tile's first row / k-row, advanced by `step` per k-tile) + off[p] (per lane,
+    // fixed for the whole launch): the loads take the SGPR-base + 32-bit-VGPR-offset form, no 64-bit pointer arithmetic per tile
+    const char* base;
+    unsigned off[PPW];
+    long step;
+
+    static __device__ __forceinline__ int kc_swz(int row) { return (row / RP) & (CPR - 1); }
+    static __device__ __forceinline__ int tr_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
+
+    __device__ __forceinline__ void init(const __bf16* __restrict__ P, long ld, int x0, int xmax, int k0, int wid, int lane) {
+        step = KC ? (long)BK * 2 : (long)BK * ld * 2;
+        base = reinterpret_cast<const char*>(KC ? P + (long)x0 * ld + k0 : P + (long)k0 * ld + x0);
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int piece = wid + p * NW;
+            if (KC) {
+                const int row = piece * (64 / CPR) + lane / CPR, slot = lane % CPR;
+                const int chunk = slot ^ kc_swz(row);
+                off[p] = (unsigned)(((long)(min(x0 + row, xmax - 1) - x0) * ld + 8 * chunk) * 2);
+            } else {
+                const int krow = piece * (64 / CPK) + lane / CPK, slot = lane % CPK;
+                const int chunk = slot ^ tr_swz(krow);
+                off[p] = (unsigned)(((long)krow * ld + (min(x0 + 8 * chunk, xmax - 8) - x0)) * 2);
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(char* __restrict__ S, int wid) {
+#pragma unroll
+        for (int p = 0; p < PPW; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (unsigned long)off[p]), (lds_void_t*)(S + (wid + p * NW) * 1024), 16, 0, 0);
+        base += step;
+    }
+    // pieces [p0, p1) only (the k-loop spreads a tile's pieces over its k-blocks); advance() once all are out
+    template <int P0, int P1>
+    __device__ __forceinline__ void issue_part(char* __restrict__ S, int wid) {
+#pragma unroll
+        for (int p = P0; p < P1; ++p)
+            if (p < PPW)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (unsigned long)off[p]), (lds_void_t*)(S + (wid + p * NW) * 1024), 16, 0, 0);
+    }
+    __device__ __forceinline__ void advance() { base += step; }
+    // fragment (8 consecutive k of the lane's row) of the 32 rows starting at r0, k-block ks (16 k)
+    static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int r0, int ks, int lane) {
+        if (KC) {
+            const int row = r0 + (lane & 31), c = 2 * ks + (lane >> 5);
+            return *reinterpret_cast<const bf16x8*>(S + row * (BK * 2) + 16 * (c ^ kc_swz(row)));
+        } else {
+            const int half = lane >> 5, cb = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+            const int ch = (r0 >> 3) + 2 * cb + (p >> 1);
+            const int k = 16 * ks + 8 * half + q;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + BX * 2 * k + 16 * (ch ^ tr_swz(k)) + 8 * (p & 1)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + BX * 2 * (k + 4) + 16 * (ch ^ tr_swz(k + 4)) + 8 * (p & 1)));
+            union { s16x4 v[2]; bf16x8 f; } u;
+            u.v[0] = lo;
+            u.v[1] = hi;
+            return u.f;
+        }
+    }
+};
+
+// WGM x WGN waves, each a (32 TM) x 64 slab (TM x 2 MFMA tiles); BM = 32 TM WGM, BN = 64 WGN; k-tile BK; NS ring stages.
+// KNOCK (only in a -DDKD_TUNING build, timing experiments whose RESULTS ARE WRONG): 1 = no DMA inside the k-loop, 2 = fragments read
+// once per k-tile only, 4 = no MFMAs, 8 = no barrier, 16 = no output stores.
+template <int WGM, int WGN, int TM, int BK, int NS, int EPI, bool A_KC, bool B_KC, bool ROWSUM, int KNOCK = 0, bool SPREAD = false>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_ring_kernel(dkd_gemm_bf16_args g, int kchunk) {
+    constexpr int BM = 32 * TM * WGM, BN = 64 * WGN, NW = WGM * WGN, WM_ROWS = 32 * TM;
+    using RA = Ring<BM, BK, A_KC, NW>;
+    using RB = Ring<BN, BK, B_KC, NW>;
+    constexpr int STAGE = RA::BYTES + RB::BYTES, PW = RA::PPW + RB::PPW;
+    static_assert(NS >= 2 && NS <= 4, "2 .. 4 stages");
+    static_assert((NS - 1) * PW < 64, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+    const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(g.A);
+    const __bf16* __restrict__ B = reinterpret_cast<const __bf16*>(g.B);
+    long coff = 0;
+    if (g.batch > 1) {
+        const long zo = blockIdx.z / g.batch_inner, zi = blockIdx.z % g.batch_inner;
+        A += zo * g.sAo + zi * g.sAi;
+        B += zo * g.sBo + zi * g.sBi;
+        coff = zo * g.sCo + zi * g.sCi;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WGN, wn = wid % WGN, half = lane >> 5, l31 = lane & 31;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
+    const int tile = xcd_remap_b(blockIdx.x, nbm * nbn);
+    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+    const int kbeg = blockIdx.y * kchunk, kend = min(g.K, kbeg + kchunk);
+    const int nk = (kend - kbeg) / BK;  // (the host only sends whole k-tiles here)
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 rs[TM];  // ROWSUM: column sums of the [K][M] operand for this wave's m-tiles (every register row identical)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[i][r] = 0.f;
+    const bool do_rs = ROWSUM && bn0 == 0 && wn == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    RA ra;
+    RB rb;
+    ra.init(A, g.lda, bm0, g.M, kbeg, wid, lane);
+    rb.init(B, g.ldb, bn0, g.N, kbeg, wid, lane);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) {
+            ra.issue(smem + s * STAGE, wid);
+            rb.issue(smem + s * STAGE + RA::BYTES, wid);
+        }
+    int st = 0;  // stage of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles kt .. min(nk, kt + NS - 1) - 1 are in flight: retire tile kt, leave the younger ones
+        const int younger = min(nk - 1 - kt, NS - 2);
+        if (younger >= 2) wait_vm<(NS > 3 ? 2 : 0) * PW>();
+        else if (younger == 1) wait_vm<(NS > 2 ? 1 : 0) * PW>();
+        else wait_vm<0>();
+        if (!(KNOCK & 8)) __builtin_amdgcn_s_barrier();  // tile kt is visible to every wave; nobody reads stage (kt - 1) % NS any more
+        const bool more = kt + NS - 1 < nk && !(KNOCK & 1);
+        const int sn = st == 0 ? NS - 1 : st - 1;  // == (kt + NS - 1) % NS
+        if (more && !SPREAD) {
+            ra.issue(smem + sn * STAGE, wid);
+            rb.issue(smem + sn * STAGE + RA::BYTES, wid);
+        }
+        const char* As = smem + st * STAGE;
+        const char* Bs = As + RA::BYTES;
+        bf16x8 a[2][TM], b[2][2];  // [buffer][tile]: the fragments of k-block ks + 1 are read under the MFMAs of k-block ks
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = RA::frag(As, wm * WM_ROWS + i * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[0][j] = RB::frag(Bs, wn * 64 + j * 32, 0, lane);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (SPREAD && more) {  // this k-block's share of the next tile's pieces goes out in front of its MFMAs
+                constexpr int KB = BK / 16, HA = (RA::PPW + KB / 2 - 1) / (KB / 2), HB = (RB::PPW + KB / 2 - 1) / (KB / 2);
+                if (ks < KB / 2) {
+                    if (ks == 0) ra.template issue_part<0, HA>(smem + sn * STAGE, wid);
+                    if (ks == 1) ra.template issue_part<HA, 2 * HA>(smem + sn * STAGE, wid);
+                } else {
+                    if (ks == KB / 2) rb.template issue_part<0, HB>(smem + sn * STAGE + RA::BYTES, wid);
+                    if (ks == KB / 2 + 1) rb.template issue_part<HB, 2 * HB>(smem + sn * STAGE + RA::BYTES, wid);
+                }
+            }
+            const int c = (KNOCK & 2) ? 0 : (ks & 1), n = c ^ 1;
+            if (ks + 1 < BK / 16 && !(KNOCK & 2)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[n][i] = RA::frag(As, wm * WM_ROWS + i * 32, ks + 1, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[n][j] = RB::frag(Bs, wn * 64 + j * 32, ks + 1, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (KNOCK & 4) {  // keep the fragments alive without the matrix instruction
+                        asm volatile("" ::"v"(a[c][i]), "v"(b[c][j]));
+                        continue;
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[c][i], acc[i][j], 0, 0, 0);  // D^T: rows = n, lanes = m
+                }
+            if (ROWSUM && do_rs) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, a[c][i], rs[i], 0, 0, 0);
+            }
+        }
+        if (SPREAD && more) {
+            ra.advance();
+            rb.advance();
+        }
+        st = st == NS - 1 ? 0 : st + 1;
+    }
+
+    // ---- epilogue.  The accumulators hold D^T: lane (l31, half) owns output row m and, per register quad q, the columns
+    // n0 + 8q + 4 half + (0..3) - stored from there a wave-instruction touches 32 rows x 16 bytes, and the output write path, not
+    // the matrix cores, sets the time of the wide shapes (200704 x 384 x 384: 130 us as built, 65 us without its stores).  So each
+    // 32 x 64 accumulator tile goes through a per-wave LDS tile (fp32, 272-byte rows: conflict-free b128 stores) and comes back
+    // row-contiguous: 8 (16-bit outputs) or 16 lanes per row, whole 128 / 256-byte runs per row and instruction for the loads of
+    // a residual as well as for the stores.  LDS operations of one wave execute in order: no barrier between a wave's own
+    // stores and loads; the one barrier in front frees the ring stages.
+    if (ROWSUM && do_rs && half == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = bm0 + wm * WM_ROWS + i * 32 + l31;
+            if (m < g.M) g.workspace[(long)gridDim.y * g.M * g.N + (long)blockIdx.y * g.M + m] = rs[i][0];
+        }
+    }
+    constexpr int TP = 68;  // floats per LDS row
+    static_assert(NW * 32 * TP * 4 <= NS * STAGE, "the epilogue tiles reuse the ring");
+    static_assert(BK == 64 || !SPREAD, "the spread schedule is written for four k-blocks per tile");
+    constexpr bool OUT16 = EPI == DKD_BF16_EPI_BF16 || EPI == DKD_BF16_EPI_BF16_GELU || EPI == DKD_BF16_EPI_BF16_RELU;
+    __syncthreads();
+    float* T = reinterpret_cast<float*>(smem) + wid * (32 * TP);
+    const bool wide = OUT16 ? ((g.N & 7) == 0 && (g.ldc & 7) == 0 && (!g.residual16 || (g.ldr & 7) == 0)) : true;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if ((KNOCK & 16) && acc[i][0][0] != 12345.678f) continue;
+        const int mt0 = bm0 + wm * WM_ROWS + i * 32, nt0 = bn0 + wn * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(T + l31 * TP + 32 * j + 8 * q + 4 * half) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if (OUT16 && wide) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {  // 8 rows per pass, 8 lanes x 8 columns per row
+                const int r = 8 * p + (lane >> 3), c = 8 * (lane & 7);
+                const int m = mt0 + r, n = nt0 + c;
+                const float4 lo = *reinterpret_cast<const float4*>(T + r * TP + c), hi = *reinterpret_cast<const float4*>(T + r * TP + c + 4);
+                if (m < g.M && n < g.N) {
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    long orow = m;
+                    if (g.row_grp > 0) orow = (long)(m / g.row_grp) * g.row_grp_stride + (m % g.row_grp) + g.row_off;
+                    if constexpr (OUT16) bf16_epilogue_oct<EPI>(g, v, orow, n, coff);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {  // 4 rows per pass, 16 lanes x 4 columns per row
+                const int r = 4 * p + (lane >> 4), c = 4 * (lane & 15);
+                const int m = mt0 + r, n = nt0 + c;
+                const float4 q4 = *reinterpret_cast<const float4*>(T + r * TP + c);
+                if (m < g.M && n < g.N) {
+                    if (EPI == DKD_BF16_EPI_PARTIAL) {
+                        *reinterpret_cast<float4*>(g.workspace + ((long)blockIdx.y * g.M + m) * g.N + n) = q4;
+                    } else {
+                        float v[4] = {q4.x, q4.y, q4.z, q4.w};
+                        long orow = m;
+                        if (g.row_grp > 0) orow = (long)(m / g.row_grp) * g.row_grp_stride + (m % g.row_grp) + g.row_off;
+                        bf16_epilogue_quad<EPI>(g, v, m, orow, n, coff);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WGM, int WGN, int TM, int BK, int NS, bool ROWSUM, bool SPREAD = false>
+int launch_ring(const dkd_gemm_bf16_args* g, int epi, int slabs, int kchunk, hipStream_t st, int knock = 0) {
+    const int batch = g->batch > 1 ? g->batch : 1;
+    const dim3 grid(dkd_cdiv(g->M, 32 * TM * WGM) * dkd_cdiv(g->N, 64 * WGN), slabs, batch), block(WGM * WGN * 64);
+#ifdef DKD_TUNING
+    if (knock && g->a_layout == 0 && g->b_layout == 0 && epi == DKD_BF16_EPI_BF16) {
+#define DKD_RING_K(KN) case KN: hipLaunchKernelGGL((gemm_bf16_ring_kernel<WGM, WGN, TM, BK, NS, DKD_BF16_EPI_BF16, true, true, false, KN, SPREAD>), grid, block, 0, st, *g, kchunk); break
+        switch (knock) {
+            DKD_RING_K(1); DKD_RING_K(2); DKD_RING_K(3); DKD_RING_K(4); DKD_RING_K(5); DKD_RING_K(6); DKD_RING_K(7); DKD_RING_K(8);
+            DKD_RING_K(16); DKD_RING_K(17); DKD_RING_K(19); DKD_RING_K(23); DKD_RING_K(31);
+            default: return DKD_ERR_BAD_ARG;
+        }
+#undef DKD_RING_K
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
+#endif
+    if (knock) return DKD_ERR_UNSUPPORTED;
+#define DKD_RING_L(E, AK, BKC, RSUM) \
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<WGM, WGN, TM, BK, NS, E, AK, BKC, RSUM, 0, SPREAD>), grid, block, 0, st, *g, kchunk)
+#define DKD_RING_LAYOUT(E)                                                      \
+    do {                                                                        \
+        if (g->a_layout == 0 && g->b_layout == 0) DKD_RING_L(E, true, true, false);   \
+        else if (g->a_layout == 0) DKD_RING_L(E, true, false, false);                 \
+        else if constexpr ((32 * TM * WGM) % 128 != 0) return DKD_ERR_UNSUPPORTED; /* 64-row tiles: K-contiguous A only */ \
+        else if (g->b_layout == 0) DKD_RING_L(E, false, true, false);                 \
+        else if (ROWSUM) DKD_RING_L(E, false, false, ROWSUM);                         \
+        else DKD_RING_L(E, false, false, false);                                      \
+    } while (0)
+    switch (epi) {
+        case DKD_BF16_EPI_BF16: DKD_RING_LAYOUT(DKD_BF16_EPI_BF16); break;
+        case DKD_BF16_EPI_BF16_GELU: DKD_RING_LAYOUT(DKD_BF16_EPI_BF16_GELU); break;
+        case DKD_BF16_EPI_BF16_RELU: DKD_RING_LAYOUT(DKD_BF16_EPI_BF16_RELU); break;
+        case DKD_BF16_EPI_F32: DKD_RING_LAYOUT(DKD_BF16_EPI_F32); break;
+        case DKD_BF16_EPI_PARTIAL: DKD_RING_LAYOUT(DKD_BF16_EPI_PARTIAL); break;
+        default: return DKD_ERR_BAD_ARG;
+    }
+#undef DKD_RING_LAYOUT
+#undef DKD_RING_L
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+}  // namespace
+
+// can the ring kernel run this launch?  whole k-tiles per slab, 16-byte pieces at every row start, at least one full piece of
+// rows / columns to clamp into
+bool dkd_bf16_ring_ok(const dkd_gemm_bf16_args* g, int kchunk, int bk) {
+    if ((g->K % bk) || (kchunk % bk)) return false;
+    if (g->a_layout == 1 && g->M < 8) return false;
+    if (g->b_layout == 1 && g->N < 8) return false;
+    return true;
+}
+
+// cfg (every one: 4 waves as 2 x 2, two ring stages):
+//      2 = 128 x 128, BK 64 (64 KB of LDS: two workgroups per CU)     10 = the same with the DMA issue spread over the k-blocks
+//      6 = 128 x 128, BK 32, 3 stages (reductions that are a multiple of 32 only: K = 96)
+// Measured and dropped (scripts/tune_bf16_ring.py, gpurun_out/r3c): 3 / 4 stages at one workgroup per CU (-15...25 %: two
+// co-resident workgroups hide more than a deeper ring), 256 x 128 and 256 x 256 tiles of 8 waves (within +-5 % on the wide
+// shapes, -40 % where they leave CUs idle), BK 32 with 4 stages, 64 x 128 tiles (+-1 us).
+int dkd_bf16_ring_launch(const dkd_gemm_bf16_args* g, int epi, int cfg, int slabs, int kchunk, bool rowsum, hipStream_t st) {
+    const bool rsum = rowsum && g->a_layout == 1 && g->b_layout == 1;
+    const int knock = cfg / 100;  // variant = 10 + c + 100 * knock (DKD_TUNING builds)
+    cfg %= 100;
+#define DKD_RING_CFG(WGM, WGN, TM, BK, NS, SPREAD)                                                       \
+    return rsum ? launch_ring<WGM, WGN, TM, BK, NS, true, SPREAD>(g, epi, slabs, kchunk, st)             \
+                : launch_ring<WGM, WGN, TM, BK, NS, false, SPREAD>(g, epi, slabs, kchunk, st, knock)
+    switch (cfg) {
+        case 2: DKD_RING_CFG(2, 2, 2, 64, 2, false);
+        case 6: DKD_RING_CFG(2, 2, 2, 32, 3, false);
+        case 10: DKD_RING_CFG(2, 2, 2, 64, 2, true);
+        default: return DKD_ERR_BAD_ARG;
+    }
+#undef DKD_RING_CFG
+}
+
+int dkd_bf16_ring_tile(int cfg, int* bm, int* bn, int* bk) {
+    switch (cfg) {
+        case 2: case 10: *bm = 128; *bn = 128; *bk = 64; return 0;
+        case 6: *bm = 128; *bn = 128; *bk = 32; return 0;
+        default: return -1;
+    }
+}

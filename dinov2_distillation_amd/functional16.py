@@ -64,28 +64,29 @@ def _rounded(t):
 
 
 def wgrad16(dy16, x16, w, b, transform=None, reshape=None):
-    """dW = rnd(dy16^T x16) and db = rnd(sum_rows dy16), as fp32 master gradients.  In-place on the weight-gradient stream when
-    the arena allows it (ops.can_async), else returned to autograd."""
+    """dW = rnd(dy16^T x16) and db = rnd(sum_rows dy16), as fp32 master gradients - ONE launch (+ its K-slab fold): the bias
+    gradient is the row sum of the weight-gradient GEMM's [rows][N_out] operand and rides on the matrix cores (dkd_hip.h,
+    dkd_gemm_bf16_args.rowsum).  In-place on the weight-gradient stream when the arena allows it (ops.can_async), else returned
+    to autograd."""
     N, K = dy16.shape[-1], x16.shape[-1]
     if ops.can_async(w, b):
         side = ops.wgrad_stream(dy16.device)
         ops.claim(w, b)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            rs = None if b is None else b.grad.view(-1)
             if transform is None:
-                ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, out=w.grad.view(N, K), ws_slot=3)
+                ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, out=w.grad.view(N, K), ws_slot=3, rowsum=rs)
             else:
-                transform(ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, ws_slot=3))
-            if b is not None:
-                ops.colreduce16(dy16, ops.RED_SUM, out=b.grad.view(1, -1), round_out=True)
+                transform(ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, ws_slot=3, rowsum=rs))
         dy16.record_stream(side)
         x16.record_stream(side)
         ops.grad_done(w, b)
         return None, None
-    dw = ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32)
+    db = None if b is None else torch.empty(N, dtype=F32, device=dy16.device)
+    dw = ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, rowsum=db)
     if reshape is not None:
         dw = reshape(dw)
-    db = None if b is None else ops.colreduce16(dy16, ops.RED_SUM, round_out=True).reshape(-1)
     return dw, db
 
 

@@ -832,12 +832,14 @@ def _chk16(t, name):
 
 
 def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, res_mod=0, row_map=None, out=None,
-              a_layout=0, b_layout=0, ws_slot=0):
+              a_layout=0, b_layout=0, ws_slot=0, rowsum=None, variant=0):
     """out = epi(Aop[M,K] @ Bop[N,K]^T), bf16 operands, fp32 accumulate, the result rounded to bf16 (see dkd_hip.h).
     a_layout 0: a is [M,K]; 1: a is [K,M].  b_layout 0: w is [N,K]; 1: w is [K,N] (dgrad: dx = dy W; weight gradient
     dW = dy^T x: a_layout = b_layout = 1).  a, w, bias: bfloat16; colscale / residual: float32; out: bfloat16 for
-    EPI_BF16 / EPI_BF16_GELU, float32 otherwise."""
+    EPI_BF16 / EPI_BF16_GELU, float32 otherwise.  rowsum (weight-gradient layout only): fp32 [M] that receives
+    rnd(sum_k a[k, :]) - the bias gradient of the same Linear - from the same launch.  variant: A/B runs (dkd_hip.h)."""
     _chk16(a, "a"), _chk16(w, "w"), _chk16(bias, "bias"), _chk(colscale, "colscale"), _chk(residual, "residual")
+    _chk(rowsum, "rowsum")
     a2 = a.reshape(-1, a.shape[-1])
     w2 = w.reshape(-1, w.shape[-1])
     M, K = (a2.shape[0], a2.shape[1]) if a_layout == 0 else (a2.shape[1], a2.shape[0])
@@ -845,6 +847,11 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
     if Kb != K:
         raise _lib.DkdError(f"gemm_bf16: reduction extents differ: {K} vs {Kb}")
     lib = _lib.binding()
+    if rowsum is not None and K % 32:
+        # the fused row sum lives in the LDS-DMA ring kernel, which takes whole 32-deep k-tiles; ragged reductions (tiny test
+        # batches) take the column reduction instead
+        colreduce16(a2, RED_SUM, out=rowsum.view(1, -1), round_out=True)
+        rowsum = None
     g = _lib.args("dkd_gemm_bf16_args")
     out_rows = M
     if row_map is not None:
@@ -854,10 +861,11 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
         out = torch.empty((out_rows, N), dtype=torch.float32 if f32_out else BF16, device=a.device)
     if out.dtype != (torch.float32 if f32_out else BF16) or not out.is_contiguous():
         raise _lib.DkdError("gemm_bf16: out has the wrong dtype / layout for this epilogue")
-    wsb = lib.dkd_gemm_bf16_workspace_bytes(M, N, K)
+    wsb = lib.dkd_gemm_bf16_workspace_bytes(M, N, K, int(rowsum is not None))
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), a2.shape[1], _p(w2), w2.shape[1], _p(out), N
     g.bias, g.colscale, g.residual, g.ldr, g.workspace = _p(bias), _p(colscale), _p(residual), N, _p(ws)
+    g.rowsum, g.variant = _p(rowsum), variant
     g.M, g.N, g.K, g.epi, g.res_mod, g.a_layout, g.b_layout = M, N, K, epi, res_mod, a_layout, b_layout
     check(lib.dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[{M}x{N}x{K} a{a_layout} b{b_layout} epi {epi}]")
     return out

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DKD_ABI_VERSION 3
+#define DKD_ABI_VERSION 4
 int dkd_abi_version(void);
 
 /* activation codes for fused epilogues */
@@ -196,9 +196,13 @@ typedef struct dkd_gemm_bf16_args {
      * zo * s?o + zi * s?i ELEMENTS to A / B / C (0 / 0 / 0 ... = one product; batch <= 1 = not batched; no K-slabs, no residual) */
     int32_t batch, batch_inner;
     int64_t sAo, sAi, sBo, sBi, sCo, sCi;
+    /* weight-gradient layout only (a_layout = b_layout = 1, plain output, workspace given): rowsum[m] = rnd_bf16(sum_k A[k][m]) as
+     * fp32 - the bias gradient of the same Linear (column sums of dy), taken on the matrix cores in the same launch */
+    float* rowsum;
+    int32_t variant; /* 0 = automatic; A/B runs: 1 = register-staged kernel, 10 + c = LDS-DMA ring configuration c */
 } dkd_gemm_bf16_args;
 int dkd_gemm_bf16(const dkd_gemm_bf16_args* args, void* stream);
-long dkd_gemm_bf16_workspace_bytes(int M, int N, int K);
+long dkd_gemm_bf16_workspace_bytes(int M, int N, int K, int with_rowsum);
 
 /* ------------------------------------------------------------------------------------------------------------
  * HBM-bound kernels of the mixed-precision student (ConvNeXt-V2 block, models/backbones/convnext.py:75-87, under the

@@ -18,7 +18,7 @@ VIEWS = ("view", "reshape", "as_strided", "empty", "detach", "slice", "permute",
 
 
 def site(skip_files=("ops.py", "_lib.py")):
-    f = sys._getframe(2)
+    f = sys._getframe(1)
     out = []
     while f is not None and len(out) < 2:
         fn = f.f_code.co_filename

@@ -81,13 +81,53 @@ def test_gemm_bf16_dgrad_and_wgrad_layouts(M, N, K):
 def test_gemm_bf16_wgrad_takes_k_slabs_on_step_shapes():
     from dinov2_distillation_amd import _lib, ops
     lib = _lib.load()
-    assert lib.dkd_gemm_bf16_workspace_bytes(1536, 384, 12544) > 0 and lib.dkd_gemm_bf16_workspace_bytes(12544, 1536, 384) == 0
+    assert lib.dkd_gemm_bf16_workspace_bytes(1536, 384, 12544, 0) > 0 and lib.dkd_gemm_bf16_workspace_bytes(12544, 1536, 384, 0) == 0
     g = torch.Generator().manual_seed(5)
     rows, n_out, k_in = 12544, 1536, 384
     dy, x = (torch.randn(rows, n_out, generator=g) * 0.1).bfloat16(), torch.randn(rows, k_in, generator=g).bfloat16()
     dw = ops.gemm_bf16(dy.cuda(), x.cuda(), a_layout=1, b_layout=1, epi=ops.EPI_F32)
     ulp_close(dw, r16((dy.double().t() @ x.double()).float()), "split wgrad")
     assert torch.equal(dw, ops.gemm_bf16(dy.cuda(), x.cuda(), a_layout=1, b_layout=1, epi=ops.EPI_F32))
+
+
+def test_gemm_bf16_ring_kernel_equals_the_register_staged_kernel_and_fuses_the_bias_gradient():
+    """csrc/gemm_bf16_ring.hip (LDS-DMA ring, LDS-transposed epilogue; the default) against csrc/gemm_bf16.hip's register-staged
+    kernel (variant 1): the same MFMA in the same k order, so the results are BIT-equal in every layout and epilogue, at ragged
+    M / N, with a bf16 residual, through K-slabs; K = 96 takes the 32-deep ring; the bias gradient (rowsum) of a weight-gradient
+    launch equals the column reduction of dy to one bf16 ulp (fp32 sums in another order, one rounding)."""
+    from dinov2_distillation_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for (M, N, K) in [(12544, 384, 1536), (1000, 200, 192), (136, 136, 64), (4104, 384, 96), (3136, 768, 3072)]:
+        for al, bl in ((0, 0), (0, 1)):
+            a = torch.randn((M, K), generator=g).bfloat16().cuda()
+            b = ((torch.randn((N, K) if bl == 0 else (K, N), generator=g)) * K ** -0.5).bfloat16().cuda()
+            bias = torch.randn(N, generator=g).bfloat16().cuda()
+            res, cs = torch.randn(M, N, generator=g).cuda(), (torch.rand(N, generator=g) + 0.5).cuda()
+            for kw in (dict(epi=ops.EPI_BF16, bias=bias), dict(epi=ops.EPI_BF16_GELU, bias=bias), dict(epi=ops.EPI_BF16_RELU),
+                       dict(epi=ops.EPI_F32, bias=bias), dict(epi=ops.EPI_F32_RESID, bias=bias, colscale=cs, residual=res)):
+                ref = ops.gemm_bf16(a, b, a_layout=al, b_layout=bl, variant=1, **kw)
+                out = ops.gemm_bf16(a, b, a_layout=al, b_layout=bl, **kw)
+                assert torch.equal(out, ref), (M, N, K, al, bl, kw["epi"], float((out.float() - ref.float()).abs().max()))
+        if N % 8 == 0:  # rnd(x16 + rnd(a w^T + b)) on a 16-bit residual stream (ConvNeXt stages 1-3): against its definition
+            a = torch.randn((M, K), generator=g).bfloat16().cuda()
+            w = (torch.randn((N, K), generator=g) * K ** -0.5).bfloat16().cuda()
+            bias = torch.randn(N, generator=g).bfloat16().cuda()
+            x16 = torch.randn(M, N, generator=g).bfloat16().cuda()
+            got = ops.gemm_bf16_resid16(a, w, bias, x16)
+            lin = ops.gemm_bf16(a, w, epi=ops.EPI_BF16, bias=bias, variant=1)
+            assert torch.equal(got, (x16.float() + lin.float()).bfloat16())
+    for (M, N, K) in [(1536, 384, 12544), (96, 384, 25088), (384, 384, 16448), (136, 200, 8192), (384, 96, 98)]:
+        dy = (torch.randn(K, M, generator=g) * 0.1).bfloat16().cuda()
+        x = torch.randn(K, N, generator=g).bfloat16().cuda()
+        ref = ops.gemm_bf16(dy, x, a_layout=1, b_layout=1, epi=ops.EPI_F32, variant=1)
+        rs = torch.full((M,), -3.0, device="cuda")
+        out = ops.gemm_bf16(dy, x, a_layout=1, b_layout=1, epi=ops.EPI_F32, rowsum=rs)
+        assert torch.equal(out, ref), (M, N, K)
+        rs_ref = ops.colreduce16(dy, ops.RED_SUM, round_out=True).reshape(-1)
+        exact = dy.double().sum(0).float().cpu()
+        assert ((rs.cpu() - exact).abs() <= 2.0 ** -8 * exact.abs() + 1e-6).all(), (M, N, K)   # half a bf16 ulp of the exact sum + fp32 noise
+        assert ((rs - rs_ref).abs() <= 2.0 ** -7 * rs_ref.abs() + 1e-6).all()
+        assert torch.equal(rs, rs.bfloat16().float())
 
 
 def test_gemm_bf16_row_map_and_periodic_residual():
