@@ -261,12 +261,28 @@ __global__ void grn_apply_kernel(const T* __restrict__ g, const float4* __restri
 
 // GRN backward, per image b and channel c, given A[b][c] = sum_hw dy*g :
 //   dnx = gamma * A;  dgx = dnx / denom - (1/C) * sum_c'(dnx[c'] * gx[c']) / denom^2;  coef = dgx / gx (0 if gx == 0)
-// one block per image; writes coef[b][c] (so that dg = dy*(gamma*nx+1) + coef*g) and dnx*nx partials for dgamma.
-__global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restrict__ A, const float* __restrict__ gx,
-                                                            const float* __restrict__ nx, const float* __restrict__ denom,
-                                                            const float* __restrict__ gamma, float* __restrict__ coef,
-                                                            float* __restrict__ dgamma_part, int C) {
+// Blocks [0, B): one per image, coef[b][c] (so that dg = dy*(gamma*nx+1) + coef*g).  Blocks [B, B + ceil(C/256)): the parameter
+// gradients, one thread per channel over the images in index order (deterministic): dgamma[c] = sum_b A[b][c] nx[b][c],
+// dbeta[c] = sum_b S[b][c] with S[b][c] = sum_hw dy - what used to be two more column reductions (four launches) per block.
+__global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restrict__ A, const float* __restrict__ S,
+                                                            const float* __restrict__ gx, const float* __restrict__ nx,
+                                                            const float* __restrict__ denom, const float* __restrict__ gamma,
+                                                            float* __restrict__ coef, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int B, int C) {
     __shared__ float red[4];
+    if ((int)blockIdx.x >= B) {
+        const int c = ((int)blockIdx.x - B) * 256 + threadIdx.x;
+        if (c >= C) return;
+        float sg = 0.f, sb = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const long i = (long)b * C + c;
+            sg += A[i] * nx[i];
+            if (S) sb += S[i];
+        }
+        dgamma[c] = sg;
+        if (S && dbeta) dbeta[c] = sb;
+        return;
+    }
     const int b = blockIdx.x;
     const float d = denom[b];
     float s = 0.f;
@@ -280,7 +296,6 @@ __global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restr
         const float a = A[i], g = gx[i];
         const float dgx = gamma[c] * a / d - corr;
         coef[i] = g > 0.f ? dgx / g : 0.f;
-        dgamma_part[i] = a * nx[i];  // dgamma[c] = sum_b A[b][c] * nx[b][c]
     }
 }
 
@@ -515,11 +530,11 @@ extern "C" int dkd_grn_apply_f32(const float* g, const float* nx, const float* g
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
-extern "C" int dkd_grn_bwd_stats_f32(const float* A, const float* gx, const float* nx, const float* denom,
-                                     const float* gamma, float* coef, float* dgamma_part, int B, int C, void* stream) {
-    if (!A || !gx || !nx || !denom || !gamma || !coef || !dgamma_part || B <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, A, gx, nx, denom, gamma, coef,
-                       dgamma_part, C);
+extern "C" int dkd_grn_bwd_stats_f32(const float* A, const float* S, const float* gx, const float* nx, const float* denom,
+                                     const float* gamma, float* coef, float* dgamma, float* dbeta, int B, int C, void* stream) {
+    if (!A || !gx || !nx || !denom || !gamma || !coef || !dgamma || B <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(B + (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, S, gx, nx, denom, gamma,
+                       coef, dgamma, dbeta, B, C);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -344,8 +344,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X,
 
 // out[g][n] = scale * sum_p ws[g][p][n]: 32 column lanes x 8 split lanes per block (grid: column chunks x groups)
 // (grid.z = result planes: the two planes of DKD_RED_DOT_SUM / DOTGELU_SUM are folded by ONE launch)
+// tr_T > 0: the result, read as [tr_T][N / tr_T], is stored transposed: out[(n % (N / tr_T)) * tr_T + n / (N / tr_T)]
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int groups,
-                                                              int nsplit, int N, float scale, int round_out = 0) {
+                                                              int nsplit, int N, float scale, int round_out = 0, int tr_T = 0) {
     __shared__ float red[256];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + cl, g = blockIdx.y;
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < 8; ++k) kahan1(s, c, red[k * 32 + cl]);
         const float r = (s - c) * scale;
-        out[(long)g * N + n] = round_out ? rnd16(r) : r;
+        const int o = tr_T > 0 ? (n % (N / tr_T)) * tr_T + n / (N / tr_T) : n;
+        out[(long)g * N + o] = round_out ? rnd16(r) : r;
     }
 }
 
@@ -687,6 +689,26 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
         hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale);
         DKD_LAUNCH_CHECK();
     }
+    return DKD_OK;
+}
+
+extern "C" long dkd_colreduce_tr_f32_workspace_bytes(long rows, int N) {
+    int cl, ns, rps, cb;
+    colreduce_plan(rows, 1, N, &cl, &ns, &rps, &cb);
+    return (long)ns * N * sizeof(float);  // (always through the fold pass, which does the transposition)
+}
+
+extern "C" int dkd_colreduce_tr_f32(const float* X, float* out, float* ws, long rows, int N, int T, int round_out, void* stream) {
+    if (!X || !out || !ws || rows <= 0 || N <= 0 || T <= 0 || (N % T)) return DKD_ERR_BAD_ARG;
+    if (N & 3) return DKD_ERR_ALIGN;
+    int cl, ns, rps, cb;
+    colreduce_plan(rows, 1, N, &cl, &ns, &rps, &cb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colreduce_kernel<DKD_RED_SUM>, dim3(cb, ns, 1), dim3(256), 0, st, X, (const float*)nullptr, (const float*)nullptr, ws,
+                       rows, N, (long)N, cl, rps, 1.0f, ns, 0);  // partial sums [ns][N] (unscaled, unrounded even when ns == 1)
+    DKD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((N + 31) / 32, 1, 1), dim3(256), 0, st, ws, out, 1, ns, N, 1.0f, round_out, T);
+    DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 

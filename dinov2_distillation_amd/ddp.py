@@ -119,6 +119,8 @@ class GradBucketReducer:
         if not self.active:
             return
         dist.broadcast(self.opt.flat_p, src=src, group=self.pg)
+        if getattr(self.opt, "flat_p16", None) is not None:  # the arena was rewritten behind the parameters' version counters
+            self.opt.enable_shadow16()
         if module is not None:
             lo, hi = self.opt.flat_p.data_ptr(), self.opt.flat_p.data_ptr() + 4 * self.opt.flat_p.numel()
             rest = [t for t in list(module.parameters()) + list(module.buffers()) if not (lo <= t.data_ptr() < hi)]

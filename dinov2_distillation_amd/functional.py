@@ -234,7 +234,7 @@ class ConvNeXtBlockFn(Function):
             side = ops.wgrad_stream(x.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ops.transpose(ops.dwconv7_wgrad(x, dd), out=o_dww.view(C, 49))
+                ops.dwconv7_wgrad_cw(x, dd, out=o_dww.view(C, 49))   # partial sums folded straight into the [C, 49] parameter layout
                 ops.colreduce(dd.reshape(M, C), ops.RED_SUM, out=o_dwb.view(1, C))
             x.record_stream(side)
             dd.record_stream(side)
@@ -242,7 +242,7 @@ class ConvNeXtBlockFn(Function):
             dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
         else:
             dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
-            ddw = ops.transpose(ops.dwconv7_wgrad(x, dd), out=None if o_dww is None else o_dww.view(C, 49)).reshape(dw_shape)
+            ddw = ops.dwconv7_wgrad_cw(x, dd, out=None if o_dww is None else o_dww.view(C, 49)).reshape(dw_shape)
             ddb = ops.colreduce(dd.reshape(M, C), ops.RED_SUM, out=None if o_dwb is None else o_dwb.view(1, C)).reshape(-1)
         return (dx, ret(o_dww, ddw, p_dww), ret(o_dwb, ddb, p_dwb), ret(o_lnw, dln_w, p_lnw), ret(o_lnb, dln_b, p_lnb),
                 dw1, db1, ret(o_gg, dgrn_g.reshape(grn_shape), p_gg), ret(o_gb, dgrn_b.reshape(grn_shape), p_gb), dw2, db2)

@@ -49,18 +49,76 @@ def _cached(w, kind, make):
 
 
 def _w16(w):
-    """a parameter as the 16-bit operand autocast makes of it"""
+    """a parameter as the 16-bit operand autocast makes of it: a view of the optimiser's bf16 shadow arena when there is one
+    (written by the AdamW kernel itself, ops.shadow16), else a cast cached per optimiser step"""
+    sh = ops.shadow16(w)
+    if sh is not None:
+        return sh.view(w.shape)
     return _cached(w, "bf16", lambda: ops.cast_bf16(w.detach().reshape(-1, w.shape[-1]) if w.dim() > 1 else w.detach().reshape(1, -1)).reshape(w.shape))
 
 
 def _w16_2d(w, rows, cols):
     """_w16 of a parameter viewed as [rows, cols] (conv weights)"""
+    sh = ops.shadow16(w)
+    if sh is not None:
+        return sh.view(rows, cols)
     return _cached(w, ("bf16", rows, cols), lambda: ops.cast_bf16(w.detach().reshape(rows, cols)))
 
 
+# ---- derived copies that are NOT plain casts (transposed taps, rounded fp32 biases, re-ordered patch weights): refreshed for ALL
+# registered parameters of a stream by one dkd_prep_batch launch when the first stale one is asked for ---------------------------------
+_PREP = {}  # device index -> {"entries": {(id(w), kind): [weakref, dst, (batch, rows, cols, flags), stamp]}, "table", "sig", "max",
+            #                  "stream" / "event": where / when the last refresh was enqueued, "cap": capture it belongs to}
+
+
+def _prepared(w, kind, batch, rows, cols, flags, out_shape):
+    """dst[b][c][r] = f(w viewed [batch, rows, cols]) (dkd_hip.h dkd_prep_batch), cached per optimiser step like _cached.  The refresh
+    is enqueued on the stream that first asks in a step; a consumer on another stream waits for its event."""
+    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
+    stamp = (w._version, ops.WEIGHT_EPOCH, w.data_ptr())
+    grp = _PREP.setdefault(w.device.index, {"entries": {}, "table": None, "sig": None, "stream": None, "event": None})
+    cur = torch.cuda.current_stream(w.device)
+    key = (id(w), kind)
+    ent = grp["entries"].get(key)
+    if ent is None or ent[0]() is not w:
+        dst = torch.empty(out_shape, dtype=BF16 if flags & 2 else F32, device=w.device)
+        ent = grp["entries"][key] = [weakref.ref(w), dst, (batch, rows, cols, flags), None]
+        grp["table"] = None
+    # (during hipGraph capture the refresh must be part of the graph - the weights change at every replay - once per captured
+    # step: the first request after the capture began, ops.CAPTURE_SERIAL, launches it)
+    if ent[3] == stamp and (not capturing or grp.get("cap") == (ops.CAPTURE_SERIAL, ops.WEIGHT_EPOCH)):
+        if grp["stream"] is not None and cur != grp["stream"]:
+            cur.wait_event(grp["event"])
+        return ent[1]
+    if capturing:
+        grp["cap"] = (ops.CAPTURE_SERIAL, ops.WEIGHT_EPOCH)
+    # refresh every live entry of the group in one launch
+    live = [(k, e) for k, e in grp["entries"].items() if e[0]() is not None]
+    if len(live) != len(grp["entries"]):
+        grp["entries"] = dict(live)
+        grp["table"] = None
+    sig = tuple((e[0]().data_ptr(), e[1].data_ptr()) for _, e in live)
+    if grp["table"] is None or grp["sig"] != sig:
+        if capturing:
+            raise RuntimeError("functional16: the parameter table changed during hipGraph capture (run a warm-up step first)")
+        rows_ = [[e[0]().data_ptr(), e[1].data_ptr(), *e[2], 0, 0] for _, e in live]
+        grp["table"] = torch.tensor(rows_, dtype=torch.int64).to(w.device)
+        grp["sig"] = sig
+        grp["max"] = max(e[2][0] * e[2][1] * e[2][2] for _, e in live)
+    if grp["stream"] is not None and cur != grp["stream"] and not capturing:
+        cur.wait_event(grp["event"])  # (the previous refresh may still be running on its stream: same destination buffers)
+    ops.prep_batch(grp["table"], len(live), grp["max"])
+    grp["stream"], grp["event"] = cur, torch.cuda.Event()
+    grp["event"].record(cur)
+    for _, e in live:
+        pw = e[0]()
+        e[3] = (pw._version, ops.WEIGHT_EPOCH, pw.data_ptr())
+    return ent[1]
+
+
 def _rounded(t):
-    """fp32 copy holding bf16 values (taps / biases that a kernel consumes as fp32)"""
-    return _cached(t, "rounded", lambda: ops.round_bf16_(t.detach().clone()))
+    """fp32 copy holding bf16 values (biases that a kernel consumes as fp32)"""
+    return _prepared(t, "rounded", 1, 1, t.numel(), 1, tuple(t.shape))
 
 
 def wgrad16(dy16, x16, w, b, transform=None, reshape=None):
@@ -141,7 +199,7 @@ class PatchConv16Fn(Function):
             B, H, W, C = x.shape
             # pure data movement: a bf16 [.., C] tensor is an fp32 [.., C / 2] tensor to the patchify kernel
             rows = ops.patchify_nhwc(x.view(F32), k).view(BF16)
-            w2 = _cached(w, "patch16", lambda: ops.cast_bf16(ops.transpose(w.detach().reshape(O, C, k * k)).reshape(O, k * k * C)))  # [O][ky][kx][c]
+            w2 = _prepared(w, "patch16", O, C, k * k, 2, (O, k * k * C))  # [O][ky][kx][c], bf16
         y = ops.gemm_bf16(rows, w2, bias=_w16(b))
         ctx.save_for_backward(rows, w2)
         ctx.meta = (k, src_nchw, tuple(x.shape), tuple(w.shape))
@@ -179,7 +237,7 @@ class ConvNeXtBlock16Fn(Function):
         B, H, W, C = x.shape
         M = B * H * W
         x16 = x if x.dtype == BF16 else ops.cast_bf16(x).reshape(x.shape)
-        wt = _cached(dw_w, "taps16", lambda: ops.round_bf16_(ops.transpose(dw_w.detach().reshape(C, 49))))  # tap-major [49, C], 16-bit values
+        wt = _prepared(dw_w, "taps16", 1, C, 49, 1, (49, C))  # tap-major [49, C], 16-bit values
         d16 = ops.dwconv7_io(x16, wt, _rounded(dw_b))
         n16, mean, rstd = ops.layernorm_fwd_io(d16, ln_w, ln_b, 1e-6, BF16)
         w1h, w2h = _w16(w1), _w16(w2)
@@ -215,7 +273,7 @@ class ConvNeXtBlock16Fn(Function):
         dd16, dln_w, dln_b = ops.layernorm_bwd_io(dn16, d16.reshape(M, C), mean, rstd, ln_w, BF16, dg_out=o_lnw, db_out=o_lnb)
         dd16 = dd16.reshape(B, H, W, C)
         dx = ops.dwconv7_io(dd16, wt, None, add=dout.reshape(B, H, W, C), flip=True, out_dtype=dout.dtype)
-        ddw = ops.round_bf16_(ops.transpose(ops.dwconv7_wgrad16(x16, dd16), out=None if o_dww is None else o_dww.view(C, 49)))
+        ddw = ops.dwconv7_wgrad_cw(x16, dd16, out=None if o_dww is None else o_dww.view(C, 49), round_out=True)
         ddb = ops.colreduce16(dd16.reshape(M, C), ops.RED_SUM, out=None if o_dwb is None else o_dwb.view(1, C), round_out=True)
         return (dx, ret(o_dww, ddw.reshape(dw_shape), p_dww), ret(o_dwb, ddb.reshape(-1), p_dwb), ret(o_lnw, dln_w, p_lnw),
                 ret(o_lnb, dln_b, p_lnb), dw1, db1, ret(o_gg, dgrn_g.reshape(grn_shape), p_gg),

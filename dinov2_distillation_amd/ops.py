@@ -125,10 +125,43 @@ def linear_wgrad(dy, x, with_bias_grad=False):
 # dW = dy^T x never feeds the rest of the backward pass: it is only needed by the optimiser.  With arena-backed gradients
 # (FusedAdamW) those GEMMs are launched on a side HIP stream straight into the parameter's .grad view, so the MFMA-bound
 # wgrad launches overlap the HBM-bound element-wise kernels (and fill the tail rounds) of the main dgrad chain.
+CAPTURE_SERIAL = 0       # bumped by trainer.DistillationStepper.capture(): derived parameter copies are refreshed inside every capture
 WEIGHT_EPOCH = 0         # bumped by FusedAdamW.step(): its kernel rewrites the parameter arena without touching torch's version counters
 ASYNC_WGRAD = False      # switched on by optim.FusedAdamW (every parameter owns a persistent .grad view, used once per backward)
 _side_streams = {}
 _grad_listeners = []     # callables(param): told when a parameter's gradient launch has been enqueued on the side stream
+
+
+# ---- bf16 shadow of the parameter arena (optim.FusedAdamW writes it with every update; functional16 reads its 16-bit weight
+# operands from it) ----------------------------------------------------------------------------------------------------------------
+_SHADOW = {}            # id(param) -> [weakref(param), weakref(optimizer), offset, numel, version when the view was last known valid, view]
+SHADOW_DIRTY = False    # a parameter was edited through torch since the shadow was written: FusedAdamW.step() re-validates
+SHADOW_ENABLED = os.environ.get("DKD_SHADOW16", "1") != "0"
+
+
+def register_arena_param(p, opt_ref, off, n):
+    import weakref
+    key = id(p)
+    _SHADOW[key] = [weakref.ref(p, lambda _r, k=key: _SHADOW.pop(k, None)), opt_ref, off, n, -1, None]
+
+
+def shadow16(w):
+    """the parameter's bf16 copy inside its optimiser's shadow arena (flat [numel] view), or None: not an arena parameter, or edited
+    in place through torch since the optimiser last wrote the shadow (load_state_dict, init: the caller casts it itself until the
+    next optimiser step re-validates the view)"""
+    global SHADOW_DIRTY
+    ent = _SHADOW.get(id(w))
+    if ent is None or not SHADOW_ENABLED or ent[0]() is not w:
+        return None
+    opt = ent[1]()
+    if opt is None:
+        return None
+    if opt.flat_p16 is None:
+        opt.enable_shadow16()
+    if w._version != ent[4] or ent[5] is None:
+        SHADOW_DIRTY = True
+        return None
+    return ent[5]
 
 
 def wgrad_stream(device=None):
@@ -476,6 +509,34 @@ def dwconv7(x, w_tap, bias=None, add=None, flip=False):
     return out
 
 
+def colreduce_tr(part, T, out=None, round_out=False):
+    """column sums of part [rows, N], the result read as [T, N / T] and stored transposed [N / T, T] (optionally 16-bit values)"""
+    lib = _lib.binding()
+    _chk(part, "part"), _chk(out, "out")
+    rows, N = part.shape
+    if out is None:
+        out = torch.empty((N // T, T), dtype=torch.float32, device=part.device)
+    ws = workspace(lib.dkd_colreduce_tr_f32_workspace_bytes(rows, N), part.device)
+    check(lib.dkd_colreduce_tr_f32(_p(part), _p(out), _p(ws), rows, N, T, int(round_out), _stream()), "dkd_colreduce_tr_f32")
+    return out
+
+
+def dwconv7_wgrad_cw(x, dout, out=None, round_out=False):
+    """-> dW in the parameter's own layout [C, 49] (x / dout fp32 or bf16): the fold of the kernel's partial sums does the transposition
+    (and, for the mixed-precision step, the 16-bit rounding)"""
+    lib = _lib.binding()
+    B, H, W, C = x.shape
+    parts = lib.dkd_dwconv7_wgrad_f32_parts(B, H)
+    part = workspace(parts * 49 * C * 4, x.device, slot=1)
+    if x.dtype == BF16:
+        _chk16(x, "x"), _chk16(dout, "dout")
+        check(lib.dkd_dwconv7_wgrad_bf16(_p(x), _p(dout), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_bf16")
+    else:
+        _chk(x, "x"), _chk(dout, "dout")
+        check(lib.dkd_dwconv7_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_f32")
+    return colreduce_tr(part[: parts * 49 * C].view(parts, 49 * C), 49, out=out, round_out=round_out)
+
+
 def dwconv7_wgrad(x, dout):
     """-> dW tap-major [49, C]"""
     lib = _lib.binding()
@@ -547,6 +608,18 @@ def grn_fwd(g, gamma, beta, B, preact=False):
     return y, (gx, nx, denom)
 
 
+def _grn_bwd_stats(both, stats, gamma, B, C, dgamma_out, dbeta_out):
+    """per-image coefficients + both parameter gradients of GRN's backward in one launch (dkd_grn_bwd_stats_f32)"""
+    gx, nx, denom = stats
+    A, S = both[0], both[1]
+    coef = torch.empty_like(A)
+    dgamma = torch.empty(C, dtype=torch.float32, device=A.device) if dgamma_out is None else dgamma_out
+    dbeta = torch.empty(C, dtype=torch.float32, device=A.device) if dbeta_out is None else dbeta_out
+    check(_lib.binding().dkd_grn_bwd_stats_f32(_p(A), _p(S), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgamma), _p(dbeta), B, C,
+                                               _stream()), "dkd_grn_bwd_stats_f32")
+    return coef, dgamma, dbeta
+
+
 def grn_gelu_bwd(dy, g, h, stats, gamma, B, dgamma_out=None, dbeta_out=None):
     """-> dh (through GRN and GELU), dgamma, dbeta.  g=None: only the pre-activation h was kept, g = gelu(h) is recomputed"""
     lib = _lib.binding()
@@ -555,12 +628,7 @@ def grn_gelu_bwd(dy, g, h, stats, gamma, B, dgamma_out=None, dbeta_out=None):
     rpi = h.numel() // C // B
     # one pass: [0] = sum_hw dy*g, [1] = sum_hw dy, per image
     both = colreduce(dy, RED_DOT_SUM, y=g, groups=B) if g is not None else colreduce(dy, RED_DOTGELU_SUM, y=h, groups=B)
-    A = both[0]
-    dbeta = colreduce(both[1], RED_SUM, out=None if dbeta_out is None else dbeta_out.view(1, C)).reshape(C)
-    coef, dgp = torch.empty_like(A), torch.empty_like(A)
-    check(lib.dkd_grn_bwd_stats_f32(_p(A), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgp), B, C, _stream()),
-          "dkd_grn_bwd_stats_f32")
-    dgamma = colreduce(dgp, RED_SUM, out=None if dgamma_out is None else dgamma_out.view(1, C)).reshape(C)
+    coef, dgamma, dbeta = _grn_bwd_stats(both, stats, gamma, B, C, dgamma_out, dbeta_out)
     dh = torch.empty_like(h)
     check(lib.dkd_grn_gelu_bwd_f32(_p(dy), _p(g), _p(h), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
           "dkd_grn_gelu_bwd_f32")
@@ -1029,16 +1097,16 @@ def grn_gelu_bwd16(dy16, h16, stats, gamma, B, dgamma_out=None, dbeta_out=None):
     C = h16.shape[-1]
     rpi = h16.numel() // C // B
     both = colreduce16(dy16, RED_DOTGELU_SUM, y=h16, groups=B, round_gelu=True)  # [0] = sum dy*g, [1] = sum dy, per image
-    A = both[0]
-    dbeta = colreduce(both[1], RED_SUM, out=None if dbeta_out is None else dbeta_out.view(1, C)).reshape(C)
-    coef, dgp = torch.empty_like(A), torch.empty_like(A)
-    check(lib.dkd_grn_bwd_stats_f32(_p(A), _p(gx), _p(nx), _p(denom), _p(gamma), _p(coef), _p(dgp), B, C, _stream()),
-          "dkd_grn_bwd_stats_f32")
-    dgamma = colreduce(dgp, RED_SUM, out=None if dgamma_out is None else dgamma_out.view(1, C)).reshape(C)
+    coef, dgamma, dbeta = _grn_bwd_stats(both, stats, gamma, B, C, dgamma_out, dbeta_out)
     dh = torch.empty_like(h16)
     check(lib.dkd_grn_gelu_bwd_bf16(_p(dy16), _p(h16), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
           "dkd_grn_gelu_bwd_bf16")
     return dh, dgamma, dbeta
+
+
+def prep_batch(table, entries, max_elems):
+    """dkd_prep_batch: every derived small-parameter copy of the table in one launch (functional16._prepared)"""
+    check(_lib.binding().dkd_prep_batch(_p(table), int(entries), int(max_elems), _stream()), "dkd_prep_batch")
 
 
 def cast_f32(x16):

@@ -28,6 +28,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self.graph_safe = False  # True: every optimiser scalar lives in device memory (hipGraph capture of the step)
         self._hyper = None
         self._expose_state()
+        # bf16 shadow of the parameters for the mixed-precision step (allocated on first use: ops.shadow16): the update kernel
+        # writes it, so the 16-bit operand copies autocast makes of every weight cost no launch
+        self.flat_p16 = None
+        import weakref
+        me = weakref.ref(self)
+        for p, off, n in self.layout:
+            ops.register_arena_param(p, me, off, n)
         # Weight gradients may now be written into the arena from the side stream (DKD_ASYNC_WGRAD=0 keeps one stream).  Whether a
         # given backward pass actually does so is decided per call by ops.can_async: never under torch DistributedDataParallel
         # (its reducer must see every gradient through autograd), never for a gradient that was already written since zero_grad.
@@ -110,6 +117,26 @@ class FusedAdamW(torch.optim.Optimizer):
             self._hyper[:, 5] = float(steps)
             self.sync_hyper()
 
+    def enable_shadow16(self):
+        """allocate the bf16 shadow arena and fill it from the current parameters (one cast over the arena); every parameter's view
+        becomes valid"""
+        if not self.flat_p.is_cuda:
+            raise _lib.DkdError("FusedAdamW needs parameters on the GPU (no CPU path)")
+        if self.flat_p16 is None:
+            self.flat_p16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat_p.device)
+        _lib.check(_lib.binding().dkd_cast_bf16(_p(self.flat_p), _p(self.flat_p16), 1, self.total, self.total, _stream()), "dkd_cast_bf16")
+        torch.cuda.current_stream().synchronize()  # built once, read from every stream (teacher / chain / weight-gradient streams)
+        self._validate_shadow()
+
+    def _validate_shadow(self):
+        for p, off, n in self.layout:
+            ent = ops._SHADOW.get(id(p))
+            if ent is not None:
+                ent[4] = p._version
+                if ent[5] is None:
+                    ent[5] = self.flat_p16[off:off + n]
+        ops.SHADOW_DIRTY = False
+
     def sync_hyper(self):
         """(graph-safe mode) push lr / betas / eps / weight_decay of every param group to the device; the step counter is kept.
         Call after a scheduler changed ``group['lr']`` - it is a small H2D copy outside the captured graph."""
@@ -178,7 +205,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 if b > a:
                     _lib.check(lib.dkd_adamw_dev_f32(_p(self.flat_p[a:b]), _p(self.flat_g[a:b]), _p(self.flat_m[a:b]),
                                                      _p(self.flat_v[a:b]), b - a, _p(self._hyper[i]), _p(gn),
-                                                     float(clip_grad_norm or 0.0), _stream()), "dkd_adamw_dev_f32")
+                                                     float(clip_grad_norm or 0.0),
+                                                     _p(None if self.flat_p16 is None else self.flat_p16[a:b]), _stream()),
+                               "dkd_adamw_dev_f32")
+            if ops.SHADOW_DIRTY and self.flat_p16 is not None:
+                self._validate_shadow()
             return loss
         for g in self.param_groups:
             a, b = g["_range"]
@@ -187,5 +218,8 @@ class FusedAdamW(torch.optim.Optimizer):
             _lib.check(lib.dkd_adamw_f32(_p(self.flat_p[a:b]), _p(self.flat_g[a:b]), _p(self.flat_m[a:b]),
                                          _p(self.flat_v[a:b]), b - a, g["lr"], g["betas"][0],
                                          g["betas"][1], g["eps"], g["weight_decay"], self._steps, _p(gn),
-                                         float(clip_grad_norm or 0.0), _stream()), "dkd_adamw_f32")
+                                         float(clip_grad_norm or 0.0),
+                                         _p(None if self.flat_p16 is None else self.flat_p16[a:b]), _stream()), "dkd_adamw_f32")
+        if ops.SHADOW_DIRTY and self.flat_p16 is not None:  # the kernel above rewrote the whole shadow: every view is valid again
+            self._validate_shadow()
         return loss

@@ -62,6 +62,7 @@ class DistillationStepper:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        ops.CAPTURE_SERIAL += 1
         with torch.cuda.graph(self.graph):
             self.static_loss = self._step_body(self.static_batch)
         return self

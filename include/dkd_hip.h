@@ -115,6 +115,11 @@ int dkd_layernorm_fwd_bf16out_f32(const float* x, const float* gamma, const floa
 int dkd_colreduce_f32(const float* X, const float* Y, const float* aux, float* out, float* ws, long rows_per_group,
                       int groups, int N, long ldx, int op, float scale, void* stream);
 long dkd_colreduce_f32_workspace_bytes(long rows_per_group, int groups, int N);
+/* out[(n % (N/T)) * T + n / (N/T)] = [rnd_bf16](sum_r X[r][n]): a column reduction whose result [T][N/T] is stored transposed
+ * (and optionally holding 16-bit values) - the fold of the depthwise-conv weight-gradient partials [parts][49][C] straight into the
+ * parameter's [C][49] layout (models/backbones/convnext.py:63) instead of reduce + transpose (+ round).  ws: the _workspace_bytes. */
+int dkd_colreduce_tr_f32(const float* X, float* out, float* ws, long rows, int N, int T, int round_out, void* stream);
+long dkd_colreduce_tr_f32_workspace_bytes(long rows, int N);
 /* out[b] = in[b]^T for `batch` dense [rows, cols] matrices (pos_embed [D,P*P] <-> token-major [P*P,D]) */
 int dkd_transpose_f32(const float* in, float* out, int rows, int cols, int batch, void* stream);
 
@@ -153,8 +158,10 @@ int dkd_bn_bwd_apply_f32(const float* dbn, const float* xhat, const float* sum_d
 int dkd_grn_stats_f32(const float* sumsq, float* gx, float* nx, float* denom, int B, int C, void* stream);
 int dkd_grn_apply_f32(const float* g, const float* nx, const float* gamma, const float* beta, float* y, int B,
                       long rows_per_img, int C, int input_is_preact, void* stream);
-int dkd_grn_bwd_stats_f32(const float* A, const float* gx, const float* nx, const float* denom, const float* gamma,
-                          float* coef, float* dgamma_part, int B, int C, void* stream);
+/* backward statistics in ONE launch: per image coef[b][c] (dg = dy (gamma nx + 1) + coef g) from A[b][c] = sum_hw dy g, and the
+ * parameter gradients dgamma[c] = sum_b A nx, dbeta[c] = sum_b S with S[b][c] = sum_hw dy (S / dbeta may be NULL) */
+int dkd_grn_bwd_stats_f32(const float* A, const float* S, const float* gx, const float* nx, const float* denom, const float* gamma,
+                          float* coef, float* dgamma, float* dbeta, int B, int C, void* stream);
 int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const float* nx, const float* coef,
                          const float* gamma, float* dh, int B, long rows_per_img, int C, void* stream);
 
@@ -356,15 +363,23 @@ int dkd_set_rows_f32(float* out, const float* vec, int B, long row_stride, int D
  * gradient_clip_val=1.0 / "norm" (train.py:267-268).  dkd_sumsq_f32 writes out2 = {sum x^2, sqrt(sum x^2)} on the
  * device; dkd_adamw_f32 takes that pointer (or NULL) and scales every gradient by min(1, max_norm/(norm+1e-6))
  * on the fly, then applies torch's AdamW update with bias corrections for `step` (>= 1).
+ * p16 (nullable, 8-byte aligned): a bf16 shadow [n] of the parameters written with the update - the mixed-precision step
+ * (train.py:263 precision=16) reads its 16-bit weight operands from it instead of casting every weight at every use.
  */
 int dkd_sumsq_f32(const float* x, long n, float* out2, float* ws, void* stream);
 long dkd_sumsq_f32_workspace_bytes(long n);
 int dkd_adamw_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, const float* gnorm2, float max_norm, void* stream);
+                  float weight_decay, int step, const float* gnorm2, float max_norm, void* p16, void* stream);
 /* the same update with {lr, beta1, beta2, eps, weight_decay, step} read from a 6-float DEVICE vector: no optimiser scalar is a
  * launch argument, so a captured hipGraph of the whole step stays valid across steps and learning-rate changes */
 int dkd_adamw_dev_f32(float* p, const float* g, float* m, float* v, long n, const float* hyper6, const float* gnorm2,
-                      float max_norm, void* stream);
+                      float max_norm, void* p16, void* stream);
+/* Derived copies of small parameters that the mixed-precision step refreshes once per optimiser step (depthwise taps [C,49] ->
+ * tap-major [49,C] with 16-bit values, models/backbones/convnext.py:63; rounded biases; the 2x2 downsample weights re-ordered
+ * for the patch GEMM, :124) in ONE launch: table = int64 [entries][8] on the device, {src float*, dst, batch, rows, cols, flags,
+ * 0, 0}: dst[b][c][r] = f(src[b][r][c]); flags & 1: round to the nearest bf16 value (fp32 dst), & 2: dst is bf16.  max_elems =
+ * the largest batch * rows * cols of the table (sizes the grid). */
+int dkd_prep_batch(const void* table, int entries, long max_elems, void* stream);
 int dkd_clip_grad_f32(float* g, long n, const float* gnorm2, float max_norm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
