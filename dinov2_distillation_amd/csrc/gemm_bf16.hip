@@ -167,20 +167,30 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(dkd_gemm_bf16_args g, int
 
 // fold of the K-slab partials: out = rnd_bf16(sum over slabs, fixed order) as bf16 or as fp32 holding the bf16 value (what
 // autocast leaves in an fp32 master gradient: the bf16 result of the backward matmul, cast up)
+// rs_parts: number of partial row-sum vectors [M] behind the slabs
 template <bool OUT_BF16>
-__global__ void bf16_fold_kernel(const float* __restrict__ ws, int slabs, long total4, void* __restrict__ out, int M, float* __restrict__ rowsum) {
+__global__ void bf16_fold_kernel(const float* __restrict__ ws, int slabs, long total4, void* __restrict__ out, int M, float* __restrict__ rowsum,
+                                 int rs_parts) {
     const long items = total4 + (rowsum ? M : 0);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
-        if (i >= total4) {  // the fused bias gradient: slab partials [slabs][M] behind the [slabs][M][N] block
+        if (i >= total4) {  // the fused bias gradient: partials [rs_parts][M] behind the [slabs][M][N] block
             const float* r = ws + (long)slabs * total4 * 4 + (i - total4);
             float a = r[0];
-            for (int z = 1; z < slabs; ++z) a += r[(long)z * M];
+            for (int z = 1; z < rs_parts; ++z) a += r[(long)z * M];
             rowsum[i - total4] = rnd_bf16(a);
             continue;
         }
         const float4* p = reinterpret_cast<const float4*>(ws) + i;
         float4 s = p[0];
-        for (int z = 1; z < slabs; ++z) {
+        int z = 1;
+        for (; z + 4 <= slabs; z += 4) {  // four slab loads in flight (a one-at-a-time walk is a latency chain on a small grid)
+            const float4 a = p[(long)z * total4], b = p[(long)(z + 1) * total4], c = p[(long)(z + 2) * total4], d = p[(long)(z + 3) * total4];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+        }
+        for (; z < slabs; ++z) {
             const float4 a = p[(long)z * total4];
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
         }
@@ -278,7 +288,7 @@ static int bf16_slabs(int M, int N, int K) {
 
 extern "C" long dkd_gemm_bf16_workspace_bytes(int M, int N, int K, int with_rowsum) {
     const int sp = bf16_slabs(M, N, K);
-    if (with_rowsum) return (long)sp * ((long)M * N + M) * sizeof(float);  // (always through the partial-sum path)
+    if (with_rowsum) return (long)sp * ((long)M * N + M) * sizeof(float);  // (always through the partial sums)
     return sp > 1 ? (long)sp * M * N * sizeof(float) : 0;
 }
 
@@ -364,10 +374,11 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
     if (partial) {
         const long total4 = (long)g->M * g->N / 4;
         const int blocks = blocks_1d(total4 + (rowsum ? g->M : 0));
+        const int rs_parts = slabs;
         if (g->epi == DKD_BF16_EPI_BF16)
-            hipLaunchKernelGGL(bf16_fold_kernel<true>, dim3(blocks), dim3(256), 0, st, g->workspace, slabs, total4, g->C, g->M, g->rowsum);
+            hipLaunchKernelGGL(bf16_fold_kernel<true>, dim3(blocks), dim3(256), 0, st, g->workspace, slabs, total4, g->C, g->M, g->rowsum, rs_parts);
         else
-            hipLaunchKernelGGL(bf16_fold_kernel<false>, dim3(blocks), dim3(256), 0, st, g->workspace, slabs, total4, g->C, g->M, g->rowsum);
+            hipLaunchKernelGGL(bf16_fold_kernel<false>, dim3(blocks), dim3(256), 0, st, g->workspace, slabs, total4, g->C, g->M, g->rowsum, rs_parts);
         DKD_LAUNCH_CHECK();
     }
     return DKD_OK;

@@ -134,7 +134,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_ring_kernel(dkd_gemm_
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x16 rs[TM];  // ROWSUM: column sums of the [K][M] operand for this wave's m-tiles (every register row identical)
+    // ROWSUM: the waves that own the first column tile also take the row sums of their A fragments: one more MFMA per m-tile and
+    // k-block against a fragment of ones (exact: bf16 x 1 products, fp32 accumulation).  Measured alternatives, not kept: the sums
+    // on the VALU (v_dot2c_f32_bf16 against ones: hipcc outlines the conditional block and branches to it per k-block, 2x slower),
+    // the duty rotated over the nbn column tiles (slabs x nbn partial vectors for the fold: slower).  With one column tile
+    // (N <= 128) every workgroup carries the extra MFMAs (+25 %): the host keeps the separate column reduction there.
+    f32x16 rs[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_ring_kernel(dkd_gemm_
     // row-contiguous: 8 (16-bit outputs) or 16 lanes per row, whole 128 / 256-byte runs per row and instruction for the loads of
     // a residual as well as for the stores.  LDS operations of one wave execute in order: no barrier between a wave's own
     // stores and loads; the one barrier in front frees the ring stages.
-    if (ROWSUM && do_rs && half == 0) {
+    if (ROWSUM && do_rs && half == 0) {  // partial row sums [slab][M] behind the [slab][M][N] block (every register row identical)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = bm0 + wm * WM_ROWS + i * 32 + l31;

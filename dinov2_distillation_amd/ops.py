@@ -915,9 +915,10 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
     if Kb != K:
         raise _lib.DkdError(f"gemm_bf16: reduction extents differ: {K} vs {Kb}")
     lib = _lib.binding()
-    if rowsum is not None and K % 32:
-        # the fused row sum lives in the LDS-DMA ring kernel, which takes whole 32-deep k-tiles; ragged reductions (tiny test
-        # batches) take the column reduction instead
+    if rowsum is not None and (K % 32 or N <= 128):
+        # the fused row sum lives in the LDS-DMA ring kernel, which takes whole 32-deep k-tiles: ragged reductions (tiny test
+        # batches) take the column reduction instead - and so do outputs of one column tile, where every workgroup would carry
+        # the extra MFMAs (+25 % on a 200704-row reduction) instead of one in nbn
         colreduce16(a2, RED_SUM, out=rowsum.view(1, -1), round_out=True)
         rowsum = None
     g = _lib.args("dkd_gemm_bf16_args")
