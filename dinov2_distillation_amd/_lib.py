@@ -225,15 +225,55 @@ else:
         return ctypes.byref(a)
 
 
+def struct_call(fname, sname):
+    """a fast caller for the hot launchers that take ONE argument struct + stream (the GEMMs): ``call(field=value, ...)`` -> status.
+    No argument-struct object per launch: under the torch binding the header's fields are one positional list (defaults NULL / 0)
+    handed straight to torch.ops.dkd.<op>; under ctypes a Structure is filled.  Same semantics as
+    ``binding().dkd_xxx(ref(args(...)), stream())``."""
+    fields = _STRUCT_DEFS[sname]
+    index = {f: i for i, (f, _) in enumerate(fields)}
+    defaults = [None if ty is ctypes.c_void_p else (0.0 if ty is ctypes.c_float else 0) for _, ty in fields]
+    state = {}
+
+    if BINDING == "torch":
+        def call(**kw):
+            op = state.get("op")
+            if op is None:
+                from . import torchlib
+                op = state["op"] = getattr(torchlib.load(), fname[4:])
+                load()
+            flat = defaults.copy()
+            for k, v in kw.items():
+                flat[index[k]] = v
+            try:
+                op(*flat)
+            except RuntimeError as e:
+                return _status_of(e)
+            return 0
+    else:
+        def call(**kw):
+            fn = state.get("fn")
+            if fn is None:
+                fn = state["fn"] = getattr(load(), fname)
+            a = STRUCTS[sname]()
+            for k, v in kw.items():
+                setattr(a, k, v)
+            return fn(ctypes.byref(a), stream())
+    return call
+
+
 _ERRS = {-1: "DKD_ERR_BAD_ARG", -2: "DKD_ERR_ALIGN", -3: "DKD_ERR_UNSUPPORTED"}
 
 
 _DEBUG_SYNC = bool(os.environ.get("DKD_DEBUG_SYNC"))
 
 
-def check(code, what):
+def check(code, what, detail=None):
+    """detail: formatted into the message only when the call failed (the hot launchers pass a tuple instead of an f-string)"""
     if _DEBUG_SYNC:  # debugging aid: serialise every launch so that a fault / race is attributed to its op
         import torch
         torch.cuda.synchronize()
     if code != 0:
+        if detail is not None:
+            what = f"{what}{list(detail)}"
         raise DkdError(f"{what} failed: {_ERRS.get(code, 'hipError_t ' + str(code))}")

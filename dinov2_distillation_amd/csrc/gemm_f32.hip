@@ -541,7 +541,9 @@ struct DmaStager {
 // M = 64 * 257 rows (257 is prime: 257 * nbn tiles never fill whole rounds of the 256 CUs) the 6 .. 24 tiles past the last
 // whole round would each run alone on a CU at the very end - 30-40 us of a lone workgroup's latency on a 160 us launch;
 // as a few dozen short slabs in the first round they cost about one tile's worth of work spread over the chip.
-template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0, bool PEEL = false>
+// SPREAD: the next tile's DMA pieces are issued between the k-blocks' MFMAs (A in front of the first, B in front of the last k-block)
+// instead of all in front of the tile's first fragment read - the order that won on every shape of the bf16 ring kernel.
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0, bool PEEL = false, bool SPREAD = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda,
                                                                     const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                     int M, int N, int K, int kchunk, Epilogue epi,
@@ -596,7 +598,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
         const int cur = kt & 1;
         const float* As = smem + cur * (A_SZ + B_SZ);
         float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
-        if (kt + 1 < nk && !(knock & 2)) {  // every wave passed the barrier: nobody reads the other buffer any more
+        const bool more = kt + 1 < nk && !(knock & 2);
+        if (more && !SPREAD) {  // every wave passed the barrier: nobody reads the other buffer any more
             da.issue(An, tid);
             if (!(knock & 4)) db.issue(An + A_SZ, tid);
         }
@@ -611,6 +614,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
             for (int i = 0; i < TM; ++i) a[i] = DA::frag(As, (wm * TM + i) * 16, kb, g, i16);
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = DB::frag(As + A_SZ, (wn * TN + j) * 16, kb, g, i16);
+            if (SPREAD && more) {
+                if (kb == 0) da.issue(An, tid);
+                if (kb == BK / 16 - 1) db.issue(An + A_SZ, tid);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1057,7 +1064,7 @@ static bool dma_ok(const dkd_gemm_args* g, int kchunk) {
     if (g->rowsum && g->a_layout == 0) return false;
     return true;
 }
-template <int WM, int WN, int TM, int TN, int BK, int KNOCK = 0>
+template <int WM, int WN, int TM, int TN, int BK, int KNOCK = 0, bool SPREAD = false>
 int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
     if (!dma_ok<BK>(g, kchunk)) return DKD_ERR_UNSUPPORTED;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -1065,7 +1072,7 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     float* ws = splits > 1 ? g->workspace : nullptr;
     const int vec = epilogue_vec_ok(g);
 #define DKD_GEMM_LAUNCH3(AKC, BKC)                                                                                          \
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK, false, SPREAD>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
                        g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec, 0, 0)
     if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH3(true, true);
     else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH3(true, false);
@@ -1147,7 +1154,7 @@ static void cfg_tile(int cfg, int* bm, int* bn) {
         case CFG_128x96_4W: *bm = 128; *bn = 96; break;
         case 43: case 55: *bm = 64; *bn = 96; break;
         case 56: *bm = 96; *bn = 64; break;
-        case 44: case 100: case 101: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
+        case 44: case 100: case 101: case 111: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
         default: *bm = 64; *bn = 128; break;  // 3, 5
     }
@@ -1238,7 +1245,7 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     if (splits > 1 && !g->workspace) splits = 1;
     int kchunk = g->K;
     if (splits > 1) {
-        const int kq = cfg >= 100 ? 32 : 16;
+        const int kq = cfg >= 100 ? 32 : 16;  // (100 keeps whole 32-deep tiles too)
         kchunk = ((g->K + splits - 1) / splits + kq - 1) / kq * kq;
         splits = (g->K + kchunk - 1) / kchunk;
     }
@@ -1262,6 +1269,7 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 44: return launch_v2<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);   // 64 x 64, 4 waves of 32 x 32
         case 100: return launch_dma<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, LDS-DMA staging, BK 16
         case 101: return launch_dma<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, BK 32
+        case 111: return launch_dma<2, 2, 2, 2, 32, 0, true>(g, epi, splits, kchunk, st);  // ... with the DMA issue spread over the k-blocks
 #ifdef DKD_TUNING  // knock-outs of variant 101: timing experiments whose RESULTS ARE WRONG - never part of the shipped library
         case 130: return launch_dma<2, 2, 2, 2, 32, 2>(g, epi, splits, kchunk, st);
         case 131: return launch_dma<2, 2, 2, 2, 32, 4>(g, epi, splits, kchunk, st);

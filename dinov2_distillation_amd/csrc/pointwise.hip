@@ -261,26 +261,44 @@ __global__ void grn_apply_kernel(const T* __restrict__ g, const float4* __restri
 
 // GRN backward, per image b and channel c, given A[b][c] = sum_hw dy*g :
 //   dnx = gamma * A;  dgx = dnx / denom - (1/C) * sum_c'(dnx[c'] * gx[c']) / denom^2;  coef = dgx / gx (0 if gx == 0)
-// Blocks [0, B): one per image, coef[b][c] (so that dg = dy*(gamma*nx+1) + coef*g).  Blocks [B, B + ceil(C/256)): the parameter
-// gradients, one thread per channel over the images in index order (deterministic): dgamma[c] = sum_b A[b][c] nx[b][c],
-// dbeta[c] = sum_b S[b][c] with S[b][c] = sum_hw dy - what used to be two more column reductions (four launches) per block.
+// Blocks [0, B): one per image, coef[b][c] (so that dg = dy*(gamma*nx+1) + coef*g).  Blocks [B, B + ceil(C/64)): the parameter
+// gradients dgamma[c] = sum_b A[b][c] nx[b][c], dbeta[c] = sum_b S[b][c] with S[b][c] = sum_hw dy, in a fixed order - what used to
+// be two more column reductions (four launches) per block.
 __global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restrict__ A, const float* __restrict__ S,
                                                             const float* __restrict__ gx, const float* __restrict__ nx,
                                                             const float* __restrict__ denom, const float* __restrict__ gamma,
                                                             float* __restrict__ coef, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int B, int C) {
     __shared__ float red[4];
+    __shared__ float pg[4][64], pb[4][64];
     if ((int)blockIdx.x >= B) {
-        const int c = ((int)blockIdx.x - B) * 256 + threadIdx.x;
-        if (c >= C) return;
+        // 64 channels x 4 image lanes per block: lane q adds the images q, q + 4, ... (loads of four images in flight), the four
+        // partial sums meet in LDS and are added in lane order - a fixed order, and 16 load rounds instead of a chain of B
+        const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+        const int c = ((int)blockIdx.x - B) * 64 + cl;
         float sg = 0.f, sb = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const long i = (long)b * C + c;
-            sg += A[i] * nx[i];
-            if (S) sb += S[i];
+        if (c < C) {
+            int b = q;
+            for (; b + 12 < B; b += 16) {
+                const long i0 = (long)b * C + c, i1 = i0 + 4L * C, i2 = i0 + 8L * C, i3 = i0 + 12L * C;
+                const float a0 = A[i0], a1 = A[i1], a2 = A[i2], a3 = A[i3];
+                const float n0 = nx[i0], n1 = nx[i1], n2 = nx[i2], n3 = nx[i3];
+                sg += a0 * n0; sg += a1 * n1; sg += a2 * n2; sg += a3 * n3;
+                if (S) { sb += S[i0]; sb += S[i1]; sb += S[i2]; sb += S[i3]; }
+            }
+            for (; b < B; b += 4) {
+                const long i = (long)b * C + c;
+                sg += A[i] * nx[i];
+                if (S) sb += S[i];
+            }
         }
-        dgamma[c] = sg;
-        if (S && dbeta) dbeta[c] = sb;
+        pg[q][cl] = sg;
+        pb[q][cl] = sb;
+        __syncthreads();
+        if (q == 0 && c < C) {
+            dgamma[c] = ((pg[0][cl] + pg[1][cl]) + pg[2][cl]) + pg[3][cl];
+            if (S && dbeta) dbeta[c] = ((pb[0][cl] + pb[1][cl]) + pb[2][cl]) + pb[3][cl];
+        }
         return;
     }
     const int b = blockIdx.x;
@@ -533,7 +551,7 @@ extern "C" int dkd_grn_apply_f32(const float* g, const float* nx, const float* g
 extern "C" int dkd_grn_bwd_stats_f32(const float* A, const float* S, const float* gx, const float* nx, const float* denom,
                                      const float* gamma, float* coef, float* dgamma, float* dbeta, int B, int C, void* stream) {
     if (!A || !gx || !nx || !denom || !gamma || !coef || !dgamma || B <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(B + (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, S, gx, nx, denom, gamma,
+    hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(B + (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, S, gx, nx, denom, gamma,
                        coef, dgamma, dbeta, B, C);
     DKD_LAUNCH_CHECK();
     return DKD_OK;

@@ -479,6 +479,38 @@ class KDLossFn(Function):
         return ds, None, None, None
 
 
+class LossCombineFn(Function):
+    """The scalar tail of ``_compute_losses`` (train/distillation_module.py:238-245) as ONE autograd node: per level
+    total = (spatial + frequency) * weight, the two weighted parts, and the sum of the totals.  Written with torch scalars it is
+    ~13 one-element kernels forward and as many autograd nodes (each a launch) at the very start of the backward pass - the one
+    place in the step where the GPU has nothing queued behind them.  Here: stack, scale, pair sums, total (4 launches), and one
+    launch backward.  inputs: s_0, f_0, s_1, f_1, ... (0-dim); returns (weighted [2L], pair totals [L], total [])."""
+
+    @staticmethod
+    def forward(ctx, wvec, *terms):
+        v = torch.stack([t.reshape(()) for t in terms])
+        w = v * wvec
+        pairs = w.view(-1, 2).sum(1)
+        total = pairs.sum()
+        ctx.save_for_backward(wvec)
+        ctx.n = len(terms)
+        return w, pairs, total
+
+    @staticmethod
+    def backward(ctx, gw, gpairs, gtotal):
+        (wvec,) = ctx.saved_tensors
+        g = None
+        if gtotal is not None:
+            g = wvec * gtotal
+        if gpairs is not None:
+            t = wvec * gpairs.repeat_interleave(2)
+            g = t if g is None else g + t
+        if gw is not None:
+            t = wvec * gw
+            g = t if g is None else g + t
+        return (None, *g.unbind(0))
+
+
 # =====================================================================================================================
 # STDC / ResNet building blocks (NHWC)
 class ConvBNActFn(Function):
@@ -987,3 +1019,7 @@ class DropoutFn(Function):
     @staticmethod
     def backward(ctx, dy):
         return _drop(_c(dy), ctx.p, ctx.seed, 3), None
+
+
+from . import _trace  # noqa: E402
+_trace.instrument(globals())

@@ -457,3 +457,7 @@ class DctRoundtrip16Fn(Function):
         d = ops.dct16_step(d, Fw, 1, transposed=True, zero_in=True)
         d = ops.dct16_step(d, Fw, 0, transposed=True, out_dtype=F32)
         return d.reshape(B, N, C), None, None
+
+
+from . import _trace  # noqa: E402
+_trace.instrument(globals())

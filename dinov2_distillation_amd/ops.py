@@ -25,6 +25,9 @@ _stream = _lib.stream  # the launch stream argument (ctypes binding: the current
 _p = _lib.ptr          # a device pointer argument (ctypes binding: c_void_p; torch binding: the tensor itself)
 
 
+_GEMM32 = _lib.struct_call("dkd_gemm_f32", "dkd_gemm_args")
+
+
 def _chk(t, name, contiguous=True):
     if t is None:
         return
@@ -37,7 +40,7 @@ def _chk(t, name, contiguous=True):
 
 def workspace(nbytes, device, slot=0):
     """Stream-ordered scratch: one growing buffer per (device, stream, slot) - kernels on different streams never share one."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, slot)
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index), slot)  # (the raw handle: no Stream object per launch)
     w = _ws.get(key)
     if w is None or w.numel() * 4 < nbytes:
         w = torch.empty(max(int(nbytes) // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
@@ -64,23 +67,20 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     lda = a2.shape[1] if lda is None else lda
     ldb = b2.shape[1] if ldb is None else ldb
     out_rows = M
-    g = _lib.args("dkd_gemm_args")
+    rg = rgs = ro = 0
     if row_map is not None:
-        g.row_grp, g.row_grp_stride, g.row_off, out_rows = row_map
+        rg, rgs, ro, out_rows = row_map
     if out is None:
         out = torch.empty((out_rows, N), dtype=torch.float32, device=a.device)
     _chk(out, "out")
     ldc = N if ldc is None else ldc
     wsb = lib.dkd_gemm_f32_workspace_bytes(M, N, K, a_layout, b_layout)
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
-    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), lda, _p(b2), ldb, _p(out), ldc
-    g.bias, g.colscale, g.residual, g.preact, g.workspace = _p(bias), _p(colscale), _p(residual), _p(preact), _p(ws)
-    g.rowsum = _p(rowsum)
-    g.precision = GEMM_PRECISION if precision is None else precision
-    g.ldr = (N if ldr is None else ldr)
-    g.a_layout, g.b_layout, g.M, g.N, g.K = a_layout, b_layout, M, N, K
-    g.act, g.res_mod, g.alpha, g.variant = act, res_mod, alpha, variant
-    check(lib.dkd_gemm_f32(_lib.ref(g), _stream()), f"dkd_gemm_f32[{M}x{N}x{K} a{a_layout} b{b_layout}]")
+    check(_GEMM32(A=_p(a2), lda=lda, B=_p(b2), ldb=ldb, C=_p(out), ldc=ldc, bias=_p(bias), colscale=_p(colscale), residual=_p(residual),
+                  preact=_p(preact), workspace=_p(ws), rowsum=_p(rowsum), precision=GEMM_PRECISION if precision is None else precision,
+                  ldr=(N if ldr is None else ldr), a_layout=a_layout, b_layout=b_layout, M=M, N=N, K=K, act=act, res_mod=res_mod,
+                  alpha=alpha, variant=variant, row_grp=rg, row_grp_stride=rgs, row_off=ro),
+          "dkd_gemm_f32", (M, N, K, a_layout, b_layout))
     return out
 
 
@@ -892,6 +892,9 @@ BF16 = torch.bfloat16
 EPI_BF16, EPI_BF16_GELU, EPI_F32_RESID, EPI_F32, EPI_BF16_RELU = 0, 1, 2, 3, 5
 
 
+_GEMM16 = _lib.struct_call("dkd_gemm_bf16", "dkd_gemm_bf16_args")  # positional fast path: no argument-struct object per launch
+
+
 def _chk16(t, name):
     if t is None:
         return
@@ -921,10 +924,10 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
         # the extra MFMAs (+25 % on a 200704-row reduction) instead of one in nbn
         colreduce16(a2, RED_SUM, out=rowsum.view(1, -1), round_out=True)
         rowsum = None
-    g = _lib.args("dkd_gemm_bf16_args")
     out_rows = M
+    rg = rgs = ro = 0
     if row_map is not None:
-        g.row_grp, g.row_grp_stride, g.row_off, out_rows = row_map
+        rg, rgs, ro, out_rows = row_map
     f32_out = epi in (EPI_F32_RESID, EPI_F32)
     if out is None:
         out = torch.empty((out_rows, N), dtype=torch.float32 if f32_out else BF16, device=a.device)
@@ -932,11 +935,10 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
         raise _lib.DkdError("gemm_bf16: out has the wrong dtype / layout for this epilogue")
     wsb = lib.dkd_gemm_bf16_workspace_bytes(M, N, K, int(rowsum is not None))
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
-    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), a2.shape[1], _p(w2), w2.shape[1], _p(out), N
-    g.bias, g.colscale, g.residual, g.ldr, g.workspace = _p(bias), _p(colscale), _p(residual), N, _p(ws)
-    g.rowsum, g.variant = _p(rowsum), variant
-    g.M, g.N, g.K, g.epi, g.res_mod, g.a_layout, g.b_layout = M, N, K, epi, res_mod, a_layout, b_layout
-    check(lib.dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[{M}x{N}x{K} a{a_layout} b{b_layout} epi {epi}]")
+    check(_GEMM16(A=_p(a2), lda=a2.shape[1], B=_p(w2), ldb=w2.shape[1], C=_p(out), ldc=N, bias=_p(bias), colscale=_p(colscale),
+                  residual=_p(residual), ldr=N, workspace=_p(ws), M=M, N=N, K=K, epi=epi, res_mod=res_mod, row_grp=rg,
+                  row_grp_stride=rgs, row_off=ro, a_layout=a_layout, b_layout=b_layout, rowsum=_p(rowsum), variant=variant),
+          "dkd_gemm_bf16", (M, N, K, a_layout, b_layout, epi))
     return out
 
 
@@ -1002,13 +1004,10 @@ def gemm_bf16_resid16(a, w, bias, residual16, out=None):
     a2 = a.reshape(-1, a.shape[-1])
     M, K = a2.shape
     N = w.shape[0]
-    g = _lib.args("dkd_gemm_bf16_args")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
-    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a2), K, _p(w), K, _p(out), N
-    g.bias, g.residual16, g.ldr = _p(bias), _p(residual16), N
-    g.M, g.N, g.K, g.epi = M, N, K, EPI_BF16
-    check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[{M}x{N}x{K} bf16 residual]")
+    check(_GEMM16(A=_p(a2), lda=K, B=_p(w), ldb=K, C=_p(out), ldc=N, bias=_p(bias), residual16=_p(residual16), ldr=N, M=M, N=N, K=K,
+                  epi=EPI_BF16), "dkd_gemm_bf16", (M, N, K, "bf16 residual"))
     return out
 
 
@@ -1133,12 +1132,9 @@ def add16(a, b):
 
 # ---- eager attention under the 16-bit policy (dkd_hip.h): two batched bf16 matmuls around an fp32 softmax ----------------------
 def _gemm16_batched(a, lda, sA, b, ldb, sB, c, ldc, sC, M, N, K, batch, inner, a_layout=0, b_layout=0, epi=EPI_BF16):
-    g = _lib.args("dkd_gemm_bf16_args")
-    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _p(a), lda, _p(b), ldb, _p(c), ldc
-    g.M, g.N, g.K, g.epi, g.a_layout, g.b_layout = M, N, K, epi, a_layout, b_layout
-    g.batch, g.batch_inner = batch, inner
-    (g.sAo, g.sAi), (g.sBo, g.sBi), (g.sCo, g.sCi) = sA, sB, sC
-    check(_lib.binding().dkd_gemm_bf16(_lib.ref(g), _stream()), f"dkd_gemm_bf16[batched {batch} x {M}x{N}x{K} a{a_layout} b{b_layout}]")
+    check(_GEMM16(A=_p(a), lda=lda, B=_p(b), ldb=ldb, C=_p(c), ldc=ldc, M=M, N=N, K=K, epi=epi, a_layout=a_layout, b_layout=b_layout,
+                  batch=batch, batch_inner=inner, sAo=sA[0], sAi=sA[1], sBo=sB[0], sBi=sB[1], sCo=sC[0], sCi=sC[1]),
+          "dkd_gemm_bf16", ("batched", batch, M, N, K, a_layout, b_layout))
 
 
 def _chk16v(t, name, ld):

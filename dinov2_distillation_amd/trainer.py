@@ -71,6 +71,10 @@ class DistillationStepper:
         if batch.data_ptr() != self.static_batch.data_ptr():
             self.static_batch.copy_(batch, non_blocking=True)
         self.graph.replay()
+        # the replayed optimiser kernel advanced the step counter on the device (optim._hyper[:, 5], captured): keep the host-side
+        # counters that optimizer.state_dict() exports in step, or a checkpoint taken after N replays resumes N steps short
+        self.optimizer._steps += 1
+        self.optimizer._step_t += 1.0
         ops.WEIGHT_EPOCH += 1  # the replayed optimiser kernel rewrote the parameters: cached 16-bit copies (functional16) are stale
         self.step_idx += 1
         return self.static_loss

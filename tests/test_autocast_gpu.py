@@ -428,15 +428,17 @@ def test_autocast_convnext_layer_by_layer_on_the_same_input():
     print(f"layer by layer: worst distance from torch.autocast on the same input {worst:.2e}")
 
 
-@pytest.mark.parametrize("stream16", [True, False])
-def test_autocast_convnext_block_vs_autocast_oracle(stream16):
-    """ONE block, where the two implementations' roundings are still strongly correlated: output, input gradient and every
-    parameter gradient against torch.autocast on the oracle's block, for a 16-bit residual stream (stages 1-3) and an fp32 one
-    (stage 0)"""
+@pytest.mark.parametrize("stream16,C,H", [(True, 192, 28), (False, 192, 28), (False, 96, 14), (True, 384, 14), (True, 768, 7)])
+def test_autocast_convnext_block_vs_autocast_oracle(stream16, C, H):
+    """ONE block fed the ORACLE'S OWN input (teacher forcing), where the two implementations' roundings are still strongly
+    correlated: output, input gradient and every parameter gradient against torch.autocast on the oracle's block, for a 16-bit
+    residual stream (stages 1-3) and an fp32 one (stage 0), at every stage's width incl. res5's 768.  These are the bounds
+    that discriminate: 0.1 / 0.25 of the distance between the policy and fp32 - an fp32 implementation sits at 1.0 of it
+    (and is asserted to be farther from us than the policy's oracle is); the whole-network comparisons decorrelate and cannot."""
     from oracle import convnext_oracle as co
     from dinov2_distillation_amd.models.convnext import Block
-    C, B, H = 192, 4, 28
-    g = torch.Generator().manual_seed(31 + stream16)
+    B = 4
+    g = torch.Generator().manual_seed(31 + stream16 + C)
     p = {k[len("stages.0.0."):]: v for k, v in co.init_convnext_params([1, 0, 0, 0], [C, C, C, C], seed=5).items() if k.startswith("stages.0.0.")}
     for k, v in p.items():
         if "grn" in k:
@@ -475,12 +477,14 @@ def test_autocast_convnext_block_vs_autocast_oracle(stream16):
     # compare the branch (what the block adds to its input): the residual itself is common to all three
     br = lambda o, xi: o.float().cpu() - xi.detach().float().cpu()
     e, noise = rel(br(out.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2)), br(o16, x16)), rel(br(o16, x16), br(o32, x32))
-    print(f"block branch: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
-    assert noise > 1e-3 and e < 0.1 * noise
+    e32 = rel(br(out.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2)), br(o32, x32))
+    print(f"block branch: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}; ours vs fp32 {e32:.2e}")
+    assert noise > 1e-3 and e < 0.1 * noise and e < e32
     (out.float() * ct.permute(0, 2, 3, 1).cuda()).sum().backward()
     e, noise = rel(xin.grad.permute(0, 3, 1, 2), x16.grad), rel(x16.grad, x32.grad)
-    print(f"block dx: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
-    assert xin.grad.dtype == x16.grad.dtype and e < 0.25 * noise
+    e32 = rel(xin.grad.permute(0, 3, 1, 2), x32.grad)
+    print(f"block dx: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}; ours vs fp32 {e32:.2e}")
+    assert xin.grad.dtype == x16.grad.dtype and e < 0.25 * noise and e < e32
     bad = []
     for k, v in blk.named_parameters():
         e, noise = rel(v.grad, q16[k].grad), rel(q16[k].grad, q32[k].grad)

@@ -132,6 +132,27 @@ def test_config1_mixed_precision_step_vs_autocast_oracle():
         e16, o = rel_l2(flat(ours, names), flat(g16, names)), rel_l2(flat(g16, names), flat(g32, names))
         print(f"configs[1] mixed precision: {tag} gradient relL2: ours vs autocast oracle {e16:.2e}; autocast oracle vs fp32 oracle {o:.2e}")
         assert e16 <= max(3e-3, 1.3 * o), (tag, e16, o)   # (sqrt(2) o: two independent realisations of one rounding policy)
+    # The bound above alone would let an fp32 implementation through (it sits at 1.0 o).  What it cannot do: move when the policy
+    # is switched on.  The SAME module in fp32 must differ from its mixed-precision run by about the distance the oracle's two
+    # runs differ (the policy is really applied, end to end), and agree with the fp32 oracle to fp32 accuracy.
+    mod32, _ = _build("dinov2_vits14", "convnext_tiny", 224, (16, 24), seed=1)
+    mod32.load_state_dict(mod.state_dict())
+    mod32.cuda().train()
+    loss32 = mod32.training_step(x.cuda(), 0)
+    loss32.backward()
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    gs_f, gl_f = module_grads(mod32)
+    for tag, ours, f32, g16, g32 in (("student", gs, gs_f, gs16, gs32), ("projectors", gl, gl_f, gl16, gl32)):
+        gmax = max(v.abs().max().item() for v in g16.values())
+        names = [k for k in sorted(g16) if g16[k].abs().max().item() >= 1e-6 * gmax]
+        moved, o = rel_l2(flat(ours, names), flat(f32, names)), rel_l2(flat(g16, names), flat(g32, names))
+        exact = rel_l2(flat(f32, names), flat(g32, names))
+        print(f"configs[1] mixed precision: {tag} gradient: policy run vs fp32 run of the same module {moved:.2e} (oracle: {o:.2e}); "
+              f"fp32 run vs fp32 oracle {exact:.2e}")
+        assert moved >= 0.5 * o and exact <= 0.2 * o, (tag, moved, o, exact)
+    l16, l32 = float(loss.detach()), float(loss32.detach())
+    assert l16 != l32 and abs(l32 - float(ref32["loss"])) <= 1e-3 * abs(float(ref32["loss"]))
 
 
 # ---- configs[2]: dinov2_vitb14 -> resnet_50, 224x224 -------------------------------------------------------------------------

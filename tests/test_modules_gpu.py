@@ -1248,6 +1248,13 @@ def test_hipgraph_replay_of_the_step_matches_eager():
                 if use_graph:
                     st.optimizer.sync_hyper()
             losses.append(float((st.step_graph(x) if use_graph else st.step(x)).detach()))
+        if use_graph:
+            # the exported optimiser state counts the replays too (it advanced only in the host-side step(), so a
+            # checkpoint taken after N replays resumed N steps short): 3 host-side steps inside capture() (two warm-ups and the
+            # captured body) + one per replay; the device counter was zeroed above and counts the replays alone
+            sd = st.optimizer.state_dict()
+            assert float(sd["state"][0]["step"]) == 3 + len(xs) and st.optimizer._steps == 3 + len(xs)
+            assert float(st.optimizer._hyper[0, 5]) == len(xs)
         return losses, st.optimizer.flat_p.clone()
 
     le, pe = run(False)
