@@ -26,7 +26,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
-PMC_FILE = "r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
+
+
+def _latest(pattern):
+    """newest committed profile summary of that kind (profiles/rNN_...)"""
+    for rnd in ("r03", "r02", "r01"):
+        if os.path.exists(os.path.join(ROOT, "profiles", rnd + pattern)):
+            return rnd + pattern
+    return "r01" + pattern
+
+
+PMC_FILE = _latest("_pmc_traffic.json")
 
 
 class GemmProfiler:
@@ -61,6 +72,35 @@ class GemmProfiler:
         tot_fl = sum(f for _, _, f, _ in self.records)
         n = len(self.records)
         return n, tot_ms, tot_fl
+
+
+class Gemm16Profiler:
+    """the same for dkd_gemm_bf16 (the mixed-precision alternates): un-batched launches only (the per-head attention products go
+    through the batched entry and are not counted)"""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def wrap(self, ops):
+        inner = ops.gemm_bf16
+
+        def gemm_bf16(a, w, **kw):
+            if not self.enabled:
+                return inner(a, w, **kw)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = inner(a, w, **kw)
+            e1.record(s)
+            al, bl = kw.get("a_layout", 0), kw.get("b_layout", 0)
+            a2, w2 = a.reshape(-1, a.shape[-1]), w.reshape(-1, w.shape[-1])
+            M, K = (a2.shape[0], a2.shape[1]) if al == 0 else (a2.shape[1], a2.shape[0])
+            N = w2.shape[0] if bl == 0 else w2.shape[1]
+            self.records.append((e0, e1, 2.0 * M * N * K))
+            return out
+
+        ops.gemm_bf16 = gemm_bf16
 
 
 class HbmProfiler:
@@ -113,7 +153,7 @@ class HbmProfiler:
         return out
 
 
-STATS_FILE = "r02_bench_bs64_serial_kernel_stats.csv"
+STATS_FILE = _latest("_bench_bs64_serial_kernel_stats.csv")
 
 
 def profiled_kernel_us(prefix):
@@ -235,10 +275,11 @@ def main():
 
     from dinov2_distillation_amd import ops
     from dinov2_distillation_amd.trainer import DistillationStepper
-    prof, hprof = GemmProfiler(), HbmProfiler()
+    prof, hprof, prof16 = GemmProfiler(), HbmProfiler(), Gemm16Profiler()
     if not args.no_roofline:
         prof.wrap(ops)
         hprof.wrap(ops)
+        prof16.wrap(ops)
     t_start = time.perf_counter()
     stepper = DistillationStepper(device=f"cuda:{local}")
     gen = torch.Generator().manual_seed(1234 + rank)
@@ -295,7 +336,7 @@ def main():
         fl_s = sum(f for _, _, f, _ in recs)
         serial = round(fl_s / (ms_s * 1e-3) / 1e12, 2) if ms_s > 0 else None
         serial_avg_us = round(ms_s * 1e3 / max(len(recs), 1), 2)
-    # Extra, clearly separated measurements: the same step with the opt-in GEMM arithmetic modes.  They never
+    # Extra, clearly separated measurements: the same step with the opt-in GEMM arithmetic modes (NOTES.md).  They never
     # feed `value`.
     alts = {}
     if not args.no_alt and ops.GEMM_PRECISION == ops.PREC_F32:
@@ -375,6 +416,32 @@ def main():
                               "GRN statistics / loss tails / residual streams that autocast keeps fp32 in fp32, fp32 master weights and "
                               "optimiser; every node tested against torch.autocast on the oracle (tests/test_autocast_gpu.py)",
             "value": round(args.batch * world * args.steps / dta, 2), "unit": "images/s", "ms_per_step": round(dta / args.steps * 1e3, 3)}
+        if not args.no_roofline:
+            # the dominant kernel of THIS mode: the bf16 ring GEMM (csrc/gemm_bf16_ring.hip), every un-batched launch of two more
+            # steps run on one stream, HIP events per launch on the launch stream - as for the fp32 figure below
+            from dinov2_distillation_amd.train import distillation_module as dm
+            async_was, side_was, chain_was = ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS
+            ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS = False, False, False
+            prof16.enabled = True
+            for _ in range(2):
+                st16.step(batch)
+            sync()
+            prof16.enabled = False
+            ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS = async_was, side_was, chain_was
+            ms16 = sum(e0.elapsed_time(e1) for e0, e1, _ in prof16.records)
+            fl16 = sum(f for _, _, f in prof16.records)
+            n16 = max(len(prof16.records), 1)
+            ach16 = fl16 / (ms16 * 1e-3) / 1e12 if ms16 > 0 else 0.0
+            alts["alt_bf16_autocast_step"]["roofline"] = {
+                "bound": "mfma", "achieved": round(ach16, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach16 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_bf16_ring_kernel (bf16 MFMA 32x32x16, LDS-DMA ring), every un-batched dkd_gemm_bf16 launch of the step "
+                          "incl. the K-slab folds of the weight gradients",
+                "launches": n16 // 2, "avg_launch_us": round(ms16 * 1e3 / n16, 2), "gemm_flop_per_step": round(fl16 / 2),
+                "gemm_ms_per_step": round(ms16 / 2, 3),
+                "note": "small GEMMs (7-19 GFLOP each, 2-3x their HBM floor of 5-16 us): per-CU LDS-fill rate and tile quantisation "
+                        "bound them well below the MFMA peak; the vendor library sits at 0.15-0.3 on the same shapes "
+                        "(scripts/bench_gemm_bf16_vendor.py)"}
         del st16
     note(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if rank != 0:

@@ -24,7 +24,7 @@ ARCH = "gfx950"
 # issue-slot anti-lever anyway (MI355X_MICROARCH.md, cycle constants), and the step time is unchanged without it (44.0 ms).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INC, "-I" + CSRC, "-Wall", "-Wno-unused-function",
          "-fno-slp-vectorize"]
-# per-file code generation switches (measured)
+# per-file code generation switches (measured, see NOTES.md section 3)
 # augment.hip reproduces Pillow's float / double arithmetic operation by operation: no fused multiply-add contraction there
 # (HIP's __fmul_rn / __dadd_rn are plain operators to the compiler, so a * b + c would still become one fma)
 FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "augment.hip": ["-ffp-contract=off"]}

@@ -2,7 +2,7 @@
 real shapes with a reduced batch, plus size-independent properties at the configs' full batch sizes.
 
 Per config: every logged scalar within 1e-3 (north star) of the fp32 oracle; gradients judged with the fp64 run of the
-same oracle as arbiter, because ReLU kinks and small-batch BatchNorm make the fp32 CPU result
+same oracle as arbiter, because (NOTES.md section 4) ReLU kinks and small-batch BatchNorm make the fp32 CPU result
 itself only "close to" the exact gradient: err(ours, fp64) <= 2 * err(cpu fp32, fp64) + 1e-3 in global relative L2, for
 the student gradient and for the projector gradient separately.  Shapes follow /root/reference/train.py:103-119 (teacher
 dims, n_patches = crop // 14, heads must divide the teacher width) and models/backbones/swin.py:696-727.

@@ -285,7 +285,7 @@ def test_full_step_config2_vs_oracle():
     # Gradient parity.  The projectors contain ReLU kinks (BN->ReLU, FFN ReLU: losses/scalekd.py:201,448).  With ~2M
     # pre-activations per projector a handful lie within fp32 rounding of 0; whichever side of 0 an implementation
     # lands on switches that element's gradient on or off.  The CPU oracle ITSELF jumps by up to 6e-2 (max-norm, on
-    # ffn.layers.0.0.weight) when its input is scaled by (1 + 1e-6) (measured, see DESIGN.md "ReLU kinks"), so a
+    # ffn.layers.0.0.weight) when its input is scaled by (1 + 1e-6) (measured, see NOTES.md section 4 "ReLU kinks"), so a
     # per-element 1e-3 bound is not a property the reference has.  Kink-robust statistics are asserted instead:
     #   * relative L2 error of the CONCATENATED student gradient and of the concatenated projector gradient <= 1e-3 x few
     #   * every tensor: relative L2 error <= 2e-2 (bounded, no O(1) mistakes anywhere)
@@ -464,7 +464,7 @@ def test_presnet_against_reference_golden(golden_dir, depth):
     f64 = po.forward(p64, g["in/x"].double(), BLOCKS[depth], bottleneck=depth >= 50)
     sum((f64[k] * g["in/cotangent_" + k].double()).sum() for k in ("res4", "res5")).backward()
     sd = dict(net.named_parameters())
-    # Round-2 diagnosis of the far-end drift (tests/diag/diag_colreduce_accuracy.py): every column reduction of
+    # Round-2 diagnosis of the far-end drift (tests/diag/diag_colreduce_accuracy.py, NOTES.md section 8.3): every column reduction of
     # this backward pass was compared with an fp64 sum of the SAME device input - the kernel was never further off than torch's
     # own fp32 sum (6.5e-7 vs 6.1e-7 of the result's magnitude; 4.6e-7 since the sums are Kahan-compensated), so the reductions
     # are not the cause.  The far-end tensors are chaotic: BatchNorm over 2 images amplifies ANY fp32 rounding difference, and
