@@ -200,12 +200,12 @@ class PackedMetrics:
 _METRIC_STREAMS = {}
 
 
-def allreduce_metrics_async(values, process_group=None, side=None):
+def allreduce_metrics_async(values, process_group=None, side=None, force=False):
     """C5 (train/distillation_module.py:353-358 logs every scalar with sync_dist=True: 12 collectives per step): pack the scalars,
     average them over the ranks with one collective on ``side`` (default: a stream of this module's own).  Returns PackedMetrics,
     or None when there is nothing to exchange (no process group / one rank)."""
-    if not values or not dist.is_initialized() or dist.get_world_size(process_group) == 1:
-        return None
+    if not values or not dist.is_initialized() or (dist.get_world_size(process_group) == 1 and not force):
+        return None  # (force: run the collective in a one-rank group too - lets a one-GPU box drive the RCCL path)
     keys = sorted(values)
     first = next(v for v in values.values() if torch.is_tensor(v))
     vec = torch.stack([(values[k].detach().float() if torch.is_tensor(values[k])

@@ -85,7 +85,41 @@ def test_every_kernel_is_bit_reproducible_beside_the_bf16_teacher():
         "attention fwd hd64": att,
         "gemm f32 NT / NN / TN": lambda: [ops.gemm(rows4, w1), ops.gemm(h4, w1, b_layout=1), ops.gemm(h4, rows4, a_layout=1, b_layout=1)],
         "gemm f32 1568x1024x4096 + residual": lambda: [ops.gemm(h4, w2, bias=b1k, residual=rows4)],
+        # ---- the kernels of the mixed-precision step (bf16 activations in HBM; ADVICE r02: they were not covered) ------------
+        "gemm bf16 ring NT / NN / TN(+rowsum) / gelu / f32 resid": lambda: [
+            ops.gemm_bf16(rows16, w1h, bias=b4h), ops.gemm_bf16(h16, w1h, b_layout=1),
+            ops.gemm_bf16(h16, rows16, a_layout=1, b_layout=1, epi=ops.EPI_F32, rowsum=rs_buf), rs_buf,
+            ops.gemm_bf16(rows16, w1h, epi=ops.EPI_BF16_GELU, bias=b4h),
+            ops.gemm_bf16(h16, w2h, epi=ops.EPI_F32_RESID, bias=b1h, colscale=g1k, residual=rows4)],
+        "gemm bf16 register-staged (ragged K)": lambda: [ops.gemm_bf16(rag16, wrag)],
+        "cast bf16 / f32, round, add16, gelu16, relu_bwd16": lambda: [
+            ops.cast_bf16(h4), ops.cast_f32(h16), ops.round_bf16_(h4.clone()), ops.add16(h16, h16), ops.gelu16(h16), ops.gelu16(h16, h16),
+            ops.relu_bwd16(h16, h16)],
+        "layernorm io fwd / bwd (bf16, cf16)": lambda: list(ops.layernorm_fwd_io(rows16, g1k, b1k, 1e-6, torch.bfloat16)) +
+            list(ops.layernorm_fwd_io(rows16, g1k, b1k, 1e-6, torch.float32, cf16=True)) +
+            list(ops.layernorm_bwd_io(rows16, rows16, mu, rs, g1k, torch.bfloat16)),
+        "dwconv7 io fwd / dgrad / wgrad (bf16)": lambda: [
+            ops.dwconv7_io(x4h, wt7, b1k), ops.dwconv7_io(x4h, wt7, None, add=x4h, flip=True),
+            ops.dwconv7_wgrad_cw(x4h, x4h, round_out=True)],
+        "colreduce16 / grn fwd16 / grn bwd16": lambda: [
+            ops.colreduce16(h16, ops.RED_SUM, round_out=True), ops.grn_fwd16(h16, g4k, b4k, B)[0]] +
+            list(ops.grn_gelu_bwd16(h16, h16, grn16_stats, g4k, B)),
+        "attention16 fwd / bwd": lambda: list(ops.attention16_forward(q16, q16, q16, B, 16, 256, 256, 24, 24 ** -0.5, 5.0)) +
+            list(ops.attention16_backward(q16, q16, q16, q16, a16[1], a16[2], B, 16, 256, 256, 24, 24 ** -0.5, 5.0)),
+        "dct16 step / swiglu bf16": lambda: [ops.dct16_step(s16.view(B, 16, 16, 1536), dctm, 0), ops.swiglu_bf16(u16),
+                                             ops.swiglu_bf16_bwd(h16, u16)],
+        "prep_batch / colreduce_tr / grn_bwd_stats": lambda: [ops.colreduce_tr(part49, 49, round_out=True)],
     }
+    b16 = lambda t: t.bfloat16()
+    rows16, h16, x4h = b16(rows4), b16(h4), b16(x4)
+    w1h, w2h, b4h, b1h = b16(r(4096, 1024) * 0.02), b16(r(1024, 4096) * 0.02), b16(r(4096)), b16(r(1024))
+    rs_buf = torch.empty(4096, device=dev)
+    rag16, wrag = b16(r(1000, 592)), b16(r(136, 592) * 0.05)
+    grn16_stats = ops.grn_fwd16(h16, g4k, b4k, B)[1]
+    q16 = b16(r(B * 256, 384))
+    a16 = ops.attention16_forward(q16, q16, q16, B, 16, 256, 256, 24, 24 ** -0.5, 5.0)
+    s16, u16, dctm = b16(s), b16(u12), r(16, 16)
+    part49 = r(448, 49 * 1024)
     dy16, wt7_128, col3 = r(B, 16, 16, 1024), r(49, 128), r(B * 196, 9 * 512)
     ap_y = ops.avgpool2(x4)
     w1, w2 = r(4096, 1024) * 0.02, r(1024, 4096) * 0.02

@@ -1054,6 +1054,13 @@ def _rccl_one_rank_worker(port, q):
     launched = min(launched, launched16)
     t = torch.ones(4, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the packed metric all-reduce (one collective per step, issued on a side stream while the main stream goes on) through RCCL
+    from dinov2_distillation_amd.ddp import allreduce_metrics_async
+    vals = {"b": torch.tensor(2.5, device="cuda"), "a": torch.tensor(-1.0, device="cuda", requires_grad=True) * 3.0}
+    packed = allreduce_metrics_async(vals, force=True)
+    busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")  # main-stream work behind it
+    got = {k: float(v) for k, v in packed.values().items()}
+    assert got == {"a": -3.0, "b": 2.5} and bool(torch.isfinite(busy).all()), got
     dist.barrier()
     q.put((err, launched, len(st.reducer.buckets), float(t.sum())))
     dist.destroy_process_group()
