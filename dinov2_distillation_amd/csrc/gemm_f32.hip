@@ -1154,6 +1154,8 @@ static void cfg_tile(int cfg, int* bm, int* bn) {
         case CFG_128x96_4W: *bm = 128; *bn = 96; break;
         case 43: case 55: *bm = 64; *bn = 96; break;
         case 56: *bm = 96; *bn = 64; break;
+        case 102: case 104: *bm = 128; *bn = 64; break;
+        case 103: *bm = 64; *bn = 128; break;
         case 44: case 100: case 101: case 111: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
         default: *bm = 64; *bn = 128; break;  // 3, 5
@@ -1270,6 +1272,11 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 100: return launch_dma<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, LDS-DMA staging, BK 16
         case 101: return launch_dma<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, BK 32
         case 111: return launch_dma<2, 2, 2, 2, 32, 0, true>(g, epi, splits, kchunk, st);  // ... with the DMA issue spread over the k-blocks
+#ifdef DKD_TUNING  // VERDICT r02 item 3a, re-measured in round 3 (scripts/tune_v2.py 0,102,103,104): one B tile under two M-tiles
+        case 102: return launch_dma<2, 2, 4, 2, 32>(g, epi, splits, kchunk, st);     // 128 x 64, 4 waves of 64 x 32
+        case 103: return launch_dma<2, 2, 2, 4, 32>(g, epi, splits, kchunk, st);     // 64 x 128, 4 waves of 32 x 64
+        case 104: return launch_dma<4, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 128 x 64, 8 waves of 32 x 32
+#endif
 #ifdef DKD_TUNING  // knock-outs of variant 101: timing experiments whose RESULTS ARE WRONG - never part of the shipped library
         case 130: return launch_dma<2, 2, 2, 2, 32, 2>(g, epi, splits, kchunk, st);
         case 131: return launch_dma<2, 2, 2, 2, 32, 4>(g, epi, splits, kchunk, st);

@@ -291,8 +291,8 @@ class AttentionProjector16Fn(Function):
     @staticmethod
     def forward(ctx, x, ext_query, self_query, bn_state, num_heads, softmax_scale, training, window, *params):
         (pos_embed, wc, bc, bn_w, bn_b, wq, bq, wk, bk, wv, bv, wp, bp, w1, b1, w2, b2, n1w, n1b, n2w, n2b) = params
-        if window[0] * window[1] != 1:
-            raise NotImplementedError("windowed projector attention has no mixed-precision path yet")
+        wh, ww = window
+        nwin = wh * ww
         from .functional import _bn_fwd_stats
         x = _c(x)
         B, Ph, Pw, Cs = x.shape
@@ -313,16 +313,29 @@ class AttentionProjector16Fn(Function):
         k16 = ops.gemm_bf16(tok16, wk16, bias=_w16(bk))
         v16 = ops.gemm_bf16(tok16, wv16, bias=_w16(bv))
         c1 = hd ** -0.5
-        o16, S, P = ops.attention16_forward(q16, k16, v16, B, num_heads, N, N, hd, c1, float(softmax_scale), q_shared=shared)
+        if nwin > 1:
+            # losses/scalekd.py:303-306,313-314: q / k / v window-major (pure data movement: a bf16 [.., D] tensor is an fp32
+            # [.., D / 2] tensor to the permute kernel), attention inside each window, the result only VIEWED back
+            if (N // nwin) % 8:
+                raise NotImplementedError("windowed attention under the policy needs windows of a multiple of 8 tokens")
+            wperm = lambda t, inv=False: ops.window_permute(t.reshape(B, N, D).view(F32), Ph, Pw, wh, ww, inverse=inv).view(BF16).reshape(M, D)
+            qfull = q16.reshape(1, N, D).expand(B, N, D).contiguous() if shared else q16
+            q16w, k16w, v16w = wperm(qfull), wperm(k16), wperm(v16)
+            o16, S, P = ops.attention16_forward(q16w, k16w, v16w, B * nwin, num_heads, N // nwin, N // nwin, hd, c1, float(softmax_scale))
+            att = (q16w, k16w, v16w)
+        else:
+            o16, S, P = ops.attention16_forward(q16, k16, v16, B, num_heads, N, N, hd, c1, float(softmax_scale), q_shared=shared)
+            att = (q16, k16, v16)
         y = ops.gemm_bf16(o16, wp16, epi=ops.EPI_F32_RESID, bias=_w16(bp), residual=tok)      # tok + rnd(proj)
         zn, m1, r1 = ops.layernorm_fwd(y, n1w, n1b, 1e-5)
         zn16 = ops.cast_bf16(zn)
         f1 = ops.gemm_bf16(zn16, w1h, epi=ops.EPI_BF16_RELU, bias=_w16(b1))
         f2 = ops.gemm_bf16(f1, w2h, epi=ops.EPI_F32_RESID, bias=_w16(b2), residual=zn)        # zn + rnd(ffn)
         out, m2, r2 = ops.layernorm_fwd(f2, n2w, n2b, 1e-5)
-        ctx.save_for_backward(x16, z, mean, rstd, tok16, qin16, q16, k16, v16, o16, S, P, y, m1, r1, zn16, f1, f2, m2, r2,
+        ctx.save_for_backward(x16, z, mean, rstd, tok16, qin16, *att, o16, S, P, y, m1, r1, zn16, f1, f2, m2, r2,
                               wc16, wq16, wk16, wv16, wp16, w1h, w2h, bn_w, bn_b, n1w, n2w)
         ctx.meta = (B, N, D, Cs, num_heads, hd, c1, float(softmax_scale), shared, tuple(pos_embed.shape), tuple(wc.shape), tuple(x.shape))
+        ctx.window = (wh, ww)
         ctx.training = training
         ctx.params = params
         return out.reshape(B, N, D)
@@ -348,7 +361,16 @@ class AttentionProjector16Fn(Function):
         dyh = ops.cast_bf16(dy)                                                         # gradient of the 16-bit proj output
         do16 = ops.gemm_bf16(dyh, wp16, b_layout=1)
         dwp, dbp = wgrad16(dyh, o16, P_wp, P_bp)
-        dq16, dk16, dv16 = ops.attention16_backward(do16, q16, k16, v16, S, P, B, H, N, N, hd, c1, c2, q_shared=shared)
+        wh, ww = ctx.window
+        nwin = wh * ww
+        if nwin > 1:
+            Ph, Pw = xshape[1], xshape[2]
+            T = N // nwin
+            dq16, dk16, dv16 = ops.attention16_backward(do16, q16, k16, v16, S, P, B * nwin, H, T, T, hd, c1, c2)
+            unperm = lambda t: ops.window_permute(t.reshape(B, N, D).view(F32), Ph, Pw, wh, ww, inverse=True).view(BF16).reshape(M, D)
+            dq16, dk16, dv16 = unperm(dq16), unperm(dk16), unperm(dv16)
+        else:
+            dq16, dk16, dv16 = ops.attention16_backward(do16, q16, k16, v16, S, P, B, H, N, N, hd, c1, c2, q_shared=shared)
         dwk, dbk = wgrad16(dk16, tok16, P_wk, P_bk)
         dwv, dbv = wgrad16(dv16, tok16, P_wv, P_bv)
         # tok feeds the k and the v Linear through two separate casts: their 16-bit input gradients are added in fp32

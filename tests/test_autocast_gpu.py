@@ -549,8 +549,9 @@ def test_attention_under_the_16_bit_policy_vs_torch_autocast(H, hd, c2):
     assert torch.equal(ops.scale16(qd, c1), (qd.float() * c1).bfloat16())
 
 
-@pytest.mark.parametrize("self_query,cs,heads", [(True, 768, 24), (False, 384, 16)])
-def test_projector_under_the_policy_vs_torch_autocast(self_query, cs, heads):
+@pytest.mark.parametrize("self_query,cs,heads,window", [(True, 768, 24, (1, 1)), (False, 384, 16, (1, 1)), (True, 384, 16, (2, 2)),
+                                                         (False, 768, 24, (2, 2))])
+def test_projector_under_the_policy_vs_torch_autocast(self_query, cs, heads, window):
     """The ScaleKD projector (losses/scalekd.py:228-245: 1x1 conv + BatchNorm + ReLU + position table, cross attention with
     softmax_scale 5, LayerNorm, FFN, LayerNorm) under the autocast policy, forward and every gradient, against torch.autocast on
     the oracle's projector (softmax and layer_norm forced to fp32 as CUDA's policy does).  Yardstick: the distance of that oracle
@@ -559,7 +560,8 @@ def test_projector_under_the_policy_vs_torch_autocast(self_query, cs, heads):
     from dinov2_distillation_amd.losses.scalekd import AttentionProjector
     D, P, B = 384, 16, 4
     g = torch.Generator().manual_seed(cs + heads)
-    m = AttentionProjector(cs, D, (P, P), D, self_query=self_query, softmax_scale=5.0, num_heads=heads)
+    # window (2, 2): losses/scalekd.py:303-306,313-314 - q / k / v window-major, attention per window, the result only viewed back
+    m = AttentionProjector(cs, D, (P, P), D, self_query=self_query, softmax_scale=5.0, num_heads=heads, window_shapes=window)
     with torch.no_grad():
         for k, v in m.named_parameters():
             if k.endswith("bias"):
@@ -578,9 +580,9 @@ def test_projector_under_the_policy_vs_torch_autocast(self_query, cs, heads):
         qr = None if query is None else query.clone().requires_grad_(True)
         if policy:
             with torch.autocast("cpu", dtype=torch.bfloat16):
-                out = so.attention_projector(p, "", xr, qr, (P, P), heads, 5.0, policy=True)
+                out = so.attention_projector(p, "", xr, qr, (P, P), heads, 5.0, window_shapes=window, policy=True)
         else:
-            out = so.attention_projector(p, "", xr, qr, (P, P), heads, 5.0)
+            out = so.attention_projector(p, "", xr, qr, (P, P), heads, 5.0, window_shapes=window)
         assert out.dtype == torch.float32
         (out * ct).sum().backward()
         return p, xr, qr, out
