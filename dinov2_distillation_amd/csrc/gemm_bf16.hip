@@ -312,6 +312,22 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
     if (!dkd_aligned16(g->A) || !dkd_aligned16(g->B) || !dkd_aligned16(g->C)) return DKD_ERR_ALIGN;
     if (g->residual && ((g->ldr & 3) || !dkd_aligned16(g->residual))) return DKD_ERR_ALIGN;
     if (g->colscale && !dkd_aligned16(g->colscale)) return DKD_ERR_ALIGN;
+    if (g->epi == DKD_BF16_EPI_F32_RAW) {
+        // raw fp32 sums: the K-slab partial path with ONE slab whose "workspace" is the output itself
+        if (g->bias || g->residual || g->residual16 || g->colscale || g->row_grp || g->ldc != g->N || g->batch > 1 || g->rowsum)
+            return DKD_ERR_BAD_ARG;
+        dkd_gemm_bf16_args r = *g;
+        r.workspace = reinterpret_cast<float*>(g->C);
+        const int cfg_raw = dkd_bf16_ring_ok(&r, r.K, 64) ? 20 : (dkd_bf16_ring_ok(&r, r.K, 32) ? 16 : 1);
+        if (cfg_raw >= 10) return dkd_bf16_ring_launch(&r, DKD_BF16_EPI_PARTIAL, cfg_raw - 10, 1, r.K, false, (hipStream_t)stream);
+        const dim3 grid(dkd_cdiv(r.M, BM) * dkd_cdiv(r.N, BN), 1, 1), block(NT);
+        if (r.a_layout == 0 && r.b_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<DKD_BF16_EPI_PARTIAL, true, true>), grid, block, 0, (hipStream_t)stream, r, r.K);
+        else if (r.a_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<DKD_BF16_EPI_PARTIAL, true, false>), grid, block, 0, (hipStream_t)stream, r, r.K);
+        else if (r.b_layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<DKD_BF16_EPI_PARTIAL, false, true>), grid, block, 0, (hipStream_t)stream, r, r.K);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<DKD_BF16_EPI_PARTIAL, false, false>), grid, block, 0, (hipStream_t)stream, r, r.K);
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
     const bool f32_out = g->epi == DKD_BF16_EPI_F32_RESID || g->epi == DKD_BF16_EPI_F32;
     if (!f32_out && (g->residual || g->colscale)) return DKD_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;

@@ -481,5 +481,169 @@ class DctRoundtrip16Fn(Function):
         return d.reshape(B, N, C), None, None
 
 
+# =====================================================================================================================
+# conv + BatchNorm + ReLU students (STDC, ResNet) under the policy.  What torch autocast makes of them: conv2d (dense and depthwise)
+# casts its operands to 16 bit and returns a 16-bit tensor; batch_norm, relu, max / avg pooling, the residual add and cat run
+# in the dtype of their 16-bit input - BatchNorm computes its statistics and the affine in fp32 and rounds the result
+# (measured on the CPU policy: bit-equal to rnd(fp32 BatchNorm of the 16-bit values)), the add and the average pool round
+# their fp32 result once.  Between the GEMMs these activations are kept as fp32 tensors HOLDING the 16-bit values (rounded where
+# the policy rounds) - the same representation the projector path uses; only the GEMM operands are bf16 in HBM.  (The
+# bandwidth half of the policy - bf16 storage for the BatchNorm / pooling passes - is not built for these families.)
+def _round16(dy):
+    """the gradient of a 16-bit tensor as a fresh fp32 tensor holding 16-bit values (never in place: autograd may hand the same
+    buffer to another consumer)"""
+    return ops.round_bf16_(_c(dy).clone())
+
+
+class RoundGradFn(Function):
+    """identity on a 16-bit-valued feature that leaves the backbone as fp32; its gradient is rounded to 16 bit on the way back
+    (the gradient of a 16-bit tensor is a 16-bit tensor)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.round_bf16_(_c(dy).clone())
+
+
+class ConvBNAct16Fn(Function):
+    """conv (k in {1, 3, 7}, stride, pad k // 2, no bias) -> train-mode BatchNorm2d -> optional ReLU under the policy
+    (models/backbones/stdc.py:8-24 ``ConvX``, resnet.py:258-289 ``Conv2d`` with norm).  x: fp32 NHWC holding 16-bit values, or the
+    fp32 NCHW image (src_nchw; the conv's cast rounds it)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bn_w, bn_b, bn_state, k, stride, relu, training, src_nchw):
+        from .functional import _bn_fwd_stats
+        x = _c(x)
+        O, pad = w.shape[0], k // 2
+        if src_nchw:
+            B, Cin, H, W = x.shape
+            rows = ops.im2col_nchw(x, k, stride, pad)                     # [M, Kp] fp32, columns (c, ky, kx), zero padded to Kp
+            Kp = (rows.shape[1] + 7) // 8 * 8
+            rows16 = ops.cast_bf16(rows, Kp)
+            kk = Cin * k * k
+            w16 = _cached(w, ("conv16 nchw", Kp), lambda: ops.cast_bf16(w.detach().reshape(O, kk), Kp))
+        else:
+            B, H, W, Cin = x.shape
+            rows = x.reshape(-1, Cin) if (k == 1 and stride == 1) else ops.im2col_nhwc(x, k, stride, pad)
+            rows16 = ops.cast_bf16(rows)                                   # exact: the values are 16-bit already
+            w16 = _w16_2d(w, O, Cin) if k == 1 else _prepared(w, "conv16", O, Cin, k * k, 2, (O, k * k * Cin))  # [O][ky][kx][c]
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        z = ops.cast_f32(ops.gemm_bf16(rows16, w16))                      # the conv's 16-bit result
+        mean, rstd = _bn_fwd_stats(z, bn_state, training)
+        y = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, None, relu=int(relu) | 16)   # rnd(bn) -> act
+        ctx.training = training
+        ctx.save_for_backward(rows16, w16, z, mean, rstd, bn_w, bn_b)
+        ctx.meta = (k, stride, pad, int(relu), src_nchw, tuple(x.shape), tuple(w.shape))
+        ctx.params = (w, bn_w, bn_b)
+        return y.reshape(B, Ho, Wo, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows16, w16, z, mean, rstd, bn_w, bn_b = ctx.saved_tensors
+        k, stride, pad, relu, src_nchw, xshape, wshape = ctx.meta
+        O = wshape[0]
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
+        p_w, p_g, p_b = ctx.params
+        o_g, o_b = direct(p_g, p_b)
+        # (the output may have several consumers - a block input feeds conv1 and the shortcut, an STDC branch feeds the next conv
+        # and the concatenation: autograd has added their 16-bit gradients in fp32, the 16-bit tensor's gradient is that sum rounded)
+        dy = _round16(dy)
+        dz, dg, db = ops.bn_bwd(dy.reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu, dgamma_out=o_g, dbeta_out=o_b)
+        dz16 = ops.cast_bf16(dz)                                          # BatchNorm's input gradient is a 16-bit tensor
+        dx = None
+        if src_nchw:
+            kk = xshape[1] * k * k
+            dw, _ = wgrad16(dz16, rows16, p_w, None, transform=lambda t: p_w.grad.view(O, kk).copy_(t[:, :kk]),
+                            reshape=lambda t: t[:, :kk].reshape(wshape))
+        else:
+            B, H, W, Cin = xshape
+            if k == 1:
+                dw, _ = wgrad16(dz16, rows16, p_w, None, reshape=lambda t: t.reshape(wshape))
+            else:
+                dw, _ = wgrad16(dz16, rows16, p_w, None,
+                                transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
+                                reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
+            if ctx.needs_input_grad[0]:
+                if k == 1 and stride == 1:
+                    dx = ops.gemm_bf16(dz16, w16, b_layout=1, epi=ops.EPI_F32).reshape(xshape)
+                else:  # the taps' products stay fp32 until col2im has summed them: ONE rounding, as conv backward does
+                    drows = ops.gemm_bf16(dz16, w16, b_layout=1, epi=ops.EPI_F32_RAW)
+                    dx = ops.round_bf16_(ops.col2im_nhwc(drows, B, H, W, Cin, k, stride, pad))
+        return dx, dw, ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None, None
+
+
+class DepthwiseBN16Fn(Function):
+    """depthwise 3 x 3 stride-s conv (no bias) + train-mode BatchNorm2d under the policy (stdc.py:113-126 ``avd_layer``): the
+    depthwise conv2d is a 16-bit op too (16-bit taps, fp32 accumulation, one rounding), BatchNorm as in ConvBNAct16Fn"""
+
+    @staticmethod
+    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training):
+        from .functional import _bn_fwd_stats
+        x = _c(x)
+        C = x.shape[3]
+        k = w.shape[-1]
+        wt = _prepared(w, ("dwtaps16", k), 1, C, k * k, 1, (k * k, C))       # tap-major, 16-bit values
+        y = ops.round_bf16_(ops.dwconv(x, wt, k, stride))
+        y2 = y.reshape(-1, C)
+        mean, rstd = _bn_fwd_stats(y2, bn_state, training)
+        ctx.training = training
+        out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=16)
+        ctx.save_for_backward(x, wt, y2, mean, rstd, bn_w, bn_b)
+        ctx.meta = (stride, tuple(w.shape), tuple(y.shape))
+        ctx.params = (w, bn_w, bn_b)
+        return out.reshape(y.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wt, y2, mean, rstd, bn_w, bn_b = ctx.saved_tensors
+        stride, wshape, yshape = ctx.meta
+        C = x.shape[3]
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
+        p_w, p_g, p_b = ctx.params
+        o_w, o_g, o_b = direct(p_w, p_g, p_b)
+        dy, dg, db = ops.bn_bwd(_round16(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=0, dgamma_out=o_g, dbeta_out=o_b)
+        dy = ops.round_bf16_(dy).reshape(yshape)
+        k = wshape[-1]
+        dx = ops.round_bf16_(ops.dwconv(dy, wt, k, stride, dgrad_shape=x.shape[1:3])) if ctx.needs_input_grad[0] else None
+        dw = ops.round_bf16_(ops.transpose(ops.dwconv_wgrad(x, dy, k, stride), out=None if o_w is None else o_w.view(C, k * k))).reshape(wshape)
+        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None
+
+
+class AvgPool3_16Fn(Function):
+    """nn.AvgPool2d(3, stride, 1) on a 16-bit tensor: rnd(fp32 average); backward likewise"""
+
+    @staticmethod
+    def forward(ctx, x, stride):
+        x = _c(x)
+        ctx.meta = (stride, tuple(x.shape[1:3]))
+        return ops.round_bf16_(ops.dwconv3(x, None, stride))
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, hw = ctx.meta
+        return ops.round_bf16_(ops.dwconv3(_round16(dy), None, stride, dgrad_shape=hw)), None
+
+
+class AddRelu16Fn(Function):
+    """relu(rnd(a + b)) on 16-bit values: ``out += shortcut; relu_`` (resnet.py:507-511) under the policy"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = ops.round_bf16_(ops.add_relu(_c(a), _c(b)))   # rounding is monotone and keeps zero: rnd(relu(s)) == relu(rnd(s))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (out,) = ctx.saved_tensors
+        g = ops.relu_bwd(_round16(dy), out)
+        return g, g
+
+
 from . import _trace  # noqa: E402
 _trace.instrument(globals())

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 
 class ConvNorm(nn.Module):
@@ -20,7 +21,8 @@ class ConvNorm(nn.Module):
     def forward(self, x, relu, src_nchw=False):
         if self.training:
             self.norm.num_batches_tracked += 1
-        return Fn.ConvBNActFn.apply(x, self.weight, self.norm.weight, self.norm.bias,
+        fn = Fn16.ConvBNAct16Fn if getattr(self, "autocast16", False) else Fn.ConvBNActFn
+        return fn.apply(x, self.weight, self.norm.weight, self.norm.bias,
                                     (self.norm.running_mean, self.norm.running_var), self.kernel, self.stride, relu,
                                     self.training, src_nchw)
 
@@ -47,7 +49,7 @@ class BottleneckBlock(nn.Module):
     def forward(self, x):
         out = self.conv3(self.conv2(self.conv1(x, True), True), False)
         sc = self.shortcut(x, False) if self.shortcut is not None else x
-        return Fn.AddReluFn.apply(out, sc)
+        return (Fn16.AddRelu16Fn if getattr(self, "autocast16", False) else Fn.AddReluFn).apply(out, sc)
 
 
 class BasicBlock(nn.Module):
@@ -61,7 +63,7 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         out = self.conv2(self.conv1(x, True), False)
         sc = self.shortcut(x, False) if self.shortcut is not None else x
-        return Fn.AddReluFn.apply(out, sc)
+        return (Fn16.AddRelu16Fn if getattr(self, "autocast16", False) else Fn.AddReluFn).apply(out, sc)
 
 
 def make_stage(block_class, num_blocks, *, in_channels, out_channels, stride_per_block, **kwargs):
@@ -102,6 +104,17 @@ class ResNet(nn.Module):
             self._out_feature_channels[name] = blocks[-1].out_channels
         self._out_features = out_features or [self.stage_names[-1]]
 
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the backbone under the reference's default precision=16 policy (train.py:263):
+        convolutions on bf16 operands with 16-bit results, BatchNorm / ReLU / pooling / the residual add on 16-bit values
+        (functional16.ConvBNAct16Fn); features leave as fp32 holding those values"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        for m in self.modules():
+            m.autocast16 = precision == "bf16_autocast"
+        return self
+
     def forward_features_nhwc(self, x):
         outs = {}
         x = self.stem(x)
@@ -109,7 +122,7 @@ class ResNet(nn.Module):
             for blk in getattr(self, name):
                 x = blk(x)
             if name in self._out_features:
-                outs[name] = x
+                outs[name] = Fn16.RoundGradFn.apply(x) if getattr(self, "autocast16", False) else x
         return outs
 
     def forward(self, x):

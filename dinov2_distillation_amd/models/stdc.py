@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 
 class ConvX(nn.Module):
@@ -22,7 +23,8 @@ class ConvX(nn.Module):
     def forward(self, x, src_nchw=False):
         if self.training:
             self.bn.num_batches_tracked += 1
-        return Fn.ConvBNActFn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias,
+        fn = Fn16.ConvBNAct16Fn if getattr(self, "autocast16", False) else Fn.ConvBNActFn
+        return fn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias,
                                     (self.bn.running_mean, self.bn.running_var), self.kernel, self.stride, True,
                                     self.training, src_nchw)
 
@@ -57,13 +59,14 @@ class CatBottleneck(nn.Module):
                 bn = self.avd_layer[1]
                 if self.training:
                     bn.num_batches_tracked += 1
-                out = conv(Fn.DepthwiseBNFn.apply(out1, self.avd_layer[0].weight, bn.weight, bn.bias,
-                                                  (bn.running_mean, bn.running_var), 2, self.training))
+                dw = Fn16.DepthwiseBN16Fn if getattr(self, "autocast16", False) else Fn.DepthwiseBNFn
+                out = conv(dw.apply(out1, self.avd_layer[0].weight, bn.weight, bn.bias, (bn.running_mean, bn.running_var), 2,
+                                    self.training))
             else:
                 out = conv(out)
             outs.append(out)
         if self.stride == 2:
-            out1 = Fn.AvgPool3Fn.apply(out1, 2)
+            out1 = (Fn16.AvgPool3_16Fn if getattr(self, "autocast16", False) else Fn.AvgPool3Fn).apply(out1, 2)
         return Fn.ConcatChannelsFn.apply(out1, *outs)
 
 
@@ -101,15 +104,27 @@ class STDCNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the backbone under the reference's default precision=16 policy (functional16:
+        ConvBNAct16Fn, DepthwiseBN16Fn, AvgPool3_16Fn; concatenation is exact)"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        for m in self.modules():
+            m.autocast16 = precision == "bf16_autocast"
+        return self
+
     def forward_features_nhwc(self, x):
+        a16 = getattr(self, "autocast16", False)
+        out_ = (lambda t: Fn16.RoundGradFn.apply(t)) if a16 else (lambda t: t)
         x = self.features[0](x, src_nchw=True)
         x = self.features[1](x)
-        outs = {"res2": x}
+        outs = {"res2": out_(x)}
         b = self._bounds + [len(self.features)]
         for s in range(3):
             for i in range(b[s], b[s + 1]):
                 x = self.features[i](x)
-            outs[f"res{s + 3}"] = x
+            outs[f"res{s + 3}"] = out_(x)
         return outs
 
     def forward(self, x):

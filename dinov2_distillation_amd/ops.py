@@ -889,7 +889,7 @@ def winattn_backward(do, qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
 
 # ---- bf16-in-HBM operators of the autocast teacher (train.py:263 precision=16 == torch autocast) --------------------
 BF16 = torch.bfloat16
-EPI_BF16, EPI_BF16_GELU, EPI_F32_RESID, EPI_F32, EPI_BF16_RELU = 0, 1, 2, 3, 5
+EPI_BF16, EPI_BF16_GELU, EPI_F32_RESID, EPI_F32, EPI_BF16_RELU, EPI_F32_RAW = 0, 1, 2, 3, 5, 6
 
 
 _GEMM16 = _lib.struct_call("dkd_gemm_bf16", "dkd_gemm_bf16_args")  # positional fast path: no argument-struct object per launch
@@ -928,12 +928,12 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
     rg = rgs = ro = 0
     if row_map is not None:
         rg, rgs, ro, out_rows = row_map
-    f32_out = epi in (EPI_F32_RESID, EPI_F32)
+    f32_out = epi in (EPI_F32_RESID, EPI_F32, EPI_F32_RAW)
     if out is None:
         out = torch.empty((out_rows, N), dtype=torch.float32 if f32_out else BF16, device=a.device)
     if out.dtype != (torch.float32 if f32_out else BF16) or not out.is_contiguous():
         raise _lib.DkdError("gemm_bf16: out has the wrong dtype / layout for this epilogue")
-    wsb = lib.dkd_gemm_bf16_workspace_bytes(M, N, K, int(rowsum is not None))
+    wsb = 0 if epi == EPI_F32_RAW else lib.dkd_gemm_bf16_workspace_bytes(M, N, K, int(rowsum is not None))
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     check(_GEMM16(A=_p(a2), lda=a2.shape[1], B=_p(w2), ldb=w2.shape[1], C=_p(out), ldc=N, bias=_p(bias), colscale=_p(colscale),
                   residual=_p(residual), ldr=N, workspace=_p(ws), M=M, N=N, K=K, epi=epi, res_mod=res_mod, row_grp=rg,

@@ -181,6 +181,8 @@ int dkd_grn_gelu_bwd_f32(const float* dy, const float* g, const float* h, const 
 #define DKD_BF16_EPI_F32 3
 #define DKD_BF16_EPI_PARTIAL 4 /* internal: raw fp32 K-slab partial sums into `workspace` */
 #define DKD_BF16_EPI_BF16_RELU 5 /* C bf16 = relu(rnd(acc + bias))   the FFN's Linear + ReLU (losses/scalekd.py:448) */
+#define DKD_BF16_EPI_F32_RAW 6 /* C f32 = acc, NOT rounded (plain output only): the per-tap products of a k x k conv's input gradient,
+                                  which conv backward sums in fp32 before its one 16-bit rounding (col2im adds them) */
 /* a_layout / b_layout as in dkd_gemm_args: 0 = [M][K] / [N][K] (reduction contiguous), 1 = [K][M] / [K][N] (the operand as it
  * lies for dx = dy W and for dW = dy^T x; the contiguous extent then has to be a multiple of 8).  `workspace` (fp32,
  * dkd_gemm_bf16_workspace_bytes; may be NULL) lets a launch whose output grid cannot fill the chip split the reduction into

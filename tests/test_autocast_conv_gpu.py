@@ -1,0 +1,198 @@
+"""SURVEY 8(f)-1 for the conv + BatchNorm + ReLU students (STDC: BASELINE configs[0]; ResNet: configs[2]) - the backbone under
+the reference's default ``precision=16`` policy (train.py:263 == torch autocast; bf16).  Oracle = the PINNED fp32 restatements
+(oracle/resnet_oracle.py, oracle/stdc_oracle.py; fixtures generated from the reference's modules) run under
+``torch.autocast("cpu", bfloat16)``: conv2d on 16-bit operands with a 16-bit result, BatchNorm / ReLU / pooling / add / cat on
+16-bit tensors (fp32 statistics and affine, one rounding).  Teacher-forced blocks (the oracle's own 16-bit input) are held to a
+fraction of the policy's distance from fp32 - bounds an fp32 implementation cannot meet; whole networks decorrelate
+(BatchNorm over a small batch amplifies every 1-ulp flip) and are held to that distance itself."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / (b.float().cpu().norm() + 1e-30)).item()
+r16 = lambda t: t.bfloat16().float()
+
+
+def _run_oracle(fn, p, autocast):
+    q = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k and "num_batches" not in k else v.clone())
+         for k, v in p.items()}
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = fn(q)
+    else:
+        out = fn(q)
+    return q, out
+
+
+def _perturb_bn(p, g):
+    for k, v in p.items():
+        if k.endswith("norm.weight") or k.endswith("bn.weight") or k.endswith("avd_layer.1.weight"):
+            v.copy_(1 + 0.2 * torch.randn(v.shape, generator=g))
+        elif k.endswith("norm.bias") or k.endswith("bn.bias") or k.endswith("avd_layer.1.bias"):
+            v.copy_(0.2 * torch.randn(v.shape, generator=g))
+
+
+@pytest.mark.parametrize("stride,cin,cout", [(1, 256, 256), (2, 256, 512), (1, 64, 256)])
+def test_resnet_bottleneck_under_the_policy_vs_torch_autocast(stride, cin, cout):
+    """one BottleneckBlock (resnet.py:402-512: 1x1 -> 3x3 (stride) -> 1x1, projection shortcut when the width changes, add, ReLU)
+    fed the oracle's own 16-bit input: output, input gradient, every parameter gradient and the running statistics"""
+    from oracle import resnet_oracle as ro
+    from dinov2_distillation_amd.models.resnet import BottleneckBlock
+    g = torch.Generator().manual_seed(7 + stride + cin)
+    B, H = 4, 16
+    blk = BottleneckBlock(cin, cout, bottleneck_channels=cout // 4, stride=stride)
+    p = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    _perturb_bn(p, g)
+    blk.load_state_dict(p)
+    x = r16(torch.randn(B, cin, H, H, generator=g).relu())     # a 16-bit, post-ReLU feature, as inside the network
+    ct = torch.randn(B, cout, H // stride, H // stride, generator=g)
+
+    def fn(xin):
+        return lambda q: ro.bottleneck(q, "", xin, stride)
+
+    x16 = x.bfloat16().requires_grad_(True)
+    x32 = x.clone().requires_grad_(True)
+    q16, o16 = _run_oracle(fn(x16), p, True)
+    q32, o32 = _run_oracle(fn(x32), p, False)
+    assert o16.dtype == torch.bfloat16
+    (o16.float() * ct).sum().backward()
+    (o32 * ct).sum().backward()
+    for m in blk.modules():
+        m.autocast16 = True
+    blk.cuda().train()
+    from dinov2_distillation_amd.functional16 import RoundGradFn
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    out = blk(RoundGradFn.apply(xg))                                        # (a 16-bit leaf accumulates its gradient in 16 bit)
+    assert out.dtype == torch.float32 and torch.equal(out, r16(out))       # fp32 holding 16-bit values
+    e, noise = rel(out.permute(0, 3, 1, 2), o16), rel(o16, o32)
+    print(f"bottleneck s{stride} {cin}->{cout}: out ours vs autocast {e:.2e}; autocast vs fp32 {noise:.2e}")
+    assert noise > 1e-3 and e < 0.25 * noise and e < rel(out.permute(0, 3, 1, 2), o32)
+    (out * ct.permute(0, 2, 3, 1).cuda()).sum().backward()
+    e, noise = rel(xg.grad.permute(0, 3, 1, 2), x16.grad), rel(x16.grad, x32.grad)
+    print(f"  dx ours vs autocast {e:.2e}; autocast vs fp32 {noise:.2e}")
+    assert e < 0.35 * noise and torch.equal(xg.grad, r16(xg.grad))
+    bad = []
+    for k, v in blk.named_parameters():
+        e, noise = rel(v.grad, q16[k].grad), rel(q16[k].grad, q32[k].grad)
+        print(f"  d{k}: {e:.2e} vs {noise:.2e}")
+        if e >= max(0.5 * noise, 2e-3):
+            bad.append((k, e, noise))
+    assert not bad, bad
+    for k, v in blk.state_dict().items():
+        if "running" in k:
+            assert rel(v, q16[k]) < 1e-4, k
+
+
+def test_stdc_cat_bottleneck_under_the_policy_vs_torch_autocast():
+    """a stride-2 CatBottleneck (stdc.py:153-172: 1x1 ConvX, depthwise 3x3 stride 2 + BatchNorm, three 3x3 ConvX, AvgPool skip,
+    concatenation) and a stride-1 one.  Every stage fed the ORACLE'S input is a few flips from torch.autocast (the depthwise conv
+    + BatchNorm and the 3x3 ConvX bit-equal); along the chain out1 -> out2 -> out3 -> out4 those flips are amplified by each
+    BatchNorm over 32-64 channels (tests/diag/diag_stdc16.py: 6e-5 -> 7e-4 -> 2e-3 -> 4e-3 of a 5e-3 ... 9e-3 policy distance), so the
+    whole block is held to 0.7 of the policy's distance and the stages to 1e-3 of their tensors."""
+    import torch.nn.functional as F
+    from oracle import stdc_oracle as so
+    from dinov2_distillation_amd import functional16 as Fn16
+    from dinov2_distillation_amd.functional16 import RoundGradFn
+    from dinov2_distillation_amd.models.stdc import CatBottleneck
+    nhwc = lambda t: t.float().permute(0, 2, 3, 1).contiguous().cuda()
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    for stride, cin, cout in ((2, 64, 256), (1, 256, 256)):
+        g = torch.Generator().manual_seed(11 + stride)
+        B, H = 4, 32
+        blk = CatBottleneck(cin, cout, 4, stride)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", generator=g)
+        p = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+        _perturb_bn(p, g)
+        blk.load_state_dict(p)
+        x = r16(torch.randn(B, cin, H, H, generator=g).relu())
+        ct = torch.randn(B, cout, H // stride, H // stride, generator=g)
+        x16, x32 = x.bfloat16().requires_grad_(True), x.clone().requires_grad_(True)
+        q16, o16 = _run_oracle(lambda q: so.cat_bottleneck(q, "", x16, stride), p, True)
+        q32, o32 = _run_oracle(lambda q: so.cat_bottleneck(q, "", x32, stride), p, False)
+        (o16.float() * ct).sum().backward()
+        (o32 * ct).sum().backward()
+        for m in blk.modules():
+            m.autocast16 = True
+        blk.cuda().train()
+        # ---- stage by stage on the oracle's own inputs
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            q = {k: v.clone() for k, v in p.items()}
+            s1 = so.convx(q, "conv_list.0.", x.bfloat16())
+            if stride == 2:
+                a = so._bn(q, "avd_layer.1.", F.conv2d(s1, q["avd_layer.0.weight"], None, stride=2, padding=1, groups=s1.shape[1]))
+                ap = F.avg_pool2d(s1, 3, 2, 1)
+            else:
+                a = s1
+            s2 = so.convx(q, "conv_list.1.", a)
+        with torch.no_grad():
+            assert rel(nchw(blk.conv_list[0](nhwc(x))), s1) < 1e-3
+            if stride == 2:
+                bn = blk.avd_layer[1]
+                m = Fn16.DepthwiseBN16Fn.apply(nhwc(s1), blk.avd_layer[0].weight, bn.weight, bn.bias, (bn.running_mean.clone(), bn.running_var.clone()), 2, True)
+                assert rel(nchw(m), a) < 1e-4, rel(nchw(m), a)
+                assert rel(nchw(Fn16.AvgPool3_16Fn.apply(nhwc(s1), 2)), ap) < 1e-3
+            assert rel(nchw(blk.conv_list[1](nhwc(a))), s2) < 1e-3
+        blk.load_state_dict(p)   # (the stage calls above moved the running statistics)
+        # ---- the whole block, forward and backward
+        xg = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+        out = blk(RoundGradFn.apply(xg))
+        e, noise = rel(out.permute(0, 3, 1, 2), o16), rel(o16, o32)
+        print(f"cat bottleneck s{stride}: out ours vs autocast {e:.2e}; autocast vs fp32 {noise:.2e}")
+        assert torch.equal(out, r16(out)) and noise > 1e-3 and e < 0.7 * noise and e < rel(out.permute(0, 3, 1, 2), o32)
+        (out * ct.permute(0, 2, 3, 1).cuda()).sum().backward()
+        e, noise = rel(xg.grad.permute(0, 3, 1, 2), x16.grad), rel(x16.grad, x32.grad)
+        print(f"  dx ours vs autocast {e:.2e}; autocast vs fp32 {noise:.2e}")
+        assert e < 0.7 * noise
+        bad = []
+        for k, v in blk.named_parameters():
+            e, noise = rel(v.grad, q16[k].grad), rel(q16[k].grad, q32[k].grad)
+            print(f"  d{k}: {e:.2e} vs {noise:.2e}")
+            if e >= max(0.8 * noise, 3e-3):
+                bad.append((k, e, noise))
+        assert not bad, bad
+
+
+@pytest.mark.parametrize("family", ["resnet", "stdc"])
+def test_whole_backbone_and_step_under_the_policy(family):
+    """the whole backbone (stem from the fp32 NCHW image, max pool, every stage) against the autocast oracle at the policy's own
+    distance from fp32, and one full distillation step of the BASELINE pair (configs[2]: vitb14 -> resnet_50; configs[0]:
+    vits14 -> stdc_2) with teacher, student and loss chain under the policy: finite, close to the fp32 step, not equal to it,
+    reproducible, learning"""
+    from dinov2_distillation_amd.models import ModelWrapper
+    from dinov2_distillation_amd.trainer import DistillationStepper
+    g = torch.Generator().manual_seed(3)
+    if family == "resnet":
+        from oracle import resnet_oracle as ro
+        w = ModelWrapper("resnet_50", [8, 8], ["res4", "res5"])
+        ofn = lambda xin: (lambda q: ro.forward(q, xin, [3, 4, 6, 3]))
+    else:
+        from oracle import stdc_oracle as so
+        w = ModelWrapper("stdc_1", [8, 8], ["res4", "res5"])
+        ofn = lambda xin: (lambda q: so.forward(q, xin, so.STDC_LAYERS["stdc_1"]))
+    net = w.model.model
+    with torch.no_grad():   # (through the modules: STDC's stage aliases x2 / x4 / ... duplicate every key of `features`)
+        _perturb_bn(dict(net.named_parameters()), g)
+    p = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(4, 3, 128, 128, generator=g)
+    _, o16 = _run_oracle(ofn(x), p, True)
+    _, o32 = _run_oracle(ofn(x), p, False)
+    w.set_precision("bf16_autocast")
+    w.cuda().train()
+    feats = net.forward_features_nhwc(x.cuda())
+    for k in ("res4", "res5"):
+        e, noise = rel(feats[k].permute(0, 3, 1, 2), o16[k]), rel(o16[k], o32[k])
+        print(f"{family} {k}: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
+        assert torch.equal(feats[k], r16(feats[k])) and noise > 1e-3 and e < 1.3 * noise
+    del w, net, feats
+    pair = dict(teacher="dinov2_vitb14", student="resnet_50") if family == "resnet" else dict(teacher="dinov2_vits14", student="stdc_2")
+    xb = torch.randn(4, 3, 224, 224, generator=g).cuda()
+    l32 = float(DistillationStepper(device="cuda:0", **pair).step(xb).detach())
+    st = DistillationStepper(device="cuda:0", precision="bf16_autocast", **pair)
+    l16 = [float(st.step(xb).detach()) for _ in range(3)]
+    st2 = DistillationStepper(device="cuda:0", precision="bf16_autocast", **pair)
+    l16b = [float(st2.step(xb).detach()) for _ in range(3)]
+    print(f"{family} step loss: fp32 {l32:.5f}; policy {l16}")
+    assert all(v == v for v in l16) and abs(l16[0] - l32) <= 3e-2 * abs(l32) and l16[0] != l32 and l16 == l16b and l16[2] < l16[0]
