@@ -367,43 +367,44 @@ __global__ void relu_bwd_bf16_kernel(const __bf16* __restrict__ dy, const __bf16
     }
 }
 // ---- the frequency loss's DCT under the 16-bit policy ---------------------------------------------------------------------------
-// losses/scalekd.py:337-428 implements the 2-D DCT / inverse DCT as nn.Linear layers (16 x 16 matrices) over the last axis, a
+// losses/scalekd.py:337-428 implements the 2-D DCT / inverse DCT as nn.Linear layers (R x R matrices, R = the token grid: 16 at
+// 224 px, 32 at 448, 37 at 518) over the last axis, a
 // transpose, and the same Linear again: under autocast each is a 16-bit matmul with a 16-bit result.  One step on an NHWC map
-// [n, a, b, c] (a, b = 16 x 16 spatial or frequency indices): out[.., i, ..] = rnd(sum_j Mx[i][j] in[.., j, ..]) along axis b
+// [n, a, b, c] (a, b = R x R spatial or frequency indices): out[.., i, ..] = rnd(sum_j Mx[i][j] in[.., j, ..]) along axis b
 // (axis = 0) or a (axis = 1); Mx holds the 16-bit matrix values in fp32; transposed = use Mx^T (the adjoint, for the backward
 // pass); zero_in / zero_out: the DC coefficient [a = 0, b = 0] is zero (scalekd.py:114-115 and its adjoint).
-template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void dct16_step_kernel(const TI* __restrict__ in, TO* __restrict__ out, const float* __restrict__ Mx,
-                                                         long lines, int C, int axis, int transposed, int zero_in, int zero_out) {
-    __shared__ float m[16][16];
-    m[threadIdx.x >> 4][threadIdx.x & 15] = transposed ? Mx[(threadIdx.x & 15) * 16 + (threadIdx.x >> 4)] : Mx[threadIdx.x];
+template <typename TI, typename TO, int R>
+__global__ __launch_bounds__(256) void dct_step_kernel(const TI* __restrict__ in, TO* __restrict__ out, const float* __restrict__ Mx,
+                                                       long lines, int C, int axis, int transposed, int zero_in, int zero_out) {
+    __shared__ float m[R][R];
+    for (int e = threadIdx.x; e < R * R; e += blockDim.x) m[e / R][e % R] = transposed ? Mx[(e % R) * R + e / R] : Mx[e];
     __syncthreads();
     const int cq = C >> 2;
-    const long total = lines * cq;  // a line = the 16 elements along the contracted axis, for one (n, other index)
+    const long total = lines * cq;  // a line = the R elements along the contracted axis, for one (n, other index)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % cq);
         const long line = idx / cq;
-        const long n = line >> 4;
-        const int o = (int)(line & 15);                      // the index that is NOT contracted
-        // 4-element index of (n, a, b, c4): ((n * 16 + a) * 16 + b) * cq + c4
-        const long base = axis == 0 ? ((n * 16 + o) * 16) * cq + c4 : (n * 256 + o) * cq + c4;
-        const long step = axis == 0 ? cq : 16L * cq;
-        float4 acc[16];
+        const long n = line / R;
+        const int o = (int)(line % R);                       // the index that is NOT contracted
+        // 4-element index of (n, a, b, c4): ((n * R + a) * R + b) * cq + c4
+        const long base = axis == 0 ? ((n * R + o) * R) * cq + c4 : (n * R * R + o) * cq + c4;
+        const long step = axis == 0 ? cq : (long)R * cq;
+        float4 acc[R];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int i = 0; i < R; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int j = 0; j < R; ++j) {
             float4 v = rnd16(ld4(in, base + j * step));        // (an fp32 input is the Linear's 16-bit operand after its cast)
             if (zero_in && o == 0 && j == 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < R; ++i) {
                 const float w = m[i][j];
                 acc[i].x = fmaf(w, v.x, acc[i].x); acc[i].y = fmaf(w, v.y, acc[i].y);
                 acc[i].z = fmaf(w, v.z, acc[i].z); acc[i].w = fmaf(w, v.w, acc[i].w);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < R; ++i) {
             float4 r = rnd16(acc[i]);
             if (zero_out && o == 0 && i == 0) r = make_float4(0.f, 0.f, 0.f, 0.f);
             st4(out, base + i * step, r);
@@ -608,17 +609,28 @@ extern "C" int dkd_round_bf16_f32(float* x, long n, void* stream) {
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
-extern "C" int dkd_dct16_step(const void* in, int in16, void* out, int out16, const float* Mx, long n_maps, int C, int axis,
-                              int transposed, int zero_in, int zero_out, void* stream) {
+extern "C" int dkd_dct_step(const void* in, int in16, void* out, int out16, const float* Mx, long n_maps, int R, int C, int axis,
+                            int transposed, int zero_in, int zero_out, void* stream) {
     EW_CHECK(C);
     if (!in || !out || !Mx || n_maps <= 0 || (axis & ~1)) return DKD_ERR_BAD_ARG;
-    const long lines = n_maps * 16, total = lines * (C / 4);
+    if (R != 16 && R != 32 && R != 37) return DKD_ERR_UNSUPPORTED;
+    const long lines = n_maps * R, total = lines * (C / 4);
     int rc = DKD_OK;
-    DKD_IO_TYPE(in16, TI, DKD_IO_TYPE(out16, TO,
-        hipLaunchKernelGGL((dct16_step_kernel<TI, TO>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const TI*>(in), reinterpret_cast<TO*>(out), Mx, lines, C, axis, transposed, zero_in, zero_out)));
+#define DKD_DCT_LAUNCH(RR)                                                                                                      \
+    DKD_IO_TYPE(in16, TI, DKD_IO_TYPE(out16, TO,                                                                                \
+        hipLaunchKernelGGL((dct_step_kernel<TI, TO, RR>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream,            \
+                           reinterpret_cast<const TI*>(in), reinterpret_cast<TO*>(out), Mx, lines, C, axis, transposed, zero_in, \
+                           zero_out)))
+    if (R == 16) { DKD_DCT_LAUNCH(16); }
+    else if (R == 32) { DKD_DCT_LAUNCH(32); }
+    else { DKD_DCT_LAUNCH(37); }
+#undef DKD_DCT_LAUNCH
     DKD_LAUNCH_CHECK();
     return rc;
+}
+extern "C" int dkd_dct16_step(const void* in, int in16, void* out, int out16, const float* Mx, long n_maps, int C, int axis,
+                              int transposed, int zero_in, int zero_out, void* stream) {
+    return dkd_dct_step(in, in16, out, out16, Mx, n_maps, 16, C, axis, transposed, zero_in, zero_out, stream);
 }
 extern "C" int dkd_gelu_bf16(const void* x, const void* dy, void* out, long n, void* stream) {
     EW_CHECK(n);

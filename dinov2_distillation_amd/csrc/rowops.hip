@@ -414,7 +414,10 @@ void colreduce_plan(long rows_per_group, int groups, int N, int* CL, int* nsplit
 // one wave per row of N logits (N % 4 == 0, N <= 64 * 4 * VPL), everything between the bf16 load and the bf16 store in fp32
 template <int VPL, bool BWD>
 __global__ __launch_bounds__(256) void attn16_softmax_kernel(const __bf16* __restrict__ S, const __bf16* __restrict__ dP,
-                                                             __bf16* __restrict__ out, long rows, int N, long ld, float c1, float c2) {
+                                                             __bf16* __restrict__ out, long rows, int N, long ld, float c1, float c2,
+                                                             int valid) {
+    // valid < N: the key columns valid..N-1 are padding (a token count that is not a multiple of 8, ops.attention16): they are
+    // masked out of the softmax and their P / dS entries are written as zeros
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nv = N >> 2;
     for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
         const long r4 = row * (ld >> 2);
@@ -427,6 +430,12 @@ __global__ __launch_bounds__(256) void attn16_softmax_kernel(const __bf16* __res
                 t[i] = rnd16(ld4(S, r4 + c));  // (bf16 already; rnd16 is the identity here)
                 t[i] = rnd16(make_float4(t[i].x * c1, t[i].y * c1, t[i].z * c1, t[i].w * c1));
                 t[i] = rnd16(make_float4(t[i].x * c2, t[i].y * c2, t[i].z * c2, t[i].w * c2));
+                if (4 * c + 3 >= valid) {
+                    if (4 * c + 0 >= valid) t[i].x = -INFINITY;
+                    if (4 * c + 1 >= valid) t[i].y = -INFINITY;
+                    if (4 * c + 2 >= valid) t[i].z = -INFINITY;
+                    t[i].w = -INFINITY;
+                }
                 mx = fmaxf(mx, fmaxf(fmaxf(t[i].x, t[i].y), fmaxf(t[i].z, t[i].w)));
             } else {
                 t[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -468,6 +477,18 @@ __global__ __launch_bounds__(256) void attn16_softmax_kernel(const __bf16* __res
                 st4(out, r4 + c, v);
             }
         }
+    }
+}
+
+// rows regrouped: dst group b holds rows 0..gs_dst-1, row i < gs_src taken from src group b, the others zero.  16-byte vectors.
+__global__ void regroup_rows16_kernel(const uint4* __restrict__ src, long lds4, int gs_src, uint4* __restrict__ dst, long ldd4,
+                                      int gs_dst, long groups, int cv) {
+    const long total = groups * gs_dst * cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        const long r = idx / cv, b = r / gs_dst;
+        const int i = (int)(r % gs_dst);
+        dst[r * ldd4 + c] = i < gs_src ? src[(b * gs_src + i) * lds4 + c] : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -758,8 +779,10 @@ extern "C" int dkd_transpose_f32(const float* in, float* out, int rows, int cols
 }
 
 template <bool BWD>
-static int launch_attn16_softmax(const void* S, const void* dP, void* out, long rows, int N, long ld, float c1, float c2, void* stream) {
-    if (!S || !out || (BWD && !dP) || rows <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
+static int launch_attn16_softmax(const void* S, const void* dP, void* out, long rows, int N, long ld, float c1, float c2, int valid,
+                                 void* stream) {
+    if (!S || !out || (BWD && !dP) || rows <= 0 || N <= 0 || valid < 0 || valid > N) return DKD_ERR_BAD_ARG;
+    if (valid == 0) valid = N;
     if ((N & 3) || (ld & 3) || ld < N) return DKD_ERR_ALIGN;
     if (N > 64 * 4 * 8) return DKD_ERR_UNSUPPORTED;
     const int nv = N / 4, vpl = (nv + 63) / 64;
@@ -767,17 +790,29 @@ static int launch_attn16_softmax(const void* S, const void* dP, void* out, long 
     const __bf16* s = reinterpret_cast<const __bf16*>(S);
     const __bf16* d = reinterpret_cast<const __bf16*>(dP);
     __bf16* o = reinterpret_cast<__bf16*>(out);
-#define DKD_SM16(V) hipLaunchKernelGGL((attn16_softmax_kernel<V, BWD>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, d, o, rows, N, ld, c1, c2)
+#define DKD_SM16(V) hipLaunchKernelGGL((attn16_softmax_kernel<V, BWD>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, d, o, rows, N, ld, c1, c2, valid)
     if (vpl <= 1) DKD_SM16(1); else if (vpl <= 2) DKD_SM16(2); else if (vpl <= 4) DKD_SM16(4); else if (vpl <= 6) DKD_SM16(6); else DKD_SM16(8);
 #undef DKD_SM16
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
-extern "C" int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, void* stream) {
-    return launch_attn16_softmax<false>(S, nullptr, P, rows, N, ld, c1, c2, stream);
+extern "C" int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, int valid, void* stream) {
+    return launch_attn16_softmax<false>(S, nullptr, P, rows, N, ld, c1, c2, valid, stream);
 }
-extern "C" int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, void* stream) {
-    return launch_attn16_softmax<true>(S, dP, dS, rows, N, ld, c1, c2, stream);
+extern "C" int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, int valid,
+                                      void* stream) {
+    return launch_attn16_softmax<true>(S, dP, dS, rows, N, ld, c1, c2, valid, stream);
+}
+extern "C" int dkd_regroup_rows_bf16(const void* src, long lds, int gs_src, void* dst, long ldd, int gs_dst, long groups, int cols,
+                                     void* stream) {
+    if (!src || !dst || gs_src <= 0 || gs_dst <= 0 || groups <= 0 || cols <= 0 || lds < cols || ldd < cols) return DKD_ERR_BAD_ARG;
+    if ((cols & 7) || (lds & 7) || (ldd & 7) || !dkd_aligned16(src) || !dkd_aligned16(dst)) return DKD_ERR_ALIGN;
+    const long total = groups * gs_dst * (cols / 8);
+    hipLaunchKernelGGL(regroup_rows16_kernel, dim3((int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const uint4*>(src), lds / 8, gs_src, reinterpret_cast<uint4*>(dst), ldd / 8,
+                       gs_dst, groups, cols / 8);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
 }
 extern "C" int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream) {
     if (!x || !out || n <= 0) return DKD_ERR_BAD_ARG;

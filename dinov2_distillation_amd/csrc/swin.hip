@@ -93,6 +93,29 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
+// nn.Dropout on a tensor torch autocast keeps in 16 bit (proj_drop / Mlp.drop on bf16 Linear outputs, swin.py:78-85,146,197),
+// optionally fused with the residual add that follows it (:331-332): d = rnd(x * mask / (1 - p)) is the 16-bit dropout result,
+// y = res + d in y's type (fp32 residual stream: exact fp32 add; bf16 stream: one more rounding).  Same mask function as
+// dropout_kernel: element t uses the same 16 random bits whatever the tensor types.
+template <typename TX, typename TR, typename TY>
+__global__ void dropout_add_io_kernel(const TX* __restrict__ x, const TR* __restrict__ res, TY* __restrict__ y, long n4, uint32_t thresh,
+                                      float inv_keep, uint64_t seed, uint64_t offset) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) {
+        const uint64_t h = mix64(seed ^ ((offset + (uint64_t)t) * 0x9E3779B97F4A7C15ull));
+        float4 v = ::ld4(x, t);
+        v.x = ((uint32_t)(h & 0xFFFF) >= thresh) ? v.x * inv_keep : 0.f;
+        v.y = ((uint32_t)((h >> 16) & 0xFFFF) >= thresh) ? v.y * inv_keep : 0.f;
+        v.z = ((uint32_t)((h >> 32) & 0xFFFF) >= thresh) ? v.z * inv_keep : 0.f;
+        v.w = ((uint32_t)(h >> 48) >= thresh) ? v.w * inv_keep : 0.f;
+        if (dkd_is16<TX>::value) v = rnd16(v);
+        if (res) {
+            const float4 a = ::ld4(res, t);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        ::st4(y, t, v);
+    }
+}
+
 // ---- window attention ---------------------------------------------------------------------------------------------
 // One wave per (window, head); a workgroup of 4 waves shares only the head's [N][N] bias tile (LDS, odd pitch: lane-per-row
 // and lane-per-column reads are conflict-free).  Lane = query row (forward, backward phase 1) or key row (backward phase 2);
@@ -391,7 +414,8 @@ extern "C" int dkd_winattn_parts(int Bw, int H) {
 extern "C" int dkd_winattn_fwd_f32(const dkd_winattn_args* a, void* stream) {
     const int rc = check_args(a, false);
     if (rc) return rc;
-    if (a->N == 49 && (a->hd == 32 || a->hd == 16) && !winattn_use_valu()) return dkd_winattn_mfma_fwd(a, (hipStream_t)stream);
+    if (a->N == 49 && (a->hd == 32 || a->hd == 16) && (a->policy16 || !winattn_use_valu())) return dkd_winattn_mfma_fwd(a, (hipStream_t)stream);
+    if (a->policy16) return DKD_ERR_UNSUPPORTED;
     if (a->N == 49 && a->hd == 32) return launch_fwd<49, 32>(a, (hipStream_t)stream);
     if (a->N == 49 && a->hd == 16) return launch_fwd<49, 16>(a, (hipStream_t)stream);
     return DKD_ERR_UNSUPPORTED;
@@ -401,7 +425,8 @@ extern "C" int dkd_winattn_bwd_f32(const dkd_winattn_args* a, void* stream) {
     const int rc = check_args(a, true);
     if (rc) return rc;
     if (a->parts != dkd_winattn_parts(a->Bw, a->H)) return DKD_ERR_BAD_ARG;
-    if (a->N == 49 && (a->hd == 32 || a->hd == 16) && !winattn_use_valu()) return dkd_winattn_mfma_bwd(a, (hipStream_t)stream);
+    if (a->N == 49 && (a->hd == 32 || a->hd == 16) && (a->policy16 || !winattn_use_valu())) return dkd_winattn_mfma_bwd(a, (hipStream_t)stream);
+    if (a->policy16) return DKD_ERR_UNSUPPORTED;
     if (a->N == 49 && a->hd == 32) return launch_bwd<49, 32>(a, (hipStream_t)stream);
     if (a->N == 49 && a->hd == 16) return launch_bwd<49, 16>(a, (hipStream_t)stream);
     return DKD_ERR_UNSUPPORTED;
@@ -436,6 +461,22 @@ extern "C" int dkd_gather_rows_f32(const float* in, const int* idx, const float*
 extern "C" int dkd_index_add_rows_f32(const float* src, const int* idx, float* out, int rows, int T, int C, void* stream) {
     if (!src || !idx || !out || rows <= 0 || T <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
     hipLaunchKernelGGL(index_add_rows_kernel, dim3(T), dim3(64), 0, (hipStream_t)stream, src, idx, out, rows, C);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_dropout_add_io(const void* x, int x16, const void* res, int res16, void* y, int y16, long n, float p, int64_t seed,
+                                  int64_t offset, void* stream) {
+    if (!x || !y || n <= 0 || !(p >= 0.f && p < 1.f)) return DKD_ERR_BAD_ARG;
+    if ((n & 3) || !dkd_aligned16(x) || !dkd_aligned16(y) || (res && !dkd_aligned16(res))) return DKD_ERR_ALIGN;
+    const uint32_t thresh = (uint32_t)(p * 65536.0f + 0.5f);
+    const long n4 = n / 4;
+    const long blocks = (n4 + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
+    DKD_IO_TYPE(x16, TX, DKD_IO_TYPE(res16, TR, DKD_IO_TYPE(y16, TY,
+        hipLaunchKernelGGL((dropout_add_io_kernel<TX, TR, TY>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const TX*>(x),
+                           reinterpret_cast<const TR*>(res), reinterpret_cast<TY*>(y), n4, thresh, 1.0f / (1.0f - p), (uint64_t)seed,
+                           (uint64_t)offset))));
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -16,6 +16,12 @@
 //
 // MFMA work per (window, head): forward 256 issues (8 k-cycles), backward 896: ~8 k / ~29 k cycles against ~130 k / ~330 k
 // for the lane-per-row VALU kernels of swin.hip, which stay selectable (DKD_WINATTN_VALU=1) as the A/B reference.
+//
+// T = __bf16 (dkd_winattn_args.policy16): the same kernels as torch autocast runs WindowAttention.forward (swin.py:151-199) - q, k,
+// v, o and their gradients are bf16 in HBM; q * scale, q k^T, P v and every matmul of the backward pass round their result to bf16
+// (fp32 MFMA on bf16 values: exact products, fp32 accumulation, one rounding - what a bf16 matmul delivers); adding the fp32
+// bias table promotes the logits to fp32, the softmax and its backward are fp32, the probabilities are rounded for P v, and
+// d(bias) is the fp32 softmax gradient summed over windows.
 #include "common.h"
 #include "dkd_hip.h"
 
@@ -27,6 +33,20 @@ constexpr float NEG = -3.0e38f;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const dkd_bf16x4 v = *reinterpret_cast<const dkd_bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+    const dkd_bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<dkd_bf16x4*>(p) = o;
+}
+// R16: the value a 16-bit tensor holds (policy kernels); the identity for the fp32 kernels
+template <bool R16> __device__ __forceinline__ float rq(float v) { return R16 ? rnd16(v) : v; }
+template <bool R16> __device__ __forceinline__ f32x4 rq(f32x4 v) {
+    if (R16) { v[0] = rnd16(v[0]); v[1] = rnd16(v[1]); v[2] = rnd16(v[2]); v[3] = rnd16(v[3]); }
+    return v;
+}
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ f32x4 mfma4(const float4 a, const float4 b, f32x4 c) {  // the four permuted k-steps of one 16-k block
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
@@ -47,28 +67,30 @@ __device__ __forceinline__ float xor_max(float v, int o) { return fmaxf(v, __shf
 __device__ __forceinline__ float xor_add(float v, int o) { return v + __shfl_xor(v, o, 64); }
 
 // row fragments: f[t][kb] = X[min(16t + c, N-1)][16kb + 4g .. +3]   (rows past the window shadow the last row)
-template <int KB>
-__device__ __forceinline__ void load_rows(float4 (&f)[4][KB], const float* __restrict__ base, long rs, int g, int c, float mul) {
+template <int KB, typename T>
+__device__ __forceinline__ void load_rows(float4 (&f)[4][KB], const T* __restrict__ base, long rs, int g, int c, float mul) {
+    constexpr bool R16 = dkd_is16<T>::value;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int row = min(16 * t + c, N - 1);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const float4 v = ld4(base + (long)row * rs + 16 * kb + 4 * g);
-            f[t][kb] = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
+            f[t][kb] = make_float4(rq<R16>(v.x * mul), rq<R16>(v.y * mul), rq<R16>(v.z * mul), rq<R16>(v.w * mul));
         }
     }
 }
 // column fragment: X[min(16t + 4g + s, N-1)][16dt + c] for s = 0..3 (the "transposed" operand of the second products)
-__device__ __forceinline__ float4 load_col(const float* __restrict__ base, long rs, int t, int dt, int g, int c) {
+template <typename T>
+__device__ __forceinline__ float4 load_col(const T* __restrict__ base, long rs, int t, int dt, int g, int c) {
     const int r0 = 16 * t + 4 * g;
-    const float* p = base + 16 * dt + c;
-    return make_float4(p[(long)min(r0, N - 1) * rs], p[(long)min(r0 + 1, N - 1) * rs], p[(long)min(r0 + 2, N - 1) * rs],
-                       p[(long)min(r0 + 3, N - 1) * rs]);
+    const T* p = base + 16 * dt + c;
+    return make_float4((float)p[(long)min(r0, N - 1) * rs], (float)p[(long)min(r0 + 1, N - 1) * rs],
+                       (float)p[(long)min(r0 + 2, N - 1) * rs], (float)p[(long)min(r0 + 3, N - 1) * rs]);
 }
 
 // logits of the T layout from accumulators: + bias + shift mask, padded keys -> NEG; returns per-it column max / fills p
-template <int KB>
+template <int KB, bool R16>
 __device__ __forceinline__ void logits_T(f32x4 (&st)[4][4], const float4 (&kf)[4][KB], const float4 (&qf)[4][KB],
                                          const float* __restrict__ sBias, const int* __restrict__ labp, int g, int c) {
 #pragma unroll
@@ -78,7 +100,7 @@ __device__ __forceinline__ void logits_T(f32x4 (&st)[4][4], const float4 (&kf)[4
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) acc = mfma4(kf[jt][kb], qf[it][kb], acc);
-            st[jt][it] = acc;
+            st[jt][it] = rq<R16>(acc);   // (policy: q k^T is a 16-bit matmul result; the bias add below is fp32)
         }
     int lab_i[4];
 #pragma unroll
@@ -128,31 +150,46 @@ __device__ __forceinline__ void softmax_T(f32x4 (&st)[4][4], float (&inv)[4]) {
     }
 }
 
-template <int HD>
+template <int HD, typename T>
 __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_fwd_kernel(dkd_winattn_args a) {
     constexpr int KB = HD / 16, DT = HD / 16;
+    constexpr bool R16 = dkd_is16<T>::value;
     __shared__ float sBias[N * NP];
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
     for (int e = threadIdx.x; e < N * N; e += blockDim.x) sBias[e] = a.bias[(long)e * a.H + h];
     __syncthreads();
+    const T* aq = reinterpret_cast<const T*>(a.q);
+    const T* ak = reinterpret_cast<const T*>(a.k);
+    const T* av = reinterpret_cast<const T*>(a.v);
+    T* ao = reinterpret_cast<T*>(a.o);
     for (int w = blockIdx.x * WA_WAVES + wave; w < a.Bw; w += gridDim.x * WA_WAVES) {
         const long row0 = (long)w * N;
         const int* labp = a.labels ? a.labels + (long)(w % a.nW) * N : nullptr;
         f32x4 st[4][4];
         {
             float4 kf[4][KB], qf[4][KB];
-            load_rows<KB>(kf, a.k + row0 * a.k_rs + h * HD, a.k_rs, g, c, 1.0f);
-            load_rows<KB>(qf, a.q + row0 * a.q_rs + h * HD, a.q_rs, g, c, a.scale);
-            logits_T<KB>(st, kf, qf, sBias, labp, g, c);
+            load_rows<KB>(kf, ak + row0 * a.k_rs + h * HD, a.k_rs, g, c, 1.0f);
+            load_rows<KB>(qf, aq + row0 * a.q_rs + h * HD, a.q_rs, g, c, a.scale);
+            logits_T<KB, R16>(st, kf, qf, sBias, labp, g, c);
         }
         float inv[4];
         softmax_T(st, inv);
+        if (R16) {  // the probabilities are cast down for the second matmul
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[jt][it][r] = rnd16(st[jt][it][r] * inv[it]);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) inv[it] = 1.0f;
+        }
         f32x4 ot[DT][4];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int it = 0; it < 4; ++it) ot[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* vb = a.v + row0 * a.v_rs + h * HD;
+        const T* vb = av + row0 * a.v_rs + h * HD;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -165,7 +202,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_fwd_kernel(dkd_win
         for (int it = 0; it < 4; ++it) {
             const int i = 16 * it + c;
             if (i >= N) continue;
-            float* op = a.o + (row0 + i) * a.o_rs + h * HD + 4 * g;
+            T* op = ao + (row0 + i) * a.o_rs + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
                 st4(op + 16 * dt, make_float4(ot[dt][it][0] * inv[it], ot[dt][it][1] * inv[it], ot[dt][it][2] * inv[it],
@@ -184,9 +221,12 @@ __device__ __forceinline__ float row16_add(float v) {
 
 // PART 0: the T-layout half (dQ, d(bias)); PART 1: the N-layout half (dK, dV); PART 2: both in one launch (the default: splitting
 // into two launches measured no faster - the hd = 32 halves still need > 128 VGPRs each, i.e. one wave per SIMD).
-template <int HD, int PART>
+template <int HD, int PART, typename T>
 __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_winattn_args a) {
     constexpr int KB = HD / 16, DT = HD / 16;
+    constexpr bool R16 = dkd_is16<T>::value;
+    // policy: q enters every product as the 16-bit tensor q * scale, and d(q) = rnd(d(q * scale) * scale)
+    const float qmul = R16 ? a.scale : 1.0f, omul = R16 ? 1.0f : a.scale;
     __shared__ float sBias[N * NP];
     // d(bias): ONE tile PER WAVE.  Inside a wave every lane owns its (i, j) of the current sub-tile, so plain read-modify-write
     // accumulates in program order; the four wave tiles are added in a fixed order at the end.  (One shared tile with LDS
@@ -203,10 +243,10 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
     for (int w = blockIdx.x * WA_WAVES + wave; w < a.Bw; w += gridDim.x * WA_WAVES) {
         const long row0 = (long)w * N;
         const int* labp = a.labels ? a.labels + (long)(w % a.nW) * N : nullptr;
-        const float* qb = a.q + row0 * a.q_rs + h * HD;
-        const float* kb_ = a.k + row0 * a.k_rs + h * HD;
-        const float* vb = a.v + row0 * a.v_rs + h * HD;
-        const float* gb = a.d_o + row0 * a.do_rs + h * HD;
+        const T* qb = reinterpret_cast<const T*>(a.q) + row0 * a.q_rs + h * HD;
+        const T* kb_ = reinterpret_cast<const T*>(a.k) + row0 * a.k_rs + h * HD;
+        const T* vb = reinterpret_cast<const T*>(a.v) + row0 * a.v_rs + h * HD;
+        const T* gb = reinterpret_cast<const T*>(a.d_o) + row0 * a.do_rs + h * HD;
         // ================= T layout (rows = key j, cols = query i): P^T, dP^T -> dS^T -> dQ, d(bias) =================
         if (PART != 1) {
             f32x4 pt[4][4];
@@ -215,7 +255,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
                 float4 kf[4][KB], qf[4][KB];
                 load_rows<KB>(kf, kb_, a.k_rs, g, c, 1.0f);
                 load_rows<KB>(qf, qb, a.q_rs, g, c, a.scale);
-                logits_T<KB>(pt, kf, qf, sBias, labp, g, c);
+                logits_T<KB, R16>(pt, kf, qf, sBias, labp, g, c);
             }
             softmax_T(pt, inv);
             f32x4 ds[4][4];
@@ -230,7 +270,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb) acc = mfma4(vf[jt][kb], gf[it][kb], acc);
-                        ds[jt][it] = acc;  // dP^T
+                        ds[jt][it] = rq<R16>(acc);  // dP^T
                     }
             }
 #pragma unroll
@@ -250,7 +290,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = pt[jt][it][r] * (ds[jt][it][r] - delta);
-                        ds[jt][it][r] = v;  // dS^T
+                        ds[jt][it][r] = rq<R16>(v);  // dS^T (policy: the logits tensor is 16-bit, the bias gradient fp32)
                         const int j = 16 * jt + 4 * g + r;
                         if (i < N && j < N) sDb[i * NP + j] += v;
                     }
@@ -273,11 +313,11 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
             for (int it = 0; it < 4; ++it) {
                 const int i = 16 * it + c;
                 if (i >= N) continue;
-                float* p = a.dq + (row0 + i) * a.dq_rs + h * HD + 4 * g;
+                T* p = reinterpret_cast<T*>(a.dq) + (row0 + i) * a.dq_rs + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
-                    st4(p + 16 * dt, make_float4(dq[dt][it][0] * a.scale, dq[dt][it][1] * a.scale, dq[dt][it][2] * a.scale,
-                                                 dq[dt][it][3] * a.scale));
+                    st4(p + 16 * dt, make_float4(rq<R16>(dq[dt][it][0]) * a.scale, rq<R16>(dq[dt][it][1]) * a.scale,
+                                                 rq<R16>(dq[dt][it][2]) * a.scale, rq<R16>(dq[dt][it][3]) * a.scale));
             }
         }
         // ================= N layout (rows = query i = 16it + 4g + r, cols = key j = 16jt + c): P, dP -> dS -> dK, dV =================
@@ -294,7 +334,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb) acc = mfma4(qf[it][kb], kf[jt][kb], acc);
-                        pn[it][jt] = acc;
+                        pn[it][jt] = rq<R16>(acc);
                     }
             }
             int lab_j[4];
@@ -344,7 +384,7 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb) acc = mfma4(gf[it][kb], vf[jt][kb], acc);
-                        ds[it][jt] = acc;
+                        ds[it][jt] = rq<R16>(acc);
                     }
             }
 #pragma unroll
@@ -359,7 +399,10 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
                     }
                     delta = row16_add(delta);
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) ds[it][jt][r] = pn[it][jt][r] * (ds[it][jt][r] - delta);
+                    for (int jt = 0; jt < 4; ++jt) {
+                        ds[it][jt][r] = rq<R16>(pn[it][jt][r] * (ds[it][jt][r] - delta));
+                        pn[it][jt][r] = rq<R16>(pn[it][jt][r]);   // (policy: the 16-bit probabilities of the P v matmul)
+                    }
                 }
             // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]   (raw Q columns: the scale is applied at the store)
             // dV^T[d][j] =         sum_i dO[i][d] P[i][j]
@@ -372,7 +415,8 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const float4 qc = load_col(qb, a.q_rs, it, dt, g, c);
+                    float4 qc = load_col(qb, a.q_rs, it, dt, g, c);
+                    qc = make_float4(rq<R16>(qc.x * qmul), rq<R16>(qc.y * qmul), rq<R16>(qc.z * qmul), rq<R16>(qc.w * qmul));
                     const float4 gc = load_col(gb, a.do_rs, it, dt, g, c);
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
@@ -384,12 +428,12 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
             for (int jt = 0; jt < 4; ++jt) {
                 const int j = 16 * jt + c;
                 if (j >= N) continue;
-                float* pk = a.dk + (row0 + j) * a.dk_rs + h * HD + 4 * g;
-                float* pv = a.dv + (row0 + j) * a.dv_rs + h * HD + 4 * g;
+                T* pk = reinterpret_cast<T*>(a.dk) + (row0 + j) * a.dk_rs + h * HD + 4 * g;
+                T* pv = reinterpret_cast<T*>(a.dv) + (row0 + j) * a.dv_rs + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    st4(pk + 16 * dt, make_float4(dk[dt][jt][0] * a.scale, dk[dt][jt][1] * a.scale, dk[dt][jt][2] * a.scale,
-                                                  dk[dt][jt][3] * a.scale));
+                    st4(pk + 16 * dt, make_float4(dk[dt][jt][0] * omul, dk[dt][jt][1] * omul, dk[dt][jt][2] * omul,
+                                                  dk[dt][jt][3] * omul));
                     st4(pv + 16 * dt, make_float4(dv[dt][jt][0], dv[dt][jt][1], dv[dt][jt][2], dv[dt][jt][3]));
                 }
             }
@@ -412,18 +456,20 @@ __global__ __launch_bounds__(WA_WAVES * 64) void winattn_mfma_bwd_kernel(dkd_win
 // launched by dkd_winattn_{fwd,bwd}_f32 (swin.hip) after argument checks; N == 49 only
 int dkd_winattn_mfma_fwd(const dkd_winattn_args* a, hipStream_t st) {
     dim3 grid(dkd_winattn_parts(a->Bw, a->H), a->H);
-    if (a->hd == 32) hipLaunchKernelGGL((winattn_mfma_fwd_kernel<32>), grid, dim3(WA_WAVES * 64), 0, st, *a);
-    else if (a->hd == 16) hipLaunchKernelGGL((winattn_mfma_fwd_kernel<16>), grid, dim3(WA_WAVES * 64), 0, st, *a);
-    else return DKD_ERR_UNSUPPORTED;
+    if (a->hd != 32 && a->hd != 16) return DKD_ERR_UNSUPPORTED;
+    DKD_IO_TYPE(a->policy16, T,
+                if (a->hd == 32) hipLaunchKernelGGL((winattn_mfma_fwd_kernel<32, T>), grid, dim3(WA_WAVES * 64), 0, st, *a);
+                else hipLaunchKernelGGL((winattn_mfma_fwd_kernel<16, T>), grid, dim3(WA_WAVES * 64), 0, st, *a));
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 
 int dkd_winattn_mfma_bwd(const dkd_winattn_args* a, hipStream_t st) {
     dim3 grid(dkd_winattn_parts(a->Bw, a->H), a->H);
-    if (a->hd == 32) hipLaunchKernelGGL((winattn_mfma_bwd_kernel<32, 2>), grid, dim3(WA_WAVES * 64), 0, st, *a);
-    else if (a->hd == 16) hipLaunchKernelGGL((winattn_mfma_bwd_kernel<16, 2>), grid, dim3(WA_WAVES * 64), 0, st, *a);
-    else return DKD_ERR_UNSUPPORTED;
+    if (a->hd != 32 && a->hd != 16) return DKD_ERR_UNSUPPORTED;
+    DKD_IO_TYPE(a->policy16, T,
+                if (a->hd == 32) hipLaunchKernelGGL((winattn_mfma_bwd_kernel<32, 2, T>), grid, dim3(WA_WAVES * 64), 0, st, *a);
+                else hipLaunchKernelGGL((winattn_mfma_bwd_kernel<16, 2, T>), grid, dim3(WA_WAVES * 64), 0, st, *a));
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -316,8 +316,6 @@ class AttentionProjector16Fn(Function):
         if nwin > 1:
             # losses/scalekd.py:303-306,313-314: q / k / v window-major (pure data movement: a bf16 [.., D] tensor is an fp32
             # [.., D / 2] tensor to the permute kernel), attention inside each window, the result only VIEWED back
-            if (N // nwin) % 8:
-                raise NotImplementedError("windowed attention under the policy needs windows of a multiple of 8 tokens")
             wperm = lambda t, inv=False: ops.window_permute(t.reshape(B, N, D).view(F32), Ph, Pw, wh, ww, inverse=inv).view(BF16).reshape(M, D)
             qfull = q16.reshape(1, N, D).expand(B, N, D).contiguous() if shared else q16
             q16w, k16w, v16w = wperm(qfull), wperm(k16), wperm(v16)
@@ -452,16 +450,17 @@ class ViTBlockFrozen16Fn(Function):
 class DctRoundtrip16Fn(Function):
     """inverse_dct(zero_dc(dct(map))) of the frequency loss (losses/scalekd.py:107-118) under the autocast policy: the reference
     builds both transforms from nn.Linear layers (:337-428), so they are four 16-bit matmuls with 16-bit matrices - NOT the exact
-    mean removal the fp32 path uses.  tok [B, 256, C] fp32 (a 16 x 16 token grid) -> the same layout, fp32 holding the 16-bit
-    result.  Fw / Gw: forward / inverse Linear weights [16, 16] (fp32 holding their 16-bit values)."""
+    mean removal the fp32 path uses.  tok [B, R*R, C] fp32 (an R x R token grid: 16 at 224 px, 37 at 518 px) -> the same
+    layout, fp32 holding the 16-bit result.  Fw / Gw: forward / inverse Linear weights [R, R] (fp32 holding their 16-bit values)."""
 
     @staticmethod
     def forward(ctx, tok, Fw, Gw):
         tok = _c(tok)
         B, N, C = tok.shape
-        if N != 256:
-            raise NotImplementedError("the mixed-precision frequency loss is written for the 16 x 16 grid (224 / 14)")
-        x = tok.reshape(B, 16, 16, C)
+        R = Fw.shape[0]
+        if N != R * R:
+            raise ValueError(f"DctRoundtrip16Fn: {N} tokens are not a {R} x {R} grid")
+        x = tok.reshape(B, R, R, C)
         x = ops.dct16_step(x, Fw, 0)                       # forward_transform along W
         x = ops.dct16_step(x, Fw, 1, zero_out=True)        # ... along H; [:, :, 0, 0] = 0
         x = ops.dct16_step(x, Gw, 0)                       # inverse_transform along the last axis
@@ -474,7 +473,8 @@ class DctRoundtrip16Fn(Function):
         Fw, Gw = ctx.saved_tensors
         dy = _c(dy)
         B, N, C = dy.shape
-        d = ops.dct16_step(dy.reshape(B, 16, 16, C), Gw, 1, transposed=True)
+        R = Fw.shape[0]
+        d = ops.dct16_step(dy.reshape(B, R, R, C), Gw, 1, transposed=True)
         d = ops.dct16_step(d, Gw, 0, transposed=True)
         d = ops.dct16_step(d, Fw, 1, transposed=True, zero_in=True)
         d = ops.dct16_step(d, Fw, 0, transposed=True, out_dtype=F32)

@@ -23,17 +23,17 @@ def _tokens_of_map(feat):
 _DCT16 = {}
 
 
-def _dct16_weights(device):
-    """weights of the reference's DCT(resolution=16) Linear layers (losses/scalekd.py:343-350: ``_dct(I).t()`` / ``_idct(I).t()``,
-    norm=None) as the 16-bit values autocast multiplies with, held in fp32: forward W[k][w] = 2 cos(pi (2w+1) k / 32), inverse
-    W[w][k] = cos(pi (2w+1) k / 32) / 16 (k = 0: / 32)"""
-    key = str(device)
+def _dct16_weights(device, R=16):
+    """weights of the reference's DCT(resolution=R) Linear layers (losses/scalekd.py:343-350: ``_dct(I).t()`` / ``_idct(I).t()``,
+    norm=None) as the 16-bit values autocast multiplies with, held in fp32: forward W[k][w] = 2 cos(pi (2w+1) k / 2R), inverse
+    W[w][k] = cos(pi (2w+1) k / 2R) / R (k = 0: / 2R)"""
+    key = (str(device), R)
     if key not in _DCT16:
         import math
-        j = torch.arange(16, dtype=torch.float64)
-        ang = math.pi * (2 * j[:, None] + 1) * j[None, :] / 32          # [w, k]
+        j = torch.arange(R, dtype=torch.float64)
+        ang = math.pi * (2 * j[:, None] + 1) * j[None, :] / (2 * R)      # [w, k]
         fw = (2 * torch.cos(ang)).t()                                     # [k, w]
-        gw = torch.cos(ang) / 16                                          # [w, k]
+        gw = torch.cos(ang) / R                                           # [w, k]
         gw[:, 0] = gw[:, 0] / 2
         rnd = lambda m: m.float().bfloat16().float().contiguous().to(device)
         _DCT16[key] = (rnd(fw), rnd(gw))
@@ -133,7 +133,7 @@ class ScaleKD(nn.Module):
         if self.projector_0.precision == "bf16_autocast":
             # under autocast the reference's DCT (nn.Linear layers, scalekd.py:337-428) is four 16-bit matmuls per map: reproduce
             # THAT rather than the exact mean removal; the normalise / MSE / cosine tail is fp32 either way
-            Fw, Gw = _dct16_weights(preds_S.device)
+            Fw, Gw = _dct16_weights(preds_S.device, preds_T.shape[-1])
             with torch.no_grad():
                 t = Fn16.DctRoundtrip16Fn.apply(_tokens_of_map(preds_T), Fw, Gw)
             return Fn.KDLossFn.apply(Fn16.DctRoundtrip16Fn.apply(preds_S, Fw, Gw), t, self.alpha[1], False)

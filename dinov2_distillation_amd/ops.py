@@ -845,7 +845,10 @@ def dropout(x, p, seed, offset, out=None):
 def _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
     a = _lib.args("dkd_winattn_args")
     C = H * hd
-    _chk(qkv, "qkv"), _chk(o, "o"), _chk(bias, "bias")
+    pol = qkv.dtype == torch.bfloat16   # the autocast policy's kernels (dkd_winattn_args.policy16): bf16 q / k / v / o, fp32 bias
+    (_chk16(qkv, "qkv"), _chk16(o, "o")) if pol else (_chk(qkv, "qkv"), _chk(o, "o"))
+    _chk(bias, "bias")
+    a.policy16 = int(pol)
     if labels is not None:
         _chk_idx(labels, "labels", qkv.device)
         if labels.numel() != nW * N:
@@ -862,7 +865,7 @@ def _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
 
 def winattn_forward(qkv, bias, labels, Bw, nW, H, N, hd, scale):
     """qkv [Bw*N, 3*H*hd] packed (3, H, hd) per row -> context [Bw*N, H*hd]"""
-    o = torch.empty((Bw * N, H * hd), dtype=torch.float32, device=qkv.device)
+    o = torch.empty((Bw * N, H * hd), dtype=qkv.dtype, device=qkv.device)
     a = _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale)
     check(_lib.binding().dkd_winattn_fwd_f32(_lib.ref(a), _stream()), f"dkd_winattn_fwd_f32[N={N},hd={hd}]")
     return o
@@ -871,7 +874,7 @@ def winattn_forward(qkv, bias, labels, Bw, nW, H, N, hd, scale):
 def winattn_backward(do, qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
     """-> (dqkv [Bw*N, 3C], dbias [N*N, H])"""
     lib = _lib.binding()
-    _chk(do, "do")
+    _chk16(do, "do") if qkv.dtype == torch.bfloat16 else _chk(do, "do")
     C = H * hd
     dqkv = torch.empty_like(qkv)
     parts = lib.dkd_winattn_parts(Bw, H)
@@ -1145,31 +1148,62 @@ def _chk16v(t, name, ld):
         raise _lib.DkdError(f"{name}: expected a bfloat16 column slice with row pitch {ld}, got strides {tuple(t.stride())}")
 
 
+def regroup_rows16(src, lds, gs_src, gs_dst, groups, cols, out=None, ldd=None):
+    """dkd_regroup_rows_bf16: bf16 rows [groups * gs_src, cols] (pitch lds) -> [groups * gs_dst, cols]; rows past gs_src are zero"""
+    if out is None:
+        out, ldd = torch.empty((groups * gs_dst, cols), dtype=BF16, device=src.device), cols
+    check(_lib.binding().dkd_regroup_rows_bf16(_p(src), lds, gs_src, _p(out), ldd, gs_dst, groups, cols, _stream()),
+          "dkd_regroup_rows_bf16", (lds, gs_src, ldd, gs_dst, groups, cols))
+    return out
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
 def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, ld=None):
     """q [B*Nq, H*hd], k / v [B*Nk, H*hd] bf16 (token-major, heads side by side; ld: they are column slices of one [rows, ld]
     buffer - a fused qkv Linear's output) -> O [B*Nq, H*hd] bf16 and the saved logits / probabilities S, P [B*H, Nq, Nk] bf16:
-    S = rnd(q k^T), P = rnd(softmax_fp32(rnd(rnd(S c1) c2))), O = rnd(P v)"""
+    S = rnd(q k^T), P = rnd(softmax_fp32(rnd(rnd(S c1) c2))), O = rnd(P v).
+    Token counts that are no multiple of 8 (the 37 x 37 grid of a 518 px crop, 1370 teacher tokens): q / k / v are copied into
+    zero-padded blocks, the padded key columns are masked out of the softmax, S and P come back padded ([B*H, Nq8, Nk8])."""
     _chk16v(q, "q", ld), _chk16v(k, "k", ld), _chk16v(v, "v", ld)
     D = H * hd
     L = D if ld is None else ld
-    if (Nk % 8) or (Nq % 8) or (hd % 8):
-        raise _lib.DkdError(f"attention16: token counts and head dim must be multiples of 8 (got {Nq}, {Nk}, {hd})")
+    if hd % 8:
+        raise _lib.DkdError(f"attention16: the head dim must be a multiple of 8 (got {hd})")
+    valid = 0
+    if (Nk % 8) or (Nq % 8):
+        Nq0, valid = Nq, Nk
+        q = regroup_rows16(q, L, Nq, _pad8(Nq), 1 if q_shared else B, D)
+        k, v = regroup_rows16(k, L, Nk, _pad8(Nk), B, D), regroup_rows16(v, L, Nk, _pad8(Nk), B, D)
+        Nq, Nk, L = _pad8(Nq), _pad8(Nk), D
     S = torch.empty((B * H, Nq, Nk), dtype=BF16, device=q.device)
     qz = (0 if q_shared else Nq * L, hd)  # q_shared: one [Nq, D] query block for every image
     _gemm16_batched(q, L, qz, k, L, (Nk * L, hd), S, Nk, (H * Nq * Nk, Nq * Nk), Nq, Nk, hd, B * H, H)
     P = torch.empty_like(S)
-    check(_lib.binding().dkd_attn16_softmax_fwd(_p(S), _p(P), B * H * Nq, Nk, Nk, c1, c2, _stream()), "dkd_attn16_softmax_fwd")
+    check(_lib.binding().dkd_attn16_softmax_fwd(_p(S), _p(P), B * H * Nq, Nk, Nk, c1, c2, valid, _stream()), "dkd_attn16_softmax_fwd")
     O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
     _gemm16_batched(P, Nk, (H * Nq * Nk, Nq * Nk), v, L, (Nk * L, hd), O, D, (Nq * D, hd), Nq, hd, Nk, B * H, H, b_layout=1)
+    if valid:
+        O = regroup_rows16(O, D, Nq, Nq0, B, D)
     return O, S, P
 
 
 def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, ld=None, out=None):
     """-> dq, dk, dv (bf16), every matmul result and every scalar product rounded as autograd's 16-bit backward does.
-    ld: q / k / v are column slices with that row pitch; out = (dq, dk, dv) column slices (same pitch) to write into."""
+    ld: q / k / v are column slices with that row pitch; out = (dq, dk, dv) column slices (same pitch) to write into.
+    S / P padded (attention16_forward on a ragged token count): the operands are padded the same way, the results cropped."""
     _chk16(dO, "dO")
     D = H * hd
     L = D if ld is None else ld
+    valid, final = 0, None
+    if (Nk % 8) or (Nq % 8):
+        valid, final, Nq0, Nk0, L0 = Nk, out, Nq, Nk, L
+        dO = regroup_rows16(dO, D, Nq, _pad8(Nq), B, D)
+        q = regroup_rows16(q, L, Nq, _pad8(Nq), 1 if q_shared else B, D)
+        k, v = regroup_rows16(k, L, Nk, _pad8(Nk), B, D), regroup_rows16(v, L, Nk, _pad8(Nk), B, D)
+        Nq, Nk, L, out = _pad8(Nq), _pad8(Nk), D, None
     pz, oz_q, oz_k = (H * Nq * Nk, Nq * Nk), (Nq * D, hd), (Nk * D, hd)   # S / P planes, dense [rows, D] tensors
     lz_q, lz_k = (0 if q_shared else Nq * L, hd), (Nk * L, hd)            # q / k / v (and dq / dk / dv when `out` is given)
     dP = torch.empty_like(S)
@@ -1185,9 +1219,19 @@ def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shar
         Lo, zq, zk = L, (Nq * L, hd), (Nk * L, hd)
     _gemm16_batched(P, Nk, pz, dO, D, oz_q, dv, Lo, zk, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)           # dv = P^T dO
     dS = dP  # in place: row r of dS depends on row r of S and dP only
-    check(_lib.binding().dkd_attn16_softmax_bwd(_p(S), _p(dP), _p(dS), B * H * Nq, Nk, Nk, c1, c2, _stream()), "dkd_attn16_softmax_bwd")
+    check(_lib.binding().dkd_attn16_softmax_bwd(_p(S), _p(dP), _p(dS), B * H * Nq, Nk, Nk, c1, c2, valid, _stream()),
+          "dkd_attn16_softmax_bwd")
     _gemm16_batched(dS, Nk, pz, k, L, lz_k, dq, Lo, zq, Nq, hd, Nk, B * H, H, b_layout=1)                       # dq = dS k
     _gemm16_batched(dS, Nk, pz, q, L, lz_q, dk, Lo, zk, Nk, hd, Nq, B * H, H, a_layout=1, b_layout=1)           # dk = dS^T q
+    if valid:
+        if final is None:
+            return (regroup_rows16(dq, D, Nq, Nq0, B, D), regroup_rows16(dk, D, Nk, Nk0, B, D), regroup_rows16(dv, D, Nk, Nk0, B, D))
+        for t, n in zip(final, ("dq", "dk", "dv")):
+            _chk16v(t, n, L0)
+        regroup_rows16(dq, D, Nq, Nq0, B, D, out=final[0], ldd=L0)
+        regroup_rows16(dk, D, Nk, Nk0, B, D, out=final[1], ldd=L0)
+        regroup_rows16(dv, D, Nk, Nk0, B, D, out=final[2], ldd=L0)
+        return final
     return dq, dk, dv
 
 
@@ -1214,12 +1258,12 @@ def gelu16(x, dy=None):
 
 
 def dct16_step(x, Mx, axis, out_dtype=BF16, transposed=False, zero_in=False, zero_out=False):
-    """one 16 x 16 Linear of the DCT pipeline along W (axis 0) or H (axis 1) of an NHWC map [B, 16, 16, C] (dkd_hip.h)"""
+    """one R x R Linear of the DCT pipeline along W (axis 0) or H (axis 1) of an NHWC map [B, R, R, C] (dkd_hip.h; R = 16, 32, 37)"""
     _chk_io(x, "x"), _chk(Mx, "Mx")
     B, H, W, C = x.shape
-    if H != 16 or W != 16 or tuple(Mx.shape) != (16, 16):
-        raise _lib.DkdError(f"dct16_step: a 16 x 16 grid is needed (got {H} x {W})")
+    if H != W or tuple(Mx.shape) != (H, H):
+        raise _lib.DkdError(f"dct_step: a square grid and a matching matrix are needed (got {H} x {W}, {tuple(Mx.shape)})")
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    check(_lib.binding().dkd_dct16_step(_p(x), _is16(x), _p(out), int(out_dtype == BF16), _p(Mx), B, C, axis, int(transposed),
-                                        int(zero_in), int(zero_out), _stream()), "dkd_dct16_step")
+    check(_lib.binding().dkd_dct_step(_p(x), _is16(x), _p(out), int(out_dtype == BF16), _p(Mx), B, H, C, axis, int(transposed),
+                                      int(zero_in), int(zero_out), _stream()), "dkd_dct_step", (H, C))
     return out

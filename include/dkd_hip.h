@@ -241,15 +241,24 @@ int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
  * 308-313 and the DINOv2 block): the logits S are a bf16 matmul result (dkd_gemm_bf16, batched), each scalar factor rounds
  * again, softmax runs in fp32 and its result is rounded to bf16 for the second matmul.  rows x N logits with row pitch ld
  * (multiples of 4).  fwd: P = rnd(softmax(rnd(rnd(S c1) c2))).  bwd: dS = rnd(rnd(rnd(dT) c2) c1) with
- * dT = P32 (dP - sum(dP P32)), P32 recomputed from S.  out = rnd(x * s) on n bf16 values (the DINOv2 block's q * scale). */
-int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, void* stream);
-int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, void* stream);
+ * dT = P32 (dP - sum(dP P32)), P32 recomputed from S.  out = rnd(x * s) on n bf16 values (the DINOv2 block's q * scale).
+ * valid (0 = N): key columns valid..N-1 are padding (token counts that are no multiple of 8, e.g. the 37 x 37 grid of a 518 px
+ * crop): excluded from the softmax, their P / dS entries written as zeros. */
+int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, float c1, float c2, int valid, void* stream);
+int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, int valid,
+                           void* stream);
 int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
+/* token padding of the same path: bf16 rows [groups * gs_src, cols] (row pitch lds) -> [groups * gs_dst, cols] (pitch ldd); row i
+ * of a group is copied while i < gs_src and zero beyond (gs_dst > gs_src pads, gs_dst < gs_src crops); cols, pitches % 8 == 0 */
+int dkd_regroup_rows_bf16(const void* src, long lds, int gs_src, void* dst, long ldd, int gs_dst, long groups, int cols, void* stream);
 /* one Linear of the frequency loss's DCT / inverse DCT (losses/scalekd.py:337-428: 16 x 16 matrices applied along one spatial
  * axis) under the 16-bit policy on an NHWC map [n_maps, 16, 16, C]: out = rnd(Mx . in) along axis 0 (W) or 1 (H); Mx[16][16] the
  * 16-bit matrix values in fp32; transposed: the adjoint; zero_in / zero_out: the DC coefficient is zero (:114-115) */
 int dkd_dct16_step(const void* in, int in16, void* out, int out16, const float* Mx, long n_maps, int C, int axis, int transposed,
                    int zero_in, int zero_out, void* stream);
+/* the same step for an R x R grid (R = 16, 32 or 37: crops of 224, 448, 518 px with 14-px patches); Mx[R][R] */
+int dkd_dct_step(const void* in, int in16, void* out, int out16, const float* Mx, long n_maps, int R, int C, int axis, int transposed,
+                 int zero_in, int zero_out, void* stream);
 int dkd_gelu_bf16(const void* x, const void* dy, void* out, long n, void* stream); /* dy NULL: gelu(x); else dy * gelu'(x); bf16 */
 int dkd_relu_bwd_bf16(const void* dy, const void* y, void* dx, long n, void* stream); /* dx = y > 0 ? dy : 0 on bf16 tensors */
 /* fp32 [rows, cols] -> bf16 [rows, out_ld] (round to nearest even; columns cols..out_ld-1 zero: K padding of the 14x14x3 = 588
@@ -456,6 +465,9 @@ typedef struct dkd_winattn_args {
     int64_t q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;
     int32_t Bw, nW, H, N, hd, parts;
     float scale;
+    int32_t policy16; /* 1: q / k / v / o / d_o / dq / dk / dv are bf16 and the arithmetic is what torch autocast makes of
+                         WindowAttention.forward (train.py:263): q * scale, q k^T, P v and the backward matmuls are 16-bit results,
+                         bias add + softmax (and d(bias)) fp32.  N = 49, hd in {16, 32} only. */
 } dkd_winattn_args;
 int dkd_winattn_fwd_f32(const dkd_winattn_args* args, void* stream);
 int dkd_winattn_bwd_f32(const dkd_winattn_args* args, void* stream);
@@ -464,6 +476,11 @@ int dkd_winattn_dbias_f32(const float* part, float* dbias, int parts, int H, int
 int dkd_gather_rows_f32(const float* in, const int* idx, const float* res, float* out, long rows, int C, void* stream);
 int dkd_index_add_rows_f32(const float* src, const int* idx, float* out, int rows, int T, int C, void* stream);
 int dkd_dropout_f32(const float* x, float* y, long n, float p, int64_t seed, int64_t offset, void* stream);
+/* the same on tensors torch autocast keeps in 16 bit, optionally fused with the residual add behind it (swin.py:331-332):
+ * d = x * mask / (1 - p) (rounded to bf16 when x is bf16: the dropout result is a 16-bit tensor), y = (res ? res : 0) + d in y's
+ * type.  x16 / res16 / y16: the tensor is bf16 (else fp32).  Same mask as dkd_dropout_f32 for the same (seed, offset). */
+int dkd_dropout_add_io(const void* x, int x16, const void* res, int res16, void* y, int y16, long n, float p, int64_t seed,
+                       int64_t offset, void* stream);
 
 #ifdef __cplusplus
 }
