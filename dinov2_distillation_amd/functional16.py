@@ -167,20 +167,23 @@ class LayerNorm16Fn(Function):
     conv applies to its input)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out16):
+    def forward(ctx, x, gamma, beta, eps, out16, plain=False):
+        """plain: nn.LayerNorm / F.layer_norm (autocast's fp32 list: the 16-bit input is cast up, everything else is fp32) rather
+        than the op-by-op channels-first form - the Swin norms (swin.py:274,332,366,536,720)"""
         x = _c(x)
-        cf16 = x.dtype == BF16
+        cf16 = x.dtype == BF16 and not plain
         y, mean, rstd = ops.layernorm_fwd_io(x, gamma, beta, eps, BF16 if out16 else F32, cf16=cf16)
         ctx.save_for_backward(x, mean, rstd, gamma)
         ctx.params = (gamma, beta)
+        ctx.cf16 = cf16
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, gamma = ctx.saved_tensors
         og, ob = direct(*ctx.params)
-        dx, dg, db = ops.layernorm_bwd_io(_c(dy), x, mean, rstd, gamma, x.dtype, dg_out=og, db_out=ob, cf16=x.dtype == BF16)
-        return dx, ret(og, dg, ctx.params[0]), ret(ob, db, ctx.params[1]), None, None
+        dx, dg, db = ops.layernorm_bwd_io(_c(dy), x, mean, rstd, gamma, x.dtype, dg_out=og, db_out=ob, cf16=ctx.cf16)
+        return dx, ret(og, dg, ctx.params[0]), ret(ob, db, ctx.params[1]), None, None, None
 
 
 class PatchConv16Fn(Function):
@@ -204,7 +207,7 @@ class PatchConv16Fn(Function):
         ctx.save_for_backward(rows, w2)
         ctx.meta = (k, src_nchw, tuple(x.shape), tuple(w.shape))
         ctx.params = (w, b)
-        return y.reshape(B, H // k, W // k, O)
+        return y.reshape(B, -(-H // k), -(-W // k), O)  # ceil: a ragged image edge is zero-padded (Swin patch-embed, swin.py:526-529)
 
     @staticmethod
     def backward(ctx, dy):
@@ -479,6 +482,153 @@ class DctRoundtrip16Fn(Function):
         d = ops.dct16_step(d, Fw, 1, transposed=True, zero_in=True)
         d = ops.dct16_step(d, Fw, 0, transposed=True, out_dtype=F32)
         return d.reshape(B, N, C), None, None
+
+
+# =====================================================================================================================
+# Swin-Transformer student under the policy (BASELINE configs[3]).  What torch autocast makes of swin.py: every nn.Linear (qkv, proj,
+# fc1, fc2, the PatchMerging reduction) and the patch-embed conv are 16-bit matmuls with 16-bit results; nn.LayerNorm runs in fp32
+# and returns fp32; GELU and Dropout act on (and return) the 16-bit Linear outputs; inside WindowAttention q * scale and q k^T are
+# 16-bit, adding the fp32 relative-position bias promotes the logits to fp32, softmax is fp32, its result is cast down for P v
+# (dkd_winattn_args.policy16).  The residual stream is fp32 in stage 0 (patch_embed.norm returns fp32; fp32 + 16-bit -> fp32)
+# and 16-bit from the first PatchMerging on (its reduction Linear returns 16 bit; 16-bit + 16-bit -> 16-bit, rounded at every
+# add).  Pad / roll / window partition / merge are data movement in whatever type they get: the same row gathers as the fp32 path.
+def _drop16(x, p, seed, slot, res=None, out_dtype=None):
+    s, call = seed
+    return ops.dropout_add(x, p, s, ((call * 4 + slot) << 40), res=res, out_dtype=out_dtype)
+
+
+class SwinBlock16Fn(Function):
+    """SwinTransformerBlock.forward (swin.py:268-334) under the autocast policy on tokens [B, H*W, C], fp32 (stage 0) or bf16.
+    Same schedule as functional.SwinBlockFn with two differences that change no value: the window merge (one row gather) is applied
+    to the attention context BEFORE proj - a Linear commutes with a row permutation, the padded slots it would have produced are
+    cropped by the reference anyway (:326-327) - so that proj's epilogue adds the residual; and dropout masks are drawn in token
+    order."""
+
+    @staticmethod
+    def forward(ctx, x, geom, num_heads, p_drop, n1w, n1b, table, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+        from .functional import _drop_seed
+        x = _c(x)
+        B, L, C = x.shape
+        M, hd, N = B * L, C // num_heads, geom.N
+        s16 = x.dtype == BF16
+        x2 = x.reshape(M, C)
+        drop = p_drop > 0.0
+        seed = _drop_seed() if drop else None
+        y16, m1, r1 = ops.layernorm_fwd_io(x2, n1w, n1b, 1e-5, BF16)
+        yw16 = ops.gather_rows16(y16, geom.to_win)                       # zero rows at padded slots, as F.pad after norm1 (:283-287)
+        wqkv, wproj, w1, w2 = (_w16(t) for t in (qkv_w, proj_w, fc1_w, fc2_w))
+        qkv16 = ops.gemm_bf16(yw16, wqkv, bias=_w16(qkv_b))
+        bias = ops.gather_rows(table, geom.rel_index)                    # [N*N, heads] fp32
+        Bw = geom.to_win.numel() // N
+        o16 = ops.winattn_forward(qkv16, bias, geom.labels, Bw, geom.nW, num_heads, N, hd, hd ** -0.5)
+        ot16 = ops.gather_rows16(o16, geom.from_win)                     # token order
+        del o16
+        if drop:
+            x1 = _drop16(ops.gemm_bf16(ot16, wproj, bias=_w16(proj_b)), p_drop, seed, 0, res=x2)
+        elif s16:
+            x1 = ops.gemm_bf16_resid16(ot16, wproj, _w16(proj_b), x2)
+        else:
+            x1 = ops.gemm_bf16(ot16, wproj, epi=ops.EPI_F32_RESID, bias=_w16(proj_b), residual=x2)
+        z16, m2, r2 = ops.layernorm_fwd_io(x1, n2w, n2b, 1e-5, BF16)
+        u16 = ops.gemm_bf16(z16, w1, bias=_w16(fc1_b))
+        g16 = ops.gelu16(u16)
+        if drop:
+            g16 = _drop16(g16, p_drop, seed, 1)
+            out = _drop16(ops.gemm_bf16(g16, w2, bias=_w16(fc2_b)), p_drop, seed, 2, res=x1)
+        elif s16:
+            out = ops.gemm_bf16_resid16(g16, w2, _w16(fc2_b), x1)
+        else:
+            out = ops.gemm_bf16(g16, w2, epi=ops.EPI_F32_RESID, bias=_w16(fc2_b), residual=x1)
+        ctx.save_for_backward(x2, m1, r1, yw16, qkv16, ot16, bias, x1, m2, r2, z16, u16, g16, n1w, n2w, wqkv, wproj, w1, w2)
+        ctx.meta = (B, L, C, num_heads, p_drop, seed, geom)
+        ctx.lin = (qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b)
+        ctx.small = (n1w, n1b, table, n2w, n2b)
+        return out.reshape(B, L, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, m1, r1, yw16, qkv16, ot16, bias, x1, m2, r2, z16, u16, g16, n1w, n2w, wqkv, wproj, w1, w2 = ctx.saved_tensors
+        B, L, C, nH, p_drop, seed, geom = ctx.meta
+        M, hd, N = B * L, C // nH, geom.N
+        s16 = x2.dtype == BF16
+        drop = p_drop > 0.0
+        pqkv_w, pqkv_b, pproj_w, pproj_b, pfc1_w, pfc1_b, pfc2_w, pfc2_b = ctx.lin
+        p_n1w, p_n1b, p_tab, p_n2w, p_n2b = ctx.small
+        o_n1w, o_n1b, o_tab, o_n2w, o_n2b = direct(*ctx.small)
+        d2 = _c(dout).reshape(M, C)
+        if d2.dtype != x2.dtype:
+            raise RuntimeError(f"SwinBlock16Fn: the gradient of a {x2.dtype} residual stream arrived as {d2.dtype}")
+        dm16 = d2 if s16 else ops.cast_bf16(d2)                          # gradient of the 16-bit fc2 (or dropout) output
+        if drop:
+            dm16 = _drop16(dm16, p_drop, seed, 2)
+        dfc2_w, dfc2_b = wgrad16(dm16, g16, pfc2_w, pfc2_b)
+        dg16 = ops.gemm_bf16(dm16, w2, b_layout=1)
+        if drop:
+            dg16 = _drop16(dg16, p_drop, seed, 1)
+        du16 = ops.gelu16(u16, dg16)
+        dfc1_w, dfc1_b = wgrad16(du16, z16, pfc1_w, pfc1_b)
+        dz16 = ops.gemm_bf16(du16, w1, b_layout=1)                       # gradient of norm2's output, cast down by fc1's input cast
+        if s16:   # x1 is 16-bit: its two consumers' gradients (the add, norm2's input cast) are 16-bit and are added in 16 bit
+            dln, dn2w, dn2b = ops.layernorm_bwd_io(dz16, x1, m2, r2, n2w, BF16, dg_out=o_n2w, db_out=o_n2b)
+            dx1 = ops.add16(dln, d2)
+            da16 = dx1
+        else:
+            dx1, dn2w, dn2b = ops.layernorm_bwd(ops.cast_f32(dz16), x1, m2, r2, n2w, add=d2, dg_out=o_n2w, db_out=o_n2b)
+            da16 = ops.cast_bf16(dx1)
+        if drop:
+            da16 = _drop16(da16, p_drop, seed, 0)
+        dproj_w, dproj_b = wgrad16(da16, ot16, pproj_w, pproj_b)
+        dot16 = ops.gemm_bf16(da16, wproj, b_layout=1)
+        do16 = ops.gather_rows16(dot16, geom.to_win)                     # adjoint of the window merge (pad slots receive nothing)
+        Bw = geom.to_win.numel() // N
+        dqkv16, dbias = ops.winattn_backward(do16, qkv16, do16, bias, geom.labels, Bw, geom.nW, nH, N, hd, hd ** -0.5)
+        dtab = ops.index_add_rows(dbias, geom.rel_index, p_tab.shape[0], out=o_tab)
+        dqkv_w, dqkv_b = wgrad16(dqkv16, yw16, pqkv_w, pqkv_b)
+        dyw16 = ops.gemm_bf16(dqkv16, wqkv, b_layout=1)
+        dy16 = ops.gather_rows16(dyw16, geom.from_win)                   # adjoint of pad + roll + partition
+        if s16:
+            dln, dn1w, dn1b = ops.layernorm_bwd_io(dy16, x2, m1, r1, n1w, BF16, dg_out=o_n1w, db_out=o_n1b)
+            dx = ops.add16(dln, dx1)
+        else:
+            dx, dn1w, dn1b = ops.layernorm_bwd(ops.cast_f32(dy16), x2, m1, r1, n1w, add=dx1, dg_out=o_n1w, db_out=o_n1b)
+        return (dx.reshape(B, L, C), None, None, None, ret(o_n1w, dn1w, p_n1w), ret(o_n1b, dn1b, p_n1b), ret(o_tab, dtab, p_tab),
+                dqkv_w, dqkv_b, dproj_w, dproj_b, ret(o_n2w, dn2w, p_n2w), ret(o_n2b, dn2b, p_n2b), dfc1_w, dfc1_b, dfc2_w, dfc2_b)
+
+
+class PatchMerge16Fn(Function):
+    """PatchMerging.forward (swin.py:350-376) under the policy: zero-padded 2x2 concat (one row gather, in the stream's type) ->
+    LayerNorm(4C) in fp32 -> the bias-free reduction Linear on 16-bit operands, 16-bit result (the residual stream is 16-bit from
+    here on)."""
+
+    @staticmethod
+    def forward(ctx, x, geom, nw, nb, red_w):
+        x = _c(x)
+        B, L, C = x.shape
+        x2 = x.reshape(B * L, C)
+        xm = (ops.gather_rows16(x2, geom.merge) if x.dtype == BF16 else ops.gather_rows(x2, geom.merge)).reshape(-1, 4 * C)
+        y16, m, r = ops.layernorm_fwd_io(xm, nw, nb, 1e-5, BF16)
+        w16 = _w16(red_w)
+        out = ops.gemm_bf16(y16, w16)
+        ctx.save_for_backward(xm, m, r, y16, nw, w16)
+        ctx.meta = (B, L, C, geom)
+        ctx.params = (nw, nb, red_w)
+        return out.reshape(B, -1, red_w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        xm, m, r, y16, nw, w16 = ctx.saved_tensors
+        B, L, C, geom = ctx.meta
+        p_nw, p_nb, p_red = ctx.params
+        o_nw, o_nb = direct(p_nw, p_nb)
+        d16 = _c(dout).reshape(-1, w16.shape[0])
+        if d16.dtype != BF16:
+            d16 = ops.cast_bf16(d16)
+        dred, _ = wgrad16(d16, y16, p_red, None)
+        dy16 = ops.gemm_bf16(d16, w16, b_layout=1)
+        dxm, dnw, dnb = ops.layernorm_bwd_io(dy16, xm, m, r, nw, xm.dtype, dg_out=o_nw, db_out=o_nb)
+        dxm = dxm.reshape(-1, C)
+        dx = ops.gather_rows16(dxm, geom.unmerge) if dxm.dtype == BF16 else ops.gather_rows(dxm, geom.unmerge)
+        return dx.reshape(B, L, C), None, ret(o_nw, dnw, p_nw), ret(o_nb, dnb, p_nb), dred
 
 
 # =====================================================================================================================

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 PATCH = 4
 
@@ -142,7 +143,8 @@ class SwinTransformerBlock(nn.Module):
         B = x.shape[0]
         g = _geom("block", B, H, W, self.window_size, self.shift_size, device=x.device)
         a, m = self.attn, self.mlp
-        return Fn.SwinBlockFn.apply(x, g, self.num_heads, self.drop if self.training else 0.0, self.norm1.weight, self.norm1.bias,
+        fn = Fn16.SwinBlock16Fn if getattr(self, "autocast16", False) else Fn.SwinBlockFn
+        return fn.apply(x, g, self.num_heads, self.drop if self.training else 0.0, self.norm1.weight, self.norm1.bias,
                                     a.relative_position_bias_table, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                     self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
@@ -155,7 +157,8 @@ class PatchMerging(nn.Module):
 
     def forward(self, x, H, W):
         g = _geom("merge", x.shape[0], H, W, device=x.device)
-        return Fn.PatchMergeFn.apply(x, g, self.norm.weight, self.norm.bias, self.reduction.weight)
+        fn = Fn16.PatchMerge16Fn if getattr(self, "autocast16", False) else Fn.PatchMergeFn
+        return fn.apply(x, g, self.norm.weight, self.norm.bias, self.reduction.weight)
 
 
 class BasicLayer(nn.Module):
@@ -198,7 +201,37 @@ class SwinTransformer(nn.Module):
         for i, c in enumerate(self.num_features):
             self.add_module(f"norm{i}", _ln(c))
 
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the reference's default trainer precision (train.py:263), i.e. what torch autocast makes
+        of swin.py (functional16.SwinBlock16Fn): 16-bit Linears / conv / window attention, fp32 LayerNorm and softmax, the residual
+        stream fp32 in stage 0 and 16-bit after the first PatchMerging"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown precision {precision!r}")
+        self.autocast16 = precision == "bf16_autocast"
+        for m in self.modules():
+            if isinstance(m, (SwinTransformerBlock, PatchMerging)):
+                m.autocast16 = self.autocast16
+        return self
+
+    def _forward_features_autocast(self, x):
+        B, _, H, W = x.shape
+        pe = self.patch_embed
+        x = Fn16.PatchConv16Fn.apply(x, pe.proj.weight, pe.proj.bias, PATCH, True)           # bf16 NHWC
+        H, W = x.shape[1], x.shape[2]
+        x = Fn16.LayerNorm16Fn.apply(x.reshape(B, H * W, self.embed_dim), pe.norm.weight, pe.norm.bias, 1e-5, False, True)  # fp32
+        if self.training and self.drop_rate > 0.0:
+            x = Fn.DropoutFn.apply(x, self.drop_rate)  # pos_drop, on the fp32 norm output
+        outs = {}
+        for i, layer in enumerate(self.layers):
+            x_out, x, Hn, Wn = layer(x, H, W)
+            n = getattr(self, f"norm{i}")
+            outs[f"res{i + 2}"] = Fn16.LayerNorm16Fn.apply(x_out, n.weight, n.bias, 1e-5, False, True).reshape(B, H, W, self.num_features[i])
+            H, W = Hn, Wn
+        return outs
+
     def forward_features_nhwc(self, x):
+        if getattr(self, "autocast16", False):
+            return self._forward_features_autocast(x)
         B, _, H, W = x.shape
         pe = self.patch_embed
         x = Fn.PatchConvFn.apply(x, pe.proj.weight, pe.proj.bias, PATCH, True)  # ragged edge == the zero pad of swin.py:526-529

@@ -842,6 +842,31 @@ def dropout(x, p, seed, offset, out=None):
     return out
 
 
+def dropout_add(x, p, seed, offset, res=None, out_dtype=None):
+    """dkd_dropout_add_io: res + dropout(x) on fp32 / bf16 tensors (the dropout result of a bf16 x is rounded to bf16 before the
+    add, as a 16-bit tensor is); out_dtype defaults to res's (x's without res)"""
+    _chk_io(x, "x")
+    if res is not None:
+        _chk_io(res, "res")
+        if res.numel() != x.numel():
+            raise _lib.DkdError("dropout_add: res must have x's element count")
+    if out_dtype is None:
+        out_dtype = (x if res is None else res).dtype
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(_lib.binding().dkd_dropout_add_io(_p(x), _is16(x), _p(res), _is16(res), _p(out), int(out_dtype == torch.bfloat16), x.numel(),
+                                            float(p), int(seed), int(offset), _stream()), "dkd_dropout_add_io")
+    return out
+
+
+def gather_rows16(x16, idx):
+    """gather_rows on a bf16 [rows, C] tensor: pure data movement, so the kernel sees it as fp32 [rows, C / 2]"""
+    _chk16(x16, "x16")
+    C = x16.shape[-1]
+    if C % 2:
+        raise _lib.DkdError("gather_rows16: an even row width is needed")
+    return gather_rows(x16.view(torch.float32), idx).view(torch.bfloat16)
+
+
 def _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
     a = _lib.args("dkd_winattn_args")
     C = H * hd

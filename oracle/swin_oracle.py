@@ -119,76 +119,101 @@ def shift_mask(H, W, ws):
     return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
 
-def window_attention(p, b, xw, nH, mask):
+# ---- the same functions under torch.autocast(bfloat16) with CUDA's op policy (the reference's default precision=16, train.py:263).
+# The oracle runs on the CPU, whose autocast policy leaves layer_norm and softmax in the input dtype where CUDA's runs them in
+# fp32 (torch/csrc/autocast_mode.cpp, the `fp32` cast-policy list): with policy=True those call sites are forced to fp32 with
+# explicit casts, and the matmul operands are made dense (torch's CPU bf16 matmuls lose accuracy on some strided layouts,
+# tests/diag/diag_projector16.py).  The CALLER opens torch.autocast("cpu", dtype=torch.bfloat16).  PARITY UNPINNED for that policy (no
+# CUDA device to run the reference's autocast on); the ops themselves are the pinned fp32 restatement.
+def _fp32(fn, *args, **kw):
+    with torch.autocast("cpu", enabled=False):
+        return fn(*[a.float() if torch.is_tensor(a) and a.is_floating_point() else a for a in args], **kw)
+
+
+def _ln(x, w, b, policy):
+    return _fp32(F.layer_norm, x, (x.shape[-1],), w, b, 1e-5) if policy else F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+def window_attention(p, b, xw, nH, mask, policy=False):
     """swin.py:151-199 on [B_, N, C] windows."""
     B_, N, C = xw.shape
     hd = C // nH
     qkv = F.linear(xw, p[b + "qkv.weight"], p[b + "qkv.bias"]).reshape(B_, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
-    logits = q @ k.transpose(-2, -1)
+    if policy:
+        q, kt, v = q.contiguous(), k.transpose(-2, -1).contiguous(), v.contiguous()
+    else:
+        kt = k.transpose(-2, -1)
+    logits = q @ kt
     bias = p[b + "relative_position_bias_table"][p[b + "relative_position_index"].reshape(-1)]
-    logits = logits + bias.reshape(N, N, nH).permute(2, 0, 1)[None]
+    logits = logits + bias.reshape(N, N, nH).permute(2, 0, 1)[None]   # (under autocast: 16-bit + fp32 -> fp32)
     if mask is not None:
         nW = mask.shape[0]
         logits = (logits.reshape(B_ // nW, nW, nH, N, N) + mask[None, :, None]).reshape(B_, nH, N, N)
-    ctx = (torch.softmax(logits, dim=-1) @ v).transpose(1, 2).reshape(B_, N, C)
+    w = _fp32(torch.softmax, logits, dim=-1) if policy else torch.softmax(logits, dim=-1)
+    ctx = (w @ v).transpose(1, 2).reshape(B_, N, C)
     return F.linear(ctx, p[b + "proj.weight"], p[b + "proj.bias"])
 
 
-def swin_block(p, b, x, H, W, nH, ws, shift, mask):
+def swin_block(p, b, x, H, W, nH, ws, shift, mask, policy=False):
     """swin.py:268-334, dropout / drop-path at rate 0."""
     B, L, C = x.shape
-    y = F.layer_norm(x, (C,), p[b + "norm1.weight"], p[b + "norm1.bias"], 1e-5).reshape(B, H, W, C)
+    y = _ln(x, p[b + "norm1.weight"], p[b + "norm1.bias"], policy).reshape(B, H, W, C)
     Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
     y = F.pad(y, (0, 0, 0, Wp - W, 0, Hp - H))
     if shift > 0:
         y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
-    a = window_attention(p, b + "attn.", to_windows(y, ws), nH, mask if shift > 0 else None)
+    a = window_attention(p, b + "attn.", to_windows(y, ws), nH, mask if shift > 0 else None, policy)
     y = from_windows(a, ws, Hp, Wp)
     if shift > 0:
         y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
     x = x + y[:, :H, :W].reshape(B, L, C)
-    z = F.layer_norm(x, (C,), p[b + "norm2.weight"], p[b + "norm2.bias"], 1e-5)
+    z = _ln(x, p[b + "norm2.weight"], p[b + "norm2.bias"], policy)
     z = F.linear(F.gelu(F.linear(z, p[b + "mlp.fc1.weight"], p[b + "mlp.fc1.bias"])), p[b + "mlp.fc2.weight"], p[b + "mlp.fc2.bias"])
     return x + z
 
 
-def patch_merging(p, b, x, H, W):
+def patch_merging(p, b, x, H, W, policy=False):
     """swin.py:350-376."""
     B, L, C = x.shape
     x = F.pad(x.reshape(B, H, W, C), (0, 0, 0, W % 2, 0, H % 2))
     x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], dim=-1)
     x = x.reshape(B, -1, 4 * C)
-    x = F.layer_norm(x, (4 * C,), p[b + "norm.weight"], p[b + "norm.bias"], 1e-5)
+    x = _ln(x, p[b + "norm.weight"], p[b + "norm.bias"], policy)
     return F.linear(x, p[b + "reduction.weight"])
 
 
-def forward_features(p, x, cfg):
-    """SwinTransformer.forward (swin.py:696-727): {'res2'..} NCHW feature maps of every stage."""
+def forward_features(p, x, cfg, policy=False, tokens=None):
+    """SwinTransformer.forward (swin.py:696-727): {'res2'..} NCHW feature maps of every stage.  tokens: an optional dict that
+    receives every block's and every PatchMerging's output tokens (teacher-forced per-stage tests)."""
     ws = cfg["window"]
     _, _, H, W = x.shape
     x = F.pad(x, (0, (-W) % PATCH, 0, (-H) % PATCH))
     x = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=PATCH)
     B, C, H, W = x.shape
     x = x.flatten(2).transpose(1, 2)
-    x = F.layer_norm(x, (C,), p["patch_embed.norm.weight"], p["patch_embed.norm.bias"], 1e-5)
+    x = _ln(x, p["patch_embed.norm.weight"], p["patch_embed.norm.bias"], policy)
     outs = {}
     n_layers = len(cfg["depths"])
     for i in range(n_layers):
         nH = cfg["num_heads"][i]
-        mask = shift_mask(H, W, ws).to(x.dtype)
+        mask = shift_mask(H, W, ws).to(torch.float32)
         for j in range(cfg["depths"][i]):
-            x = swin_block(p, f"layers.{i}.blocks.{j}.", x, H, W, nH, ws, 0 if j % 2 == 0 else ws // 2, mask)
+            x = swin_block(p, f"layers.{i}.blocks.{j}.", x, H, W, nH, ws, 0 if j % 2 == 0 else ws // 2, mask, policy)
+            if tokens is not None:
+                tokens[f"layers.{i}.blocks.{j}"] = x
         C = x.shape[-1]
-        o = F.layer_norm(x, (C,), p[f"norm{i}.weight"], p[f"norm{i}.bias"], 1e-5)
+        o = _ln(x, p[f"norm{i}.weight"], p[f"norm{i}.bias"], policy)
         outs[f"res{i + 2}"] = o.reshape(B, H, W, C).permute(0, 3, 1, 2)
         if i < n_layers - 1:
-            x = patch_merging(p, f"layers.{i}.downsample.", x, H, W)
+            x = patch_merging(p, f"layers.{i}.downsample.", x, H, W, policy)
+            if tokens is not None:
+                tokens[f"layers.{i}.downsample"] = x
             H, W = (H + 1) // 2, (W + 1) // 2
     return outs
 
 
-def student_features(p, x, cfg, n_patches, keys=("res4", "res5")):
+def student_features(p, x, cfg, n_patches, keys=("res4", "res5"), policy=False):
     """ModelWrapper.forward (models/model_zoo.py:116-129): bilinear resize of the chosen levels to the teacher grid."""
-    feats = forward_features(p, x, cfg)
+    feats = forward_features(p, x, cfg, policy)
     return {k: F.interpolate(feats[k], size=tuple(n_patches), mode="bilinear", align_corners=False) for k in keys}
