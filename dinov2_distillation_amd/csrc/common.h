@@ -45,6 +45,29 @@ template <> struct dkd_is16<__bf16> { static constexpr bool value = true; };
         else { using NAME = float; __VA_ARGS__; } \
     } while (0)
 
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// nn.Hardswish: x * relu6(x + 3) / 6; derivative 0 below -3, 1 above 3, (2x + 3) / 6 between (MobileNetV3)
+__device__ __forceinline__ float hswish_f(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+__device__ __forceinline__ float hswish_grad_f(float x) { return x < -3.f ? 0.f : (x > 3.f ? 1.f : fmaf(x, 1.f / 3.f, 0.5f)); }
+__device__ __forceinline__ float silu_grad_f(float y) {
+    const float sg = sigmoid_f(y);
+    return sg * fmaf(y, 1.f - sg, 1.f);
+}
+// gradient of the activation behind a BatchNorm, as a factor of the incoming gradient, from the BatchNorm OUTPUT y:
+// act 0 none, 1 ReLU, 2 ReLU6 (1 strictly inside (0, 6), as F.relu6 / hardtanh), 3 SiLU, 4 Hardswish (dkd_hip.h, `relu`)
+__device__ __forceinline__ float bn_act_grad(float d, float y, int act) {
+    if (act == 3) return d * silu_grad_f(y);
+    if (act == 4) return d * hswish_grad_f(y);
+    if (act) return (y > 0.f && y < (act == 2 ? 6.f : INFINITY)) ? d : 0.f;
+    return d;
+}
+// the per-column operands of a BatchNorm backward pass, handed to a kernel by value
+struct dkd_bn_cols {
+    const float *mean, *rstd, *gamma, *beta;
+    int act;
+    float* out2;  // (reductions) where the second result plane goes instead of behind the first
+};
+
 static inline int dkd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool dkd_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -30,6 +30,7 @@ struct Epilogue {
     int act;
     int row_grp, row_grp_stride, row_off;
     float alpha;
+    int order;  // tile order experiment (DKD_TILE_ORDER, scripts/pmc_tile_order.sh): 0 = xcd_remap (shipped)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -106,6 +107,18 @@ struct Stager {
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// DKD_TILE_ORDER experiment: 1 = the launch order itself (column tile fastest, consecutive tiles on different XCDs);
+// 2 = xcd_remap over row-panel PAIRS (the two row panels of a pair alternate, so 12 tiles share two A panels and each B tile twice)
+__device__ __forceinline__ int tile_order(int bid, int nbm, int nbn, int order) {
+    const int nblk = nbm * nbn;
+    if (order == 1) return bid;
+    if (order == 2 && (nbm & 1) == 0) {
+        const int t = xcd_remap(bid, nblk), pair = t / (2 * nbn), w = t % (2 * nbn);
+        return (2 * pair + (w & 1)) * nbn + (w >> 1);
+    }
+    return xcd_remap(bid, nblk);
 }
 
 // SCHED 0: load(t+1) | compute(t) | store(t+1) | barrier        (store after the MFMA block)
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
         kbeg = ((int)blockIdx.x / nbn) * peel_kchunk;
         kend = min(K, kbeg + peel_kchunk);
     } else {
-        const int tile = PEEL ? xcd_remap(blockIdx.x - peel_blocks, (nbm - 1) * nbn) : xcd_remap(blockIdx.x, nbm * nbn);
+        const int tile = PEEL ? tile_order(blockIdx.x - peel_blocks, nbm - 1, nbn, epi.order) : tile_order(blockIdx.x, nbm, nbn, epi.order);
         bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
         kbeg = blockIdx.y * kchunk;
         kend = min(K, kbeg + kchunk);
@@ -1218,6 +1231,8 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     epi.row_grp_stride = g->row_grp_stride;
     epi.row_off = g->row_off;
     epi.alpha = g->alpha;
+    static const int tile_order_env = getenv("DKD_TILE_ORDER") ? atoi(getenv("DKD_TILE_ORDER")) : 0;
+    epi.order = tile_order_env;
     if ((g->precision == DKD_PREC_BF16 || g->precision == DKD_PREC_BF16X3) && g->a_layout == 1 && g->b_layout == 1 && !g->rowsum &&
         g->variant == 0) {
         const int max_sp = auto_splits(g->M, g->N, g->K, 1, 1);  // the workspace was sized for this many slabs

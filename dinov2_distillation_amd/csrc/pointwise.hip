@@ -123,14 +123,6 @@ __global__ void window_permute_kernel(const float4* __restrict__ in, float4* __r
     }
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
-// nn.Hardswish: x * relu6(x + 3) / 6; derivative 0 below -3, 1 above 3, (2x + 3) / 6 between (MobileNetV3)
-__device__ __forceinline__ float hswish_f(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
-__device__ __forceinline__ float hswish_grad_f(float x) { return x < -3.f ? 0.f : (x > 3.f ? 1.f : fmaf(x, 1.f / 3.f, 0.5f)); }
-__device__ __forceinline__ float silu_grad_f(float y) {
-    const float sg = sigmoid_f(y);
-    return sg * fmaf(y, 1.f - sg, 1.f);
-}
 
 // ---- BatchNorm (train mode) ------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rstd,
@@ -216,6 +208,29 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dbn, const float4
                             g.y * rs.y * (d.y - a.y * inv_count - xh.y * b.y * inv_count),
                             g.z * rs.z * (d.z - a.z * inv_count - xh.z * b.z * inv_count),
                             g.w * rs.w * (d.w - a.w * inv_count - xh.w * b.w * inv_count));
+    }
+}
+
+// pass 2 of the BatchNorm backward without intermediates: dbn and xhat recomputed from (dt, z), dz fp32 or bf16 (the mixed-precision
+// step: BatchNorm's input is a 16-bit tensor, so its gradient is rounded)
+template <typename TO>
+__global__ void bn_bwd_apply_direct_kernel(const float* __restrict__ dt, const float* __restrict__ z, dkd_bn_cols bn,
+                                           const float* __restrict__ s1, const float* __restrict__ s2, TO* __restrict__ dz, int nv,
+                                           float inv_count, long nvec) {
+    EW_LOOP(i, nvec) {
+        const int c = (int)(i % nv);
+        const float4 x = ld4(z, i), mu = ld4(bn.mean, c), rs = ld4(bn.rstd, c), g = ld4(bn.gamma, c), bt = ld4(bn.beta, c);
+        const float4 a = ld4(s1, c), b = ld4(s2, c);
+        float4 d = ld4(dt, i);
+        const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
+        if (bn.act) {
+            d.x = bn_act_grad(d.x, g.x * xh.x + bt.x, bn.act); d.y = bn_act_grad(d.y, g.y * xh.y + bt.y, bn.act);
+            d.z = bn_act_grad(d.z, g.z * xh.z + bt.z, bn.act); d.w = bn_act_grad(d.w, g.w * xh.w + bt.w, bn.act);
+        }
+        st4(dz, i, make_float4(g.x * rs.x * (d.x - a.x * inv_count - xh.x * b.x * inv_count),
+                               g.y * rs.y * (d.y - a.y * inv_count - xh.y * b.y * inv_count),
+                               g.z * rs.z * (d.z - a.z * inv_count - xh.z * b.z * inv_count),
+                               g.w * rs.w * (d.w - a.w * inv_count - xh.w * b.w * inv_count)));
     }
 }
 
@@ -359,6 +374,9 @@ __global__ void cast_f32_kernel(const __bf16* __restrict__ in, float* __restrict
 }
 __global__ void round_bf16_kernel(float* __restrict__ x, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = rnd16(x[i]);
+}
+__global__ void round_bf16_copy_kernel(const float* __restrict__ x, float* __restrict__ y, long nvec) {
+    EW_LOOP(i, nvec) st4(y, i, rnd16(ld4(x, i)));
 }
 __global__ void relu_bwd_bf16_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y, __bf16* __restrict__ dx, long nvec) {
     EW_LOOP(i, nvec) {
@@ -529,6 +547,19 @@ extern "C" int dkd_bn_bwd_apply_f32(const float* dbn, const float* xhat, const f
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
+extern "C" int dkd_bn_bwd_apply_direct_f32(const float* dt, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                          const float* beta, const float* sum_dbn, const float* sum_dbn_xhat, void* dz, int dz16, long rows,
+                                          int N, int relu, void* stream) {
+    EW_CHECK(N);
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !sum_dbn || !sum_dbn_xhat || !dz || rows <= 0 || relu < 0 || relu > 4)
+        return DKD_ERR_BAD_ARG;
+    const long nvec = rows * (N / 4);
+    dkd_bn_cols bn{mean, rstd, gamma, beta, relu, nullptr};
+    DKD_IO_TYPE(dz16, TO, hipLaunchKernelGGL((bn_bwd_apply_direct_kernel<TO>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream,
+                                             dt, z, bn, sum_dbn, sum_dbn_xhat, reinterpret_cast<TO*>(dz), N / 4, 1.0f / (float)rows, nvec));
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
 extern "C" int dkd_grn_stats_f32(const float* sumsq, float* gx, float* nx, float* denom, int B, int C, void* stream) {
     if (!sumsq || !gx || !nx || !denom || B <= 0 || C <= 0) return DKD_ERR_BAD_ARG;
     hipLaunchKernelGGL(grn_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sumsq, gx, nx, denom, C);
@@ -606,6 +637,13 @@ extern "C" int dkd_cast_f32_from_bf16(const void* in, float* out, long n, void* 
 extern "C" int dkd_round_bf16_f32(float* x, long n, void* stream) {
     if (!x || n <= 0) return DKD_ERR_BAD_ARG;
     hipLaunchKernelGGL(round_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_round_bf16_copy_f32(const float* x, float* y, long n, void* stream) {
+    EW_CHECK(n);
+    if (!x || !y) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(round_bf16_copy_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

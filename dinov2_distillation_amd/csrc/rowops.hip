@@ -267,11 +267,14 @@ __device__ __forceinline__ float4 colop(const float4 x, const float4 y, const fl
 // OP == DKD_RED_DOT_SUM: two results per column, sum x*y -> out[.], sum x -> out[groups*nsplit*N + .]
 // T: element type of X and Y (float or __bf16).  R16 (the mixed-precision step): the GELU inside the gelu variants is rounded to
 // bf16 first - the value the 16-bit GELU output tensor of the autocast step holds.
+// OP == DKD_RED_BN_BWD (X = the gradient behind BatchNorm + activation, Y = the BatchNorm INPUT z, bn = the per-column mean / rstd /
+// gamma / beta): the two sums of BatchNorm's backward pass in one pass over the two tensors, dbn = X * act'(bn(z)) and
+// xhat = (z - mean) * rstd recomputed on the fly: plane 0 = sum dbn * xhat (d gamma), plane 1 = sum dbn (d beta).
 template <int OP, typename T = float, bool R16 = false>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X, const T* __restrict__ Y,
                                                         const float* __restrict__ aux, float* __restrict__ out,
                                                         long rows_per_group, int N, long ldx, int CL, int rows_per_split,
-                                                        float scale, int nsplit, int round_out = 0) {
+                                                        float scale, int nsplit, int round_out = 0, dkd_bn_cols bn = dkd_bn_cols{}) {
     __shared__ float4 red[256];
     const int RL = 256 / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -280,14 +283,29 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X,
     const long r0 = (long)sp * rows_per_split;
     const long r1 = min(rows_per_group, r0 + rows_per_split);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc, cmp = acc, cmp2 = acc;
-    constexpr bool TWO = OP == DKD_RED_DOT_SUM || OP == DKD_RED_DOTGELU_SUM;
+    constexpr bool TWO = OP == DKD_RED_DOT_SUM || OP == DKD_RED_DOTGELU_SUM || OP == DKD_RED_BN_BWD;
     if (4 * c4 < N) {
         const float4 a = OP == DKD_RED_SQDIFF ? reinterpret_cast<const float4*>(aux)[c4] : acc;
+        float4 mu = acc, rs = acc, gm = acc, bt = acc;
+        if (OP == DKD_RED_BN_BWD) {
+            mu = reinterpret_cast<const float4*>(bn.mean)[c4], rs = reinterpret_cast<const float4*>(bn.rstd)[c4];
+            gm = reinterpret_cast<const float4*>(bn.gamma)[c4], bt = reinterpret_cast<const float4*>(bn.beta)[c4];
+        }
         const long base = (long)g * rows_per_group;
         // Kahan-compensated accumulation: a column of B*H*W gradients summed in plain fp32 carries an error that grows with the
         // number of rows a thread folds; the BatchNorm / bias gradients of a 50-layer student amplify it (the PResNet-50 case of
         // round 1).  The kernel is HBM-bound, the three extra VALU ops per element are free (scripts/bench_colreduce.py).
         auto fold = [&](float4 x, float4 y) {
+            if (OP == DKD_RED_BN_BWD) {
+                const float4 xh = make_float4((y.x - mu.x) * rs.x, (y.y - mu.y) * rs.y, (y.z - mu.z) * rs.z, (y.w - mu.w) * rs.w);
+                if (bn.act) {
+                    x.x = bn_act_grad(x.x, gm.x * xh.x + bt.x, bn.act); x.y = bn_act_grad(x.y, gm.y * xh.y + bt.y, bn.act);
+                    x.z = bn_act_grad(x.z, gm.z * xh.z + bt.z, bn.act); x.w = bn_act_grad(x.w, gm.w * xh.w + bt.w, bn.act);
+                }
+                kahan4(acc, cmp, make_float4(x.x * xh.x, x.y * xh.y, x.z * xh.z, x.w * xh.w));
+                kahan4(acc2, cmp2, x);
+                return;
+            }
             if (OP == DKD_RED_DOTGELU_SUM) {
                 y = make_float4(gelu_f(y.x), gelu_f(y.y), gelu_f(y.z), gelu_f(y.w));
                 if (R16) y = rnd16(y);
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X,
             kahan4(acc, cmp, v);
             if (TWO) kahan4(acc2, cmp2, x);
         };
-        constexpr bool HAS_Y = OP == DKD_RED_DOT || TWO;
+        constexpr bool HAS_Y = OP == DKD_RED_DOT || TWO;  // (DKD_RED_BN_BWD included)
         long r = r0 + rl;
         // keep several rows' loads in flight ahead of the (for the gelu variants VALU-heavy) arithmetic: four rows for the
         // one-operand reductions, the plain loop for the two-operand ones (eight float4 in flight cost occupancy: +12 %)
@@ -333,6 +351,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X,
             acc.x -= cmp.x; acc.y -= cmp.y; acc.z -= cmp.z; acc.w -= cmp.w;
             // partial layout [g][split][N]; with nsplit == 1 this IS the output
             float4* o = reinterpret_cast<float4*>(out + pass * second + ((long)g * nsplit + sp) * N) + c4;
+            if (OP == DKD_RED_BN_BWD && pass == 1 && nsplit == 1 && bn.out2) o = reinterpret_cast<float4*>(bn.out2) + c4;
             if (nsplit == 1) {
                 acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
                 if (round_out) acc = rnd16(acc);  // (a 16-bit reduction result held in fp32: the mixed-precision step's bias gradients)
@@ -346,12 +365,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ X,
 // (grid.z = result planes: the two planes of DKD_RED_DOT_SUM / DOTGELU_SUM are folded by ONE launch)
 // tr_T > 0: the result, read as [tr_T][N / tr_T], is stored transposed: out[(n % (N / tr_T)) * tr_T + n / (N / tr_T)]
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int groups,
-                                                              int nsplit, int N, float scale, int round_out = 0, int tr_T = 0) {
+                                                              int nsplit, int N, float scale, int round_out = 0, int tr_T = 0,
+                                                              float* __restrict__ out2 = nullptr) {
     __shared__ float red[256];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + cl, g = blockIdx.y;
     ws += (long)blockIdx.z * groups * nsplit * N;
-    out += (long)blockIdx.z * groups * N;
+    if (blockIdx.z == 1 && out2) out = out2;  // (the second result plane has its own destination)
+    else out += (long)blockIdx.z * groups * N;
     float s0 = 0.f, s1 = 0.f, c0 = 0.f, c1 = 0.f;
     if (n < N) {
         const float* w = ws + (long)g * nsplit * N + n;
@@ -708,6 +729,28 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
     if (ns > 1) {
         const dim3 fgrid((N + 31) / 32, groups, two ? 2 : 1);
         hipLaunchKernelGGL(colreduce_final_kernel, fgrid, dim3(256), 0, st, ws, out, groups, ns, N, scale);
+        DKD_LAUNCH_CHECK();
+    }
+    return DKD_OK;
+}
+
+// BatchNorm backward, pass 1 of 2 (pointwise.hip holds pass 2): d gamma = sum dbn * xhat and d beta = sum dbn over the rows, straight
+// from (dt, z) - no dbn / xhat tensors in HBM.  ws: dkd_colreduce_f32_workspace_bytes(rows, 1, N).
+extern "C" int dkd_bn_bwd_stats_f32(const float* dt, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, float* dgamma, float* dbeta, float* ws, long rows, int N, int relu, void* stream) {
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || rows <= 0 || N <= 0 || relu < 0 || relu > 4)
+        return DKD_ERR_BAD_ARG;
+    if (N & 3) return DKD_ERR_ALIGN;
+    int cl, ns, rps, cb;
+    colreduce_plan(rows, 1, N, &cl, &ns, &rps, &cb);
+    if (ns > 1 && !ws) return DKD_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dkd_bn_cols bn{mean, rstd, gamma, beta, relu, dbeta};
+    hipLaunchKernelGGL(colreduce_kernel<DKD_RED_BN_BWD>, dim3(cb, ns, 1), dim3(256), 0, st, dt, z, (const float*)nullptr,
+                       ns > 1 ? ws : dgamma, rows, N, (long)N, cl, rps, 1.0f, ns, 0, bn);
+    DKD_LAUNCH_CHECK();
+    if (ns > 1) {
+        hipLaunchKernelGGL(colreduce_final_kernel, dim3((N + 31) / 32, 1, 2), dim3(256), 0, st, ws, dgamma, 1, ns, N, 1.0f, 0, 0, dbeta);
         DKD_LAUNCH_CHECK();
     }
     return DKD_OK;

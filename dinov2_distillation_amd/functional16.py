@@ -389,8 +389,8 @@ class AttentionProjector16Fn(Function):
         dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D),
                              out=None if o_pos is None else o_pos.view(D, N)).reshape(pos_shape)
         # BatchNorm + ReLU on 16-bit tensors: the incoming gradient is rounded (it belongs to a 16-bit tensor), the arithmetic is fp32
-        dz, dbn_w, dbn_b = ops.bn_bwd(ops.round_bf16_(dtok), z, mean, rstd, bn_w, bn_b, relu=True, dgamma_out=o_bnw, dbeta_out=o_bnb)
-        dz16 = ops.cast_bf16(dz)
+        dz16, dbn_w, dbn_b = ops.bn_bwd(ops.round_bf16_(dtok), z, mean, rstd, bn_w, bn_b, relu=True, dgamma_out=o_bnw, dbeta_out=o_bnb,
+                                        out_dtype=BF16)
         dwc, dbc = wgrad16(dz16, x16, P_wc, P_bc, reshape=lambda t: t.reshape(wc_shape))
         dx = ops.gemm_bf16(dz16, wc16, b_layout=1, epi=ops.EPI_F32).reshape(xshape) if ctx.needs_input_grad[0] else None
         return (dx, dext, dself, None, None, None, None, None,
@@ -642,7 +642,7 @@ class PatchMerge16Fn(Function):
 def _round16(dy):
     """the gradient of a 16-bit tensor as a fresh fp32 tensor holding 16-bit values (never in place: autograd may hand the same
     buffer to another consumer)"""
-    return ops.round_bf16_(_c(dy).clone())
+    return ops.round_bf16(_c(dy))
 
 
 class RoundGradFn(Function):
@@ -655,7 +655,7 @@ class RoundGradFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.round_bf16_(_c(dy).clone())
+        return ops.round_bf16(_c(dy))
 
 
 class ConvBNAct16Fn(Function):
@@ -677,11 +677,16 @@ class ConvBNAct16Fn(Function):
             w16 = _cached(w, ("conv16 nchw", Kp), lambda: ops.cast_bf16(w.detach().reshape(O, kk), Kp))
         else:
             B, H, W, Cin = x.shape
-            rows = x.reshape(-1, Cin) if (k == 1 and stride == 1) else ops.im2col_nhwc(x, k, stride, pad)
-            rows16 = ops.cast_bf16(rows)                                   # exact: the values are 16-bit already
+            x16 = ops.cast_bf16(x)                                         # exact: the values are 16-bit already
+            if k == 1 and stride == 1:
+                rows16 = x16
+            elif Cin % 8 == 0:   # im2col is data movement: on the bf16 copy, whose channel pairs are fp32 words to the kernel
+                rows16 = ops.im2col_nhwc(x16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
+            else:
+                rows16 = ops.cast_bf16(ops.im2col_nhwc(x, k, stride, pad))
             w16 = _w16_2d(w, O, Cin) if k == 1 else _prepared(w, "conv16", O, Cin, k * k, 2, (O, k * k * Cin))  # [O][ky][kx][c]
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
-        z = ops.cast_f32(ops.gemm_bf16(rows16, w16))                      # the conv's 16-bit result
+        z = ops.gemm_bf16(rows16, w16, epi=ops.EPI_F32)                   # the conv's 16-bit result (rounded, held in fp32)
         mean, rstd = _bn_fwd_stats(z, bn_state, training)
         y = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, None, relu=int(relu) | 16)   # rnd(bn) -> act
         ctx.training = training
@@ -702,8 +707,8 @@ class ConvBNAct16Fn(Function):
         # (the output may have several consumers - a block input feeds conv1 and the shortcut, an STDC branch feeds the next conv
         # and the concatenation: autograd has added their 16-bit gradients in fp32, the 16-bit tensor's gradient is that sum rounded)
         dy = _round16(dy)
-        dz, dg, db = ops.bn_bwd(dy.reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu, dgamma_out=o_g, dbeta_out=o_b)
-        dz16 = ops.cast_bf16(dz)                                          # BatchNorm's input gradient is a 16-bit tensor
+        dz16, dg, db = ops.bn_bwd(dy.reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu, dgamma_out=o_g, dbeta_out=o_b,
+                                  out_dtype=BF16)                         # BatchNorm's input gradient is a 16-bit tensor
         dx = None
         if src_nchw:
             kk = xshape[1] * k * k

@@ -481,20 +481,22 @@ def bn_act_pos_fwd(z, mean, rstd, gamma, beta, pos=None, relu=True):
     return out
 
 
-def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True, dgamma_out=None, dbeta_out=None):
-    """-> dz, dgamma, dbeta for out = relu(bn(z)) (+ pos)."""
+def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True, dgamma_out=None, dbeta_out=None, out_dtype=torch.float32):
+    """-> dz, dgamma, dbeta for out = relu(bn(z)) (+ pos).  Two passes over (dt, z): the column sums, then dz (fp32, or bf16 for
+    the mixed-precision step) - dbn and xhat are recomputed in both instead of being written out."""
     lib = _lib.binding()
+    _chk(dt, "dt"), _chk(z, "z")
     N = z.shape[-1]
     rows = z.numel() // N
-    dbn = torch.empty_like(z)
-    xhat = torch.empty_like(z)
-    check(lib.dkd_bn_bwd_prep_f32(_p(dt), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dbn), _p(xhat), rows, N,
-                                  int(relu), _stream()), "dkd_bn_bwd_prep_f32")
-    dbeta = colreduce(dbn, RED_SUM, out=None if dbeta_out is None else dbeta_out.view(1, N)).reshape(N)
-    dgamma = colreduce(dbn, RED_DOT, y=xhat, out=None if dgamma_out is None else dgamma_out.view(1, N)).reshape(N)
-    dz = torch.empty_like(z)
-    check(lib.dkd_bn_bwd_apply_f32(_p(dbn), _p(xhat), _p(dbeta), _p(dgamma), _p(gamma), _p(rstd), _p(dz), rows, N,
-                                   _stream()), "dkd_bn_bwd_apply_f32")
+    dgamma = torch.empty(N, dtype=torch.float32, device=z.device) if dgamma_out is None else dgamma_out.view(N)
+    dbeta = torch.empty(N, dtype=torch.float32, device=z.device) if dbeta_out is None else dbeta_out.view(N)
+    wsb = lib.dkd_colreduce_f32_workspace_bytes(rows, 1, N)
+    ws = workspace(wsb, z.device) if wsb else None
+    check(lib.dkd_bn_bwd_stats_f32(_p(dt), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(ws), rows, N,
+                                   int(relu), _stream()), "dkd_bn_bwd_stats_f32")
+    dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
+    check(lib.dkd_bn_bwd_apply_direct_f32(_p(dt), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dbeta), _p(dgamma), _p(dz),
+                                          int(out_dtype == torch.bfloat16), rows, N, int(relu), _stream()), "dkd_bn_bwd_apply_direct_f32")
     return dz, dgamma, dbeta
 
 
@@ -1149,6 +1151,16 @@ def round_bf16_(x):
     _chk(x, "x")
     check(_lib.binding().dkd_round_bf16_f32(_p(x), x.numel(), _stream()), "dkd_round_bf16_f32")
     return x
+
+
+def round_bf16(x):
+    """out of place: a fresh fp32 tensor holding x rounded to bf16 values"""
+    _chk(x, "x")
+    if x.numel() % 4:
+        return round_bf16_(x.clone())
+    out = torch.empty_like(x)
+    check(_lib.binding().dkd_round_bf16_copy_f32(_p(x), _p(out), x.numel(), _stream()), "dkd_round_bf16_copy_f32")
+    return out
 
 
 def add16(a, b):

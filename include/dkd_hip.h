@@ -112,6 +112,7 @@ int dkd_layernorm_fwd_bf16out_f32(const float* x, const float* gamma, const floa
 #define DKD_RED_DOT_SUM 4 /* two planes: out[0:G*N] = sum x*y, out[G*N:2*G*N] = sum x (one pass over x) */
 #define DKD_RED_GELUSQ 5  /* gelu(x)^2 : GRN energies straight from the pre-activation */
 #define DKD_RED_DOTGELU_SUM 6 /* DKD_RED_DOT_SUM with y := gelu(y) */
+#define DKD_RED_BN_BWD 7 /* internal (dkd_bn_bwd_stats_f32): the two sums of BatchNorm's backward pass from (dt, z) */
 int dkd_colreduce_f32(const float* X, const float* Y, const float* aux, float* out, float* ws, long rows_per_group,
                       int groups, int N, long ldx, int op, float scale, void* stream);
 long dkd_colreduce_f32_workspace_bytes(long rows_per_group, int groups, int N);
@@ -152,6 +153,14 @@ int dkd_bn_bwd_prep_f32(const float* dt, const float* z, const float* mean, cons
                         const float* beta, float* dbn, float* xhat, long rows, int N, int relu, void* stream);
 int dkd_bn_bwd_apply_f32(const float* dbn, const float* xhat, const float* sum_dbn, const float* sum_dbn_xhat,
                          const float* gamma, const float* rstd, float* dz, long rows, int N, void* stream);
+/* The same backward pass without the dbn / xhat tensors (4 reads + 1 write per element instead of 7 + 3): _stats reduces
+ * d gamma = sum dbn * xhat and d beta = sum dbn straight from (dt, z) (ws: dkd_colreduce_f32_workspace_bytes(rows, 1, N)),
+ * _apply_direct recomputes dbn and xhat and writes dz, fp32 or (dz16) bf16 - BatchNorm's input gradient under the 16-bit policy. */
+int dkd_bn_bwd_stats_f32(const float* dt, const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         float* dgamma, float* dbeta, float* ws, long rows, int N, int relu, void* stream);
+int dkd_bn_bwd_apply_direct_f32(const float* dt, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, const float* sum_dbn, const float* sum_dbn_xhat, void* dz, int dz16, long rows, int N,
+                                int relu, void* stream);
 /* ConvNeXt-V2 GRN on NHWC rows (models/backbones/convnext.py:39-50): sumsq[b][c] from dkd_colreduce_f32.
  * The block (convnext.py:75-87) keeps only the pre-activation h of its GELU: input_is_preact != 0 makes dkd_grn_apply_f32
  * read h and recompute g = gelu(h) (energies: DKD_RED_GELUSQ), and dkd_grn_gelu_bwd_f32 with g == NULL does the same. */
@@ -236,6 +245,8 @@ int dkd_grn_gelu_bwd_bf16(const void* dy, const void* h, const float* nx, const 
                           long rows_per_img, int C, void* stream);
 int dkd_cast_f32_from_bf16(const void* in, float* out, long n, void* stream);
 int dkd_round_bf16_f32(float* x, long n, void* stream); /* in place: every value to the nearest bf16 */
+int dkd_round_bf16_copy_f32(const float* x, float* y, long n, void* stream); /* y = rnd_bf16(x), n % 4 == 0: the gradient of a 16-bit
+    tensor as a fresh fp32 tensor (autograd may hand the incoming buffer to another consumer) */
 int dkd_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
 /* Eager attention under the 16-bit policy (what torch autocast makes of `softmax((q @ k^T) * c1 * c2) @ v`, losses/scalekd.py:
  * 308-313 and the DINOv2 block): the logits S are a bf16 matmul result (dkd_gemm_bf16, batched), each scalar factor rounds

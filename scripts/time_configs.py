@@ -48,8 +48,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)
     a = ap.parse_args()
-    for idx in (int(v) for v in a.configs.split(",")):
-        for prec in (None, "bf16_autocast"):
+    for tok in a.configs.split(","):   # "3": fp32 then policy; "3p": policy only; "3f": fp32 only
+        idx = int(tok.rstrip("pf"))
+        for prec in ((None, "bf16_autocast") if tok.isdigit() else ("bf16_autocast",) if tok.endswith("p") else (None,)):
             print(json.dumps(run(idx, prec, a.steps, a.warmup)), flush=True)
 
 
