@@ -9,6 +9,7 @@ architecture is built locally with synthetic (seeded) weights under the public c
 (see DESIGN.md).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -23,6 +24,8 @@ VIT_CONFIGS = {  # embed dims: train.py:103-108; depth / heads: published models
     "dinov2_vitg14": dict(embed_dim=1536, depth=40, num_heads=24, ffn="swiglu"),
 }
 PATCH, POS_GRID = 14, 37
+# the autocast teacher's attention: bf16-MFMA flash kernel (csrc/attention16_flash.hip); 0 = the fp32-MFMA kernel's round_bf16 mode (A/B)
+FLASH16 = os.environ.get("DKD_FLASH16", "1") != "0"
 
 
 def _tn(*shape, gen):
@@ -130,11 +133,14 @@ class Block(nn.Module):
         # q, k, v as bf16 VALUES in an fp32 buffer: the flash kernel multiplies them exactly (bf16 x bf16 products are exact in
         # fp32), rounds logits and probabilities to bf16 where eager attention under autocast does (matmul result / operand;
         # the softmax itself is fp32) and accumulates in fp32; q * hd^-0.5 is exact for the 64-wide heads of every DINOv2 model
-        qkv = ops.gemm_bf16(h1, p["wqkv"], epi=ops.EPI_F32, bias=p["bqkv"])
-        st = (N * 3 * D, 3 * D)
-        o, _ = ops.attention_forward(qkv, qkv[:, D:], qkv[:, 2 * D:], H, hd, hd ** -0.5, B, N, N, st, st, st, round_bf16=True)
-        x1 = ops.gemm_bf16(ops.cast_bf16(o.reshape(B * N, D)), p["wproj"], epi=ops.EPI_F32_RESID, bias=p["bproj"],
-                           colscale=p["ls1"], residual=x2)
+        if hd == 64 and FLASH16:   # every DINOv2 model: the bf16-MFMA flash kernel on the qkv Linear's own 16-bit output
+            o16 = ops.attention16_flash(ops.gemm_bf16(h1, p["wqkv"], bias=p["bqkv"]), B, H, N, hd, hd ** -0.5)
+        else:
+            qkv = ops.gemm_bf16(h1, p["wqkv"], epi=ops.EPI_F32, bias=p["bqkv"])
+            st = (N * 3 * D, 3 * D)
+            o, _ = ops.attention_forward(qkv, qkv[:, D:], qkv[:, 2 * D:], H, hd, hd ** -0.5, B, N, N, st, st, st, round_bf16=True)
+            o16 = ops.cast_bf16(o.reshape(B * N, D))
+        x1 = ops.gemm_bf16(o16, p["wproj"], epi=ops.EPI_F32_RESID, bias=p["bproj"], colscale=p["ls1"], residual=x2)
         h2 = ops.layernorm_fwd_bf16out(x1, p["n2w"], p["n2b"], 1e-6)
         if p["swiglu"]:
             a = ops.swiglu_bf16(ops.gemm_bf16(h2, p["w1"], epi=ops.EPI_BF16, bias=p["b1"]))

@@ -1272,6 +1272,18 @@ def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shar
     return dq, dk, dv
 
 
+def attention16_flash(qkv, B, H, N, hd, scale):
+    """dkd_attn16_flash_fwd on a packed bf16 qkv buffer [B*N, 3*H*hd] (columns (3, H, hd)) -> context [B*N, H*hd] bf16 (hd 64)"""
+    _chk16(qkv, "qkv")
+    D = H * hd
+    if qkv.shape != (B * N, 3 * D):
+        raise _lib.DkdError(f"attention16_flash: qkv {tuple(qkv.shape)} is not [B*N, 3*H*hd] = [{B * N}, {3 * D}]")
+    o = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
+    check(_lib.binding().dkd_attn16_flash_fwd(_p(qkv), _p(qkv[:, D:]), _p(qkv[:, 2 * D:]), _p(o), 3 * D, D, B, H, N, hd, float(scale),
+                                              _stream()), "dkd_attn16_flash_fwd", (B, H, N, hd))
+    return o
+
+
 def scale16(x, s):
     _chk16(x, "x")
     out = torch.empty_like(x)

@@ -259,6 +259,12 @@ int dkd_attn16_softmax_fwd(const void* S, void* P, long rows, int N, long ld, fl
 int dkd_attn16_softmax_bwd(const void* S, const void* dP, void* dS, long rows, int N, long ld, float c1, float c2, int valid,
                            void* stream);
 int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
+/* The frozen teacher's own attention under the same policy, flash-style on the bf16 matrix cores (csrc/attention16_flash.hip):
+ * q / k / v bf16 [B*N, ld] column slices (element (b, token, head, d) at x[(b*N + token)*ld + head*hd + d]: the fused qkv Linear's
+ * 16-bit output), o bf16 [B*N, ldo].  S = rnd(q k^T) * scale, softmax fp32 (online), probabilities rounded to bf16 for the second
+ * matmul, fp32 accumulation, one rounding at the store.  Forward only; hd == 64; ld % 8 == 0, ldo % 4 == 0. */
+int dkd_attn16_flash_fwd(const void* q, const void* k, const void* v, void* o, long ld, long ldo, int B, int H, int N, int hd,
+                         float scale, void* stream);
 /* token padding of the same path: bf16 rows [groups * gs_src, cols] (row pitch lds) -> [groups * gs_dst, cols] (pitch ldd); row i
  * of a group is copied while i < gs_src and zero beyond (gs_dst > gs_src pads, gs_dst < gs_src crops); cols, pitches % 8 == 0 */
 int dkd_regroup_rows_bf16(const void* src, long lds, int gs_src, void* dst, long ldd, int gs_dst, long groups, int cols, void* stream);
