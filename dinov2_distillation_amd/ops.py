@@ -1198,6 +1198,18 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+# flash form of the policy attention (csrc/attention16_train.hip, hd 64): 0 = always the materialised path (A/B, tests)
+ATTN16_FLASH = os.environ.get("DKD_ATTN16_FLASH", "1") != "0"
+
+
+def _attn16_train_args(q, k, v, B, H, Nq, Nk, hd, c1, c2, q_shared, L):
+    a = _lib.args("dkd_attn16_args")
+    a.q, a.k, a.v = _p(q), _p(k), _p(v)
+    a.ldq = a.ldkv = L
+    a.B, a.H, a.Nq, a.Nk, a.hd, a.q_shared, a.c1, a.c2 = B, H, Nq, Nk, hd, int(q_shared), float(c1), float(c2)
+    return a
+
+
 def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, ld=None):
     """q [B*Nq, H*hd], k / v [B*Nk, H*hd] bf16 (token-major, heads side by side; ld: they are column slices of one [rows, ld]
     buffer - a fused qkv Linear's output) -> O [B*Nq, H*hd] bf16 and the saved logits / probabilities S, P [B*H, Nq, Nk] bf16:
@@ -1209,6 +1221,15 @@ def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, l
     L = D if ld is None else ld
     if hd % 8:
         raise _lib.DkdError(f"attention16: the head dim must be a multiple of 8 (got {hd})")
+    if hd == 64 and ATTN16_FLASH:
+        # flash form: O plus the fp32 row statistics (max, 1 / sum) in place of the logit / probability tensors
+        a = _attn16_train_args(q, k, v, B, H, Nq, Nk, hd, c1, c2, q_shared, L)
+        O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
+        m = torch.empty((B * H * Nq,), dtype=torch.float32, device=q.device)
+        linv = torch.empty_like(m)
+        a.o, a.ldo, a.m, a.linv = _p(O), D, _p(m), _p(linv)
+        check(_lib.binding().dkd_attn16_train_fwd(_lib.ref(a), _stream()), "dkd_attn16_train_fwd", (B, H, Nq, Nk, hd))
+        return O, m, linv
     valid = 0
     if (Nk % 8) or (Nq % 8):
         Nq0, valid = Nq, Nk
@@ -1234,6 +1255,23 @@ def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shar
     _chk16(dO, "dO")
     D = H * hd
     L = D if ld is None else ld
+    if S.dtype == torch.float32:   # the flash form's row statistics (attention16_forward): S = max, P = 1 / sum
+        _chk16v(q, "q", ld), _chk16v(k, "k", ld), _chk16v(v, "v", ld)
+        a = _attn16_train_args(q, k, v, B, H, Nq, Nk, hd, c1, c2, q_shared, L)
+        if out is None:
+            dq = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
+            dk, dv = torch.empty((B * Nk, D), dtype=BF16, device=q.device), torch.empty((B * Nk, D), dtype=BF16, device=q.device)
+            Lo = D
+        else:
+            dq, dk, dv = out
+            for t, n in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+                _chk16v(t, n, L)
+            Lo = L
+        delta = torch.empty_like(S)
+        a.m, a.linv, a.delta, a.d_o, a.lddo = _p(S), _p(P), _p(delta), _p(dO), D
+        a.dq, a.dk, a.dv, a.lddq, a.lddkv = _p(dq), _p(dk), _p(dv), Lo, Lo
+        check(_lib.binding().dkd_attn16_train_bwd(_lib.ref(a), _stream()), "dkd_attn16_train_bwd", (B, H, Nq, Nk, hd))
+        return dq, dk, dv
     valid, final = 0, None
     if (Nk % 8) or (Nq % 8):
         valid, final, Nq0, Nk0, L0 = Nk, out, Nq, Nk, L

@@ -263,6 +263,25 @@ int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
  * q / k / v bf16 [B*N, ld] column slices (element (b, token, head, d) at x[(b*N + token)*ld + head*hd + d]: the fused qkv Linear's
  * 16-bit output), o bf16 [B*N, ldo].  S = rnd(q k^T) * scale, softmax fp32 (online), probabilities rounded to bf16 for the second
  * matmul, fp32 accumulation, one rounding at the store.  Forward only; hd == 64; ld % 8 == 0, ldo % 4 == 0. */
+/* The SAME policy attention with gradients, flash-style (csrc/attention16_train.hip; hd == 64): no [B*H, Nq, Nk] tensors in HBM.  The
+ * roundings are those of dkd_attn16_softmax_* around the batched dkd_gemm_bf16 calls (eager attention under autocast and autograd's
+ * backward through it): S = rnd(q k^T), T = rnd(rnd(S c1) c2), P = rnd(softmax_fp32(T)) with the final row max / sum (two key sweeps),
+ * O = rnd(P v); dP = rnd(dO v^T), dT = P32 (dP - sum dP P32), dS = rnd(rnd(rnd(dT) c2) c1), dq = rnd(dS k), dk = rnd(dS^T q),
+ * dv = rnd(P^T dO).  q [B*Nq, ldq] (q_shared: [Nq, ldq], one query block for every image), k / v [B*Nk, ldkv], o [B*Nq, ldo], all bf16,
+ * element (b, token, head, d) at x[(b*N + token)*ld + head*hd + d]; m / linv / delta: fp32 [B, H, Nq] row statistics kept between
+ * forward and backward (delta is scratch of the backward call).  Pitches in elements: inputs % 8, outputs % 4. */
+typedef struct dkd_attn16_args {
+    const void *q, *k, *v;
+    void* o;
+    float *m, *linv, *delta;
+    const void* d_o;
+    void *dq, *dk, *dv;
+    int64_t ldq, ldkv, ldo, lddo, lddq, lddkv;
+    int32_t B, H, Nq, Nk, hd, q_shared;
+    float c1, c2;
+} dkd_attn16_args;
+int dkd_attn16_train_fwd(const dkd_attn16_args* args, void* stream);
+int dkd_attn16_train_bwd(const dkd_attn16_args* args, void* stream);
 int dkd_attn16_flash_fwd(const void* q, const void* k, const void* v, void* o, long ld, long ldo, int B, int H, int N, int hd,
                          float scale, void* stream);
 /* token padding of the same path: bf16 rows [groups * gs_src, cols] (row pitch lds) -> [groups * gs_dst, cols] (pitch ldd); row i

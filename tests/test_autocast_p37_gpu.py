@@ -195,3 +195,60 @@ def test_frozen_block_reuse_on_1369_tokens_under_the_policy_vs_torch_autocast():
     e, noise = rel(xg.grad - ct.cuda(), x16.grad - ct), rel(x16.grad - ct, x32.grad - ct)
     print(f"frozen block on 1369 tokens d(tokens) minus the residual path: ours vs torch autocast {e:.2e}; torch autocast vs fp32 {noise:.2e}")
     assert e < 0.5 * noise
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,shared,c2", [(3, 6, 256, 256, False, 1.0), (2, 4, 77, 1369, False, 5.0), (2, 3, 1369, 1369, True, 5.0),
+                                                (2, 2, 64, 64, False, 5.0)])
+def test_flash_policy_attention_equals_the_materialised_path(B, H, Nq, Nk, shared, c2):
+    """csrc/attention16_train.hip (hd 64: the frozen teacher blocks, the 16-head projector of configs[3]) against the materialised
+    path it replaces (batched bf16 GEMMs around dkd_attn16_softmax_*) and against torch.autocast: same rounding points, so the two
+    differ by fp32 summation order only (a handful of 1-ulp bf16 flips), far inside the policy's distance from exact attention."""
+    from dinov2_distillation_amd import ops
+    hd = 64
+    D = H * hd
+    g = torch.Generator().manual_seed(Nq + Nk + H)
+    q = torch.randn(1 if shared else B, Nq, D, generator=g).bfloat16()
+    k, v = (torch.randn(B, Nk, D, generator=g).bfloat16() for _ in range(2))
+    do = torch.randn(B, Nq, D, generator=g).bfloat16()
+    c1 = hd ** -0.5
+    qd = q.reshape(-1, D).cuda()
+    kd, vd, dod = (t.reshape(-1, D).cuda() for t in (k, v, do))
+    assert ops.ATTN16_FLASH
+    O, m, linv = ops.attention16_forward(qd, kd, vd, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+    assert m.dtype == torch.float32 and m.numel() == B * H * Nq     # row statistics, no [B*H, Nq, Nk] tensors
+    dq, dk, dv = ops.attention16_backward(dod, qd, kd, vd, m, linv, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+    ops.ATTN16_FLASH = False
+    try:
+        O2, S, P = ops.attention16_forward(qd, kd, vd, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+        dq2, dk2, dv2 = ops.attention16_backward(dod, qd, kd, vd, S, P, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+    finally:
+        ops.ATTN16_FLASH = True
+    assert S.dtype == torch.bfloat16
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        qh = qr.expand(B, Nq, D).reshape(B, Nq, H, hd).permute(0, 2, 1, 3)
+        kh, vh = (t.reshape(B, Nk, H, hd).permute(0, 2, 1, 3) for t in (kr, vr))
+        attn = (qh @ kh.transpose(-2, -1)) * c1 * c2
+        with torch.autocast("cpu", enabled=False):
+            attn = attn.float().softmax(dim=-1)
+        ref = (attn @ vh).transpose(1, 2).reshape(B, Nq, D)
+    ref.backward(do)
+    exact = (torch.softmax((q.double().expand(B, Nq, D).reshape(B, Nq, H, hd).permute(0, 2, 1, 3)
+                            @ k.double().reshape(B, Nk, H, hd).permute(0, 2, 3, 1)) * c1 * c2, -1)
+             @ v.double().reshape(B, Nk, H, hd).permute(0, 2, 1, 3)).transpose(1, 2).reshape(B, Nq, D)
+    noise = rel(ref, exact)
+    dqs = dq.float().reshape(B, Nq, D).sum(0) if shared else dq
+    dq2s = dq2.float().reshape(B, Nq, D).sum(0) if shared else dq2
+    print(f"flash policy attention ({Nq} x {Nk}, H {H}, shared {shared}, c2 {c2}): vs materialised O {rel(O, O2.cpu()):.2e} dq {rel(dq, dq2.cpu()):.2e} "
+          f"dk {rel(dk, dk2.cpu()):.2e} dv {rel(dv, dv2.cpu()):.2e}; vs torch autocast O {rel(O, ref):.2e} dq {rel(dqs, qr.grad):.2e} "
+          f"dk {rel(dk, kr.grad):.2e} dv {rel(dv, vr.grad):.2e} (materialised: {rel(O2, ref):.2e} {rel(dq2s, qr.grad):.2e} "
+          f"{rel(dk2, kr.grad):.2e} {rel(dv2, vr.grad):.2e}); torch autocast vs exact {noise:.2e}")
+    assert torch.isfinite(O.float()).all() and torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all()
+    assert rel(O, O2.cpu()) < 0.05 * noise and rel(O, ref) < 0.15 * noise and noise > 1e-3
+    assert rel(dqs, qr.grad) < 3e-3 and rel(dk, kr.grad) < 3e-3 and rel(dv, vr.grad) < 2e-3
+    assert rel(dq, dq2.cpu()) < 2e-3 and rel(dk, dk2.cpu()) < 2e-3 and rel(dv, dv2.cpu()) < 1e-3
+    # deterministic
+    O3, m3, l3 = ops.attention16_forward(qd, kd, vd, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+    d3 = ops.attention16_backward(dod, qd, kd, vd, m3, l3, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+    assert torch.equal(O, O3) and all(torch.equal(x, y) for x, y in zip((dq, dk, dv), d3))
+
