@@ -15,6 +15,8 @@
 // STREAMED set arrives as 64-row tiles in LDS (LDS-DMA, two stages, one barrier per tile) and lands on the accumulator registers
 // - which, packed to bf16 eight at a time, are the B operand of the second product, whose A operand is the streamed tile read
 // transposed (ds_read_b64_tr_b16).  One LDS image serves both read forms: 128-byte rows, 16-byte chunk XOR (row / 2) % 8.
+#include <cmath>
+
 #include "common.h"
 #include "dkd_hip.h"
 #include "gemm_bf16_common.h"
@@ -69,9 +71,23 @@ __device__ __forceinline__ void load_resident(bf16x8 (&f)[4], const __bf16* __re
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) f[kc] = *reinterpret_cast<const bf16x8*>(p + 16 * kc);
 }
-// the 16-bit logit chain in log2 units: T = rnd(rnd(rnd(acc) c1) c2)
-__device__ __forceinline__ float logit2(float acc, float c1, float c2) { return rnd16(rnd16(rnd16(acc) * c1) * c2) * LOG2E; }
-__device__ __forceinline__ float dlogit(float dT, float c1, float c2) { return rnd16(rnd16(rnd16(dT) * c2) * c1); }
+// the 16-bit logit chain in log2 units, T = rnd(rnd(rnd(acc) c1) c2), and its backward dS = rnd(rnd(rnd(dT) c2) c1).  The kernels are
+// bound by this per-element VALU work (three evaluations per logit in the backward pass), so the roundings that are exact are not
+// executed: MODE 1: c1 is a power of two (head_dim 64: 2^-3) - rnd(x) c1 needs no second rounding; MODE 2: additionally c2 == 1
+// (the re-used teacher blocks).  k12 = c1 c2 LOG2E, c12 = c1 c2.
+struct Scales { float c1, c2, c12, k12; };
+template <int MODE>
+__device__ __forceinline__ float logit2(float acc, const Scales& s) {
+    if (MODE == 2) return rnd16(acc) * s.k12;
+    if (MODE == 1) return rnd16(rnd16(acc) * s.c12) * LOG2E;
+    return rnd16(rnd16(rnd16(acc) * s.c1) * s.c2) * LOG2E;
+}
+template <int MODE>
+__device__ __forceinline__ float dlogit(float dT, const Scales& s) {
+    if (MODE == 2) return rnd16(dT) * s.c1;
+    if (MODE == 1) return rnd16(rnd16(dT) * s.c2) * s.c1;
+    return rnd16(rnd16(rnd16(dT) * s.c2) * s.c1);
+}
 
 // S^T block (32 streamed rows x this lane's resident token): acc[r] <-> streamed row r0 + frag_row(r, half)
 __device__ __forceinline__ f32x16 product_T(const char* __restrict__ T, int r0, const bf16x8 (&res)[4], int lane) {
@@ -114,6 +130,7 @@ struct Ptrs {
 };
 
 // ---- forward: queries resident; sweep 1 = row max / sum over all keys, sweep 2 = P v ------------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];  // [stage][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
@@ -123,6 +140,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
     bf16x8 qf[4];
     load_resident(qf, a.q + b * a.q_bs + h * HD, a.ldq, q, a.Nq, half);
     const int nkt = (a.Nk + TR - 1) / TR;
+    const Scales sc{a.c1, a.c2, a.c1 * a.c2, a.c1 * a.c2 * LOG2E};
     float m = -INFINITY, l = 0.f;
     // sweep 1
     issue_tile(Kb, a.ldkv, 0, a.Nk, smem, wid, lane);
@@ -138,8 +156,8 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
             s[kb] = product_T(Ks, 32 * kb, qf, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float u = logit2(s[kb][r], a.c1, a.c2);
-                if (kt * TR + 32 * kb + frag_row(r, half) >= a.Nk) u = -INFINITY;
+                float u = logit2<MODE>(s[kb][r], sc);
+                if (kt == nkt - 1 && kt * TR + 32 * kb + frag_row(r, half) >= a.Nk) u = -INFINITY;   // (only the last tile is ragged)
                 s[kb][r] = u;
                 mt = fmaxf(mt, u);
             }
@@ -180,8 +198,8 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
             f32x16 s = product_T(Ks, 32 * kb, qf, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float u = logit2(s[r], a.c1, a.c2);
-                const bool dead = kt * TR + 32 * kb + frag_row(r, half) >= a.Nk;
+                const float u = logit2<MODE>(s[r], sc);
+                const bool dead = kt == nkt - 1 && kt * TR + 32 * kb + frag_row(r, half) >= a.Nk;
                 s[r] = dead ? 0.f : rnd16(exp2_raw(u - m) * linv);
             }
             accumulate_T(o, Vs, 32 * kb, s, lane);
@@ -198,6 +216,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
 }
 
 // ---- backward, queries resident: delta = sum_k dP P32 (sweep 1), dq = rnd(dS k) (sweep 2) ---------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
@@ -210,6 +229,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
     const long si = ((long)b * a.H + h) * a.Nq + min(q, a.Nq - 1);
     const float m = a.m[si], linv = a.linv[si];
     const int nkt = (a.Nk + TR - 1) / TR;
+    const Scales sc{a.c1, a.c2, a.c1 * a.c2, a.c1 * a.c2 * LOG2E};
     float delta = 0.f;
     f32x16 dq[2];
 #pragma unroll
@@ -239,11 +259,11 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
                 const f32x16 dp = product_T(Vs, 32 * kb, gf, lane);  // dP^T = V dO^T
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool dead = kt * TR + 32 * kb + frag_row(r, half) >= a.Nk;
-                    const float p32 = dead ? 0.f : exp2_raw(logit2(s[r], a.c1, a.c2) - m) * linv;
+                    const bool dead = kt == nkt - 1 && kt * TR + 32 * kb + frag_row(r, half) >= a.Nk;
+                    const float p32 = dead ? 0.f : exp2_raw(logit2<MODE>(s[r], sc) - m) * linv;
                     const float d16 = rnd16(dp[r]);
                     if (sweep == 0) delta = fmaf(d16, p32, delta);
-                    else s[r] = dlogit(p32 * (d16 - delta), a.c1, a.c2);
+                    else s[r] = dlogit<MODE>(p32 * (d16 - delta), sc);
                 }
                 if (sweep == 1) accumulate_T(dq, Ks, 32 * kb, s, lane);   // dq^T += K^T dS^T
             }
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
 }
 
 // ---- backward, keys resident: dk = rnd(dS^T q), dv = rnd(P^T dO); queries streamed --------------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];   // [stage][Q | dO]
     __shared__ __attribute__((aligned(16))) float stats[2][3][TR];                               // [stage][m | linv | delta][query of the tile]
@@ -271,6 +292,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
     load_resident(vf, a.v + (long)b * a.Nk * a.ldkv + h * HD, a.ldkv, key, a.Nk, half);
     const bool dead_key = key >= a.Nk;
     const int nqt = (a.Nq + TR - 1) / TR;
+    const Scales sc{a.c1, a.c2, a.c1 * a.c2, a.c1 * a.c2 * LOG2E};
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -312,11 +334,12 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int r = 4 * g + u;
-                    const bool dead = dead_key || qt * TR + qo + u >= a.Nq;
-                    const float p32 = dead ? 0.f : exp2_raw(logit2(s[r], a.c1, a.c2) - mm[u]) * ll[u];
+                    // (a lane past the last key works on a repeated row and is never stored: only ragged QUERY rows need zeros)
+                    const bool dead = qt == nqt - 1 && qt * TR + qo + u >= a.Nq;
+                    const float p32 = dead ? 0.f : exp2_raw(logit2<MODE>(s[r], sc) - mm[u]) * ll[u];
                     const float d16 = rnd16(dp[r]);
-                    dp[r] = dead ? 0.f : dlogit(p32 * (d16 - dd[u]), a.c1, a.c2);   // dS
-                    s[r] = rnd16(p32);                                                // P
+                    dp[r] = dlogit<MODE>(p32 * (d16 - dd[u]), sc);   // dS (0 where p32 is 0)
+                    s[r] = rnd16(p32);                               // P
                 }
             }
             accumulate_T(dv, Gs, 32 * qb, s, lane);    // dV^T += dO^T P
@@ -360,11 +383,25 @@ Ptrs pack(const dkd_attn16_args* g) {
 
 }  // namespace
 
+// MODE of the logit chain (see logit2): 2 = c1 a power of two and c2 == 1, 1 = c1 a power of two, 0 = general
+static int scale_mode(float c1, float c2) {
+    int e;
+    const bool pow2 = c1 > 0.f && frexpf(c1, &e) == 0.5f;
+    return pow2 ? (c2 == 1.0f ? 2 : 1) : 0;
+}
+#define DKD_A16_MODE(mode, K, grid, a)                                                                                      \
+    do {                                                                                                                    \
+        if ((mode) == 2) hipLaunchKernelGGL(K<2>, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                          \
+        else if ((mode) == 1) hipLaunchKernelGGL(K<1>, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                     \
+        else hipLaunchKernelGGL(K<0>, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                                      \
+    } while (0)
+
 extern "C" int dkd_attn16_train_fwd(const dkd_attn16_args* g, void* stream) {
     const int rc = check(g, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn16_train_fwd_kernel, dim3((g->Nq + 32 * NW - 1) / (32 * NW), g->H, g->B), dim3(NW * 64), 0, (hipStream_t)stream,
-                       pack(g));
+    const Ptrs a = pack(g);
+    const int mode = scale_mode(g->c1, g->c2);
+    DKD_A16_MODE(mode, attn16_train_fwd_kernel, dim3((g->Nq + 32 * NW - 1) / (32 * NW), g->H, g->B), a);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
@@ -373,11 +410,10 @@ extern "C" int dkd_attn16_train_bwd(const dkd_attn16_args* g, void* stream) {
     const int rc = check(g, true);
     if (rc) return rc;
     const Ptrs a = pack(g);
-    hipLaunchKernelGGL(attn16_train_bwd_dq_kernel, dim3((g->Nq + 32 * NW - 1) / (32 * NW), g->H, g->B), dim3(NW * 64), 0,
-                       (hipStream_t)stream, a);
+    const int mode = scale_mode(g->c1, g->c2);
+    DKD_A16_MODE(mode, attn16_train_bwd_dq_kernel, dim3((g->Nq + 32 * NW - 1) / (32 * NW), g->H, g->B), a);
     DKD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn16_train_bwd_dkv_kernel, dim3((g->Nk + 32 * NW - 1) / (32 * NW), g->H, g->B), dim3(NW * 64), 0,
-                       (hipStream_t)stream, a);
+    DKD_A16_MODE(mode, attn16_train_bwd_dkv_kernel, dim3((g->Nk + 32 * NW - 1) / (32 * NW), g->H, g->B), a);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
