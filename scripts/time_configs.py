@@ -16,6 +16,8 @@ CONFIGS = {
     0: dict(teacher="dinov2_vits14", student="stdc_2", crop=224, heads=(16, 24), batch=2),
     2: dict(teacher="dinov2_vitb14", student="resnet_50", crop=224, heads=(16, 24), batch=128),
     3: dict(teacher="dinov2_vitl14", student="swin_tiny", crop=518, heads=(16, 32), batch=16),
+    4: dict(teacher="dinov2_vitg14", student="convnext_base", crop=224, heads=(16, 24), batch=32),
+    1: dict(teacher="dinov2_vits14", student="convnext_tiny", crop=224, heads=(16, 24), batch=64),
 }
 
 
