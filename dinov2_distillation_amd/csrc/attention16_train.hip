@@ -1,4 +1,5 @@
-// The 16-bit policy's attention WITH gradients, flash-style on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), head_dim 64: the
+// The 16-bit policy's attention WITH gradients, flash-style on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), head dims 16 / 24 /
+// 32 (tiles padded to 32: HDP = 32) and 64 (HDP = 64): the
 // ScaleKD projectors' cross attention (losses/scalekd.py:308-313) and the frozen DINOv2 blocks re-used on student tokens
 // (train/distillation_module.py:176-177) under the reference's default precision=16 (train.py:263 == torch autocast).
 //
@@ -14,7 +15,9 @@
 // lanes (B operands held in registers: rows of q / dO for the forward and dq kernels, rows of k / v for the dk / dv kernel), the
 // STREAMED set arrives as 64-row tiles in LDS (LDS-DMA, two stages, one barrier per tile) and lands on the accumulator registers
 // - which, packed to bf16 eight at a time, are the B operand of the second product, whose A operand is the streamed tile read
-// transposed (ds_read_b64_tr_b16).  One LDS image serves both read forms: 128-byte rows, 16-byte chunk XOR (row / 2) % 8.
+// transposed (ds_read_b64_tr_b16).  One LDS image serves both read forms: rows of 2 HDP bytes whose 16-byte chunk index is XOR-ed
+// with the row's position in its 256-byte bank period group ((row / 2) % 8 for 128-byte rows, (row / 4) % 4 for 64-byte rows); chunks
+// past the real head dim (24 in a 32-wide tile) are never loaded and stay zero.
 #include <cmath>
 
 #include "common.h"
@@ -26,37 +29,55 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int HD = 64, TR = 64, NW = 4, ROWB = HD * 2, TILE = TR * ROWB;
+constexpr int TR = 64, NW = 4;
 
 __device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// one wave's two 1-KiB pieces (8 rows x 128 B each) of a 64-row tile; rows past `nrows` repeat the last row (finite values that
-// the masks below turn into exact zeros)
-__device__ __forceinline__ void issue_tile(const __bf16* __restrict__ base, long ld, int row0, int nrows, char* __restrict__ S, int wid,
+template <int HDP>
+struct Geo {
+    static constexpr int ROWB = HDP * 2, TILE = TR * ROWB, CPR = HDP / 8, RPP = 1024 / ROWB, PIECES = TILE / 1024, PPW = PIECES / NW;
+    static constexpr int KC = HDP / 16, DB = HDP / 32;
+    static_assert(HDP == 64 || HDP == 32, "tiles are 32 or 64 wide");
+    static __device__ __forceinline__ int swz(int row) { return HDP == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+};
+
+// one wave's PPW 1-KiB pieces of a 64-row tile; rows past `nrows` repeat the last row (finite values that the masks below turn into
+// exact zeros); chunks at or past the real head dim are not loaded (their LDS slots were zeroed once and are never written)
+template <int HDP>
+__device__ __forceinline__ void issue_tile(const __bf16* __restrict__ base, long ld, int row0, int nrows, int hd, char* __restrict__ S, int wid,
                                            int lane) {
+    using G = Geo<HDP>;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int piece = wid + NW * p, row = 8 * piece + (lane >> 3), slot = lane & 7;
-        const __bf16* src = base + (long)min(row0 + row, nrows - 1) * ld + 8 * (slot ^ swz(row));
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(S + piece * 1024), 16, 0, 0);
+    for (int p = 0; p < G::PPW; ++p) {
+        const int piece = wid + NW * p, row = G::RPP * piece + lane / G::CPR, chunk = (lane % G::CPR) ^ G::swz(row);
+        const __bf16* src = base + (long)min(row0 + row, nrows - 1) * ld + 8 * chunk;
+        if (8 * chunk < hd) __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(S + piece * 1024), 16, 0, 0);
     }
 }
+template <int BYTES>
+__device__ __forceinline__ void zero_lds(char* __restrict__ S, int tid) {
+    for (int i = tid; i < BYTES / 16; i += NW * 64) reinterpret_cast<uint4*>(S)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+}
 // A operand, rows r0 + (lane & 31) of a tile, k = d in [16 kc + 8 half, +8)
+template <int HDP>
 __device__ __forceinline__ bf16x8 row_frag(const char* __restrict__ T, int r0, int kc, int lane) {
+    using G = Geo<HDP>;
     const int row = r0 + (lane & 31);
-    return *reinterpret_cast<const bf16x8*>(T + row * ROWB + 16 * ((2 * kc + (lane >> 5)) ^ swz(row)));
+    return *reinterpret_cast<const bf16x8*>(T + row * G::ROWB + 16 * ((2 * kc + (lane >> 5)) ^ G::swz(row)));
 }
 // A operand of a TRANSPOSED tile: rows = d in [32 c + (lane & 31)], k = tile rows rb + 4 half + {0..3} and rb + 8 + 4 half + {0..3}
 // (the token order the accumulator registers 8 b .. 8 b + 7 of the other product hold, rb = 32 block + 16 b)
+template <int HDP>
 __device__ __forceinline__ bf16x8 tr_frag(const char* __restrict__ T, int rb, int c, int lane) {
+    using G = Geo<HDP>;
     const int half = lane >> 5, cb = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
     const int r_lo = rb + 4 * half + qq, r_hi = r_lo + 8, ch = 4 * c + 2 * cb + (pp >> 1);
     union { s16x4 v[2]; bf16x8 f; } u;
-    u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + r_lo * ROWB + 16 * (ch ^ swz(r_lo)) + 8 * (pp & 1)));
-    u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + r_hi * ROWB + 16 * (ch ^ swz(r_hi)) + 8 * (pp & 1)));
+    u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + r_lo * G::ROWB + 16 * (ch ^ G::swz(r_lo)) + 8 * (pp & 1)));
+    u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + r_hi * G::ROWB + 16 * (ch ^ G::swz(r_hi)) + 8 * (pp & 1)));
     return u.f;
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int b16) {
@@ -65,11 +86,18 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int b16) {
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[8 * b16 + e];
     return o;
 }
-// this lane's resident row (token `row` of a [rows, ld] slice at column offset of the head): 4 fragments of 8 d
-__device__ __forceinline__ void load_resident(bf16x8 (&f)[4], const __bf16* __restrict__ base, long ld, int row, int nrows, int half) {
+// this lane's resident row (token `row` of a [rows, ld] slice at the column offset of the head): KC fragments of 8 d, zero past hd
+template <int HDP>
+__device__ __forceinline__ void load_resident(bf16x8 (&f)[Geo<HDP>::KC], const __bf16* __restrict__ base, long ld, int row, int nrows,
+                                              int hd, int half) {
     const __bf16* p = base + (long)min(row, nrows - 1) * ld + 8 * half;
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) f[kc] = *reinterpret_cast<const bf16x8*>(p + 16 * kc);
+    for (int kc = 0; kc < Geo<HDP>::KC; ++kc) {
+        if (16 * kc + 8 * half < hd) f[kc] = *reinterpret_cast<const bf16x8*>(p + 16 * kc);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[kc][e] = (__bf16)0.f;
+    }
 }
 // the 16-bit logit chain in log2 units, T = rnd(rnd(rnd(acc) c1) c2), and its backward dS = rnd(rnd(rnd(dT) c2) c1).  The kernels are
 // bound by this per-element VALU work (three evaluations per logit in the backward pass), so the roundings that are exact are not
@@ -90,32 +118,39 @@ __device__ __forceinline__ float dlogit(float dT, const Scales& s) {
 }
 
 // S^T block (32 streamed rows x this lane's resident token): acc[r] <-> streamed row r0 + frag_row(r, half)
-__device__ __forceinline__ f32x16 product_T(const char* __restrict__ T, int r0, const bf16x8 (&res)[4], int lane) {
+template <int HDP>
+__device__ __forceinline__ f32x16 product_T(const char* __restrict__ T, int r0, const bf16x8 (&res)[Geo<HDP>::KC], int lane) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(T, r0, kc, lane), res[kc], acc, 0, 0, 0);
+    for (int kc = 0; kc < Geo<HDP>::KC; ++kc)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(T, r0, kc, lane), res[kc], acc, 0, 0, 0);
     return acc;
 }
-// out^T (64 d x resident token) += tile^T x packed accumulators of one 32-row block
-__device__ __forceinline__ void accumulate_T(f32x16 (&out)[2], const char* __restrict__ T, int r0, const f32x16& p, int lane) {
+// out^T (HDP d x resident token) += tile^T x packed accumulators of one 32-row block
+template <int HDP>
+__device__ __forceinline__ void accumulate_T(f32x16 (&out)[Geo<HDP>::DB], const char* __restrict__ T, int r0, const f32x16& p, int lane) {
 #pragma unroll
     for (int b16 = 0; b16 < 2; ++b16) {
         const bf16x8 pf = pack8(p, b16);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) out[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(T, r0 + 16 * b16, c, lane), pf, out[c], 0, 0, 0);
+        for (int c = 0; c < Geo<HDP>::DB; ++c)
+            out[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(T, r0 + 16 * b16, c, lane), pf, out[c], 0, 0, 0);
     }
 }
-// store a transposed accumulator pair (rows = d, lane = token) as the token's 64 bf16 values
-__device__ __forceinline__ void store_T(const f32x16 (&acc)[2], __bf16* __restrict__ row, int half, float mul) {
+// store a transposed accumulator set (rows = d, lane = token) as the token's hd bf16 values
+template <int HDP>
+__device__ __forceinline__ void store_T(const f32x16 (&acc)[Geo<HDP>::DB], __bf16* __restrict__ row, int hd, int half) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < Geo<HDP>::DB; ++c)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const bf16x4 v = {(__bf16)(acc[c][4 * g] * mul), (__bf16)(acc[c][4 * g + 1] * mul), (__bf16)(acc[c][4 * g + 2] * mul),
-                              (__bf16)(acc[c][4 * g + 3] * mul)};
-            *reinterpret_cast<bf16x4*>(row + 32 * c + 8 * g + 4 * half) = v;
+            const int d = 32 * c + 8 * g + 4 * half;
+            if (d < hd) {
+                const bf16x4 v = {(__bf16)acc[c][4 * g], (__bf16)acc[c][4 * g + 1], (__bf16)acc[c][4 * g + 2], (__bf16)acc[c][4 * g + 3]};
+                *reinterpret_cast<bf16x4*>(row + d) = v;
+            }
         }
 }
 
@@ -125,35 +160,38 @@ struct Ptrs {
     float *m, *linv, *delta;
     long ldq, ldkv, ldo, lddo, lddq, lddkv;
     long q_bs;   // q batch stride in elements (0: one query block for every image)
-    int B, H, Nq, Nk;
+    int B, H, Nq, Nk, hd;
     float c1, c2;
 };
 
 // ---- forward: queries resident; sweep 1 = row max / sum over all keys, sweep 2 = P v ------------------------------------------
-template <int MODE>
+template <int HDP, int MODE>
 __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
+    using G = Geo<HDP>;
+    constexpr int TILE = G::TILE;
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];  // [stage][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, q = (blockIdx.x * NW + wid) * 32 + l31;
-    const __bf16* Kb = a.k + (long)b * a.Nk * a.ldkv + h * HD;
-    const __bf16* Vb = a.v + (long)b * a.Nk * a.ldkv + h * HD;
-    bf16x8 qf[4];
-    load_resident(qf, a.q + b * a.q_bs + h * HD, a.ldq, q, a.Nq, half);
+    const __bf16* Kb = a.k + (long)b * a.Nk * a.ldkv + h * a.hd;
+    const __bf16* Vb = a.v + (long)b * a.Nk * a.ldkv + h * a.hd;
+    bf16x8 qf[G::KC];
+    zero_lds<4 * TILE>(smem, tid);
+    load_resident<HDP>(qf, a.q + b * a.q_bs + h * a.hd, a.ldq, q, a.Nq, a.hd, half);
     const int nkt = (a.Nk + TR - 1) / TR;
     const Scales sc{a.c1, a.c2, a.c1 * a.c2, a.c1 * a.c2 * LOG2E};
     float m = -INFINITY, l = 0.f;
     // sweep 1
-    issue_tile(Kb, a.ldkv, 0, a.Nk, smem, wid, lane);
+    issue_tile<HDP>(Kb, a.ldkv, 0, a.Nk, a.hd, smem, wid, lane);
     for (int kt = 0; kt < nkt; ++kt) {
         wait_dma();
         __builtin_amdgcn_s_barrier();
         const char* Ks = smem + (kt & 1) * 2 * TILE;
-        if (kt + 1 < nkt) issue_tile(Kb, a.ldkv, (kt + 1) * TR, a.Nk, smem + ((kt + 1) & 1) * 2 * TILE, wid, lane);
+        if (kt + 1 < nkt) issue_tile<HDP>(Kb, a.ldkv, (kt + 1) * TR, a.Nk, a.hd, smem + ((kt + 1) & 1) * 2 * TILE, wid, lane);
         f32x16 s[2];
         float mt = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = product_T(Ks, 32 * kb, qf, lane);
+            s[kb] = product_T<HDP>(Ks, 32 * kb, qf, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float u = logit2<MODE>(s[kb][r], sc);
@@ -175,14 +213,14 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
     l += __shfl_xor(l, 32, 64);
     const float linv = 1.0f / l;
     // sweep 2 (the barrier at its first tile also fences the last reads of sweep 1)
-    f32x16 o[2];
+    f32x16 o[G::DB];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < G::DB; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     __builtin_amdgcn_s_barrier();
-    issue_tile(Kb, a.ldkv, 0, a.Nk, smem, wid, lane);
-    issue_tile(Vb, a.ldkv, 0, a.Nk, smem + TILE, wid, lane);
+    issue_tile<HDP>(Kb, a.ldkv, 0, a.Nk, a.hd, smem, wid, lane);
+    issue_tile<HDP>(Vb, a.ldkv, 0, a.Nk, a.hd, smem + TILE, wid, lane);
     for (int kt = 0; kt < nkt; ++kt) {
         wait_dma();
         __builtin_amdgcn_s_barrier();
@@ -190,23 +228,23 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
         const char* Vs = Ks + TILE;
         if (kt + 1 < nkt) {
             char* nx = smem + ((kt + 1) & 1) * 2 * TILE;
-            issue_tile(Kb, a.ldkv, (kt + 1) * TR, a.Nk, nx, wid, lane);
-            issue_tile(Vb, a.ldkv, (kt + 1) * TR, a.Nk, nx + TILE, wid, lane);
+            issue_tile<HDP>(Kb, a.ldkv, (kt + 1) * TR, a.Nk, a.hd, nx, wid, lane);
+            issue_tile<HDP>(Vb, a.ldkv, (kt + 1) * TR, a.Nk, a.hd, nx + TILE, wid, lane);
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s = product_T(Ks, 32 * kb, qf, lane);
+            f32x16 s = product_T<HDP>(Ks, 32 * kb, qf, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float u = logit2<MODE>(s[r], sc);
                 const bool dead = kt == nkt - 1 && kt * TR + 32 * kb + frag_row(r, half) >= a.Nk;
                 s[r] = dead ? 0.f : rnd16(exp2_raw(u - m) * linv);
             }
-            accumulate_T(o, Vs, 32 * kb, s, lane);
+            accumulate_T<HDP>(o, Vs, 32 * kb, s, lane);
         }
     }
     if (q < a.Nq) {
-        store_T(o, a.o + ((long)b * a.Nq + q) * a.ldo + h * HD, half, 1.0f);
+        store_T<HDP>(o, a.o + ((long)b * a.Nq + q) * a.ldo + h * a.hd, a.hd, half);
         if (half == 0) {
             const long si = ((long)b * a.H + h) * a.Nq + q;
             a.m[si] = m;
@@ -216,24 +254,27 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_fwd_kernel(Ptrs a) {
 }
 
 // ---- backward, queries resident: delta = sum_k dP P32 (sweep 1), dq = rnd(dS k) (sweep 2) ---------------------------------------
-template <int MODE>
+template <int HDP, int MODE>
 __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
+    using G = Geo<HDP>;
+    constexpr int TILE = G::TILE;
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, q = (blockIdx.x * NW + wid) * 32 + l31;
-    const __bf16* Kb = a.k + (long)b * a.Nk * a.ldkv + h * HD;
-    const __bf16* Vb = a.v + (long)b * a.Nk * a.ldkv + h * HD;
-    bf16x8 qf[4], gf[4];
-    load_resident(qf, a.q + b * a.q_bs + h * HD, a.ldq, q, a.Nq, half);
-    load_resident(gf, a.d_o + (long)b * a.Nq * a.lddo + h * HD, a.lddo, q, a.Nq, half);
+    const __bf16* Kb = a.k + (long)b * a.Nk * a.ldkv + h * a.hd;
+    const __bf16* Vb = a.v + (long)b * a.Nk * a.ldkv + h * a.hd;
+    bf16x8 qf[G::KC], gf[G::KC];
+    zero_lds<4 * TILE>(smem, tid);
+    load_resident<HDP>(qf, a.q + b * a.q_bs + h * a.hd, a.ldq, q, a.Nq, a.hd, half);
+    load_resident<HDP>(gf, a.d_o + (long)b * a.Nq * a.lddo + h * a.hd, a.lddo, q, a.Nq, a.hd, half);
     const long si = ((long)b * a.H + h) * a.Nq + min(q, a.Nq - 1);
     const float m = a.m[si], linv = a.linv[si];
     const int nkt = (a.Nk + TR - 1) / TR;
     const Scales sc{a.c1, a.c2, a.c1 * a.c2, a.c1 * a.c2 * LOG2E};
     float delta = 0.f;
-    f32x16 dq[2];
+    f32x16 dq[G::DB];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < G::DB; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[c][r] = 0.f;
     for (int sweep = 0; sweep < 2; ++sweep) {
@@ -241,8 +282,8 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
             delta += __shfl_xor(delta, 32, 64);
             __builtin_amdgcn_s_barrier();  // every wave is done reading the last tile of sweep 1
         }
-        issue_tile(Kb, a.ldkv, 0, a.Nk, smem, wid, lane);
-        issue_tile(Vb, a.ldkv, 0, a.Nk, smem + TILE, wid, lane);
+        issue_tile<HDP>(Kb, a.ldkv, 0, a.Nk, a.hd, smem, wid, lane);
+        issue_tile<HDP>(Vb, a.ldkv, 0, a.Nk, a.hd, smem + TILE, wid, lane);
         for (int kt = 0; kt < nkt; ++kt) {
             wait_dma();
             __builtin_amdgcn_s_barrier();
@@ -250,13 +291,13 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
             const char* Vs = Ks + TILE;
             if (kt + 1 < nkt) {
                 char* nx = smem + ((kt + 1) & 1) * 2 * TILE;
-                issue_tile(Kb, a.ldkv, (kt + 1) * TR, a.Nk, nx, wid, lane);
-                issue_tile(Vb, a.ldkv, (kt + 1) * TR, a.Nk, nx + TILE, wid, lane);
+                issue_tile<HDP>(Kb, a.ldkv, (kt + 1) * TR, a.Nk, a.hd, nx, wid, lane);
+                issue_tile<HDP>(Vb, a.ldkv, (kt + 1) * TR, a.Nk, a.hd, nx + TILE, wid, lane);
             }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                f32x16 s = product_T(Ks, 32 * kb, qf, lane);    // S^T
-                const f32x16 dp = product_T(Vs, 32 * kb, gf, lane);  // dP^T = V dO^T
+                f32x16 s = product_T<HDP>(Ks, 32 * kb, qf, lane);    // S^T
+                const f32x16 dp = product_T<HDP>(Vs, 32 * kb, gf, lane);  // dP^T = V dO^T
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const bool dead = kt == nkt - 1 && kt * TR + 32 * kb + frag_row(r, half) >= a.Nk;
@@ -265,37 +306,40 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dq_kernel(Ptrs a) {
                     if (sweep == 0) delta = fmaf(d16, p32, delta);
                     else s[r] = dlogit<MODE>(p32 * (d16 - delta), sc);
                 }
-                if (sweep == 1) accumulate_T(dq, Ks, 32 * kb, s, lane);   // dq^T += K^T dS^T
+                if (sweep == 1) accumulate_T<HDP>(dq, Ks, 32 * kb, s, lane);   // dq^T += K^T dS^T
             }
         }
     }
     if (q < a.Nq) {
-        store_T(dq, a.dq + ((long)b * a.Nq + q) * a.lddq + h * HD, half, 1.0f);
+        store_T<HDP>(dq, a.dq + ((long)b * a.Nq + q) * a.lddq + h * a.hd, a.hd, half);
         if (half == 0) a.delta[((long)b * a.H + h) * a.Nq + q] = delta;
     }
 }
 
 // ---- backward, keys resident: dk = rnd(dS^T q), dv = rnd(P^T dO); queries streamed --------------------------------------------
-template <int MODE>
+template <int HDP, int MODE>
 __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
+    using G = Geo<HDP>;
+    constexpr int TILE = G::TILE;
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];   // [stage][Q | dO]
     __shared__ __attribute__((aligned(16))) float stats[2][3][TR];                               // [stage][m | linv | delta][query of the tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, key = (blockIdx.x * NW + wid) * 32 + l31;
-    const __bf16* Qb = a.q + b * a.q_bs + h * HD;
-    const __bf16* Gb = a.d_o + (long)b * a.Nq * a.lddo + h * HD;
+    const __bf16* Qb = a.q + b * a.q_bs + h * a.hd;
+    const __bf16* Gb = a.d_o + (long)b * a.Nq * a.lddo + h * a.hd;
     const float* Mb = a.m + ((long)b * a.H + h) * a.Nq;
     const float* Lb = a.linv + ((long)b * a.H + h) * a.Nq;
     const float* Db = a.delta + ((long)b * a.H + h) * a.Nq;
-    bf16x8 kf[4], vf[4];
-    load_resident(kf, a.k + (long)b * a.Nk * a.ldkv + h * HD, a.ldkv, key, a.Nk, half);
-    load_resident(vf, a.v + (long)b * a.Nk * a.ldkv + h * HD, a.ldkv, key, a.Nk, half);
+    bf16x8 kf[G::KC], vf[G::KC];
+    zero_lds<4 * TILE>(smem, tid);
+    load_resident<HDP>(kf, a.k + (long)b * a.Nk * a.ldkv + h * a.hd, a.ldkv, key, a.Nk, a.hd, half);
+    load_resident<HDP>(vf, a.v + (long)b * a.Nk * a.ldkv + h * a.hd, a.ldkv, key, a.Nk, a.hd, half);
     const bool dead_key = key >= a.Nk;
     const int nqt = (a.Nq + TR - 1) / TR;
     const Scales sc{a.c1, a.c2, a.c1 * a.c2, a.c1 * a.c2 * LOG2E};
-    f32x16 dk[2], dv[2];
+    f32x16 dk[G::DB], dv[G::DB];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < G::DB; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[c][r] = dv[c][r] = 0.f;
     auto stage_stats = [&](int qt, int st) {
@@ -306,8 +350,8 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
             stats[st][2][tid] = Db[qi];
         }
     };
-    issue_tile(Qb, a.ldq, 0, a.Nq, smem, wid, lane);
-    issue_tile(Gb, a.lddo, 0, a.Nq, smem + TILE, wid, lane);
+    issue_tile<HDP>(Qb, a.ldq, 0, a.Nq, a.hd, smem, wid, lane);
+    issue_tile<HDP>(Gb, a.lddo, 0, a.Nq, a.hd, smem + TILE, wid, lane);
     stage_stats(0, 0);
     for (int qt = 0; qt < nqt; ++qt) {
         wait_dma();
@@ -316,14 +360,14 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
         const char* Gs = Qs + TILE;
         if (qt + 1 < nqt) {
             char* nx = smem + ((qt + 1) & 1) * 2 * TILE;
-            issue_tile(Qb, a.ldq, (qt + 1) * TR, a.Nq, nx, wid, lane);
-            issue_tile(Gb, a.lddo, (qt + 1) * TR, a.Nq, nx + TILE, wid, lane);
+            issue_tile<HDP>(Qb, a.ldq, (qt + 1) * TR, a.Nq, a.hd, nx, wid, lane);
+            issue_tile<HDP>(Gb, a.lddo, (qt + 1) * TR, a.Nq, a.hd, nx + TILE, wid, lane);
             stage_stats(qt + 1, (qt + 1) & 1);
         }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            f32x16 s = product_T(Qs, 32 * qb, kf, lane);          // S: rows = queries (registers), lane = key
-            f32x16 dp = product_T(Gs, 32 * qb, vf, lane);         // dP
+            f32x16 s = product_T<HDP>(Qs, 32 * qb, kf, lane);          // S: rows = queries (registers), lane = key
+            f32x16 dp = product_T<HDP>(Gs, 32 * qb, vf, lane);         // dP
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int qo = 32 * qb + 8 * g + 4 * half;        // the 4 consecutive queries of registers 4 g .. 4 g + 3
@@ -342,21 +386,21 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
                     s[r] = rnd16(p32);                               // P
                 }
             }
-            accumulate_T(dv, Gs, 32 * qb, s, lane);    // dV^T += dO^T P
-            accumulate_T(dk, Qs, 32 * qb, dp, lane);   // dK^T += Q^T dS
+            accumulate_T<HDP>(dv, Gs, 32 * qb, s, lane);    // dV^T += dO^T P
+            accumulate_T<HDP>(dk, Qs, 32 * qb, dp, lane);   // dK^T += Q^T dS
         }
     }
     if (!dead_key) {
-        store_T(dk, a.dk + ((long)b * a.Nk + key) * a.lddkv + h * HD, half, 1.0f);
-        store_T(dv, a.dv + ((long)b * a.Nk + key) * a.lddkv + h * HD, half, 1.0f);
+        store_T<HDP>(dk, a.dk + ((long)b * a.Nk + key) * a.lddkv + h * a.hd, a.hd, half);
+        store_T<HDP>(dv, a.dv + ((long)b * a.Nk + key) * a.lddkv + h * a.hd, a.hd, half);
     }
 }
 
 int check(const dkd_attn16_args* g, bool bwd) {
     if (!g || !g->q || !g->k || !g->v || !g->m || !g->linv || g->B <= 0 || g->H <= 0 || g->Nq <= 0 || g->Nk <= 0) return DKD_ERR_BAD_ARG;
-    if (g->hd != HD) return DKD_ERR_UNSUPPORTED;
+    if (g->hd != 64 && g->hd != 32 && g->hd != 24 && g->hd != 16) return DKD_ERR_UNSUPPORTED;
     if (g->H > 65535 || g->B > 65535) return DKD_ERR_UNSUPPORTED;
-    const long w = (long)g->H * HD;
+    const long w = (long)g->H * g->hd;
     if ((g->ldq & 7) || (g->ldkv & 7) || g->ldq < w || g->ldkv < w) return DKD_ERR_ALIGN;
     if (!dkd_aligned16(g->q) || !dkd_aligned16(g->k) || !dkd_aligned16(g->v)) return DKD_ERR_ALIGN;
     if (!bwd) {
@@ -377,7 +421,7 @@ Ptrs pack(const dkd_attn16_args* g) {
     a.m = g->m, a.linv = g->linv, a.delta = g->delta;
     a.ldq = g->ldq, a.ldkv = g->ldkv, a.ldo = g->ldo, a.lddo = g->lddo, a.lddq = g->lddq, a.lddkv = g->lddkv;
     a.q_bs = g->q_shared ? 0 : (long)g->Nq * g->ldq;
-    a.B = g->B, a.H = g->H, a.Nq = g->Nq, a.Nk = g->Nk, a.c1 = g->c1, a.c2 = g->c2;
+    a.B = g->B, a.H = g->H, a.Nq = g->Nq, a.Nk = g->Nk, a.hd = g->hd, a.c1 = g->c1, a.c2 = g->c2;
     return a;
 }
 
@@ -391,9 +435,15 @@ static int scale_mode(float c1, float c2) {
 }
 #define DKD_A16_MODE(mode, K, grid, a)                                                                                      \
     do {                                                                                                                    \
-        if ((mode) == 2) hipLaunchKernelGGL(K<2>, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                          \
-        else if ((mode) == 1) hipLaunchKernelGGL(K<1>, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                     \
-        else hipLaunchKernelGGL(K<0>, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                                      \
+        if (a.hd == 64) {                                                                                                   \
+            if ((mode) == 2) hipLaunchKernelGGL((K<64, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                \
+            else if ((mode) == 1) hipLaunchKernelGGL((K<64, 1>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);           \
+            else hipLaunchKernelGGL((K<64, 0>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                            \
+        } else {                                                                                                            \
+            if ((mode) == 2) hipLaunchKernelGGL((K<32, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                \
+            else if ((mode) == 1) hipLaunchKernelGGL((K<32, 1>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);           \
+            else hipLaunchKernelGGL((K<32, 0>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                            \
+        }                                                                                                                   \
     } while (0)
 
 extern "C" int dkd_attn16_train_fwd(const dkd_attn16_args* g, void* stream) {

@@ -197,14 +197,16 @@ def test_frozen_block_reuse_on_1369_tokens_under_the_policy_vs_torch_autocast():
     assert e < 0.5 * noise
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk,shared,c2", [(3, 6, 256, 256, False, 1.0), (2, 4, 77, 1369, False, 5.0), (2, 3, 1369, 1369, True, 5.0),
-                                                (2, 2, 64, 64, False, 5.0)])
-def test_flash_policy_attention_equals_the_materialised_path(B, H, Nq, Nk, shared, c2):
-    """csrc/attention16_train.hip (hd 64: the frozen teacher blocks, the 16-head projector of configs[3]) against the materialised
-    path it replaces (batched bf16 GEMMs around dkd_attn16_softmax_*) and against torch.autocast: same rounding points, so the two
-    differ by fp32 summation order only (a handful of 1-ulp bf16 flips), far inside the policy's distance from exact attention."""
+@pytest.mark.parametrize("B,H,Nq,Nk,shared,c2,hd", [(3, 6, 256, 256, False, 1.0, 64), (2, 4, 77, 1369, False, 5.0, 64),
+                                                   (2, 3, 1369, 1369, True, 5.0, 64), (2, 2, 64, 64, False, 5.0, 64),
+                                                   (2, 16, 256, 256, True, 5.0, 24), (2, 24, 256, 256, False, 5.0, 16),
+                                                   (2, 8, 1369, 1369, True, 5.0, 32), (3, 5, 100, 36, False, 1.0, 24)])
+def test_flash_policy_attention_equals_the_materialised_path(B, H, Nq, Nk, shared, c2, hd):
+    """csrc/attention16_train.hip (hd 64: the frozen teacher blocks and the 16-head projector of configs[3]; hd 24 / 16: the projectors of
+    configs[1]; 32: configs[3]'s second level) against the materialised path it replaces (batched bf16 GEMMs around
+    dkd_attn16_softmax_*) and against torch.autocast: same rounding points, so the two differ by fp32 summation order only (a
+    handful of 1-ulp bf16 flips), far inside the policy's distance from exact attention."""
     from dinov2_distillation_amd import ops
-    hd = 64
     D = H * hd
     g = torch.Generator().manual_seed(Nq + Nk + H)
     q = torch.randn(1 if shared else B, Nq, D, generator=g).bfloat16()
@@ -239,7 +241,7 @@ def test_flash_policy_attention_equals_the_materialised_path(B, H, Nq, Nk, share
     noise = rel(ref, exact)
     dqs = dq.float().reshape(B, Nq, D).sum(0) if shared else dq
     dq2s = dq2.float().reshape(B, Nq, D).sum(0) if shared else dq2
-    print(f"flash policy attention ({Nq} x {Nk}, H {H}, shared {shared}, c2 {c2}): vs materialised O {rel(O, O2.cpu()):.2e} dq {rel(dq, dq2.cpu()):.2e} "
+    print(f"flash policy attention ({Nq} x {Nk}, H {H}, hd {hd}, shared {shared}, c2 {c2}): vs materialised O {rel(O, O2.cpu()):.2e} dq {rel(dq, dq2.cpu()):.2e} "
           f"dk {rel(dk, dk2.cpu()):.2e} dv {rel(dv, dv2.cpu()):.2e}; vs torch autocast O {rel(O, ref):.2e} dq {rel(dqs, qr.grad):.2e} "
           f"dk {rel(dk, kr.grad):.2e} dv {rel(dv, vr.grad):.2e} (materialised: {rel(O2, ref):.2e} {rel(dq2s, qr.grad):.2e} "
           f"{rel(dk2, kr.grad):.2e} {rel(dv2, vr.grad):.2e}); torch autocast vs exact {noise:.2e}")
