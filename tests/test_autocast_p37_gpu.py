@@ -31,11 +31,15 @@ def test_attention16_ragged_token_counts_vs_torch_autocast(Nq, Nk, shared):
     ref.backward(do)
     qd = q.reshape(-1, D).cuda()
     kd, vd = (t.reshape(B * Nk, D).cuda() for t in (k, v))
-    O, S, P = ops.attention16_forward(qd, kd, vd, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
-    assert O.shape == (B * Nq, D) and S.shape[-1] % 8 == 0 and S.shape[-2] % 8 == 0
-    # the padded key columns carry no probability
-    assert float(P[:, :, Nk:].float().abs().max() if P.shape[-1] > Nk else 0.0) == 0.0
-    dq, dk, dv = ops.attention16_backward(do.reshape(B * Nq, D).cuda(), qd, kd, vd, S, P, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+    ops.ATTN16_FLASH = False   # this test is about the MATERIALISED path's padding (head dims 48 / 96 and A/B runs take it)
+    try:
+        O, S, P = ops.attention16_forward(qd, kd, vd, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+        assert O.shape == (B * Nq, D) and S.shape[-1] % 8 == 0 and S.shape[-2] % 8 == 0
+        # the padded key columns carry no probability
+        assert float(P[:, :, Nk:].float().abs().max() if P.shape[-1] > Nk else 0.0) == 0.0
+        dq, dk, dv = ops.attention16_backward(do.reshape(B * Nq, D).cuda(), qd, kd, vd, S, P, B, H, Nq, Nk, hd, c1, c2, q_shared=shared)
+    finally:
+        ops.ATTN16_FLASH = True
     qd64, kd64, vd64 = (t.double() for t in (q.expand(B, Nq, D), k, v))
     exact = (torch.softmax((qd64.reshape(B, Nq, H, hd).permute(0, 2, 1, 3) @ kd64.reshape(B, Nk, H, hd).permute(0, 2, 3, 1)) * c1 * c2, -1)
              @ vd64.reshape(B, Nk, H, hd).permute(0, 2, 1, 3)).transpose(1, 2).reshape(B, Nq, D)
@@ -59,6 +63,15 @@ def test_attention16_ragged_column_slices_of_a_packed_qkv_buffer():
     qkv = torch.randn(B * N, 3 * D, generator=g).bfloat16().cuda()
     do = torch.randn(B * N, D, generator=g).bfloat16().cuda()
     q, k, v = (qkv[:, i * D:(i + 1) * D] for i in range(3))
+    _packed_slices_check(ops, qkv, do, q, k, v, B, H, N, hd, D)            # flash kernels
+    ops.ATTN16_FLASH = False
+    try:
+        _packed_slices_check(ops, qkv, do, q, k, v, B, H, N, hd, D)        # materialised path (padding copies with the slice pitch)
+    finally:
+        ops.ATTN16_FLASH = True
+
+
+def _packed_slices_check(ops, qkv, do, q, k, v, B, H, N, hd, D):
     O1, S1, P1 = ops.attention16_forward(q, k, v, B, H, N, N, hd, 0.125, ld=3 * D)
     O2, S2, P2 = ops.attention16_forward(q.contiguous(), k.contiguous(), v.contiguous(), B, H, N, N, hd, 0.125)
     assert torch.equal(O1, O2) and torch.equal(P1, P2)
