@@ -1,5 +1,5 @@
 // The 16-bit policy's attention WITH gradients, flash-style on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), head dims 16 / 24 /
-// 32 (tiles padded to 32: HDP = 32) and 64 (HDP = 64): the
+// 32 (tiles padded to 32: HDP = 32) and 48 / 64 (HDP = 64): the
 // ScaleKD projectors' cross attention (losses/scalekd.py:308-313) and the frozen DINOv2 blocks re-used on student tokens
 // (train/distillation_module.py:176-177) under the reference's default precision=16 (train.py:263 == torch autocast).
 //
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
 
 int check(const dkd_attn16_args* g, bool bwd) {
     if (!g || !g->q || !g->k || !g->v || !g->m || !g->linv || g->B <= 0 || g->H <= 0 || g->Nq <= 0 || g->Nk <= 0) return DKD_ERR_BAD_ARG;
-    if (g->hd != 64 && g->hd != 32 && g->hd != 24 && g->hd != 16) return DKD_ERR_UNSUPPORTED;
+    if (g->hd != 64 && g->hd != 48 && g->hd != 32 && g->hd != 24 && g->hd != 16) return DKD_ERR_UNSUPPORTED;
     if (g->H > 65535 || g->B > 65535) return DKD_ERR_UNSUPPORTED;
     const long w = (long)g->H * g->hd;
     if ((g->ldq & 7) || (g->ldkv & 7) || g->ldq < w || g->ldkv < w) return DKD_ERR_ALIGN;
@@ -435,7 +435,7 @@ static int scale_mode(float c1, float c2) {
 }
 #define DKD_A16_MODE(mode, K, grid, a)                                                                                      \
     do {                                                                                                                    \
-        if (a.hd == 64) {                                                                                                   \
+        if (a.hd > 32) {                                                                                                    \
             if ((mode) == 2) hipLaunchKernelGGL((K<64, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                \
             else if ((mode) == 1) hipLaunchKernelGGL((K<64, 1>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);           \
             else hipLaunchKernelGGL((K<64, 0>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                            \

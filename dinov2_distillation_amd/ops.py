@@ -1198,7 +1198,7 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-# flash form of the policy attention (csrc/attention16_train.hip, hd 16 / 24 / 32 / 64): 0 = always the materialised path (A/B, tests)
+# flash form of the policy attention (csrc/attention16_train.hip, hd 16 / 24 / 32 / 48 / 64): 0 = always the materialised path (A/B, tests)
 ATTN16_FLASH = os.environ.get("DKD_ATTN16_FLASH", "1") != "0"
 
 
@@ -1221,7 +1221,7 @@ def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, l
     L = D if ld is None else ld
     if hd % 8:
         raise _lib.DkdError(f"attention16: the head dim must be a multiple of 8 (got {hd})")
-    if hd in (16, 24, 32, 64) and ATTN16_FLASH:
+    if hd in (16, 24, 32, 48, 64) and ATTN16_FLASH:
         # flash form: O plus the fp32 row statistics (max, 1 / sum) in place of the logit / probability tensors
         a = _attn16_train_args(q, k, v, B, H, Nq, Nk, hd, c1, c2, q_shared, L)
         O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
