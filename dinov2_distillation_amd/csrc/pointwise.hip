@@ -213,8 +213,8 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dbn, const float4
 
 // pass 2 of the BatchNorm backward without intermediates: dbn and xhat recomputed from (dt, z), dz fp32 or bf16 (the mixed-precision
 // step: BatchNorm's input is a 16-bit tensor, so its gradient is rounded)
-template <typename TO>
-__global__ void bn_bwd_apply_direct_kernel(const float* __restrict__ dt, const float* __restrict__ z, dkd_bn_cols bn,
+template <typename TO, typename TI = float>
+__global__ void bn_bwd_apply_direct_kernel(const TI* __restrict__ dt, const TI* __restrict__ z, dkd_bn_cols bn,
                                            const float* __restrict__ s1, const float* __restrict__ s2, TO* __restrict__ dz, int nv,
                                            float inv_count, long nvec) {
     EW_LOOP(i, nvec) {
@@ -231,6 +231,29 @@ __global__ void bn_bwd_apply_direct_kernel(const float* __restrict__ dt, const f
                                g.y * rs.y * (d.y - a.y * inv_count - xh.y * b.y * inv_count),
                                g.z * rs.z * (d.z - a.z * inv_count - xh.z * b.z * inv_count),
                                g.w * rs.w * (d.w - a.w * inv_count - xh.w * b.w * inv_count)));
+    }
+}
+
+// BatchNorm + activation on a bf16 conv output -> bf16 (the policy: BatchNorm returns a 16-bit tensor - rounded - and the activation
+// acts on it); ReLU / ReLU6 / none
+__global__ void bn_act_fwd_bf16_kernel(const __bf16* __restrict__ z, dkd_bn_cols bn, __bf16* __restrict__ out, int nv, long nvec) {
+    EW_LOOP(i, nvec) {
+        const int c = (int)(i % nv);
+        const float4 x = ld4(z, i), mu = ld4(bn.mean, c), rs = ld4(bn.rstd, c), g = ld4(bn.gamma, c), b = ld4(bn.beta, c);
+        float4 o = rnd16(make_float4(g.x * (x.x - mu.x) * rs.x + b.x, g.y * (x.y - mu.y) * rs.y + b.y,
+                                     g.z * (x.z - mu.z) * rs.z + b.z, g.w * (x.w - mu.w) * rs.w + b.w));
+        if (bn.act) {
+            o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+            if (bn.act == 2) o = make_float4(fminf(o.x, 6.f), fminf(o.y, 6.f), fminf(o.z, 6.f), fminf(o.w, 6.f));
+        }
+        st4(out, i, o);
+    }
+}
+// relu(rnd(a + b)) on bf16 tensors: the residual add of a 16-bit block output and its 16-bit shortcut, then ReLU (resnet.py:395-397)
+__global__ void add_relu_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ out, long nvec) {
+    EW_LOOP(i, nvec) {
+        const float4 x = ld4(a, i), y = ld4(b, i);
+        st4(out, i, make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f)));
     }
 }
 
@@ -557,6 +580,39 @@ extern "C" int dkd_bn_bwd_apply_direct_f32(const float* dt, const float* z, cons
     dkd_bn_cols bn{mean, rstd, gamma, beta, relu, nullptr};
     DKD_IO_TYPE(dz16, TO, hipLaunchKernelGGL((bn_bwd_apply_direct_kernel<TO>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream,
                                              dt, z, bn, sum_dbn, sum_dbn_xhat, reinterpret_cast<TO*>(dz), N / 4, 1.0f / (float)rows, nvec));
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_bn_bwd_apply_direct_bf16(const void* dt, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                           const float* beta, const float* sum_dbn, const float* sum_dbn_xhat, void* dz, long rows, int N,
+                                           int relu, void* stream) {
+    EW_CHECK(N);
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !sum_dbn || !sum_dbn_xhat || !dz || rows <= 0 || relu < 0 || relu > 4)
+        return DKD_ERR_BAD_ARG;
+    const long nvec = rows * (N / 4);
+    dkd_bn_cols bn{mean, rstd, gamma, beta, relu, nullptr};
+    hipLaunchKernelGGL((bn_bwd_apply_direct_kernel<__bf16, __bf16>), dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(dt), reinterpret_cast<const __bf16*>(z), bn, sum_dbn, sum_dbn_xhat,
+                       reinterpret_cast<__bf16*>(dz), N / 4, 1.0f / (float)rows, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_bn_act_fwd_bf16(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, void* out,
+                                   long rows, int N, int relu, void* stream) {
+    EW_CHECK(N);
+    if (!z || !mean || !rstd || !gamma || !beta || !out || rows <= 0 || relu < 0 || relu > 2) return DKD_ERR_BAD_ARG;
+    const long nvec = rows * (N / 4);
+    dkd_bn_cols bn{mean, rstd, gamma, beta, relu, nullptr};
+    hipLaunchKernelGGL(bn_act_fwd_bf16_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(z),
+                       bn, reinterpret_cast<__bf16*>(out), N / 4, nvec);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_add_relu_bf16(const void* a, const void* b, void* out, long n, void* stream) {
+    EW_CHECK(n);
+    if (!a || !b || !out) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_relu_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(a),
+                       reinterpret_cast<const __bf16*>(b), reinterpret_cast<__bf16*>(out), n / 4);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }

@@ -756,6 +756,55 @@ extern "C" int dkd_bn_bwd_stats_f32(const float* dt, const float* z, const float
     return DKD_OK;
 }
 
+// ---- BatchNorm on a bf16 conv output (the mixed-precision ResNet keeps its activations as bf16 in HBM) ------------------------
+// train-mode statistics: mean, then the centred (biased) variance - two passes, fp32 accumulation; ws as dkd_colreduce_f32
+extern "C" int dkd_bn_stats_bf16(const void* z, float* mean, float* var, float* ws, long rows, int N, void* stream) {
+    if (!z || !mean || !var || rows <= 0 || N <= 0) return DKD_ERR_BAD_ARG;
+    if (N & 3) return DKD_ERR_ALIGN;
+    int cl, ns, rps, cb;
+    colreduce_plan(rows, 1, N, &cl, &ns, &rps, &cb);
+    if (ns > 1 && !ws) return DKD_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* x = reinterpret_cast<const __bf16*>(z);
+    const float inv = 1.0f / (float)rows;
+    for (int pass = 0; pass < 2; ++pass) {
+        float* out = pass ? var : mean;
+        if (pass == 0)
+            hipLaunchKernelGGL((colreduce_kernel<DKD_RED_SUM, __bf16, false>), dim3(cb, ns, 1), dim3(256), 0, st, x, (const __bf16*)nullptr,
+                               (const float*)nullptr, ns > 1 ? ws : out, rows, N, (long)N, cl, rps, inv, ns, 0);
+        else
+            hipLaunchKernelGGL((colreduce_kernel<DKD_RED_SQDIFF, __bf16, false>), dim3(cb, ns, 1), dim3(256), 0, st, x, (const __bf16*)nullptr,
+                               (const float*)mean, ns > 1 ? ws : out, rows, N, (long)N, cl, rps, inv, ns, 0);
+        DKD_LAUNCH_CHECK();
+        if (ns > 1) {
+            hipLaunchKernelGGL(colreduce_final_kernel, dim3((N + 31) / 32, 1, 1), dim3(256), 0, st, ws, out, 1, ns, N, inv);
+            DKD_LAUNCH_CHECK();
+        }
+    }
+    return DKD_OK;
+}
+// dkd_bn_bwd_stats_f32 on bf16 dt and z
+extern "C" int dkd_bn_bwd_stats_bf16(const void* dt, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, float* dgamma, float* dbeta, float* ws, long rows, int N, int relu, void* stream) {
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || rows <= 0 || N <= 0 || relu < 0 || relu > 4)
+        return DKD_ERR_BAD_ARG;
+    if (N & 3) return DKD_ERR_ALIGN;
+    int cl, ns, rps, cb;
+    colreduce_plan(rows, 1, N, &cl, &ns, &rps, &cb);
+    if (ns > 1 && !ws) return DKD_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dkd_bn_cols bn{mean, rstd, gamma, beta, relu, dbeta};
+    hipLaunchKernelGGL((colreduce_kernel<DKD_RED_BN_BWD, __bf16, false>), dim3(cb, ns, 1), dim3(256), 0, st,
+                       reinterpret_cast<const __bf16*>(dt), reinterpret_cast<const __bf16*>(z), (const float*)nullptr,
+                       ns > 1 ? ws : dgamma, rows, N, (long)N, cl, rps, 1.0f, ns, 0, bn);
+    DKD_LAUNCH_CHECK();
+    if (ns > 1) {
+        hipLaunchKernelGGL(colreduce_final_kernel, dim3((N + 31) / 32, 1, 2), dim3(256), 0, st, ws, dgamma, 1, ns, N, 1.0f, 0, 0, dbeta);
+        DKD_LAUNCH_CHECK();
+    }
+    return DKD_OK;
+}
+
 extern "C" long dkd_colreduce_tr_f32_workspace_bytes(long rows, int N) {
     int cl, ns, rps, cb;
     colreduce_plan(rows, 1, N, &cl, &ns, &rps, &cb);

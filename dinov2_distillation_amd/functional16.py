@@ -668,6 +668,9 @@ class ConvBNAct16Fn(Function):
         from .functional import _bn_fwd_stats
         x = _c(x)
         O, pad = w.shape[0], k // 2
+        if x.dtype == BF16:   # bf16 activations in HBM (ResNet): the same arithmetic, every tensor between the kernels in 16 bit
+            return ConvBNAct16Fn._forward_io16(ctx, x, w, bn_w, bn_b, bn_state, k, stride, relu, training)
+        ctx.io16 = False
         if src_nchw:
             B, Cin, H, W = x.shape
             rows = ops.im2col_nchw(x, k, stride, pad)                     # [M, Kp] fp32, columns (c, ky, kx), zero padded to Kp
@@ -696,12 +699,67 @@ class ConvBNAct16Fn(Function):
         return y.reshape(B, Ho, Wo, O)
 
     @staticmethod
+    def _forward_io16(ctx, x, w, bn_w, bn_b, bn_state, k, stride, relu, training):
+        from .functional import _bn_fwd_stats
+        O, pad = w.shape[0], k // 2
+        B, H, W, Cin = x.shape
+        if Cin % 8:
+            raise NotImplementedError("the bf16-storage conv path needs channel counts that are multiples of 8")
+        if k == 1 and stride == 1:
+            rows16 = x.reshape(-1, Cin)
+        else:   # im2col is data movement: channel pairs of the bf16 tensor are fp32 words to the kernel
+            rows16 = ops.im2col_nhwc(x.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
+        w16 = _w16_2d(w, O, Cin) if k == 1 else _prepared(w, "conv16", O, Cin, k * k, 2, (O, k * k * Cin))  # [O][ky][kx][c]
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        z16 = ops.gemm_bf16(rows16, w16)                                   # the conv's 16-bit result
+        if training:
+            running_mean, running_var = bn_state[:2]
+            momentum, eps = bn_state[2:] if len(bn_state) == 4 else (0.1, 1e-5)
+            mean, rstd = ops.bn_stats16(z16, running_mean, running_var, momentum, eps)
+        else:
+            mean, rstd = _bn_fwd_stats(z16, bn_state, False)               # (running statistics: z is not read)
+        y16 = ops.bn_act16(z16, mean, rstd, bn_w, bn_b, int(relu))
+        ctx.training, ctx.io16 = training, True
+        ctx.save_for_backward(rows16, w16, z16, mean, rstd, bn_w, bn_b)
+        ctx.meta = (k, stride, pad, int(relu), False, tuple(x.shape), tuple(w.shape))
+        ctx.params = (w, bn_w, bn_b)
+        return y16.reshape(B, Ho, Wo, O)
+
+    @staticmethod
+    def _backward_io16(ctx, dy):
+        rows16, w16, z16, mean, rstd, bn_w, bn_b = ctx.saved_tensors
+        k, stride, pad, relu, _, xshape, wshape = ctx.meta
+        O = wshape[0]
+        p_w, p_g, p_b = ctx.params
+        o_g, o_b = direct(p_g, p_b)
+        # (a 16-bit output with several consumers - a block input feeds conv1 and the shortcut - arrives here as autograd's 16-bit
+        # sum of their 16-bit gradients: nothing to round)
+        dz16, dg, db = ops.bn_bwd16(_c(dy).reshape(-1, O), z16, mean, rstd, bn_w, bn_b, relu, dgamma_out=o_g, dbeta_out=o_b)
+        B, H, W, Cin = xshape
+        if k == 1:
+            dw, _ = wgrad16(dz16, rows16, p_w, None, reshape=lambda t: t.reshape(wshape))
+        else:
+            dw, _ = wgrad16(dz16, rows16, p_w, None,
+                            transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
+                            reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if k == 1 and stride == 1:
+                dx = ops.gemm_bf16(dz16, w16, b_layout=1).reshape(xshape)
+            else:   # the taps' products stay fp32 until col2im has summed them: ONE rounding, as conv backward does
+                drows = ops.gemm_bf16(dz16, w16, b_layout=1, epi=ops.EPI_F32_RAW)
+                dx = ops.cast_bf16(ops.col2im_nhwc(drows, B, H, W, Cin, k, stride, pad)).reshape(xshape)
+        return dx, dw, ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
+        if ctx.io16:
+            return ConvBNAct16Fn._backward_io16(ctx, dy)
         rows16, w16, z, mean, rstd, bn_w, bn_b = ctx.saved_tensors
         k, stride, pad, relu, src_nchw, xshape, wshape = ctx.meta
         O = wshape[0]
-        if not ctx.training:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         p_w, p_g, p_b = ctx.params
         o_g, o_b = direct(p_g, p_b)
         # (the output may have several consumers - a block input feeds conv1 and the shortcut, an STDC branch feeds the next conv
@@ -789,15 +847,30 @@ class AddRelu16Fn(Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        out = ops.round_bf16_(ops.add_relu(_c(a), _c(b)))   # rounding is monotone and keeps zero: rnd(relu(s)) == relu(rnd(s))
+        if a.dtype == BF16:   # bf16 activations in HBM (ResNet)
+            out = ops.add_relu16(_c(a), _c(b))
+        else:
+            out = ops.round_bf16_(ops.add_relu(_c(a), _c(b)))   # rounding is monotone and keeps zero: rnd(relu(s)) == relu(rnd(s))
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (out,) = ctx.saved_tensors
-        g = ops.relu_bwd(_round16(dy), out)
+        g = ops.relu_bwd16(_c(dy), out) if out.dtype == BF16 else ops.relu_bwd(_round16(dy), out)
         return g, g
+
+
+class ToBf16Fn(Function):
+    """fp32 tensor holding 16-bit values -> the same values as bf16 in HBM (exact); the 16-bit gradient comes back as fp32 holding it"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.cast_bf16(_c(x)).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast_f32(_c(dy)).reshape(dy.shape)
 
 
 from . import _trace  # noqa: E402

@@ -34,7 +34,10 @@ class BasicStem(nn.Module):
         self.out_channels, self.stride = out_channels, 4
 
     def forward(self, x):  # NCHW image -> NHWC
-        return Fn.MaxPool3Fn.apply(self.conv1(x, True, src_nchw=True))
+        y = Fn.MaxPool3Fn.apply(self.conv1(x, True, src_nchw=True))
+        # under the policy the stem and its max pool keep their 16-bit values in fp32 (3-channel im2col, arg-max pooling); from here
+        # on the activations are bf16 in HBM
+        return Fn16.ToBf16Fn.apply(y) if getattr(self, "autocast16", False) else y
 
 
 class BottleneckBlock(nn.Module):
@@ -107,7 +110,7 @@ class ResNet(nn.Module):
     def set_precision(self, precision):
         """"fp32" (exact) or "bf16_autocast": the backbone under the reference's default precision=16 policy (train.py:263):
         convolutions on bf16 operands with 16-bit results, BatchNorm / ReLU / pooling / the residual add on 16-bit values
-        (functional16.ConvBNAct16Fn); features leave as fp32 holding those values"""
+        (functional16.ConvBNAct16Fn), bf16 in HBM behind the stem; features leave as fp32 holding those values"""
         if precision not in ("fp32", "bf16_autocast"):
             raise ValueError(f"unknown student precision {precision!r}")
         self.precision = precision
@@ -122,7 +125,7 @@ class ResNet(nn.Module):
             for blk in getattr(self, name):
                 x = blk(x)
             if name in self._out_features:
-                outs[name] = Fn16.RoundGradFn.apply(x) if getattr(self, "autocast16", False) else x
+                outs[name] = Fn16.ToFloatFn.apply(x) if getattr(self, "autocast16", False) else x
         return outs
 
     def forward(self, x):

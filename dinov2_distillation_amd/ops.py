@@ -1163,6 +1163,57 @@ def round_bf16(x):
     return out
 
 
+def bn_stats16(z16, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """bn_stats on a bf16 conv output [rows, N] -> mean, rstd (fp32; running statistics updated as nn.BatchNorm2d does)"""
+    lib = _lib.binding()
+    _chk16(z16, "z16")
+    N = z16.shape[-1]
+    rows = z16.numel() // N
+    mean = torch.empty(N, dtype=torch.float32, device=z16.device)
+    var, rstd = torch.empty_like(mean), torch.empty_like(mean)
+    wsb = lib.dkd_colreduce_f32_workspace_bytes(rows, 1, N)
+    ws = workspace(wsb, z16.device) if wsb else None
+    check(lib.dkd_bn_stats_bf16(_p(z16), _p(mean), _p(var), _p(ws), rows, N, _stream()), "dkd_bn_stats_bf16")
+    check(lib.dkd_bn_finalize_f32(_p(mean), _p(var), _p(rstd), _p(running_mean), _p(running_var), N, rows, momentum, eps,
+                                  _stream()), "dkd_bn_finalize_f32")
+    return mean, rstd
+
+
+def bn_act16(z16, mean, rstd, gamma, beta, relu):
+    """act(rnd(bn(z16))) as bf16 (relu 0 / 1 / 2)"""
+    _chk16(z16, "z16")
+    N = z16.shape[-1]
+    out = torch.empty_like(z16)
+    check(_lib.binding().dkd_bn_act_fwd_bf16(_p(z16), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(out), z16.numel() // N, N, int(relu),
+                                             _stream()), "dkd_bn_act_fwd_bf16")
+    return out
+
+
+def bn_bwd16(dt16, z16, mean, rstd, gamma, beta, relu, dgamma_out=None, dbeta_out=None):
+    """bn_bwd on bf16 dt / z -> dz (bf16), dgamma, dbeta (fp32)"""
+    lib = _lib.binding()
+    _chk16(dt16, "dt16"), _chk16(z16, "z16")
+    N = z16.shape[-1]
+    rows = z16.numel() // N
+    dgamma = torch.empty(N, dtype=torch.float32, device=z16.device) if dgamma_out is None else dgamma_out.view(N)
+    dbeta = torch.empty(N, dtype=torch.float32, device=z16.device) if dbeta_out is None else dbeta_out.view(N)
+    wsb = lib.dkd_colreduce_f32_workspace_bytes(rows, 1, N)
+    ws = workspace(wsb, z16.device) if wsb else None
+    check(lib.dkd_bn_bwd_stats_bf16(_p(dt16), _p(z16), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(ws), rows, N,
+                                    int(relu), _stream()), "dkd_bn_bwd_stats_bf16")
+    dz = torch.empty_like(z16)
+    check(lib.dkd_bn_bwd_apply_direct_bf16(_p(dt16), _p(z16), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dbeta), _p(dgamma), _p(dz),
+                                           rows, N, int(relu), _stream()), "dkd_bn_bwd_apply_direct_bf16")
+    return dz, dgamma, dbeta
+
+
+def add_relu16(a, b):
+    _chk16(a, "a"), _chk16(b, "b")
+    out = torch.empty_like(a)
+    check(_lib.binding().dkd_add_relu_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "dkd_add_relu_bf16")
+    return out
+
+
 def add16(a, b):
     _chk16(a, "a"), _chk16(b, "b")
     out = torch.empty_like(a)

@@ -161,6 +161,18 @@ int dkd_bn_bwd_stats_f32(const float* dt, const float* z, const float* mean, con
 int dkd_bn_bwd_apply_direct_f32(const float* dt, const float* z, const float* mean, const float* rstd, const float* gamma,
                                 const float* beta, const float* sum_dbn, const float* sum_dbn_xhat, void* dz, int dz16, long rows, int N,
                                 int relu, void* stream);
+/* BatchNorm of the mixed-precision ResNet (bf16 activations in HBM; models/backbones/resnet.py:258-289 under train.py:263's policy): batch
+ * statistics of a bf16 conv output (mean, biased variance; fp32 accumulation, two passes), out = act(rnd(bn(z))) as bf16 (relu 0 / 1 /
+ * 2), the backward pass of dkd_bn_bwd_*_f32 on bf16 dt / z with a bf16 dz, and relu(rnd(a + b)) for the residual add. */
+int dkd_bn_stats_bf16(const void* z, float* mean, float* var, float* ws, long rows, int N, void* stream);
+int dkd_bn_act_fwd_bf16(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, void* out, long rows,
+                        int N, int relu, void* stream);
+int dkd_bn_bwd_stats_bf16(const void* dt, const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          float* dgamma, float* dbeta, float* ws, long rows, int N, int relu, void* stream);
+int dkd_bn_bwd_apply_direct_bf16(const void* dt, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, const float* sum_dbn, const float* sum_dbn_xhat, void* dz, long rows, int N, int relu,
+                                 void* stream);
+int dkd_add_relu_bf16(const void* a, const void* b, void* out, long n, void* stream);
 /* ConvNeXt-V2 GRN on NHWC rows (models/backbones/convnext.py:39-50): sumsq[b][c] from dkd_colreduce_f32.
  * The block (convnext.py:75-87) keeps only the pre-activation h of its GELU: input_is_preact != 0 makes dkd_grn_apply_f32
  * read h and recompute g = gelu(h) (energies: DKD_RED_GELUSQ), and dkd_grn_gelu_bwd_f32 with g == NULL does the same. */

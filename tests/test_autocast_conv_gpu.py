@@ -84,6 +84,49 @@ def test_resnet_bottleneck_under_the_policy_vs_torch_autocast(stride, cin, cout)
             assert rel(v, q16[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("stride,cin,cout", [(1, 256, 256), (2, 256, 512)])
+def test_resnet_bottleneck_bf16_storage_is_bit_equal_to_the_fp32_held_form(stride, cin, cout):
+    """Behind its stem the ResNet keeps the policy's 16-bit activations as bf16 in HBM (ConvBNAct16Fn / AddRelu16Fn on bf16 tensors:
+    bf16 BatchNorm statistics / apply / backward kernels, im2col on the bf16 tensor, autograd's own 16-bit gradient sums).  It is the
+    SAME arithmetic as the fp32-held form the test above pins against torch.autocast (and STDC still uses): output, input gradient,
+    every parameter gradient and the running statistics are bit-equal."""
+    from dinov2_distillation_amd.models.resnet import BottleneckBlock
+    from dinov2_distillation_amd.functional16 import RoundGradFn
+    g = torch.Generator().manual_seed(70 + stride)
+    B, H = 4, 16
+    x = r16(torch.randn(B, H, H, cin, generator=g).relu())
+    ct = r16(torch.randn(B, H // stride, H // stride, cout, generator=g))
+    results = []
+    for io16 in (False, True):
+        torch.manual_seed(5)
+        blk = BottleneckBlock(cin, cout, bottleneck_channels=cout // 4, stride=stride)
+        p = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+        _perturb_bn(p, torch.Generator().manual_seed(9))
+        blk.load_state_dict(p)
+        for m in blk.modules():
+            m.autocast16 = True
+        blk.cuda().train()
+        if io16:
+            xg = x.cuda().bfloat16().requires_grad_(True)
+            out = blk(xg)
+            assert out.dtype == torch.bfloat16
+            (out.float() * ct.cuda()).sum().backward()
+        else:
+            xg = x.cuda().requires_grad_(True)
+            out = blk(RoundGradFn.apply(xg))
+            assert out.dtype == torch.float32
+            (out * ct.cuda()).sum().backward()
+        results.append((out.detach().float(), xg.grad.float(), {k: v.grad.clone() for k, v in blk.named_parameters()},
+                        {k: v.clone() for k, v in blk.state_dict().items() if "running" in k}))
+    (o0, dx0, g0, r0), (o1, dx1, g1, r1) = results
+    assert torch.equal(o0, o1), rel(o1, o0)
+    assert torch.equal(dx0, dx1), rel(dx1, dx0)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), (k, rel(g1[k], g0[k]))
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+
+
 def test_stdc_cat_bottleneck_under_the_policy_vs_torch_autocast():
     """a stride-2 CatBottleneck (stdc.py:153-172: 1x1 ConvX, depthwise 3x3 stride 2 + BatchNorm, three 3x3 ConvX, AvgPool skip,
     concatenation) and a stride-1 one.  Every stage fed the ORACLE'S input is a few flips from torch.autocast (the depthwise conv
