@@ -205,3 +205,15 @@ def test_torch_gradscaler_drives_the_fused_optimizer(student_precision):
     scaler.update()
     torch.cuda.synchronize()
     assert torch.equal(b.optimizer.flat_p, before) and scaler.get_scale() == 1024.0
+
+
+def test_two_rank_exchange_under_the_policy_is_bit_exact():
+    """scripts/ddp_policy_check.py: two gloo ranks on this GPU run the data-parallel step with teacher, student and loss chain under the
+    autocast policy; the bucketed exchange's result equals the mean of the two ranks' local gradients bit for bit (the 16-bit weight
+    gradients land in the arena on the weight-gradient stream, which the exchange waits for) and the parameters stay identical
+    across ranks through three optimiser steps"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ddp_policy_check.py"), "convnext_tiny"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "exchanged gradient == mean of local gradients: True" in r.stdout and "identical across ranks after 3 steps: True" in r.stdout
+
