@@ -861,6 +861,21 @@ class AddRelu16Fn(Function):
         return g, g
 
 
+class AvgPool2_16Fn(Function):
+    """nn.AvgPool2d(2, 2, 0, ceil_mode=True) on 16-bit values (PResNet's "d" shortcut, presnet.py:227,268): fp32 window mean, one
+    rounding; its backward spreads dy / count, which is exact in 16 bit (counts 1, 2, 4)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.hw = tuple(x.shape[1:3])
+        return ops.round_bf16_(ops.avgpool2(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool2(_round16(dy), backward_hw=ctx.hw)
+
+
 class ToBf16Fn(Function):
     """fp32 tensor holding 16-bit values -> the same values as bf16 in HBM (exact); the 16-bit gradient comes back as fp32 holding it"""
 

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}  # presnet.py:186-191
 
@@ -34,9 +35,10 @@ class ConvNormLayer(nn.Module):
     def forward(self, x, src_nchw=False):
         if self.training:
             self.norm.num_batches_tracked += 1
-        return Fn.ConvBNActFn.apply(x, self.conv.weight, self.norm.weight, self.norm.bias,
-                                    (self.norm.running_mean, self.norm.running_var), self.kernel, self.stride, self.relu,
-                                    self.training, src_nchw)
+        fn = Fn16.ConvBNAct16Fn if getattr(self, "autocast16", False) else Fn.ConvBNActFn
+        return fn.apply(x, self.conv.weight, self.norm.weight, self.norm.bias,
+                        (self.norm.running_mean, self.norm.running_var), self.kernel, self.stride, self.relu,
+                        self.training, src_nchw)
 
 
 class _PoolShort(nn.Module):
@@ -47,7 +49,7 @@ class _PoolShort(nn.Module):
         self.conv = ConvNormLayer(cin, cout, 1, 1)
 
     def forward(self, x):
-        return self.conv(Fn.AvgPool2Fn.apply(x))
+        return self.conv((Fn16.AvgPool2_16Fn if getattr(self, "autocast16", False) else Fn.AvgPool2Fn).apply(x))
 
 
 def _shortcut(cin, cout, stride):
@@ -67,7 +69,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = self.branch2b(self.branch2a(x))
-        return Fn.AddReluFn.apply(out, x if self.shortcut else self.short(x))
+        return (Fn16.AddRelu16Fn if getattr(self, "autocast16", False) else Fn.AddReluFn).apply(out, x if self.shortcut else self.short(x))
 
 
 class BottleNeck(nn.Module):
@@ -84,7 +86,7 @@ class BottleNeck(nn.Module):
 
     def forward(self, x):
         out = self.branch2c(self.branch2b(self.branch2a(x)))
-        return Fn.AddReluFn.apply(out, x if self.shortcut else self.short(x))
+        return (Fn16.AddRelu16Fn if getattr(self, "autocast16", False) else Fn.AddReluFn).apply(out, x if self.shortcut else self.short(x))
 
 
 class Blocks(nn.Module):
@@ -123,14 +125,26 @@ class D2Presnet(nn.Module):
         self._out_feature_channels = {n: w * block.expansion for n, w in zip(names, widths)}
         self._out_feature_strides = dict(zip(names, (4, 8, 16, 32)))
 
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the reference's default precision=16 policy (train.py:263) - convolutions on bf16 operands
+        with 16-bit results, BatchNorm / ReLU / pooling / the residual add on 16-bit values held in fp32 tensors (the form
+        functional16.ConvBNAct16Fn pins against torch.autocast for ResNet and STDC)"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        for m in self.modules():
+            m.autocast16 = precision == "bf16_autocast"
+        return self
+
     def forward_features_nhwc(self, x):
         x = self.conv1.conv1_1(x, src_nchw=True)
         x = self.conv1.conv1_3(self.conv1.conv1_2(x))
         x = Fn.MaxPool3Fn.apply(x)
+        a16 = getattr(self, "autocast16", False)
         outs = {}
         for i, stage in enumerate(self.res_layers):
             x = stage(x)
-            outs[f"res{i + 2}"] = x
+            outs[f"res{i + 2}"] = Fn16.RoundGradFn.apply(x) if a16 else x
         return outs
 
     def forward(self, x):
