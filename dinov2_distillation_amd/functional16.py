@@ -148,6 +148,37 @@ def wgrad16(dy16, x16, w, b, transform=None, reshape=None):
     return dw, db
 
 
+def wgrad16_many(items):
+    """several wgrad16 in ONE fork of the weight-gradient stream: items = [(dy16, x16, w, b) or (dy16, x16, w, b, transform, reshape)].
+    The stream bookkeeping of a fork (current-stream lookup, event record + wait, two stream switches: ~35 us of host time) is paid
+    once instead of once per gradient - the mixed-precision step is host-bound on most boxes (NOTES 9.13).  -> [(dw, db), ...] in
+    the order of items ((None, None) where the gradient went straight into the arena)."""
+    items = [tuple(it) + (None, None) * (len(it) == 4) for it in items]
+    params = [p for it in items for p in (it[2], it[3])]
+    if not ops.can_async(*params):
+        return [wgrad16(*it) for it in items]
+    dev = items[0][0].device
+    side = ops.wgrad_stream(dev)
+    ops.claim(*params)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for dy16, x16, w, b, transform, _ in items:
+            N, K = dy16.shape[-1], x16.shape[-1]
+            rs = None if b is None else b.grad.view(-1)
+            if transform is None:
+                ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, out=w.grad.view(N, K), ws_slot=3, rowsum=rs)
+            else:
+                transform(ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, ws_slot=3, rowsum=rs))
+    seen = set()
+    for it in items:
+        for t in it[:2]:
+            if id(t) not in seen:
+                seen.add(id(t))
+                t.record_stream(side)
+    ops.grad_done(*params)
+    return [(None, None)] * len(items)
+
+
 class ToFloatFn(Function):
     """16-bit feature -> fp32 (what an fp32 consumer of an autocast tensor sees); the gradient comes back rounded to 16 bit"""
 
@@ -265,13 +296,13 @@ class ConvNeXtBlock16Fn(Function):
         dout = _c(dout)
         do16 = (dout if dout.dtype == BF16 else ops.cast_bf16(dout)).reshape(M, C)
         pw1, pb1, pw2, pb2 = ctx.params
-        dw2, db2 = wgrad16(do16, y16, pw2, pb2)
         dy16 = ops.gemm_bf16(do16, w2h, b_layout=1)  # [M, 4C]
         p_dww, p_dwb, p_lnw, p_lnb, p_gg, p_gb = ctx.small
         o_dww, o_dwb, o_lnw, o_lnb, o_gg, o_gb = direct(*ctx.small)
         dh16, dgrn_g, dgrn_b = ops.grn_gelu_bwd16(dy16, h16, (gx, nx, denom), gg, B,
                                                   None if o_gg is None else o_gg.view(-1), None if o_gb is None else o_gb.view(-1))
-        dw1, db1 = wgrad16(dh16, n16.reshape(M, C), pw1, pb1)
+        # both Linear weight gradients in one fork of the weight-gradient stream (pwconv2's waits for the GRN backward: ~100 us)
+        (dw2, db2), (dw1, db1) = wgrad16_many([(do16, y16, pw2, pb2), (dh16, n16.reshape(M, C), pw1, pb1)])
         dn16 = ops.gemm_bf16(dh16, w1h, b_layout=1)  # [M, C]
         dd16, dln_w, dln_b = ops.layernorm_bwd_io(dn16, d16.reshape(M, C), mean, rstd, ln_w, BF16, dg_out=o_lnw, db_out=o_lnb)
         dd16 = dd16.reshape(B, H, W, C)
@@ -355,13 +386,12 @@ class AttentionProjector16Fn(Function):
         df2, dn2w, dn2b = ops.layernorm_bwd(_c(dout).reshape(M, D), f2, m2, r2, n2w, dg_out=o_n2w, db_out=o_n2b)
         df2h = ops.cast_bf16(df2)                                                       # gradient of the 16-bit FFN output
         dh = ops.relu_bwd16(ops.gemm_bf16(df2h, w2h, b_layout=1), f1)
-        dw2, db2 = wgrad16(df2h, f1, P_w2, P_b2)
-        dw1, db1 = wgrad16(dh, zn16, P_w1, P_b1)
         dzn = ops.gemm_bf16(dh, w1h, b_layout=1, epi=ops.EPI_F32_RESID, residual=df2)   # + the FFN residual branch (fp32 add)
         dy, dn1w, dn1b = ops.layernorm_bwd(dzn, y, m1, r1, n1w, dg_out=o_n1w, db_out=o_n1b)
         dyh = ops.cast_bf16(dy)                                                         # gradient of the 16-bit proj output
         do16 = ops.gemm_bf16(dyh, wp16, b_layout=1)
-        dwp, dbp = wgrad16(dyh, o16, P_wp, P_bp)
+        # the FFN's and proj's weight gradients in one fork of the weight-gradient stream: they run beside the attention backward
+        (dw2, db2), (dw1, db1), (dwp, dbp) = wgrad16_many([(df2h, f1, P_w2, P_b2), (dh, zn16, P_w1, P_b1), (dyh, o16, P_wp, P_bp)])
         wh, ww = ctx.window
         nwin = wh * ww
         if nwin > 1:
@@ -372,8 +402,6 @@ class AttentionProjector16Fn(Function):
             dq16, dk16, dv16 = unperm(dq16), unperm(dk16), unperm(dv16)
         else:
             dq16, dk16, dv16 = ops.attention16_backward(do16, q16, k16, v16, S, P, B, H, N, N, hd, c1, c2, q_shared=shared)
-        dwk, dbk = wgrad16(dk16, tok16, P_wk, P_bk)
-        dwv, dbv = wgrad16(dv16, tok16, P_wv, P_bv)
         # tok feeds the k and the v Linear through two separate casts: their 16-bit input gradients are added in fp32
         dtok = ops.gemm_bf16(dk16, wk16, b_layout=1, epi=ops.EPI_F32_RESID, residual=dy)
         dtok = ops.gemm_bf16(dv16, wv16, b_layout=1, epi=ops.EPI_F32_RESID, residual=dtok, out=dtok)
@@ -381,17 +409,19 @@ class AttentionProjector16Fn(Function):
         if shared:   # the embedding was repeated over the batch (:234): its gradient is the fp32 sum of the per-image gradients
             o_sq = ops.grad_out(ctx.sq)
             dself = ops.colreduce(dqin.reshape(B, N * D), ops.RED_SUM, out=None if o_sq is None else o_sq.view(1, N * D)).reshape(N, D)
-            dwq, dbq = wgrad16(dq16, qin16.reshape(1, N, D).expand(B, N, D).reshape(M, D).contiguous(), P_wq, P_bq)
+            qrep = qin16.reshape(1, N, D).expand(B, N, D).reshape(M, D).contiguous()
             dext, dself = None, ret(o_sq, dself, ctx.sq)
         else:
-            dwq, dbq = wgrad16(dq16, qin16, P_wq, P_bq)
+            qrep = qin16
             dext, dself = dqin.reshape(B, N, D), None
         dpos = ops.transpose(ops.colreduce(dtok.reshape(B, N * D), ops.RED_SUM).reshape(N, D),
                              out=None if o_pos is None else o_pos.view(D, N)).reshape(pos_shape)
         # BatchNorm + ReLU on 16-bit tensors: the incoming gradient is rounded (it belongs to a 16-bit tensor), the arithmetic is fp32
         dz16, dbn_w, dbn_b = ops.bn_bwd(ops.round_bf16_(dtok), z, mean, rstd, bn_w, bn_b, relu=True, dgamma_out=o_bnw, dbeta_out=o_bnb,
                                         out_dtype=BF16)
-        dwc, dbc = wgrad16(dz16, x16, P_wc, P_bc, reshape=lambda t: t.reshape(wc_shape))
+        (dwk, dbk), (dwv, dbv), (dwq, dbq), (dwc, dbc) = wgrad16_many([
+            (dk16, tok16, P_wk, P_bk), (dv16, tok16, P_wv, P_bv), (dq16, qrep, P_wq, P_bq),
+            (dz16, x16, P_wc, P_bc, None, lambda t: t.reshape(wc_shape))])
         dx = ops.gemm_bf16(dz16, wc16, b_layout=1, epi=ops.EPI_F32).reshape(xshape) if ctx.needs_input_grad[0] else None
         return (dx, dext, dself, None, None, None, None, None,
                 ret(o_pos, dpos, P_pos), dwc, dbc, ret(o_bnw, dbn_w, P_bnw), ret(o_bnb, dbn_b, P_bnb), dwq, dbq, dwk, dbk,

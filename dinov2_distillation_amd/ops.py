@@ -27,6 +27,18 @@ _p = _lib.ptr          # a device pointer argument (ctypes binding: c_void_p; to
 
 _GEMM32 = _lib.struct_call("dkd_gemm_f32", "dkd_gemm_args")
 
+_SIZES = {}
+
+
+def _size(fname, *args):
+    """a workspace / partial-count query of the C ABI (a pure function of its integer arguments), asked once per shape: the hot
+    wrappers would otherwise pay one more binding call per launch for it"""
+    key = (fname, args)
+    v = _SIZES.get(key)
+    if v is None:
+        v = _SIZES[key] = int(getattr(_lib.binding(), fname)(*args))
+    return v
+
 
 def _chk(t, name, contiguous=True):
     if t is None:
@@ -74,7 +86,7 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
         out = torch.empty((out_rows, N), dtype=torch.float32, device=a.device)
     _chk(out, "out")
     ldc = N if ldc is None else ldc
-    wsb = lib.dkd_gemm_f32_workspace_bytes(M, N, K, a_layout, b_layout)
+    wsb = _size("dkd_gemm_f32_workspace_bytes", M, N, K, a_layout, b_layout)
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     check(_GEMM32(A=_p(a2), lda=lda, B=_p(b2), ldb=ldb, C=_p(out), ldc=ldc, bias=_p(bias), colscale=_p(colscale), residual=_p(residual),
                   preact=_p(preact), workspace=_p(ws), rowsum=_p(rowsum), precision=GEMM_PRECISION if precision is None else precision,
@@ -299,7 +311,7 @@ def colreduce(x, op=RED_SUM, y=None, aux=None, groups=1, scale=1.0, out=None):
     rpg = rows // groups
     if out is None:
         out = torch.empty((2, groups, N) if op in (RED_DOT_SUM, RED_DOTGELU_SUM) else (groups, N), dtype=torch.float32, device=x.device)
-    wsb = lib.dkd_colreduce_f32_workspace_bytes(rpg, groups, N)
+    wsb = _size("dkd_colreduce_f32_workspace_bytes", rpg, groups, N)
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.dkd_colreduce_f32(_p(x), _p(y), _p(aux), _p(out), _p(ws), rpg, groups, N, N, op, scale, _stream()),
           "dkd_colreduce_f32")
@@ -349,7 +361,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, affine=True, add=None, dg_out=None, 
     if affine:
         dg = torch.empty(C, dtype=torch.float32, device=x.device) if dg_out is None else dg_out
         db = torch.empty(C, dtype=torch.float32, device=x.device) if db_out is None else db_out
-        ws = workspace(lib.dkd_layernorm_bwd_f32_workspace_bytes(rows, C), x.device)
+        ws = workspace(_size("dkd_layernorm_bwd_f32_workspace_bytes", rows, C), x.device)
     check(lib.dkd_layernorm_bwd_f32(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(add), _p(dx), _p(dg), _p(db), _p(ws),
                                     rows, C, _stream()), "dkd_layernorm_bwd_f32")
     return dx, dg, db
@@ -440,7 +452,7 @@ def kd_loss_fwd(s, t, rows_per_img, alpha, mean_s=None, mean_t=None):
     D = s.shape[-1]
     rows = s.numel() // D
     out = torch.empty(2, dtype=torch.float32, device=s.device)
-    ws = workspace(lib.dkd_kd_loss_f32_workspace_bytes(rows), s.device)  # per-stream scratch: the two chains run concurrently
+    ws = workspace(_size("dkd_kd_loss_f32_workspace_bytes", rows), s.device)  # per-stream scratch: the two chains run concurrently
     check(lib.dkd_kd_loss_fwd_f32(_p(s), _p(t), _p(mean_s), _p(mean_t), _p(out), _p(ws), rows, rows_per_img, D, alpha,
                                   _stream()), "dkd_kd_loss_fwd_f32")
     return out
@@ -490,7 +502,7 @@ def bn_bwd(dt, z, mean, rstd, gamma, beta, relu=True, dgamma_out=None, dbeta_out
     rows = z.numel() // N
     dgamma = torch.empty(N, dtype=torch.float32, device=z.device) if dgamma_out is None else dgamma_out.view(N)
     dbeta = torch.empty(N, dtype=torch.float32, device=z.device) if dbeta_out is None else dbeta_out.view(N)
-    wsb = lib.dkd_colreduce_f32_workspace_bytes(rows, 1, N)
+    wsb = _size("dkd_colreduce_f32_workspace_bytes", rows, 1, N)
     ws = workspace(wsb, z.device) if wsb else None
     check(lib.dkd_bn_bwd_stats_f32(_p(dt), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(ws), rows, N,
                                    int(relu), _stream()), "dkd_bn_bwd_stats_f32")
@@ -518,7 +530,7 @@ def colreduce_tr(part, T, out=None, round_out=False):
     rows, N = part.shape
     if out is None:
         out = torch.empty((N // T, T), dtype=torch.float32, device=part.device)
-    ws = workspace(lib.dkd_colreduce_tr_f32_workspace_bytes(rows, N), part.device)
+    ws = workspace(_size("dkd_colreduce_tr_f32_workspace_bytes", rows, N), part.device)
     check(lib.dkd_colreduce_tr_f32(_p(part), _p(out), _p(ws), rows, N, T, int(round_out), _stream()), "dkd_colreduce_tr_f32")
     return out
 
@@ -528,7 +540,7 @@ def dwconv7_wgrad_cw(x, dout, out=None, round_out=False):
     (and, for the mixed-precision step, the 16-bit rounding)"""
     lib = _lib.binding()
     B, H, W, C = x.shape
-    parts = lib.dkd_dwconv7_wgrad_f32_parts(B, H)
+    parts = _size("dkd_dwconv7_wgrad_f32_parts", B, H)
     part = workspace(parts * 49 * C * 4, x.device, slot=1)
     if x.dtype == BF16:
         _chk16(x, "x"), _chk16(dout, "dout")
@@ -544,7 +556,7 @@ def dwconv7_wgrad(x, dout):
     lib = _lib.binding()
     _chk(x, "x"), _chk(dout, "dout")
     B, H, W, C = x.shape
-    parts = lib.dkd_dwconv7_wgrad_f32_parts(B, H)
+    parts = _size("dkd_dwconv7_wgrad_f32_parts", B, H)
     part = workspace(parts * 49 * C * 4, x.device, slot=1)
     check(lib.dkd_dwconv7_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_f32")
     return colreduce(part[: parts * 49 * C].view(parts, 49 * C)).view(49, C)
@@ -904,7 +916,7 @@ def winattn_backward(do, qkv, o, bias, labels, Bw, nW, H, N, hd, scale):
     _chk16(do, "do") if qkv.dtype == torch.bfloat16 else _chk(do, "do")
     C = H * hd
     dqkv = torch.empty_like(qkv)
-    parts = lib.dkd_winattn_parts(Bw, H)
+    parts = _size("dkd_winattn_parts", Bw, H)
     part = torch.empty((parts, H * N * N), dtype=torch.float32, device=qkv.device)
     a = _winattn_args(qkv, o, bias, labels, Bw, nW, H, N, hd, scale)
     a.d_o, a.do_rs = _p(do), C
@@ -963,7 +975,7 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
         out = torch.empty((out_rows, N), dtype=torch.float32 if f32_out else BF16, device=a.device)
     if out.dtype != (torch.float32 if f32_out else BF16) or not out.is_contiguous():
         raise _lib.DkdError("gemm_bf16: out has the wrong dtype / layout for this epilogue")
-    wsb = 0 if epi == EPI_F32_RAW else lib.dkd_gemm_bf16_workspace_bytes(M, N, K, int(rowsum is not None))
+    wsb = 0 if epi == EPI_F32_RAW else _size("dkd_gemm_bf16_workspace_bytes", M, N, K, int(rowsum is not None))
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     check(_GEMM16(A=_p(a2), lda=a2.shape[1], B=_p(w2), ldb=w2.shape[1], C=_p(out), ldc=N, bias=_p(bias), colscale=_p(colscale),
                   residual=_p(residual), ldr=N, workspace=_p(ws), M=M, N=N, K=K, epi=epi, res_mod=res_mod, row_grp=rg,
@@ -1057,7 +1069,7 @@ def dwconv7_wgrad16(x16, dout16):
     lib = _lib.binding()
     _chk16(x16, "x16"), _chk16(dout16, "dout16")
     B, H, W, C = x16.shape
-    parts = lib.dkd_dwconv7_wgrad_f32_parts(B, H)
+    parts = _size("dkd_dwconv7_wgrad_f32_parts", B, H)
     part = workspace(parts * 49 * C * 4, x16.device, slot=1)
     check(lib.dkd_dwconv7_wgrad_bf16(_p(x16), _p(dout16), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_bf16")
     return colreduce(part[: parts * 49 * C].view(parts, 49 * C)).view(49, C)
@@ -1085,7 +1097,7 @@ def layernorm_bwd_io(dy, x, mean, rstd, gamma, out_dtype, dg_out=None, db_out=No
     dx = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     dg = torch.empty(C, dtype=torch.float32, device=x.device) if dg_out is None else dg_out
     db = torch.empty(C, dtype=torch.float32, device=x.device) if db_out is None else db_out
-    ws = workspace(lib.dkd_layernorm_bwd_f32_workspace_bytes(rows, C), x.device)
+    ws = workspace(_size("dkd_layernorm_bwd_f32_workspace_bytes", rows, C), x.device)
     check(lib.dkd_layernorm_bwd_io(_p(dy), _is16(dy), _p(x), _is16(x), _p(mean), _p(rstd), _p(gamma), _p(dx), int(out_dtype == BF16),
                                    _p(dg), _p(db), _p(ws), rows, C, int(cf16), _stream()), "dkd_layernorm_bwd_io")
     return dx, dg, db
@@ -1099,7 +1111,7 @@ def colreduce16(x, op=RED_SUM, y=None, groups=1, round_gelu=False, scale=1.0, ou
     rpg = x.numel() // N // groups
     if out is None:
         out = torch.empty((2, groups, N) if op == RED_DOTGELU_SUM else (groups, N), dtype=torch.float32, device=x.device)
-    wsb = lib.dkd_colreduce_f32_workspace_bytes(rpg, groups, N)
+    wsb = _size("dkd_colreduce_f32_workspace_bytes", rpg, groups, N)
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.dkd_colreduce_bf16(_p(x), _p(y), _p(out), _p(ws), rpg, groups, N, op, int(round_gelu), int(round_out), scale, _stream()),
           "dkd_colreduce_bf16")
@@ -1171,7 +1183,7 @@ def bn_stats16(z16, running_mean=None, running_var=None, momentum=0.1, eps=1e-5)
     rows = z16.numel() // N
     mean = torch.empty(N, dtype=torch.float32, device=z16.device)
     var, rstd = torch.empty_like(mean), torch.empty_like(mean)
-    wsb = lib.dkd_colreduce_f32_workspace_bytes(rows, 1, N)
+    wsb = _size("dkd_colreduce_f32_workspace_bytes", rows, 1, N)
     ws = workspace(wsb, z16.device) if wsb else None
     check(lib.dkd_bn_stats_bf16(_p(z16), _p(mean), _p(var), _p(ws), rows, N, _stream()), "dkd_bn_stats_bf16")
     check(lib.dkd_bn_finalize_f32(_p(mean), _p(var), _p(rstd), _p(running_mean), _p(running_var), N, rows, momentum, eps,
@@ -1197,7 +1209,7 @@ def bn_bwd16(dt16, z16, mean, rstd, gamma, beta, relu, dgamma_out=None, dbeta_ou
     rows = z16.numel() // N
     dgamma = torch.empty(N, dtype=torch.float32, device=z16.device) if dgamma_out is None else dgamma_out.view(N)
     dbeta = torch.empty(N, dtype=torch.float32, device=z16.device) if dbeta_out is None else dbeta_out.view(N)
-    wsb = lib.dkd_colreduce_f32_workspace_bytes(rows, 1, N)
+    wsb = _size("dkd_colreduce_f32_workspace_bytes", rows, 1, N)
     ws = workspace(wsb, z16.device) if wsb else None
     check(lib.dkd_bn_bwd_stats_bf16(_p(dt16), _p(z16), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(ws), rows, N,
                                     int(relu), _stream()), "dkd_bn_bwd_stats_bf16")
