@@ -1,0 +1,38 @@
+// Launch sequences: several kernels of one logical operator behind ONE host call.  Nothing here computes - every function below calls
+// the C ABI's own entry points in order on the caller's stream.  Why they exist: the mixed-precision step is bound by the host's
+// enqueue time on most boxes (~775 launcher calls of ~25 us per step, NOTES 9.13), and a Python -> C -> launch round trip per kernel
+// is most of that; the three operators below are 9 of the 19 launcher calls of a ConvNeXt block (18 blocks per step).
+#include "common.h"
+#include "dkd_hip.h"
+
+// GRN forward on the 16-bit pre-activation h (models/backbones/convnext.py:39-50,80-82 under the policy): energies of
+// g = rnd(gelu(h)) per (image, channel) -> per-image normalisers -> y = rnd(gamma (g nx) + beta + g)
+extern "C" int dkd_grn_fwd_bf16(const void* h, const float* gamma, const float* beta, float* sumsq, float* gx, float* nx, float* denom,
+                                void* y, float* ws, int B, long rows_per_img, int C, void* stream) {
+    int rc = dkd_colreduce_bf16(h, nullptr, sumsq, ws, rows_per_img, B, C, DKD_RED_GELUSQ, 1, 0, 1.0f, stream);
+    if (rc) return rc;
+    if ((rc = dkd_grn_stats_f32(sumsq, gx, nx, denom, B, C, stream))) return rc;
+    return dkd_grn_apply_bf16(h, nx, gamma, beta, y, B, rows_per_img, C, stream);
+}
+
+// ... and its backward through GRN and GELU: the two per-image sums (sum dy g, sum dy), the per-image coefficients + parameter
+// gradients, dh.  both: scratch [2][B][C]
+extern "C" int dkd_grn_bwd_bf16(const void* dy, const void* h, const float* gx, const float* nx, const float* denom, const float* gamma,
+                                float* both, float* coef, float* dgamma, float* dbeta, void* dh, float* ws, int B, long rows_per_img,
+                                int C, void* stream) {
+    int rc = dkd_colreduce_bf16(dy, h, both, ws, rows_per_img, B, C, DKD_RED_DOTGELU_SUM, 1, 0, 1.0f, stream);
+    if (rc) return rc;
+    if ((rc = dkd_grn_bwd_stats_f32(both, both + (long)B * C, gx, nx, denom, gamma, coef, dgamma, dbeta, B, C, stream))) return rc;
+    return dkd_grn_gelu_bwd_bf16(dy, h, nx, coef, gamma, dh, B, rows_per_img, C, stream);
+}
+
+// depthwise 7 x 7 weight gradient in the parameter's own [C][49] layout: the partial-sum kernel and the transposing (optionally
+// rounding) fold.  io16: in / dout are bf16.  part: dkd_dwconv7_wgrad_f32_parts(B, H) * 49 * C floats; ws: dkd_colreduce_tr_f32's
+extern "C" int dkd_dwconv7_wgrad_cw(const void* in, const void* dout, int io16, float* part, float* out, float* ws, int B, int H, int W,
+                                    int C, int round_out, void* stream) {
+    const int rc = io16 ? dkd_dwconv7_wgrad_bf16(in, dout, part, B, H, W, C, stream)
+                        : dkd_dwconv7_wgrad_f32(reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(dout), part, B, H, W, C,
+                                                stream);
+    if (rc) return rc;
+    return dkd_colreduce_tr_f32(part, out, ws, dkd_dwconv7_wgrad_f32_parts(B, H), 49 * C, 49, round_out, stream);
+}

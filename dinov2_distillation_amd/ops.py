@@ -537,18 +537,19 @@ def colreduce_tr(part, T, out=None, round_out=False):
 
 def dwconv7_wgrad_cw(x, dout, out=None, round_out=False):
     """-> dW in the parameter's own layout [C, 49] (x / dout fp32 or bf16): the fold of the kernel's partial sums does the transposition
-    (and, for the mixed-precision step, the 16-bit rounding)"""
-    lib = _lib.binding()
+    (and, for the mixed-precision step, the 16-bit rounding); both launches behind one host call (dkd_dwconv7_wgrad_cw)"""
     B, H, W, C = x.shape
     parts = _size("dkd_dwconv7_wgrad_f32_parts", B, H)
     part = workspace(parts * 49 * C * 4, x.device, slot=1)
-    if x.dtype == BF16:
-        _chk16(x, "x"), _chk16(dout, "dout")
-        check(lib.dkd_dwconv7_wgrad_bf16(_p(x), _p(dout), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_bf16")
-    else:
-        _chk(x, "x"), _chk(dout, "dout")
-        check(lib.dkd_dwconv7_wgrad_f32(_p(x), _p(dout), _p(part), B, H, W, C, _stream()), "dkd_dwconv7_wgrad_f32")
-    return colreduce_tr(part[: parts * 49 * C].view(parts, 49 * C), 49, out=out, round_out=round_out)
+    io16 = x.dtype == BF16
+    (_chk16(x, "x"), _chk16(dout, "dout")) if io16 else (_chk(x, "x"), _chk(dout, "dout"))
+    _chk(out, "out")
+    if out is None:
+        out = torch.empty((C, 49), dtype=torch.float32, device=x.device)
+    ws = workspace(_size("dkd_colreduce_tr_f32_workspace_bytes", parts, 49 * C), x.device)
+    check(_lib.binding().dkd_dwconv7_wgrad_cw(_p(x), _p(dout), int(io16), _p(part), _p(out), _p(ws), B, H, W, C, int(round_out),
+                                              _stream()), "dkd_dwconv7_wgrad_cw")
+    return out
 
 
 def dwconv7_wgrad(x, dout):
@@ -1119,30 +1120,35 @@ def colreduce16(x, op=RED_SUM, y=None, groups=1, round_gelu=False, scale=1.0, ou
 
 
 def grn_fwd16(h16, gamma, beta, B):
-    """GRN on g = rnd(gelu(h16)) (h16 [B*HW, C] bf16, the 16-bit pre-activation) -> y16, (gx, nx, denom)"""
-    lib = _lib.binding()
+    """GRN on g = rnd(gelu(h16)) (h16 [B*HW, C] bf16, the 16-bit pre-activation) -> y16, (gx, nx, denom); three launches behind one
+    host call (dkd_grn_fwd_bf16)"""
+    _chk16(h16, "h16")
     C = h16.shape[-1]
     rpi = h16.numel() // C // B
-    sumsq = colreduce16(h16, RED_GELUSQ, groups=B, round_gelu=True)
-    gx, nx = torch.empty_like(sumsq), torch.empty_like(sumsq)
+    st = torch.empty((3, B, C), dtype=torch.float32, device=h16.device)   # sumsq | gx | nx
     denom = torch.empty(B, dtype=torch.float32, device=h16.device)
-    check(lib.dkd_grn_stats_f32(_p(sumsq), _p(gx), _p(nx), _p(denom), B, C, _stream()), "dkd_grn_stats_f32")
     y = torch.empty_like(h16)
-    check(lib.dkd_grn_apply_bf16(_p(h16), _p(nx), _p(gamma), _p(beta), _p(y), B, rpi, C, _stream()), "dkd_grn_apply_bf16")
-    return y, (gx, nx, denom)
+    wsb = _size("dkd_colreduce_f32_workspace_bytes", rpi, B, C)
+    ws = workspace(wsb, h16.device) if wsb else None
+    check(_lib.binding().dkd_grn_fwd_bf16(_p(h16), _p(gamma), _p(beta), _p(st[0]), _p(st[1]), _p(st[2]), _p(denom), _p(y), _p(ws), B, rpi,
+                                          C, _stream()), "dkd_grn_fwd_bf16")
+    return y, (st[1], st[2], denom)
 
 
 def grn_gelu_bwd16(dy16, h16, stats, gamma, B, dgamma_out=None, dbeta_out=None):
-    """-> dh16 (through GRN and GELU), dgamma, dbeta (fp32)"""
-    lib = _lib.binding()
+    """-> dh16 (through GRN and GELU), dgamma, dbeta (fp32); three launches behind one host call (dkd_grn_bwd_bf16)"""
+    _chk16(dy16, "dy16"), _chk16(h16, "h16")
     gx, nx, denom = stats
     C = h16.shape[-1]
     rpi = h16.numel() // C // B
-    both = colreduce16(dy16, RED_DOTGELU_SUM, y=h16, groups=B, round_gelu=True)  # [0] = sum dy*g, [1] = sum dy, per image
-    coef, dgamma, dbeta = _grn_bwd_stats(both, stats, gamma, B, C, dgamma_out, dbeta_out)
+    scratch = torch.empty((3, B, C), dtype=torch.float32, device=h16.device)   # both [2] | coef
+    dgamma = torch.empty(C, dtype=torch.float32, device=h16.device) if dgamma_out is None else dgamma_out
+    dbeta = torch.empty(C, dtype=torch.float32, device=h16.device) if dbeta_out is None else dbeta_out
     dh = torch.empty_like(h16)
-    check(lib.dkd_grn_gelu_bwd_bf16(_p(dy16), _p(h16), _p(nx), _p(coef), _p(gamma), _p(dh), B, rpi, C, _stream()),
-          "dkd_grn_gelu_bwd_bf16")
+    wsb = _size("dkd_colreduce_f32_workspace_bytes", rpi, B, C)
+    ws = workspace(wsb, h16.device) if wsb else None
+    check(_lib.binding().dkd_grn_bwd_bf16(_p(dy16), _p(h16), _p(gx), _p(nx), _p(denom), _p(gamma), _p(scratch), _p(scratch[2]), _p(dgamma),
+                                          _p(dbeta), _p(dh), _p(ws), B, rpi, C, _stream()), "dkd_grn_bwd_bf16")
     return dh, dgamma, dbeta
 
 

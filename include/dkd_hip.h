@@ -251,6 +251,17 @@ int dkd_layernorm_bwd_io(const void* dy, int dy16, const void* x, int x16, const
  * round_out: the fp32 results hold bf16 values - a 16-bit bias gradient); ws sized by dkd_colreduce_f32_workspace_bytes */
 int dkd_colreduce_bf16(const void* X, const void* Y, float* out, float* ws, long rows_per_group, int groups, int N, int op,
                        int round_gelu, int round_out, float scale, void* stream);
+/* Launch sequences (csrc/sequences.hip): the kernels of one operator behind one host call - the mixed-precision step is bound by
+ * host enqueue time.  GRN forward / backward on the 16-bit pre-activation (dkd_colreduce_bf16 + dkd_grn_stats_f32 +
+ * dkd_grn_apply_bf16; dkd_colreduce_bf16 + dkd_grn_bwd_stats_f32 + dkd_grn_gelu_bwd_bf16; both: scratch [2][B][C]; ws:
+ * dkd_colreduce_f32_workspace_bytes(rows_per_img, B, C)) and the depthwise weight gradient in [C][49] layout (partial sums + the
+ * transposing fold; part: parts * 49 * C floats, ws: dkd_colreduce_tr_f32_workspace_bytes(parts, 49 * C)). */
+int dkd_grn_fwd_bf16(const void* h, const float* gamma, const float* beta, float* sumsq, float* gx, float* nx, float* denom, void* y,
+                     float* ws, int B, long rows_per_img, int C, void* stream);
+int dkd_grn_bwd_bf16(const void* dy, const void* h, const float* gx, const float* nx, const float* denom, const float* gamma, float* both,
+                     float* coef, float* dgamma, float* dbeta, void* dh, float* ws, int B, long rows_per_img, int C, void* stream);
+int dkd_dwconv7_wgrad_cw(const void* in, const void* dout, int io16, float* part, float* out, float* ws, int B, int H, int W, int C,
+                         int round_out, void* stream);
 int dkd_grn_apply_bf16(const void* h, const float* nx, const float* gamma, const float* beta, void* y, int B, long rows_per_img,
                        int C, void* stream);
 int dkd_grn_gelu_bwd_bf16(const void* dy, const void* h, const float* nx, const float* coef, const float* gamma, void* dh, int B,
