@@ -26,6 +26,8 @@ VIT_CONFIGS = {  # embed dims: train.py:103-108; depth / heads: published models
 PATCH, POS_GRID = 14, 37
 # the autocast teacher's attention: bf16-MFMA flash kernel (csrc/attention16_flash.hip); 0 = the fp32-MFMA kernel's round_bf16 mode (A/B)
 FLASH16 = os.environ.get("DKD_FLASH16", "1") != "0"
+# the autocast teacher's forward as one hipGraph launch after two eager calls per input shape (VisionTransformer._forward_tokens_autocast_graph)
+TEACHER_GRAPH = os.environ.get("DKD_TEACHER_GRAPH", "1") != "0"
 
 
 def _tn(*shape, gen):
@@ -181,6 +183,7 @@ class VisionTransformer(nn.Module):
         self.norm.bias = nn.Parameter(torch.zeros(D), requires_grad=False)
         self._pos_cache = {}
         self._pe16 = None
+        self._tgraph = {}
         self.precision = None
         self.autocast = False
 
@@ -188,6 +191,7 @@ class VisionTransformer(nn.Module):
         """GEMM arithmetic of the frozen teacher: None / "f32" (exact fp32 MFMA), "bf16x3" (split precision) or "bf16"
         (operands rounded to bf16, fp32 accumulate - BASELINE configs[4]'s "bf16 teacher on MFMA")."""
         self.autocast = precision == "bf16_autocast"
+        self._tgraph = {}
         if self.autocast:
             # the teacher's OWN forward follows torch.autocast(bf16) with bf16 activations in HBM (forward_tokens_autocast); the
             # re-use of its blocks on student tokens (with gradient) keeps the bf16-operand kernels of the "bf16" mode
@@ -200,6 +204,7 @@ class VisionTransformer(nn.Module):
     def _apply(self, fn, *a, **k):
         self._pos_cache = {}
         self._pe16 = None
+        self._tgraph = {}
         return super()._apply(fn, *a, **k)
 
     def _pos_table(self, ph, pw):
@@ -248,9 +253,42 @@ class VisionTransformer(nn.Module):
         out, _, _ = ops.layernorm_fwd(t, self.norm.weight, self.norm.bias, 1e-6, need_stats=False, in_rows=(n, n + 1, 1, B * n))
         return out.view(B, n, D)
 
+    def _forward_tokens_autocast_graph(self, x):
+        """forward_tokens_autocast replayed as ONE hipGraph launch.  The frozen teacher's forward is a fixed single-stream sequence of
+        ~90 launches with no autograd state, so after two eager calls on a given input shape (which build every cached weight copy) it
+        is captured once - static input and output buffers, private memory pool - and each later call is a copy into the input buffer
+        + one graph launch: ~2 ms less host enqueue per step, which is what bounds the mixed-precision step on most boxes (NOTES
+        9.13).  DKD_TEACHER_GRAPH=0 keeps the eager launches; so does any call made while a surrounding capture is in progress."""
+        # (weights loaded or edited after the capture: the graph reads the OLD bf16 copies - start over)
+        stamp = (self.patch_embed.proj.weight._version,) + tuple(b.attn.qkv.weight._version for b in self.blocks)
+        key = (tuple(x.shape), x.device.index)
+        ent = self._tgraph.get(key)
+        if ent is None or ent["stamp"] != stamp:
+            ent = self._tgraph[key] = {"calls": 0, "stamp": stamp}
+        if "graph" not in ent:
+            ent["calls"] += 1
+            if ent["calls"] <= 2:
+                return self.forward_tokens_autocast(x)
+            cur = torch.cuda.current_stream()
+            static_in = torch.empty_like(x)
+            static_in.copy_(x)
+            cap = torch.cuda.Stream(device=x.device)
+            cap.wait_stream(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(cap):
+                with torch.cuda.graph(g, stream=cap):
+                    static_out = self.forward_tokens_autocast(static_in)
+            cur.wait_stream(cap)
+            ent.update(graph=g, inp=static_in, out=static_out)
+        ent["inp"].copy_(x)
+        ent["graph"].replay()
+        return ent["out"]
+
     def forward_tokens(self, x):
         """-> final-norm patch tokens [B, P*P, D], dense (CLS dropped by the norm kernel's row gather)."""
         if self.autocast and not (torch.is_grad_enabled() and x.requires_grad):
+            if TEACHER_GRAPH and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+                return self._forward_tokens_autocast_graph(x)
             return self.forward_tokens_autocast(x)
         B, _, Himg, Wimg = x.shape
         ph, pw = Himg // PATCH, Wimg // PATCH

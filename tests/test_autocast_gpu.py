@@ -272,6 +272,35 @@ def test_autocast_teacher_block_and_forward_vs_autocast_oracle():
     assert tg.grad is not None and torch.isfinite(tg.grad).all()
 
 
+def test_autocast_teacher_graph_replay_is_bit_equal_to_the_eager_launches():
+    """VisionTransformer._forward_tokens_autocast_graph: the third call on an input shape captures the frozen teacher's forward into a
+    hipGraph, later calls replay it - same bits as the eager launches, for new inputs too, and a weight edit drops the graph"""
+    from dinov2_distillation_amd.models import dinov2 as dv
+    assert dv.TEACHER_GRAPH
+    t = _teacher("bf16_autocast").cuda()
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, 3, 224, 224, generator=g).cuda() for _ in range(5)]
+    dv.TEACHER_GRAPH = False
+    try:
+        eager = [t(x)["feature_map"].clone() for x in xs]
+    finally:
+        dv.TEACHER_GRAPH = True
+    outs = [t(x)["feature_map"].clone() for x in xs]          # calls 1-2 eager, 3 captures, 4-5 replay
+    ent = next(iter(t.model._tgraph.values()))
+    assert "graph" in ent
+    for a, b in zip(eager, outs):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        t.model.blocks[3].attn.qkv.weight.mul_(1.01)
+    y = t(xs[0])["feature_map"].clone()
+    assert "graph" not in next(iter(t.model._tgraph.values())) and not torch.equal(y, eager[0])
+    dv.TEACHER_GRAPH = False
+    try:
+        assert torch.equal(y, t(xs[0])["feature_map"])
+    finally:
+        dv.TEACHER_GRAPH = True
+
+
 def test_step_with_autocast_teacher_stays_close_to_the_fp32_step():
     from dinov2_distillation_amd.trainer import DistillationStepper
     x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(77)).cuda()
