@@ -420,13 +420,16 @@ def main():
             # the dominant kernel of THIS mode: the bf16 ring GEMM (csrc/gemm_bf16_ring.hip), every un-batched launch of two more
             # steps run on one stream, HIP events per launch on the launch stream - as for the fp32 figure below
             from dinov2_distillation_amd.train import distillation_module as dm
+            from dinov2_distillation_amd.models import dinov2 as dv
             async_was, side_was, chain_was = ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS
             ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS = False, False, False
+            graph_was, dv.TEACHER_GRAPH = dv.TEACHER_GRAPH, False   # (the teacher's GEMMs launched one by one: a graph replay hides them)
             prof16.enabled = True
             for _ in range(2):
                 st16.step(batch)
             sync()
             prof16.enabled = False
+            dv.TEACHER_GRAPH = graph_was
             ops.ASYNC_WGRAD, dm.TEACHER_ON_SIDE_STREAM, dm.TWO_CHAIN_STREAMS = async_was, side_was, chain_was
             ms16 = sum(e0.elapsed_time(e1) for e0, e1, _ in prof16.records)
             fl16 = sum(f for _, _, f in prof16.records)
