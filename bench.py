@@ -367,7 +367,7 @@ def main():
         # the frozen teacher in the reference's DEFAULT precision policy (train.py:263 precision=16 == autocast; bf16 here) with
         # bf16 activations in HBM; student, projectors, losses and optimiser exact fp32 as in `value`
         st16 = DistillationStepper(device=f"cuda:{local}", teacher_precision="bf16_autocast")
-        for _ in range(3):
+        for _ in range(4):   # (two eager teacher forwards, its hipGraph capture, one replay: models/dinov2.py)
             st16.step(batch)
         sync()
         t1 = time.perf_counter()
@@ -384,7 +384,7 @@ def main():
         # ... and with the ConvNeXt student under the same policy too (bf16 activations in HBM, bf16 MFMA GEMMs in all three
         # roles, functional16.py); the ScaleKD projectors, block re-use, losses and the optimiser stay exact fp32
         st16 = DistillationStepper(device=f"cuda:{local}", teacher_precision="bf16_autocast", student_precision="bf16_autocast")
-        for _ in range(3):
+        for _ in range(4):   # (two eager teacher forwards, its hipGraph capture, one replay: models/dinov2.py)
             st16.step(batch)
         sync()
         t1 = time.perf_counter()
@@ -402,7 +402,7 @@ def main():
         # ... and the whole step under the policy: ScaleKD projectors, the re-use of teacher blocks on the student tokens (forward and
         # input gradient) and the frequency loss's Linear-built DCT as well (functional16.py); optimiser and master weights fp32
         st16 = DistillationStepper(device=f"cuda:{local}", precision="bf16_autocast")
-        for _ in range(3):
+        for _ in range(4):   # (two eager teacher forwards, its hipGraph capture, one replay: models/dinov2.py)
             st16.step(batch)
         sync()
         t1 = time.perf_counter()
