@@ -1,3 +1,5 @@
+"""Diagnostic: per-step wall time of the step with the autocast teacher while its forward goes eager -> captured -> replayed
+(models/dinov2.py, VisionTransformer._forward_tokens_autocast_graph): steps 0-1 eager, step 2 captures, later steps replay."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
