@@ -276,7 +276,8 @@ class VisionTransformer(nn.Module):
             cap.wait_stream(cur)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(cap):
-                with torch.cuda.graph(g, stream=cap):
+                # (thread_local: a data-loader pin-memory thread or a communication thread may call the runtime meanwhile)
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
                     static_out = self.forward_tokens_autocast(static_in)
             cur.wait_stream(cap)
             ent.update(graph=g, inp=static_in, out=static_out)
