@@ -257,7 +257,55 @@ int kd_blocks(long rows, int D) {
     const long b = (rows + per - 1) / per;
     return (int)(b < resident ? b : resident);
 }
+// the scalar tail of _compute_losses (train/distillation_module.py:238-245) in one launch: up to 8 loss terms, each its own
+// one-element tensor (pointers by value: no device-side table), weighted[i] = w[i] t[i], pairs[l] = weighted[2l] + weighted[2l+1],
+// total = sum_l pairs[l] in index order; backward g[i] = w[i] (gtotal + gpairs[i / 2] + gweighted[i]) (absent terms NULL)
+struct LossTerms { const float* t[8]; };
+__global__ void loss_combine_fwd_kernel(LossTerms in, const float* __restrict__ w, int n, float* __restrict__ weighted,
+                                        float* __restrict__ pairs, float* __restrict__ total) {
+    if (threadIdx.x != 0) return;
+    float tot = 0.f;
+    for (int l = 0; l < n / 2; ++l) {
+        const float a = in.t[2 * l][0] * w[2 * l], b = in.t[2 * l + 1][0] * w[2 * l + 1];
+        weighted[2 * l] = a;
+        weighted[2 * l + 1] = b;
+        const float p = a + b;
+        pairs[l] = p;
+        tot += p;
+    }
+    *total = tot;
+}
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ w, const float* __restrict__ gw, const float* __restrict__ gpairs,
+                                        const float* __restrict__ gtotal, int n, float* __restrict__ g) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;   // (the order autograd's chain of adds takes: total, then pairs, then weighted)
+    bool any = false;
+    if (gtotal) { v = w[i] * gtotal[0]; any = true; }
+    if (gpairs) { const float t = w[i] * gpairs[i / 2]; v = any ? v + t : t; any = true; }
+    if (gw) { const float t = w[i] * gw[i]; v = any ? v + t : t; }
+    g[i] = v;
+}
 }  // namespace
+
+extern "C" int dkd_loss_combine_fwd_f32(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4,
+                                        const float* t5, const float* t6, const float* t7, const float* w, int n, float* weighted,
+                                        float* pairs, float* total, void* stream) {
+    if (!w || !weighted || !pairs || !total || n <= 0 || n > 8 || (n & 1)) return DKD_ERR_BAD_ARG;
+    LossTerms in{{t0, t1, t2, t3, t4, t5, t6, t7}};
+    for (int i = 0; i < n; ++i)
+        if (!in.t[i]) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, w, n, weighted, pairs, total);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+extern "C" int dkd_loss_combine_bwd_f32(const float* w, const float* gweighted, const float* gpairs, const float* gtotal, int n, float* g,
+                                        void* stream) {
+    if (!w || !g || n <= 0 || n > 8 || (!gweighted && !gpairs && !gtotal)) return DKD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, gweighted, gpairs, gtotal, n, g);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
 
 extern "C" long dkd_kd_loss_f32_workspace_bytes(long rows) { return 2L * KD_MAX_BLOCKS * sizeof(float); }
 

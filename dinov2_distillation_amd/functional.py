@@ -483,22 +483,36 @@ class LossCombineFn(Function):
     """The scalar tail of ``_compute_losses`` (train/distillation_module.py:238-245) as ONE autograd node: per level
     total = (spatial + frequency) * weight, the two weighted parts, and the sum of the totals.  Written with torch scalars it is
     ~13 one-element kernels forward and as many autograd nodes (each a launch) at the very start of the backward pass - the one
-    place in the step where the GPU has nothing queued behind them.  Here: stack, scale, pair sums, total (4 launches), and one
-    launch backward.  inputs: s_0, f_0, s_1, f_1, ... (0-dim); returns (weighted [2L], pair totals [L], total [])."""
+    place in the step where the GPU has nothing queued behind them.  Here: ONE launch forward (dkd_loss_combine_fwd_f32: the terms'
+    pointers go by value) and one backward; the ATen form below is the non-HIP / > 4-level fallback.  inputs: s_0, f_0, s_1, f_1, ... (0-dim); returns (weighted [2L], pair totals [L], total [])."""
 
     @staticmethod
     def forward(ctx, wvec, *terms):
+        n = len(terms)
+        ctx.save_for_backward(wvec)
+        ctx.n = n
+        if wvec.is_cuda and n <= 8 and n % 2 == 0 and all(t.is_cuda and t.dtype == F32 and t.numel() == 1 for t in terms):
+            out = torch.empty(n + n // 2 + 1, dtype=F32, device=wvec.device)       # weighted | pairs | total
+            ptrs = [ops._p(_c(t).reshape(1)) for t in terms] + [None] * (8 - n)
+            ops.check(ops._lib.binding().dkd_loss_combine_fwd_f32(*ptrs, ops._p(wvec), n, ops._p(out), ops._p(out[n:]), ops._p(out[n + n // 2:]),
+                                                                  ops._stream()), "dkd_loss_combine_fwd_f32")
+            return out[:n], out[n:n + n // 2], out[n + n // 2]
         v = torch.stack([t.reshape(()) for t in terms])
         w = v * wvec
         pairs = w.view(-1, 2).sum(1)
         total = pairs.sum()
-        ctx.save_for_backward(wvec)
-        ctx.n = len(terms)
         return w, pairs, total
 
     @staticmethod
     def backward(ctx, gw, gpairs, gtotal):
         (wvec,) = ctx.saved_tensors
+        if wvec.is_cuda and ctx.n <= 8:
+            g = torch.empty(ctx.n, dtype=F32, device=wvec.device)
+            cz = lambda t: None if t is None else _c(t)
+            ops.check(ops._lib.binding().dkd_loss_combine_bwd_f32(ops._p(wvec), ops._p(cz(gw)), ops._p(cz(gpairs)),
+                                                                  ops._p(None if gtotal is None else _c(gtotal).reshape(1)), ctx.n, ops._p(g),
+                                                                  ops._stream()), "dkd_loss_combine_bwd_f32")
+            return (None, *g.unbind(0))
         g = None
         if gtotal is not None:
             g = wvec * gtotal

@@ -377,6 +377,14 @@ int dkd_kd_loss_fwd_f32(const float* S, const float* T, const float* mean_s, con
 int dkd_kd_loss_bwd_f32(const float* S, const float* T, const float* mean_s, const float* mean_t, const float* grad_out,
                         float* dS, long rows, long rows_per_img, int D, float alpha, void* stream);
 long dkd_kd_loss_f32_workspace_bytes(long rows);
+/* The scalar tail of _compute_losses (train/distillation_module.py:238-245) in one launch each way: n <= 8 one-element loss terms
+ * (spatial_0, frequency_0, spatial_1, ...), per-term weights w[n] -> weighted[n] = w t, pairs[n/2] = the per-level totals, total =
+ * their sum; backward g[i] = w[i] (gtotal + gpairs[i/2] + gweighted[i]), absent incoming gradients NULL. */
+int dkd_loss_combine_fwd_f32(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4, const float* t5,
+                             const float* t6, const float* t7, const float* w, int n, float* weighted, float* pairs, float* total,
+                             void* stream);
+int dkd_loss_combine_bwd_f32(const float* w, const float* gweighted, const float* gpairs, const float* gtotal, int n, float* g,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-head attention, flash-style, exact fp32 MFMA.  softmax(scale * q k^T) v per (batch, head).
