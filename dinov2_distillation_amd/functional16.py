@@ -824,37 +824,42 @@ class DepthwiseBN16Fn(Function):
     depthwise conv2d is a 16-bit op too (16-bit taps, fp32 accumulation, one rounding), BatchNorm as in ConvBNAct16Fn"""
 
     @staticmethod
-    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training):
+    def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training, act=0, dilation=1):
+        """act: 0 none (STDC), 1 ReLU, 2 ReLU6 (MobileNetV2's depthwise stage, mobilenet_v2.py:344-352) - exact on 16-bit values"""
         from .functional import _bn_fwd_stats
+        if act not in (0, 1, 2):
+            raise NotImplementedError("SiLU / Hardswish behind a 16-bit BatchNorm need a rounding after the activation")
         x = _c(x)
         C = x.shape[3]
         k = w.shape[-1]
         wt = _prepared(w, ("dwtaps16", k), 1, C, k * k, 1, (k * k, C))       # tap-major, 16-bit values
-        y = ops.round_bf16_(ops.dwconv(x, wt, k, stride))
+        y = ops.round_bf16_(ops.dwconv(x, wt, k, stride, dilation=dilation))
         y2 = y.reshape(-1, C)
         mean, rstd = _bn_fwd_stats(y2, bn_state, training)
         ctx.training = training
-        out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=16)
+        out = ops.bn_act_pos_fwd(y2, mean, rstd, bn_w, bn_b, None, relu=int(act) | 16)
         ctx.save_for_backward(x, wt, y2, mean, rstd, bn_w, bn_b)
-        ctx.meta = (stride, tuple(w.shape), tuple(y.shape))
+        ctx.meta = (stride, tuple(w.shape), tuple(y.shape), int(act), dilation)
         ctx.params = (w, bn_w, bn_b)
         return out.reshape(y.shape)
 
     @staticmethod
     def backward(ctx, dout):
         x, wt, y2, mean, rstd, bn_w, bn_b = ctx.saved_tensors
-        stride, wshape, yshape = ctx.meta
+        stride, wshape, yshape, act, dilation = ctx.meta
         C = x.shape[3]
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         p_w, p_g, p_b = ctx.params
         o_w, o_g, o_b = direct(p_w, p_g, p_b)
-        dy, dg, db = ops.bn_bwd(_round16(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=0, dgamma_out=o_g, dbeta_out=o_b)
+        dy, dg, db = ops.bn_bwd(_round16(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=act, dgamma_out=o_g, dbeta_out=o_b)
         dy = ops.round_bf16_(dy).reshape(yshape)
         k = wshape[-1]
-        dx = ops.round_bf16_(ops.dwconv(dy, wt, k, stride, dgrad_shape=x.shape[1:3])) if ctx.needs_input_grad[0] else None
-        dw = ops.round_bf16_(ops.transpose(ops.dwconv_wgrad(x, dy, k, stride), out=None if o_w is None else o_w.view(C, k * k))).reshape(wshape)
-        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None
+        dx = (ops.round_bf16_(ops.dwconv(dy, wt, k, stride, dgrad_shape=x.shape[1:3], dilation=dilation))
+              if ctx.needs_input_grad[0] else None)
+        dw = ops.round_bf16_(ops.transpose(ops.dwconv_wgrad(x, dy, k, stride, dilation=dilation),
+                                           out=None if o_w is None else o_w.view(C, k * k))).reshape(wshape)
+        return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None
 
 
 class AvgPool3_16Fn(Function):
@@ -904,6 +909,19 @@ class AvgPool2_16Fn(Function):
     @staticmethod
     def backward(ctx, dy):
         return ops.avgpool2(_round16(dy), backward_hw=ctx.hw)
+
+
+class Add16Fn(Function):
+    """rnd(a + b) on 16-bit values: the residual add of an inverted-residual block (mobilenet_v2.py:369) under the policy"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.round_bf16_(ops.axpby(_c(a), _c(b), 1.0, 1.0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = _round16(dy)
+        return g, g
 
 
 class ToBf16Fn(Function):

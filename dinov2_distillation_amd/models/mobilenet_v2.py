@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 ARCH = [[1, 16, 1], [6, 24, 2], [6, 32, 3], [6, 64, 4], [6, 96, 3], [6, 160, 3], [6, 320, 1]]  # mobilenet_v2.py:391-399
 LAYER_TO_RES = {"layer2": "res2", "layer3": "res3", "layer5": "res4", "layer7": "res5"}        # :439-444
@@ -30,11 +31,12 @@ class ConvNormAct(nn.Module):
         if self.training:
             self.norm.num_batches_tracked += 1
         state = (self.norm.running_mean, self.norm.running_var)
+        a16 = getattr(self, "autocast16", False)
         if self.depthwise:
-            return Fn.DepthwiseBNFn.apply(x, self.weight, self.norm.weight, self.norm.bias, state, self.stride, self.training,
-                                          RELU6, self.dilation)
-        return Fn.ConvBNActFn.apply(x, self.weight, self.norm.weight, self.norm.bias, state, self.kernel, self.stride, RELU6,
-                                    self.training, src_nchw)
+            return (Fn16.DepthwiseBN16Fn if a16 else Fn.DepthwiseBNFn).apply(x, self.weight, self.norm.weight, self.norm.bias, state,
+                                                                           self.stride, self.training, RELU6, self.dilation)
+        return (Fn16.ConvBNAct16Fn if a16 else Fn.ConvBNActFn).apply(x, self.weight, self.norm.weight, self.norm.bias, state,
+                                                                    self.kernel, self.stride, RELU6, self.training, src_nchw)
 
 
 class InvertedResidual(nn.Module):
@@ -50,7 +52,7 @@ class InvertedResidual(nn.Module):
 
     def forward(self, x):
         y = self.conv(x)
-        return Fn.AddFn.apply(x, y) if self.use_res_connect else y
+        return (Fn16.Add16Fn if getattr(self, "autocast16", False) else Fn.AddFn).apply(x, y) if self.use_res_connect else y
 
 
 class D2MobileNetV2(nn.Module):
@@ -77,13 +79,24 @@ class D2MobileNetV2(nn.Module):
                 self._out_feature_channels[LAYER_TO_RES[name]] = cout
                 self._out_feature_strides[LAYER_TO_RES[name]] = tot
 
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the reference's default precision=16 policy (train.py:263) - dense and depthwise
+        convolutions on bf16 operands with 16-bit results, BatchNorm / ReLU6 / the residual add on 16-bit values held in fp32 tensors"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        for m in self.modules():
+            m.autocast16 = precision == "bf16_autocast"
+        return self
+
     def forward_features_nhwc(self, x):
         x = self.conv1(x, src_nchw=True)
+        a16 = getattr(self, "autocast16", False)
         outs = {}
         for name in self.layers:
             x = getattr(self, name)(x)
             if name in LAYER_TO_RES and LAYER_TO_RES[name] in self._out_features:
-                outs[LAYER_TO_RES[name]] = x
+                outs[LAYER_TO_RES[name]] = Fn16.RoundGradFn.apply(x) if a16 else x
         return outs
 
     def forward(self, x):

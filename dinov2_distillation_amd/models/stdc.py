@@ -61,7 +61,7 @@ class CatBottleneck(nn.Module):
                     bn.num_batches_tracked += 1
                 dw = Fn16.DepthwiseBN16Fn if getattr(self, "autocast16", False) else Fn.DepthwiseBNFn
                 out = conv(dw.apply(out1, self.avd_layer[0].weight, bn.weight, bn.bias, (bn.running_mean, bn.running_var), 2,
-                                    self.training))
+                                    self.training, 0, 1))
             else:
                 out = conv(out)
             outs.append(out)

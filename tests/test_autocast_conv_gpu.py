@@ -198,7 +198,7 @@ def test_stdc_cat_bottleneck_under_the_policy_vs_torch_autocast():
         assert not bad, bad
 
 
-@pytest.mark.parametrize("family", ["resnet", "stdc", "presnet"])
+@pytest.mark.parametrize("family", ["resnet", "stdc", "presnet", "mobilenet_v2"])
 def test_whole_backbone_and_step_under_the_policy(family):
     """the whole backbone (stem from the fp32 NCHW image, max pool, every stage) against the autocast oracle at the policy's own
     distance from fp32, and one full distillation step of the BASELINE pair (configs[2]: vitb14 -> resnet_50; configs[0]:
@@ -211,6 +211,10 @@ def test_whole_backbone_and_step_under_the_policy(family):
         from oracle import resnet_oracle as ro
         w = ModelWrapper("resnet_50", [8, 8], ["res4", "res5"])
         ofn = lambda xin: (lambda q: ro.forward(q, xin, [3, 4, 6, 3]))
+    elif family == "mobilenet_v2":   # (not a BASELINE config: ReLU6 behind every conv, depthwise 3 x 3 + BatchNorm, plain residual add)
+        from oracle import mobilenet_v2_oracle as mo
+        w = ModelWrapper("mobilenet_v2", [8, 8], ["res4", "res5"])
+        ofn = lambda xin: (lambda q: mo.forward(q, xin))
     elif family == "presnet":   # (ResNet-vd, not a BASELINE config: the same nodes plus the average-pool "d" shortcut)
         from oracle import presnet_oracle as po
         w = ModelWrapper("presnet_50", [8, 8], ["res4", "res5"])
@@ -235,7 +239,8 @@ def test_whole_backbone_and_step_under_the_policy(family):
         assert torch.equal(feats[k], r16(feats[k])) and noise > 1e-3 and e < 1.3 * noise
     del w, net, feats
     pair = {"resnet": dict(teacher="dinov2_vitb14", student="resnet_50"), "stdc": dict(teacher="dinov2_vits14", student="stdc_2"),
-            "presnet": dict(teacher="dinov2_vits14", student="presnet_50")}[family]
+            "presnet": dict(teacher="dinov2_vits14", student="presnet_50"),
+            "mobilenet_v2": dict(teacher="dinov2_vits14", student="mobilenet_v2")}[family]
     xb = torch.randn(4, 3, 224, 224, generator=g).cuda()
     l32 = float(DistillationStepper(device="cuda:0", **pair).step(xb).detach())
     st = DistillationStepper(device="cuda:0", precision="bf16_autocast", **pair)
