@@ -55,9 +55,14 @@ __device__ __forceinline__ float silu_grad_f(float y) {
 }
 // gradient of the activation behind a BatchNorm, as a factor of the incoming gradient, from the BatchNorm OUTPUT y:
 // act 0 none, 1 ReLU, 2 ReLU6 (1 strictly inside (0, 6), as F.relu6 / hardtanh), 3 SiLU, 4 Hardswish (dkd_hip.h, `relu`)
+// act | 16 (the mixed-precision step): the BatchNorm output is a 16-bit tensor - the activation's derivative is taken at rnd(y) - and
+// so is the gradient of a smooth activation (SiLU / Hardswish backward returns a 16-bit tensor; ReLU's is d or 0 as it stands)
 __device__ __forceinline__ float bn_act_grad(float d, float y, int act) {
-    if (act == 3) return d * silu_grad_f(y);
-    if (act == 4) return d * hswish_grad_f(y);
+    const bool p16 = (act & 16) != 0;
+    act &= 15;
+    if (p16) y = rnd16(y);
+    if (act == 3) return p16 ? rnd16(d * silu_grad_f(y)) : d * silu_grad_f(y);
+    if (act == 4) return p16 ? rnd16(d * hswish_grad_f(y)) : d * hswish_grad_f(y);
     if (act) return (y > 0.f && y < (act == 2 ? 6.f : INFINITY)) ? d : 0.f;
     return d;
 }

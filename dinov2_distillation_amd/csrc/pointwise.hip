@@ -159,6 +159,7 @@ __global__ void bn_act_pos_fwd_kernel(const float4* __restrict__ z, const float4
             o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
             if (relu == 2) o = make_float4(fminf(o.x, 6.f), fminf(o.y, 6.f), fminf(o.z, 6.f), fminf(o.w, 6.f));  // ReLU6
         }
+        if (r16 && relu >= 3) o = rnd16(o);   // (a smooth activation of a 16-bit tensor returns a 16-bit tensor; ReLU / ReLU6 are exact)
         if (pos) {
             const float4 p = pos[(r % period) * nv + c];
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
@@ -574,7 +575,7 @@ extern "C" int dkd_bn_bwd_apply_direct_f32(const float* dt, const float* z, cons
                                           const float* beta, const float* sum_dbn, const float* sum_dbn_xhat, void* dz, int dz16, long rows,
                                           int N, int relu, void* stream) {
     EW_CHECK(N);
-    if (!dt || !z || !mean || !rstd || !gamma || !beta || !sum_dbn || !sum_dbn_xhat || !dz || rows <= 0 || relu < 0 || relu > 4)
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !sum_dbn || !sum_dbn_xhat || !dz || rows <= 0 || relu < 0 || (relu & ~16) > 4)
         return DKD_ERR_BAD_ARG;
     const long nvec = rows * (N / 4);
     dkd_bn_cols bn{mean, rstd, gamma, beta, relu, nullptr};
@@ -587,7 +588,7 @@ extern "C" int dkd_bn_bwd_apply_direct_bf16(const void* dt, const void* z, const
                                            const float* beta, const float* sum_dbn, const float* sum_dbn_xhat, void* dz, long rows, int N,
                                            int relu, void* stream) {
     EW_CHECK(N);
-    if (!dt || !z || !mean || !rstd || !gamma || !beta || !sum_dbn || !sum_dbn_xhat || !dz || rows <= 0 || relu < 0 || relu > 4)
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !sum_dbn || !sum_dbn_xhat || !dz || rows <= 0 || relu < 0 || (relu & ~16) > 4)
         return DKD_ERR_BAD_ARG;
     const long nvec = rows * (N / 4);
     dkd_bn_cols bn{mean, rstd, gamma, beta, relu, nullptr};

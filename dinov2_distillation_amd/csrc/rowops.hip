@@ -738,7 +738,7 @@ extern "C" int dkd_colreduce_f32(const float* X, const float* Y, const float* au
 // from (dt, z) - no dbn / xhat tensors in HBM.  ws: dkd_colreduce_f32_workspace_bytes(rows, 1, N).
 extern "C" int dkd_bn_bwd_stats_f32(const float* dt, const float* z, const float* mean, const float* rstd, const float* gamma,
                                     const float* beta, float* dgamma, float* dbeta, float* ws, long rows, int N, int relu, void* stream) {
-    if (!dt || !z || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || rows <= 0 || N <= 0 || relu < 0 || relu > 4)
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || rows <= 0 || N <= 0 || relu < 0 || (relu & ~16) > 4)
         return DKD_ERR_BAD_ARG;
     if (N & 3) return DKD_ERR_ALIGN;
     int cl, ns, rps, cb;
@@ -786,7 +786,7 @@ extern "C" int dkd_bn_stats_bf16(const void* z, float* mean, float* var, float* 
 // dkd_bn_bwd_stats_f32 on bf16 dt and z
 extern "C" int dkd_bn_bwd_stats_bf16(const void* dt, const void* z, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, float* dgamma, float* dbeta, float* ws, long rows, int N, int relu, void* stream) {
-    if (!dt || !z || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || rows <= 0 || N <= 0 || relu < 0 || relu > 4)
+    if (!dt || !z || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || rows <= 0 || N <= 0 || relu < 0 || (relu & ~16) > 4)
         return DKD_ERR_BAD_ARG;
     if (N & 3) return DKD_ERR_ALIGN;
     int cl, ns, rps, cb;

@@ -795,8 +795,9 @@ class ConvBNAct16Fn(Function):
         # (the output may have several consumers - a block input feeds conv1 and the shortcut, an STDC branch feeds the next conv
         # and the concatenation: autograd has added their 16-bit gradients in fp32, the 16-bit tensor's gradient is that sum rounded)
         dy = _round16(dy)
-        dz16, dg, db = ops.bn_bwd(dy.reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu, dgamma_out=o_g, dbeta_out=o_b,
-                                  out_dtype=BF16)                         # BatchNorm's input gradient is a 16-bit tensor
+        # (SiLU / Hardswish: their derivative is taken at the 16-bit BatchNorm output and their gradient is a 16-bit tensor - flag 16)
+        dz16, dg, db = ops.bn_bwd(dy.reshape(-1, O), z, mean, rstd, bn_w, bn_b, relu=relu | 16 if relu >= 3 else relu, dgamma_out=o_g,
+                                  dbeta_out=o_b, out_dtype=BF16)          # BatchNorm's input gradient is a 16-bit tensor
         dx = None
         if src_nchw:
             kk = xshape[1] * k * k
@@ -825,10 +826,9 @@ class DepthwiseBN16Fn(Function):
 
     @staticmethod
     def forward(ctx, x, w, bn_w, bn_b, bn_state, stride, training, act=0, dilation=1):
-        """act: 0 none (STDC), 1 ReLU, 2 ReLU6 (MobileNetV2's depthwise stage, mobilenet_v2.py:344-352) - exact on 16-bit values"""
+        """act: 0 none (STDC), 1 ReLU, 2 ReLU6 (MobileNetV2's depthwise stage, mobilenet_v2.py:344-352): exact on 16-bit values; 3 SiLU /
+        4 Hardswish: rounded once more (the kernels' flag 16)"""
         from .functional import _bn_fwd_stats
-        if act not in (0, 1, 2):
-            raise NotImplementedError("SiLU / Hardswish behind a 16-bit BatchNorm need a rounding after the activation")
         x = _c(x)
         C = x.shape[3]
         k = w.shape[-1]
@@ -852,7 +852,8 @@ class DepthwiseBN16Fn(Function):
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (validation runs under no_grad)")
         p_w, p_g, p_b = ctx.params
         o_w, o_g, o_b = direct(p_w, p_g, p_b)
-        dy, dg, db = ops.bn_bwd(_round16(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=act, dgamma_out=o_g, dbeta_out=o_b)
+        dy, dg, db = ops.bn_bwd(_round16(dout).reshape(-1, C), y2, mean, rstd, bn_w, bn_b, relu=act | 16 if act >= 3 else act,
+                                dgamma_out=o_g, dbeta_out=o_b)
         dy = ops.round_bf16_(dy).reshape(yshape)
         k = wshape[-1]
         dx = (ops.round_bf16_(ops.dwconv(dy, wt, k, stride, dgrad_shape=x.shape[1:3], dilation=dilation))

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 ACT_SILU = 3  # dkd_bn_act_pos_fwd_f32 / dkd_bn_bwd_prep_f32 activation code
 
@@ -41,9 +42,10 @@ class Conv(nn.Module):
     def forward(self, x, src_nchw=False):
         if self.training:
             self.bn.num_batches_tracked += 1
-        return Fn.ConvBNActFn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias,
-                                    (self.bn.running_mean, self.bn.running_var, self.bn.momentum, self.bn.eps),
-                                    self.kernel, self.stride, ACT_SILU, self.training, src_nchw)
+        fn = Fn16.ConvBNAct16Fn if getattr(self, "autocast16", False) else Fn.ConvBNActFn
+        return fn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias,
+                        (self.bn.running_mean, self.bn.running_var, self.bn.momentum, self.bn.eps),
+                        self.kernel, self.stride, ACT_SILU, self.training, src_nchw)
 
 
 class Bottleneck(nn.Module):
@@ -57,7 +59,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         y = self.cv2(self.cv1(x))
-        return Fn.AddFn.apply(x, y) if self.add else y
+        return (Fn16.Add16Fn if getattr(self, "autocast16", False) else Fn.AddFn).apply(x, y) if self.add else y
 
 
 class C2f(nn.Module):
@@ -92,12 +94,23 @@ class DarkNet(nn.Module):
         self._out_feature_strides = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
         self._out_feature_channels = {f"res{i + 2}": width[i + 2] for i in range(4)}
 
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the reference's default precision=16 policy (train.py:263) - convolutions on bf16 operands
+        with 16-bit results, BatchNorm and SiLU on 16-bit tensors (each rounded), 16-bit residual adds; values held in fp32 tensors"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        for m in self.modules():
+            m.autocast16 = precision == "bf16_autocast"
+        return self
+
     def forward_features_nhwc(self, x):
         x = self.p1[0](x, src_nchw=True)
+        a16 = getattr(self, "autocast16", False)
         outs = {}
         for i in range(4):
             x = getattr(self, f"p{i + 2}")(x)
-            outs[f"res{i + 2}"] = x
+            outs[f"res{i + 2}"] = Fn16.RoundGradFn.apply(x) if a16 else x
         return outs
 
     def forward(self, x):

@@ -304,13 +304,13 @@ class ModelWrapper(nn.Module):
 
     def set_precision(self, precision):
         """"fp32" (default, exact) or "bf16_autocast": the backbone under the reference's default precision=16 policy (functional16.py):
-        ConvNeXt-V2, Swin and ResNet with bf16 activations in HBM, STDC / PResNet / MobileNetV2 with 16-bit values in fp32 tensors.  MobileNetV3, MiT
-        and DarkNet have no mixed-precision path."""
+        ConvNeXt-V2, Swin and ResNet with bf16 activations in HBM, STDC / PResNet / MobileNetV2 / DarkNet with 16-bit values in fp32 tensors.  MobileNetV3 and
+        MiT have no mixed-precision path."""
         backbone = self.model.model
         if not hasattr(backbone, "set_precision"):
             if precision in (None, "fp32"):
                 return self
-            raise NotImplementedError(f"{type(backbone).__name__} has no mixed-precision path (ConvNeXt-V2, Swin, STDC, ResNet, PResNet and MobileNetV2 students have one)")
+            raise NotImplementedError(f"{type(backbone).__name__} has no mixed-precision path (ConvNeXt-V2, Swin, STDC, ResNet, PResNet, MobileNetV2 and DarkNet students have one)")
         backbone.set_precision(precision or "fp32")
         return self
 

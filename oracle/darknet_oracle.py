@@ -12,7 +12,7 @@ def conv(p, pre, x, stride=1, training=True):
     y = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2)
     y = F.batch_norm(y, p[pre + "bn.running_mean"], p[pre + "bn.running_var"], p[pre + "bn.weight"], p[pre + "bn.bias"],
                      training, 0.03, 1e-3)
-    return y * torch.sigmoid(y)
+    return F.silu(y)   # nn.SiLU (darknet.py:47): ONE op - under autocast one rounding, not the two of y * sigmoid(y)
 
 
 def bottleneck(p, pre, x, training=True):

@@ -198,7 +198,7 @@ def test_stdc_cat_bottleneck_under_the_policy_vs_torch_autocast():
         assert not bad, bad
 
 
-@pytest.mark.parametrize("family", ["resnet", "stdc", "presnet", "mobilenet_v2"])
+@pytest.mark.parametrize("family", ["resnet", "stdc", "presnet", "mobilenet_v2", "darknet"])
 def test_whole_backbone_and_step_under_the_policy(family):
     """the whole backbone (stem from the fp32 NCHW image, max pool, every stage) against the autocast oracle at the policy's own
     distance from fp32, and one full distillation step of the BASELINE pair (configs[2]: vitb14 -> resnet_50; configs[0]:
@@ -211,6 +211,11 @@ def test_whole_backbone_and_step_under_the_policy(family):
         from oracle import resnet_oracle as ro
         w = ModelWrapper("resnet_50", [8, 8], ["res4", "res5"])
         ofn = lambda xin: (lambda q: ro.forward(q, xin, [3, 4, 6, 3]))
+    elif family == "darknet":   # (not a BASELINE config: SiLU behind every BatchNorm - a rounding after the activation and in its backward)
+        from oracle import darknet_oracle as do
+        from dinov2_distillation_amd.models.darknet import VERSIONS
+        w = ModelWrapper("darknet_s", [8, 8], ["res4", "res5"])
+        ofn = lambda xin: (lambda q: do.forward(q, xin, VERSIONS["s"][0]))
     elif family == "mobilenet_v2":   # (not a BASELINE config: ReLU6 behind every conv, depthwise 3 x 3 + BatchNorm, plain residual add)
         from oracle import mobilenet_v2_oracle as mo
         w = ModelWrapper("mobilenet_v2", [8, 8], ["res4", "res5"])
@@ -240,7 +245,8 @@ def test_whole_backbone_and_step_under_the_policy(family):
     del w, net, feats
     pair = {"resnet": dict(teacher="dinov2_vitb14", student="resnet_50"), "stdc": dict(teacher="dinov2_vits14", student="stdc_2"),
             "presnet": dict(teacher="dinov2_vits14", student="presnet_50"),
-            "mobilenet_v2": dict(teacher="dinov2_vits14", student="mobilenet_v2")}[family]
+            "mobilenet_v2": dict(teacher="dinov2_vits14", student="mobilenet_v2"),
+            "darknet": dict(teacher="dinov2_vits14", student="darknet_s")}[family]
     xb = torch.randn(4, 3, 224, 224, generator=g).cuda()
     l32 = float(DistillationStepper(device="cuda:0", **pair).step(xb).detach())
     st = DistillationStepper(device="cuda:0", precision="bf16_autocast", **pair)
