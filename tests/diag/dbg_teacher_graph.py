@@ -8,11 +8,14 @@ from dinov2_distillation_amd.trainer import DistillationStepper
 if len(sys.argv) > 1 and sys.argv[1] == "config3":
     st = DistillationStepper(device="cuda:0", precision="bf16_autocast", teacher="dinov2_vitl14", student="swin_tiny", crop=518, heads=(16, 32))
     x = torch.randn(16, 3, 518, 518).cuda()
+elif len(sys.argv) > 1 and sys.argv[1] == "config2":
+    st = DistillationStepper(device="cuda:0", precision="bf16_autocast", teacher="dinov2_vitb14", student="resnet_50")
+    x = torch.randn(128, 3, 224, 224).cuda()
 else:
     st = DistillationStepper(device="cuda:0", teacher_precision="bf16_autocast")
     x = torch.randn(64, 3, 224, 224).cuda()
 vt = st.teacher.model
-for i in range(14):
+for i in range(int(os.environ.get("STEPS", "14"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st.step(x)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
