@@ -1134,6 +1134,198 @@ static int launch_dma_peel(const dkd_gemm_args* g, const Epilogue& epi, int slab
     return launch_splitk_reduce(&g2, e2, slabs, st);
 }
 
+
+// =====================================================================================================================
+// Implicit-GEMM k x k convolution (NHWC fp32): the LDS-DMA kernel above with the im2col addresses generated in the operand loader.
+// An LDS-DMA takes a PER-LANE global address, so the gather costs no extra instruction class: the lane that owns LDS slot (row r,
+// k-quad q) of the [64][32] image fetches x[b, oy*s + ky - p, ox*s + kx - p, c0 + 4q .. +3] of "its" output pixel (b, oy, ox) - or 16
+// bytes of a zero page for a tap that falls into the padding - and the tile lands in the SAME swizzled image the dense kernel
+// builds: fragment reads, MFMA block, epilogue and split-K fold are shared.  No [rows, k*k*C] buffer exists at any point.
+//   forward (WG = false): out[(b,oy,ox)][o] = sum_(ky,kx,c) x[..] w[o][(ky,kx,c)]      A gathered (K-contiguous), B = weights, NT
+//   wgrad   (WG = true):  dw[o][(ky,kx,c)] = sum_pix dz[pix][o] x[..]                  A = dz (M-contiguous), B gathered (N-contiguous), TN
+// C % 32 == 0 keeps a 32-deep k-tile inside ONE tap (forward: the tap walk is wave-uniform scalar arithmetic), and a float4
+// inside one tap in the weight-gradient layout, where the reduction index is the pixel and each lane decomposes its pixel per
+// k-tile (two float-reciprocal divisions, exact below 2^24 pixels).  Replaces im2col_nhwc_kernel + gemm + (for the stride-1
+// input gradient, run as the forward of the flipped kernel) col2im_nhwc_kernel; models/backbones/resnet.py:258-289, stdc.py:8-24.
+struct ConvGeom {
+    const float* x;
+    int H, W, C, k, s, p, Ho, Wo;
+    float inv_wo, inv_howo;
+};
+__device__ __attribute__((aligned(16))) float conv_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void divmod_f(int n, int d, float inv, int& q, int& r) {  // exact for 0 <= n < 2^24
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
+template <int EXT, int BK, int NT>
+struct ConvGatherKC {  // gathered operand, K-contiguous image [EXT][BK] (the forward's A)
+    static constexpr int SPR = BK / 4, SLOTS = EXT * BK / 4, NP = SLOTS / NT;
+    static_assert(SLOTS % NT == 0 && SLOTS % 64 == 0, "whole pieces");
+    const float* base[NP];
+    int iy0[NP], ix0[NP];
+    int c0, ky, kx;  // wave-uniform: where the next k-tile starts
+    __device__ __forceinline__ void init(const ConvGeom& cg, int row0, int rows, int k0, int tid) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int q = tid + p * NT, r = q / SPR, c = q % SPR;
+            const int kq = Stager2<EXT, BK, true, NT>::swz(r, c);
+            int b, rem, oy, ox;
+            divmod_f(min(row0 + r, rows - 1), cg.Ho * cg.Wo, cg.inv_howo, b, rem);
+            divmod_f(rem, cg.Wo, cg.inv_wo, oy, ox);
+            base[p] = cg.x + (long)b * cg.H * cg.W * cg.C + 4 * kq;
+            iy0[p] = oy * cg.s - cg.p;
+            ix0[p] = ox * cg.s - cg.p;
+        }
+        const int tap = k0 / cg.C;
+        c0 = k0 - tap * cg.C;
+        ky = tap / cg.k;
+        kx = tap - ky * cg.k;
+    }
+    __device__ __forceinline__ void issue(float* __restrict__ S, int tid, const ConvGeom& cg) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int q0 = (tid & ~63) + p * NT;
+            const int y = iy0[p] + ky, xx = ix0[p] + kx;
+            const bool ok = (unsigned)y < (unsigned)cg.H && (unsigned)xx < (unsigned)cg.W;
+            const float* src = ok ? base[p] + ((y * cg.W + xx) * cg.C + c0) : conv_zero16;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(S + 4 * q0), 16, 0, 0);
+        }
+        c0 += BK;
+        if (c0 >= cg.C) {
+            c0 = 0;
+            if (++kx == cg.k) { kx = 0; ++ky; }
+        }
+    }
+};
+
+template <int EXT, int BK, int NT>
+struct ConvGatherMC {  // gathered operand, k-major image [BK][EXT] (the weight gradient's B: reduction index = output pixel)
+    static constexpr int SPR = EXT / 4, SLOTS = EXT * BK / 4, NP = SLOTS / NT;
+    static_assert(SLOTS % NT == 0 && SLOTS % 64 == 0 && EXT % 64 == 0, "whole pieces; the XOR needs 16 slots per row");
+    int offy[NP], offx[NP], coff[NP], pix[NP];
+    __device__ __forceinline__ void init(const ConvGeom& cg, int col0, int cols, int k0, int tid) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int q = tid + p * NT, r = q / SPR, c = q % SPR;
+            const int mq = c ^ (((r >> 2) & 3) << 2);
+            const int n = min(col0 + 4 * mq, cols - 4);
+            const int tap = n / cg.C, ky = tap / cg.k;
+            coff[p] = n - tap * cg.C;
+            offy[p] = ky - cg.p;
+            offx[p] = tap - ky * cg.k - cg.p;
+            pix[p] = k0 + r;
+        }
+    }
+    __device__ __forceinline__ void issue(float* __restrict__ S, int tid, const ConvGeom& cg) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int q0 = (tid & ~63) + p * NT;
+            int b, rem, oy, ox;
+            divmod_f(pix[p], cg.Ho * cg.Wo, cg.inv_howo, b, rem);
+            divmod_f(rem, cg.Wo, cg.inv_wo, oy, ox);
+            const int y = oy * cg.s + offy[p], xx = ox * cg.s + offx[p];
+            const bool ok = (unsigned)y < (unsigned)cg.H && (unsigned)xx < (unsigned)cg.W;
+            const float* src = ok ? cg.x + (((long)b * cg.H + y) * cg.W + xx) * cg.C + coff[p] : conv_zero16;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(S + 4 * q0), 16, 0, 0);
+            pix[p] += BK;
+        }
+    }
+};
+
+// D = the dense operand: the weights [N][K] (forward) or dz [K][M] (weight gradient).  M, N, K are the GEMM extents:
+// forward M = B*Ho*Wo, N = O, K = k*k*C;  weight gradient M = O, N = k*k*C, K = B*Ho*Wo (split over blockIdx.y in kchunk slabs).
+template <bool WG>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvGeom cg, const float* __restrict__ D, long ldd, float* C, long ldc,
+                                                             int M, int N, int K, int kchunk, Epilogue epi,
+                                                             float* __restrict__ ws, int vec_ok) {
+    constexpr int BM = 64, BN = 64, BK = 32, NT = 256, TM = 2, TN = 2, WN = 2;
+    using DA = DmaStager<BM, BK, !WG, NT>;   // image formats (and fragment reads) of the two operands
+    using DB = DmaStager<BN, BK, !WG, NT>;
+    constexpr int A_SZ = BM * BK, B_SZ = BN * BK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+    const int tile = tile_order(blockIdx.x, nbm, nbn, 0);
+    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    const int g = lane >> 4, i16 = lane & 15;
+    const int nk = (kend - kbeg) / BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ConvGatherKC<BM, BK, NT> ga;
+    ConvGatherMC<BN, BK, NT> gb;
+    DmaStager<WG ? BM : BN, BK, !WG, NT> dd;
+    if (WG) {
+        dd.init(D, ldd, bm0, M, kbeg, tid);
+        gb.init(cg, bn0, N, kbeg, tid);
+    } else {
+        ga.init(cg, bm0, M, kbeg, tid);
+        dd.init(D, ldd, bn0, N, kbeg, tid);
+    }
+    auto issue = [&](float* S) {
+        if (WG) {
+            dd.issue(S, tid);
+            gb.issue(S + A_SZ, tid, cg);
+        } else {
+            ga.issue(S, tid, cg);
+            dd.issue(S + A_SZ, tid);
+        }
+    };
+    if (nk > 0) issue(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const float* As = smem + cur * (A_SZ + B_SZ);
+        if (kt + 1 < nk) issue(smem + (cur ^ 1) * (A_SZ + B_SZ));
+#pragma unroll
+        for (int kb = 0; kb < BK / 16; ++kb) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = DA::frag(As, (wm * TM + i) * 16, kb, g, i16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = DB::frag(As + A_SZ, (wn * TN + j) * 16, kb, g, i16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].x, a[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].y, a[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const bool partial = ws != nullptr;
+    float* out = partial ? ws + (long)blockIdx.y * M * N : C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = bm0 + (wm * TM + i) * 16 + i16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn0 + (wn * TN + j) * 16 + 4 * g;
+            if (n >= N) continue;
+            if (partial)
+                *reinterpret_cast<float4*>(out + (long)m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            else
+                epilogue_store4(epi, C, ldc, m, n, N, acc[i][j], vec_ok != 0);
+        }
+    }
+}
+
 }  // namespace
 
 // ---- automatic configuration --------------------------------------------------------------------------------------
@@ -1306,4 +1498,81 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 56: return launch_v2<2, 2, 3, 2, 32>(g, epi, splits, kchunk, st);   // 96 x 64, BK 32
         default: return DKD_ERR_BAD_ARG;
     }
+}
+
+// ---- implicit-GEMM convolution: host side ---------------------------------------------------------------------------------
+namespace {
+struct ConvPlan {
+    int M, N, K, Ho, Wo, splits, kchunk;
+};
+int conv_igemm_plan(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode, ConvPlan* pl) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || k <= 0 || stride <= 0 || pad < 0 || (mode != 0 && mode != 1)) return DKD_ERR_BAD_ARG;
+    const long Ho = ((long)H + 2 * pad - k) / stride + 1, Wo = ((long)W + 2 * pad - k) / stride + 1;
+    if ((long)H + 2 * pad < k || (long)W + 2 * pad < k) return DKD_ERR_BAD_ARG;
+    const long pix = (long)B * Ho * Wo, kk = (long)k * k * C;
+    // a 32-deep k-tile inside one tap; float4 columns; exact float pixel decomposition; 32-bit offsets inside one image
+    if ((C % 32) || (O % 4) || pix >= (1L << 24) || (long)H * W * C >= (1L << 31) || kk >= (1L << 24)) return DKD_ERR_UNSUPPORTED;
+    if (mode == 1 && (pix % 32)) return DKD_ERR_UNSUPPORTED;  // whole k-tiles of output pixels (the dense operand is not predicated)
+    pl->Ho = (int)Ho, pl->Wo = (int)Wo;
+    pl->M = mode == 0 ? (int)pix : O;
+    pl->N = mode == 0 ? O : (int)kk;
+    pl->K = mode == 0 ? (int)kk : (int)pix;
+    int splits = pick_splits(pl->M, pl->N, pl->K, DMA_64x64_BK32);
+    int kchunk = pl->K;
+    if (splits > 1) {
+        kchunk = ((pl->K + splits - 1) / splits + 31) / 32 * 32;
+        splits = (pl->K + kchunk - 1) / kchunk;
+    }
+    pl->splits = splits, pl->kchunk = kchunk;
+    return DKD_OK;
+}
+}  // namespace
+
+extern "C" int dkd_conv_igemm_f32_supported(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode) {
+    ConvPlan pl;
+    return conv_igemm_plan(B, H, W, C, O, k, stride, pad, mode, &pl) == DKD_OK ? 1 : 0;
+}
+
+extern "C" long dkd_conv_igemm_f32_workspace_bytes(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode) {
+    ConvPlan pl;
+    if (conv_igemm_plan(B, H, W, C, O, k, stride, pad, mode, &pl) != DKD_OK) return 0;
+    return pl.splits > 1 ? (long)pl.splits * pl.M * pl.N * (long)sizeof(float) : 0;
+}
+
+extern "C" int dkd_conv_igemm_f32(const float* x, const float* d, float* out, const float* bias, float* workspace, int B, int H,
+                                  int W, int C, int O, int k, int stride, int pad, int mode, void* stream) {
+    if (!x || !d || !out) return DKD_ERR_BAD_ARG;
+    ConvPlan pl;
+    const int rc = conv_igemm_plan(B, H, W, C, O, k, stride, pad, mode, &pl);
+    if (rc != DKD_OK) return rc;
+    if (!dkd_aligned16(x) || !dkd_aligned16(d) || !dkd_aligned16(out) || (bias && mode == 1)) return bias && mode == 1 ? DKD_ERR_BAD_ARG : DKD_ERR_ALIGN;
+    if (pl.splits > 1 && (!workspace || !dkd_aligned16(workspace))) return DKD_ERR_BAD_ARG;
+    dkd_gemm_args g = {};  // what the shared epilogue / split-K fold read
+    g.C = out;
+    g.ldc = pl.N;
+    g.M = pl.M, g.N = pl.N, g.K = pl.K;
+    g.bias = bias;
+    g.alpha = 1.f;
+    g.workspace = workspace;
+    Epilogue epi = {};
+    epi.bias = bias;
+    epi.alpha = 1.f;
+    ConvGeom cg;
+    cg.x = x;
+    cg.H = H, cg.W = W, cg.C = C, cg.k = k, cg.s = stride, cg.p = pad, cg.Ho = pl.Ho, cg.Wo = pl.Wo;
+    cg.inv_wo = 1.f / (float)pl.Wo;
+    cg.inv_howo = 1.f / (float)(pl.Ho * pl.Wo);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(dkd_cdiv(pl.M, 64) * dkd_cdiv(pl.N, 64), pl.splits), block(256);
+    float* ws = pl.splits > 1 ? workspace : nullptr;
+    const int vec = epilogue_vec_ok(&g);
+    if (mode == 0)
+        hipLaunchKernelGGL(conv_igemm_f32_kernel<false>, grid, block, 0, st, cg, d, (long)pl.K, out, (long)pl.N, pl.M, pl.N, pl.K, pl.kchunk,
+                           epi, ws, vec);
+    else
+        hipLaunchKernelGGL(conv_igemm_f32_kernel<true>, grid, block, 0, st, cg, d, (long)O, out, (long)pl.N, pl.M, pl.N, pl.K, pl.kchunk, epi,
+                           ws, vec);
+    DKD_LAUNCH_CHECK();
+    if (pl.splits > 1) return launch_splitk_reduce(&g, epi, pl.splits, st);
+    return DKD_OK;
 }

@@ -2,6 +2,8 @@
 (forward) with a hand-written backward - torch.autograd only records the nodes and routes gradients between them.
 All activations are fp32, channels-last / token-major.  No ATen arithmetic happens inside these nodes.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -36,14 +38,17 @@ def ret(out, value, param):
     return None
 
 
-def wgrad(dy2, x2, w, b, need_w=True, need_b=True, transform=None, reshape=None, fork=True):
+def wgrad(dy2, x2, w, b, need_w=True, need_b=True, transform=None, reshape=None, fork=True, compute=None):
     """Weight (+bias) gradient of y = x W^T + b.  Returns (dW, db); in async mode (ops.can_async) the launches go to the side
-    stream straight into w.grad / b.grad and (None, None) is returned."""
+    stream straight into w.grad / b.grad and (None, None) is returned.  compute(ws_slot) -> raw [N, K] gradient replaces the
+    dy2^T x2 GEMM (the implicit-GEMM convolution: x2 is then the NHWC image itself, b must be None)."""
     if need_w and (b is None or need_b) and ops.can_async(w, b):
-        ops.wgrad_into(dy2, x2, w, b, transform, fork=fork)
+        ops.wgrad_into(dy2, x2, w, b, transform, fork=fork, compute=compute)
         return None, None
     dw = db = None
-    if need_w and b is not None and need_b:
+    if need_w and compute is not None:
+        dw = compute(0)
+    elif need_w and b is not None and need_b:
         dw, db = ops.linear_wgrad(dy2, x2, True)
     elif need_w:
         dw = ops.linear_wgrad(dy2, x2)
@@ -525,6 +530,38 @@ class LossCombineFn(Function):
         return (None, *g.unbind(0))
 
 
+# implicit-GEMM k x k convolution (csrc/gemm_f32.hip conv_igemm_f32_kernel): DKD_CONV_IGEMM=0 restores im2col + GEMM + col2im (A/B)
+CONV_IGEMM = os.environ.get("DKD_CONV_IGEMM", "1") != "0"
+
+
+def _conv_kxk_backward(igemm, rows, w2, dz, p_w, xshape, wshape, k, stride, pad, need_dx):
+    """weight and input gradient of a k x k (or strided 1 x 1) convolution on NHWC.  igemm: ``rows`` is the NHWC input itself and
+    both gradients come from the implicit-GEMM kernel where its geometry allows (the weight gradient needs whole 32-pixel
+    k-tiles, the input gradient stride 1); otherwise ``rows`` are the materialised patches (im2col now if the forward ran implicit)."""
+    B, H, W, Cin = xshape
+    O = wshape[0]
+    compute = None
+    x2 = rows
+    if igemm:
+        x = rows
+        if ops.conv_igemm_ok(B, H, W, Cin, O, k, stride, pad, 1):
+            compute = lambda slot: ops.conv_igemm_wgrad(x, dz, k, stride, pad, ws_slot=slot)  # noqa: E731
+        else:
+            x2 = ops.im2col_nhwc(x, k, stride, pad)
+    dw, _ = wgrad(dz, x2, p_w, None, compute=compute,
+                  transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
+                  reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
+    dx = None
+    if need_dx:
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        if igemm and stride == 1 and k - 1 - pad >= 0 and ops.conv_igemm_ok(B, Ho, Wo, O, Cin, k, 1, k - 1 - pad):
+            wf = w2.view(O, k * k, Cin).flip(1).permute(2, 1, 0).reshape(Cin, k * k * O)  # [c][(ky',kx',o)]: the flipped kernel
+            dx = ops.conv_igemm_fwd(dz.view(B, Ho, Wo, O), wf, k, 1, k - 1 - pad).view(B, H, W, Cin)
+        else:
+            dx = ops.col2im_nhwc(ops.dgrad(dz, w2), B, H, W, Cin, k, stride, pad)
+    return dw, dx
+
+
 # =====================================================================================================================
 # STDC / ResNet building blocks (NHWC)
 class ConvBNActFn(Function):
@@ -537,6 +574,7 @@ class ConvBNActFn(Function):
         x = _c(x)
         O = w.shape[0]
         pad = k // 2
+        igemm = False
         if src_nchw:
             B, Cin, H, W = x.shape
             rows = ops.im2col_nchw(x, k, stride, pad)
@@ -548,14 +586,16 @@ class ConvBNActFn(Function):
                 rows = x.reshape(-1, Cin)
                 w2 = w.reshape(O, Cin)
             else:
-                rows = ops.im2col_nhwc(x, k, stride, pad)
                 w2 = ops.transpose(w.reshape(O, Cin, k * k)).reshape(O, k * k * Cin)  # [O][ky][kx][c]
+                igemm = CONV_IGEMM and ops.conv_igemm_ok(B, H, W, Cin, O, k, stride, pad)
+                rows = x if igemm else ops.im2col_nhwc(x, k, stride, pad)   # implicit GEMM: the patches never exist in HBM
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
-        z = ops.gemm(rows, w2)
+        z = ops.conv_igemm_fwd(x, w2, k, stride, pad) if igemm else ops.gemm(rows, w2)
         mean, rstd = _bn_fwd_stats(z, bn_state, training)
         ctx.training = training
         y = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, None, relu=relu)
         ctx.save_for_backward(rows, w2, z, mean, rstd, bn_w, bn_b)
+        ctx.igemm = igemm
         ctx.meta = (k, stride, pad, relu, src_nchw, tuple(x.shape), tuple(w.shape))
         ctx.params = (w, bn_w, bn_b)
         return y.reshape(B, Ho, Wo, O)
@@ -583,11 +623,7 @@ class ConvBNActFn(Function):
                 if ctx.needs_input_grad[0]:
                     dx = ops.dgrad(dz, w2).reshape(xshape)
             else:
-                dw, _ = wgrad(dz, rows, p_w, None,
-                              transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
-                              reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
-                if ctx.needs_input_grad[0]:
-                    dx = ops.col2im_nhwc(ops.dgrad(dz, w2), B, H, W, Cin, k, stride, pad)
+                dw, dx = _conv_kxk_backward(ctx.igemm, rows, w2, dz, p_w, xshape, wshape, k, stride, pad, ctx.needs_input_grad[0])
         return dx, dw, ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None, None
 
 

@@ -258,7 +258,7 @@ def claim(*params):
             _written.add(id(p))
 
 
-def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True):
+def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True, compute=None):
     """dW = dy2^T x2 (and db = column sums of dy2) written into w.grad / b.grad on the side stream.
     transform(dw2) -> None may post-process the raw [N, K] result into w.grad (layout changes) on the same stream.
     fork=False: the caller has enqueued nothing on the current stream since its previous wgrad_into (the side stream already
@@ -274,7 +274,9 @@ def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True):
         if rs is not None and GEMM_PRECISION != PREC_F32:  # the bf16 weight-gradient kernels have no fused row sum
             colreduce(dy2, RED_SUM, out=rs.view(1, -1))
             rs = None
-        if transform is None:
+        if compute is not None:    # the caller's own weight-gradient launch (implicit-GEMM convolution), raw [N, K] result
+            transform(compute(3))
+        elif transform is None:
             gemm(dy2, x2, a_layout=1, b_layout=1, out=w.grad.view(N, K), rowsum=rs, ws_slot=3)
         else:
             transform(gemm(dy2, x2, a_layout=1, b_layout=1, rowsum=rs, ws_slot=3))
@@ -669,6 +671,55 @@ def col2im_nhwc(drows, B, H, W, C, k, stride, pad):
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=drows.device)
     check(_lib.binding().dkd_im2col_nhwc_f32(_p(dx), _p(drows), B, H, W, C, k, stride, pad, 1, _stream()), "dkd_col2im_nhwc_f32")
     return dx
+
+
+def conv_igemm_ok(B, H, W, C, O, k, stride, pad, mode=0):
+    """can dkd_conv_igemm_f32 run this geometry (C % 32 == 0, O % 4 == 0, ...; the weight gradient, mode 1, also needs a whole
+    number of 32-pixel k-tiles)?  A pure function of the integers, asked once per shape."""
+    return bool(_size("dkd_conv_igemm_f32_supported", B, H, W, C, O, k, stride, pad, mode))
+
+
+def conv_igemm_fwd(x, w2, k, stride, pad, bias=None, out=None):
+    """implicit-GEMM convolution: x [B,H,W,C] NHWC, w2 [O, k*k*C] in (ky,kx,c) order -> [B*Ho*Wo, O] (no im2col rows in HBM)"""
+    _chk(x, "x"), _chk(w2, "w2"), _chk(bias, "bias")
+    B, H, W, C = x.shape
+    O = w2.shape[0]
+    if w2.shape[1] != k * k * C:
+        raise _lib.DkdError(f"conv_igemm_fwd: weight is {tuple(w2.shape)}, expected [O, {k * k * C}]")
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    if out is None:
+        out = torch.empty((B * Ho * Wo, O), dtype=torch.float32, device=x.device)
+    _chk(out, "out")
+    wsb = _size("dkd_conv_igemm_f32_workspace_bytes", B, H, W, C, O, k, stride, pad, 0)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(_lib.binding().dkd_conv_igemm_f32(_p(x), _p(w2), _p(out), _p(bias), _p(ws), B, H, W, C, O, k, stride, pad, 0, _stream()),
+          "dkd_conv_igemm_f32", (B, H, W, C, O, k, stride, pad))
+    return out
+
+
+def conv_igemm_dgrad(dy, w, xshape, k, pad):
+    """stride-1 input gradient as the forward of the flipped kernel: dx[b,y,x,c] = sum dy[b, y+ky'-(k-1-p), x+kx'-(k-1-p), o]
+    w[o, c, k-1-ky', k-1-kx'].  dy [B,Ho,Wo,O] NHWC, w [O,C,k,k] (the parameter's own layout) -> dx [B,H,W,C]"""
+    B, H, W, C = xshape
+    O = w.shape[0]
+    wf = w.flip(2, 3).permute(1, 2, 3, 0).reshape(C, k * k * O).contiguous()   # [c][(ky',kx',o)]: layout plumbing on the weight
+    dx = conv_igemm_fwd(dy.reshape(B, H + 2 * pad - k + 1, W + 2 * pad - k + 1, O), wf, k, 1, k - 1 - pad)
+    return dx.reshape(B, H, W, C)
+
+
+def conv_igemm_wgrad(x, dz, k, stride, pad, out=None, ws_slot=0):
+    """dw2[o][(ky,kx,c)] = sum_pixels dz[pix][o] * patch(x)[pix][(ky,kx,c)] without the patches in HBM.  x [B,H,W,C], dz [B*Ho*Wo, O]"""
+    _chk(x, "x"), _chk(dz, "dz")
+    B, H, W, C = x.shape
+    O = dz.shape[-1]
+    if out is None:
+        out = torch.empty((O, k * k * C), dtype=torch.float32, device=x.device)
+    _chk(out, "out")
+    wsb = _size("dkd_conv_igemm_f32_workspace_bytes", B, H, W, C, O, k, stride, pad, 1)
+    ws = workspace(wsb, x.device, slot=ws_slot) if wsb else None
+    check(_lib.binding().dkd_conv_igemm_f32(_p(x), _p(dz), _p(out), None, _p(ws), B, H, W, C, O, k, stride, pad, 1, _stream()),
+          "dkd_conv_igemm_f32", (B, H, W, C, O, k, stride, pad, "wgrad"))
+    return out
 
 
 def im2col_nchw(img, k, stride, pad):

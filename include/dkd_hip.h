@@ -478,6 +478,21 @@ int dkd_im2col_nhwc_f32(const float* x, float* rows, int B, int H, int W, int C,
                         void* stream);
 int dkd_im2col_nchw_f32(const float* img, float* rows, int B, int Cin, int H, int W, int k, int stride, int pad, int Kp,
                         void* stream);
+/* Implicit-GEMM k x k convolution on NHWC fp32 (the im2col addresses are generated inside the LDS-DMA operand loader of the 64x64
+ * fp32 MFMA kernel; no [rows, k*k*C] buffer).  Replaces dkd_im2col_nhwc_f32 + dkd_gemm_f32 of the same conv
+ * (models/backbones/resnet.py:258-289 conv3x3 of Bottleneck / BasicBlock, stdc.py:8-24 ConvX) whenever C % 32 == 0 and O % 4 == 0.
+ *   mode 0 (forward):  out[(b,oy,ox)][o] = bias[o] + sum_(ky,kx,c) x[b, oy*s+ky-p, ox*s+kx-p, c] * d[o][(ky,kx,c)]
+ *                      d = the weight as [O][k*k*C] in (ky,kx,c) order; bias nullable.  The stride-1 input gradient is the
+ *                      same call with x = dy, C = O_fwd, O = C_fwd, pad = k-1-p and d = the flipped, transposed weight.
+ *   mode 1 (weight gradient): out[o][(ky,kx,c)] = sum_(b,oy,ox) d[(b,oy,ox)][o] * x[b, oy*s+ky-p, ox*s+kx-p, c]
+ *                      d = dy as [B*Ho*Wo][O]; needs B*Ho*Wo % 32 == 0; bias must be NULL.
+ * workspace: dkd_conv_igemm_f32_workspace_bytes (K-slab partial sums when the output grid alone cannot fill the chip; folded in
+ * a fixed order).  dkd_conv_igemm_f32_supported: 1 when the geometry is handled (else the call returns DKD_ERR_UNSUPPORTED and
+ * the caller keeps the materialised path). */
+int dkd_conv_igemm_f32(const float* x, const float* d, float* out, const float* bias, float* workspace, int B, int H, int W, int C,
+                       int O, int k, int stride, int pad, int mode, void* stream);
+long dkd_conv_igemm_f32_workspace_bytes(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode);
+int dkd_conv_igemm_f32_supported(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode);
 /* depthwise k x k (k = 3 or 5; MobileNetV3 uses both), padding (k/2)*dilation: the k-generic form of dkd_dwconv3_* below */
 int dkd_dwconvk_f32(const float* in, const float* w_tap_major, float* out, int B, int H, int W, int C, int k, int stride,
                     int dilation, int mode, void* stream);
