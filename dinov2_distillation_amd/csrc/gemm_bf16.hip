@@ -400,6 +400,75 @@ extern "C" int dkd_gemm_bf16(const dkd_gemm_bf16_args* g, void* stream) {
     return DKD_OK;
 }
 
+// ---- implicit-GEMM convolution on bf16 NHWC (the policy's k x k convs): gathered A operand on the ring kernel ------------------
+namespace {
+struct Conv16Plan {
+    int M, N, K, Ho, Wo, slabs, kchunk;
+};
+int conv16_plan(int B, int H, int W, int C, int O, int k, int stride, int pad, Conv16Plan* pl) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || k <= 0 || stride <= 0 || pad < 0) return DKD_ERR_BAD_ARG;
+    if ((long)H + 2 * pad < k || (long)W + 2 * pad < k) return DKD_ERR_BAD_ARG;
+    const long Ho = ((long)H + 2 * pad - k) / stride + 1, Wo = ((long)W + 2 * pad - k) / stride + 1;
+    const long pix = (long)B * Ho * Wo, kk = (long)k * k * C;
+    // a 64-deep k-tile inside one tap; 16-byte output pieces; exact float pixel decomposition; 32-bit byte offsets
+    if ((C % 64) || (O % 8) || pix >= (1L << 24) || kk >= (1L << 24) || (long)B * H * W * C * 2 >= (1L << 32) ||
+        (long)H * W * C * 2 >= (1L << 31))
+        return DKD_ERR_UNSUPPORTED;
+    pl->Ho = (int)Ho, pl->Wo = (int)Wo, pl->M = (int)pix, pl->N = O, pl->K = (int)kk;
+    int slabs = bf16_slabs(pl->M, pl->N, pl->K), kchunk = pl->K;
+    if (slabs > 1) {
+        kchunk = ((pl->K + slabs - 1) / slabs + 63) / 64 * 64;
+        slabs = dkd_cdiv(pl->K, kchunk);
+    }
+    pl->slabs = slabs, pl->kchunk = kchunk;
+    return DKD_OK;
+}
+}  // namespace
+
+extern "C" int dkd_conv_igemm_bf16_supported(int B, int H, int W, int C, int O, int k, int stride, int pad) {
+    Conv16Plan pl;
+    return conv16_plan(B, H, W, C, O, k, stride, pad, &pl) == DKD_OK ? 1 : 0;
+}
+
+extern "C" long dkd_conv_igemm_bf16_workspace_bytes(int B, int H, int W, int C, int O, int k, int stride, int pad) {
+    Conv16Plan pl;
+    if (conv16_plan(B, H, W, C, O, k, stride, pad, &pl) != DKD_OK) return 0;
+    return pl.slabs > 1 ? (long)pl.slabs * pl.M * pl.N * (long)sizeof(float) : 0;
+}
+
+extern "C" int dkd_conv_igemm_bf16(const void* x16, const void* w16, void* out, float* workspace, int B, int H, int W, int C, int O, int k,
+                                   int stride, int pad, int epi, void* stream) {
+    if (!x16 || !w16 || !out || (epi != DKD_BF16_EPI_BF16 && epi != DKD_BF16_EPI_F32)) return DKD_ERR_BAD_ARG;
+    Conv16Plan pl;
+    const int rc = conv16_plan(B, H, W, C, O, k, stride, pad, &pl);
+    if (rc != DKD_OK) return rc;
+    if (!dkd_aligned16(x16) || !dkd_aligned16(w16) || !dkd_aligned16(out)) return DKD_ERR_ALIGN;
+    if (pl.slabs > 1 && (!workspace || !dkd_aligned16(workspace))) return DKD_ERR_BAD_ARG;
+    dkd_gemm_bf16_args g = {};
+    g.B = w16, g.ldb = pl.K;
+    g.C = out, g.ldc = pl.N;
+    g.M = pl.M, g.N = pl.N, g.K = pl.K;
+    g.epi = epi;
+    g.workspace = workspace;
+    Conv16Geom cg;
+    cg.x = reinterpret_cast<const __bf16*>(x16);
+    cg.H = H, cg.W = W, cg.C = C, cg.kw = k, cg.s = stride, cg.p = pad, cg.Ho = pl.Ho, cg.Wo = pl.Wo;
+    cg.inv_wo = 1.f / (float)pl.Wo;
+    cg.inv_howo = 1.f / (float)(pl.Ho * pl.Wo);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc2 = dkd_bf16_ring_launch_conv(&g, cg, pl.slabs > 1 ? DKD_BF16_EPI_PARTIAL : epi, pl.slabs, pl.kchunk, st);
+    if (rc2 != DKD_OK) return rc2;
+    if (pl.slabs > 1) {
+        const long total4 = (long)pl.M * pl.N / 4;
+        if (epi == DKD_BF16_EPI_BF16)
+            hipLaunchKernelGGL(bf16_fold_kernel<true>, dim3(blocks_1d(total4)), dim3(256), 0, st, workspace, pl.slabs, total4, out, pl.M, (float*)nullptr, pl.slabs);
+        else
+            hipLaunchKernelGGL(bf16_fold_kernel<false>, dim3(blocks_1d(total4)), dim3(256), 0, st, workspace, pl.slabs, total4, out, pl.M, (float*)nullptr, pl.slabs);
+        DKD_LAUNCH_CHECK();
+    }
+    return DKD_OK;
+}
+
 extern "C" int dkd_cast_bf16(const float* in, void* out, long rows, int cols, int out_ld, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0 || out_ld < cols) return DKD_ERR_BAD_ARG;
     if (out_ld & 3) return DKD_ERR_ALIGN;

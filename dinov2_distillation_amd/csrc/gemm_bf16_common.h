@@ -169,3 +169,10 @@ __device__ __forceinline__ void bf16_epilogue_row(const dkd_gemm_bf16_args& g, c
 bool dkd_bf16_ring_ok(const dkd_gemm_bf16_args* g, int kchunk, int bk);
 int dkd_bf16_ring_launch(const dkd_gemm_bf16_args* g, int epi, int cfg, int slabs, int kchunk, bool rowsum, hipStream_t st);
 int dkd_bf16_ring_tile(int cfg, int* bm, int* bn, int* bk);
+// implicit-GEMM convolution on the ring kernel (gemm_bf16_ring.hip): the A operand is gathered from the NHWC bf16 image
+struct Conv16Geom {
+    const __bf16* x;
+    int H, W, C, kw, s, p, Ho, Wo;
+    float inv_wo, inv_howo;
+};
+int dkd_bf16_ring_launch_conv(const dkd_gemm_bf16_args* g, const Conv16Geom& cg, int epi, int slabs, int kchunk, hipStream_t st);

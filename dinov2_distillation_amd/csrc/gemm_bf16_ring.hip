@@ -17,6 +17,7 @@
 #include "common.h"
 #include "dkd_hip.h"
 #include "gemm_bf16_common.h"
+#include <type_traits>
 
 namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -98,13 +99,88 @@ struct Ring {
     }
 };
 
+// Implicit-GEMM convolution: the A operand's share of the ring, gathered.  Same lane-linear K-contiguous image as Ring<.., true, ..>
+// (so the fragment reads are shared), but the lane that owns (row, chunk) fetches 8 channels of "its" output pixel's current tap:
+// x[b, oy*s + ky - p, ox*s + kx - p, c0 + 8 chunk ..] - or 16 bytes of a zero page when the tap falls into the padding.  C % BK == 0
+// keeps a k-tile inside one tap: the tap walk (c0, kx, ky) is wave-uniform scalar arithmetic, the per-lane part is two compares and
+// one multiply-add per piece.  Forward and (with the flipped kernel) the stride-1 input gradient of resnet.py:258-289 / stdc.py:8-24
+// under the policy: no [rows, k*k*C] tensor, and the input gradient's taps are summed in the fp32 accumulators before its ONE rounding.
+struct NoConv {};
+__device__ __attribute__((aligned(16))) unsigned conv16_zero[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void divmod_f16(int n, int d, float inv, int& q, int& r) {  // exact for 0 <= n < 2^24
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
+template <int BX, int BK, int NW>
+struct ConvRingKC {
+    using Dense = Ring<BX, BK, true, NW>;
+    static constexpr int BYTES = Dense::BYTES, PPW = Dense::PPW, CPR = Dense::CPR;
+    Conv16Geom cg;
+    unsigned boff[PPW];   // byte offset of the lane's image + its 16-byte chunk
+    int iy0[PPW], ix0[PPW];
+    int c0, ky, kx;       // wave-uniform: where the next k-tile starts
+
+    __device__ __forceinline__ void init(const Conv16Geom& geom, int x0, int xmax, int k0, int wid, int lane) {
+        cg = geom;
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int piece = wid + p * NW;
+            const int row = piece * (64 / CPR) + lane / CPR, slot = lane % CPR;
+            const int chunk = slot ^ Dense::kc_swz(row);
+            int b, rem, oy, ox;
+            divmod_f16(min(x0 + row, xmax - 1), cg.Ho * cg.Wo, cg.inv_howo, b, rem);
+            divmod_f16(rem, cg.Wo, cg.inv_wo, oy, ox);
+            boff[p] = (unsigned)(((long)b * cg.H * cg.W * cg.C + 8 * chunk) * 2);
+            iy0[p] = oy * cg.s - cg.p;
+            ix0[p] = ox * cg.s - cg.p;
+        }
+        const int tap = k0 / cg.C;
+        c0 = k0 - tap * cg.C;
+        ky = tap / cg.kw;
+        kx = tap - ky * cg.kw;
+    }
+    template <int P0, int P1>
+    __device__ __forceinline__ void issue_part(char* __restrict__ S, int wid) {
+        const char* xb = reinterpret_cast<const char*>(cg.x);
+#pragma unroll
+        for (int p = P0; p < P1; ++p)
+            if (p < PPW) {
+                const int y = iy0[p] + ky, xx = ix0[p] + kx;
+                const bool ok = (unsigned)y < (unsigned)cg.H && (unsigned)xx < (unsigned)cg.W;
+                const char* src = ok ? xb + ((unsigned long)boff[p] + (unsigned long)(unsigned)(((y * cg.W + xx) * cg.C + c0) * 2))
+                                     : reinterpret_cast<const char*>(conv16_zero);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(S + (wid + p * NW) * 1024), 16, 0, 0);
+            }
+    }
+    __device__ __forceinline__ void advance() {
+        c0 += BK;
+        if (c0 >= cg.C) {
+            c0 = 0;
+            if (++kx == cg.kw) { kx = 0; ++ky; }
+        }
+    }
+    __device__ __forceinline__ void issue(char* __restrict__ S, int wid) {
+        issue_part<0, PPW>(S, wid);
+        advance();
+    }
+    static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int r0, int ks, int lane) { return Dense::frag(S, r0, ks, lane); }
+};
+
 // WGM x WGN waves, each a (32 TM) x 64 slab (TM x 2 MFMA tiles); BM = 32 TM WGM, BN = 64 WGN; k-tile BK; NS ring stages.
 // KNOCK (only in a -DDKD_TUNING build, timing experiments whose RESULTS ARE WRONG): 1 = no DMA inside the k-loop, 2 = fragments read
 // once per k-tile only, 4 = no MFMAs, 8 = no barrier, 16 = no output stores.
-template <int WGM, int WGN, int TM, int BK, int NS, int EPI, bool A_KC, bool B_KC, bool ROWSUM, int KNOCK = 0, bool SPREAD = false>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_ring_kernel(dkd_gemm_bf16_args g, int kchunk) {
+// CG = Conv16Geom: the A operand is gathered from an NHWC image (implicit-GEMM convolution, see ConvRingKC); NoConv: dense operands.
+template <int WGM, int WGN, int TM, int BK, int NS, int EPI, bool A_KC, bool B_KC, bool ROWSUM, int KNOCK = 0, bool SPREAD = false,
+          class CG = NoConv>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_ring_kernel(dkd_gemm_bf16_args g, int kchunk, CG cgeom) {
     constexpr int BM = 32 * TM * WGM, BN = 64 * WGN, NW = WGM * WGN, WM_ROWS = 32 * TM;
-    using RA = Ring<BM, BK, A_KC, NW>;
+    constexpr bool CONV = !std::is_same<CG, NoConv>::value;
+    static_assert(!CONV || A_KC, "the gathered operand is K-contiguous");
+    using RA = typename std::conditional<CONV, ConvRingKC<BM, BK, NW>, Ring<BM, BK, A_KC, NW>>::type;
     using RB = Ring<BN, BK, B_KC, NW>;
     constexpr int STAGE = RA::BYTES + RB::BYTES, PW = RA::PPW + RB::PPW;
     static_assert(NS >= 2 && NS <= 4, "2 .. 4 stages");
@@ -151,7 +227,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_ring_kernel(dkd_gemm_
 
     RA ra;
     RB rb;
-    ra.init(A, g.lda, bm0, g.M, kbeg, wid, lane);
+    if constexpr (CONV) ra.init(cgeom, bm0, g.M, kbeg, wid, lane);
+    else ra.init(A, g.lda, bm0, g.M, kbeg, wid, lane);
     rb.init(B, g.ldb, bn0, g.N, kbeg, wid, lane);
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -292,7 +369,7 @@ int launch_ring(const dkd_gemm_bf16_args* g, int epi, int slabs, int kchunk, hip
     const dim3 grid(dkd_cdiv(g->M, 32 * TM * WGM) * dkd_cdiv(g->N, 64 * WGN), slabs, batch), block(WGM * WGN * 64);
 #ifdef DKD_TUNING
     if (knock && g->a_layout == 0 && g->b_layout == 0 && epi == DKD_BF16_EPI_BF16) {
-#define DKD_RING_K(KN) case KN: hipLaunchKernelGGL((gemm_bf16_ring_kernel<WGM, WGN, TM, BK, NS, DKD_BF16_EPI_BF16, true, true, false, KN, SPREAD>), grid, block, 0, st, *g, kchunk); break
+#define DKD_RING_K(KN) case KN: hipLaunchKernelGGL((gemm_bf16_ring_kernel<WGM, WGN, TM, BK, NS, DKD_BF16_EPI_BF16, true, true, false, KN, SPREAD>), grid, block, 0, st, *g, kchunk, NoConv{}); break
         switch (knock) {
             DKD_RING_K(1); DKD_RING_K(2); DKD_RING_K(3); DKD_RING_K(4); DKD_RING_K(5); DKD_RING_K(6); DKD_RING_K(7); DKD_RING_K(8);
             DKD_RING_K(16); DKD_RING_K(17); DKD_RING_K(19); DKD_RING_K(23); DKD_RING_K(31);
@@ -305,7 +382,7 @@ int launch_ring(const dkd_gemm_bf16_args* g, int epi, int slabs, int kchunk, hip
 #endif
     if (knock) return DKD_ERR_UNSUPPORTED;
 #define DKD_RING_L(E, AK, BKC, RSUM) \
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<WGM, WGN, TM, BK, NS, E, AK, BKC, RSUM, 0, SPREAD>), grid, block, 0, st, *g, kchunk)
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<WGM, WGN, TM, BK, NS, E, AK, BKC, RSUM, 0, SPREAD>), grid, block, 0, st, *g, kchunk, NoConv{})
 #define DKD_RING_LAYOUT(E)                                                      \
     do {                                                                        \
         if (g->a_layout == 0 && g->b_layout == 0) DKD_RING_L(E, true, true, false);   \
@@ -337,6 +414,23 @@ bool dkd_bf16_ring_ok(const dkd_gemm_bf16_args* g, int kchunk, int bk) {
     if (g->a_layout == 1 && g->M < 8) return false;
     if (g->b_layout == 1 && g->N < 8) return false;
     return true;
+}
+
+// the gathered-A (implicit-GEMM convolution) instantiations: configuration 10 (128 x 128 x 64, two stages, spread DMA issue), NT layout
+int dkd_bf16_ring_launch_conv(const dkd_gemm_bf16_args* g, const Conv16Geom& cg, int epi, int slabs, int kchunk, hipStream_t st) {
+    if ((cg.C % 64) || (g->K % 64) || (kchunk % 64) || g->a_layout != 0 || g->b_layout != 0 || g->batch > 1) return DKD_ERR_UNSUPPORTED;
+    const dim3 grid(dkd_cdiv(g->M, 128) * dkd_cdiv(g->N, 128), slabs, 1), block(256);
+#define DKD_RING_CONV(E) \
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<2, 2, 2, 64, 2, E, true, true, false, 0, true, Conv16Geom>), grid, block, 0, st, *g, kchunk, cg)
+    switch (epi) {
+        case DKD_BF16_EPI_BF16: DKD_RING_CONV(DKD_BF16_EPI_BF16); break;
+        case DKD_BF16_EPI_F32: DKD_RING_CONV(DKD_BF16_EPI_F32); break;
+        case DKD_BF16_EPI_PARTIAL: DKD_RING_CONV(DKD_BF16_EPI_PARTIAL); break;
+        default: return DKD_ERR_BAD_ARG;
+    }
+#undef DKD_RING_CONV
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
 }
 
 // cfg (every one: 4 waves as 2 x 2, two ring stages):

@@ -688,6 +688,24 @@ class RoundGradFn(Function):
         return ops.round_bf16(_c(dy))
 
 
+def _igemm16_ok(B, H, W, Cin, O, k, stride, pad):
+    from . import functional as _f
+    return _f.CONV_IGEMM and (k > 1 or stride > 1) and ops.conv_igemm16_ok(B, H, W, Cin, O, k, stride, pad)
+
+
+def _igemm16_dgrad_ok(B, H, W, Cin, O, k, stride, pad):
+    """the input gradient as the forward of the flipped kernel: stride 1 only (a strided conv's adjoint is a dilated one)"""
+    if stride != 1 or k - 1 - pad < 0:
+        return False
+    Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+    return ops.conv_igemm16_ok(B, Ho, Wo, O, Cin, k, 1, k - 1 - pad)
+
+
+def _flipped16(w, w16, O, Cin, k):
+    """[c][(ky', kx', o)] = w16[o][(k-1-ky', k-1-kx', c)]: the 16-bit weight of the adjoint convolution, cached per optimiser step"""
+    return _cached(w, ("conv16 flipped", k), lambda: w16.view(O, k * k, Cin).flip(1).permute(2, 1, 0).reshape(Cin, k * k * O).contiguous())
+
+
 class ConvBNAct16Fn(Function):
     """conv (k in {1, 3, 7}, stride, pad k // 2, no bias) -> train-mode BatchNorm2d -> optional ReLU under the policy
     (models/backbones/stdc.py:8-24 ``ConvX``, resnet.py:258-289 ``Conv2d`` with norm).  x: fp32 NHWC holding 16-bit values, or the
@@ -701,6 +719,7 @@ class ConvBNAct16Fn(Function):
         if x.dtype == BF16:   # bf16 activations in HBM (ResNet): the same arithmetic, every tensor between the kernels in 16 bit
             return ConvBNAct16Fn._forward_io16(ctx, x, w, bn_w, bn_b, bn_state, k, stride, relu, training)
         ctx.io16 = False
+        igemm = False
         if src_nchw:
             B, Cin, H, W = x.shape
             rows = ops.im2col_nchw(x, k, stride, pad)                     # [M, Kp] fp32, columns (c, ky, kx), zero padded to Kp
@@ -713,17 +732,21 @@ class ConvBNAct16Fn(Function):
             x16 = ops.cast_bf16(x)                                         # exact: the values are 16-bit already
             if k == 1 and stride == 1:
                 rows16 = x16
+            elif _igemm16_ok(B, H, W, Cin, O, k, stride, pad):   # implicit GEMM: the patches never exist in HBM
+                rows16, igemm = x16.reshape(B, H, W, Cin), True
             elif Cin % 8 == 0:   # im2col is data movement: on the bf16 copy, whose channel pairs are fp32 words to the kernel
                 rows16 = ops.im2col_nhwc(x16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
             else:
                 rows16 = ops.cast_bf16(ops.im2col_nhwc(x, k, stride, pad))
             w16 = _w16_2d(w, O, Cin) if k == 1 else _prepared(w, "conv16", O, Cin, k * k, 2, (O, k * k * Cin))  # [O][ky][kx][c]
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
-        z = ops.gemm_bf16(rows16, w16, epi=ops.EPI_F32)                   # the conv's 16-bit result (rounded, held in fp32)
+        # the conv's 16-bit result (rounded, held in fp32)
+        z = ops.conv_igemm16(rows16, w16, k, stride, pad, epi=ops.EPI_F32) if igemm else ops.gemm_bf16(rows16, w16, epi=ops.EPI_F32)
         mean, rstd = _bn_fwd_stats(z, bn_state, training)
         y = ops.bn_act_pos_fwd(z, mean, rstd, bn_w, bn_b, None, relu=int(relu) | 16)   # rnd(bn) -> act
         ctx.training = training
         ctx.save_for_backward(rows16, w16, z, mean, rstd, bn_w, bn_b)
+        ctx.igemm = igemm
         ctx.meta = (k, stride, pad, int(relu), src_nchw, tuple(x.shape), tuple(w.shape))
         ctx.params = (w, bn_w, bn_b)
         return y.reshape(B, Ho, Wo, O)
@@ -735,13 +758,17 @@ class ConvBNAct16Fn(Function):
         B, H, W, Cin = x.shape
         if Cin % 8:
             raise NotImplementedError("the bf16-storage conv path needs channel counts that are multiples of 8")
+        igemm = False
         if k == 1 and stride == 1:
             rows16 = x.reshape(-1, Cin)
+        elif _igemm16_ok(B, H, W, Cin, O, k, stride, pad):   # implicit GEMM: the patches never exist in HBM
+            rows16, igemm = x, True
         else:   # im2col is data movement: channel pairs of the bf16 tensor are fp32 words to the kernel
             rows16 = ops.im2col_nhwc(x.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
         w16 = _w16_2d(w, O, Cin) if k == 1 else _prepared(w, "conv16", O, Cin, k * k, 2, (O, k * k * Cin))  # [O][ky][kx][c]
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
-        z16 = ops.gemm_bf16(rows16, w16)                                   # the conv's 16-bit result
+        z16 = ops.conv_igemm16(rows16, w16, k, stride, pad) if igemm else ops.gemm_bf16(rows16, w16)   # the conv's 16-bit result
+        ctx.igemm = igemm
         if training:
             running_mean, running_var = bn_state[:2]
             momentum, eps = bn_state[2:] if len(bn_state) == 4 else (0.1, 1e-5)
@@ -766,6 +793,10 @@ class ConvBNAct16Fn(Function):
         # sum of their 16-bit gradients: nothing to round)
         dz16, dg, db = ops.bn_bwd16(_c(dy).reshape(-1, O), z16, mean, rstd, bn_w, bn_b, relu, dgamma_out=o_g, dbeta_out=o_b)
         B, H, W, Cin = xshape
+        x16 = None
+        if ctx.igemm:   # the forward ran implicit: the weight gradient's patches are built now (and freed after its launch)
+            x16 = rows16
+            rows16 = ops.im2col_nhwc(x16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
         if k == 1:
             dw, _ = wgrad16(dz16, rows16, p_w, None, reshape=lambda t: t.reshape(wshape))
         else:
@@ -776,6 +807,10 @@ class ConvBNAct16Fn(Function):
         if ctx.needs_input_grad[0]:
             if k == 1 and stride == 1:
                 dx = ops.gemm_bf16(dz16, w16, b_layout=1).reshape(xshape)
+            elif ctx.igemm and _igemm16_dgrad_ok(B, H, W, Cin, O, k, stride, pad):
+                # the forward of the flipped kernel over dy: the taps are summed in the fp32 accumulators, ONE rounding
+                Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+                dx = ops.conv_igemm16(dz16.view(B, Ho, Wo, O), _flipped16(p_w, w16, O, Cin, k), k, 1, k - 1 - pad).reshape(xshape)
             else:   # the taps' products stay fp32 until col2im has summed them: ONE rounding, as conv backward does
                 drows = ops.gemm_bf16(dz16, w16, b_layout=1, epi=ops.EPI_F32_RAW)
                 dx = ops.cast_bf16(ops.col2im_nhwc(drows, B, H, W, Cin, k, stride, pad)).reshape(xshape)
@@ -805,6 +840,8 @@ class ConvBNAct16Fn(Function):
                             reshape=lambda t: t[:, :kk].reshape(wshape))
         else:
             B, H, W, Cin = xshape
+            if ctx.igemm:   # the forward ran implicit: the weight gradient's patches are built now (and freed after its launch)
+                rows16 = ops.im2col_nhwc(rows16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
             if k == 1:
                 dw, _ = wgrad16(dz16, rows16, p_w, None, reshape=lambda t: t.reshape(wshape))
             else:
@@ -814,6 +851,10 @@ class ConvBNAct16Fn(Function):
             if ctx.needs_input_grad[0]:
                 if k == 1 and stride == 1:
                     dx = ops.gemm_bf16(dz16, w16, b_layout=1, epi=ops.EPI_F32).reshape(xshape)
+                elif ctx.igemm and _igemm16_dgrad_ok(B, H, W, Cin, O, k, stride, pad):
+                    Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)   # the forward of the flipped kernel over dy: ONE rounding
+                    dx = ops.conv_igemm16(dz16.view(B, Ho, Wo, O), _flipped16(p_w, w16, O, Cin, k), k, 1, k - 1 - pad,
+                                          epi=ops.EPI_F32).reshape(xshape)
                 else:  # the taps' products stay fp32 until col2im has summed them: ONE rounding, as conv backward does
                     drows = ops.gemm_bf16(dz16, w16, b_layout=1, epi=ops.EPI_F32_RAW)
                     dx = ops.round_bf16_(ops.col2im_nhwc(drows, B, H, W, Cin, k, stride, pad))

@@ -1036,6 +1036,28 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
     return out
 
 
+def conv_igemm16_ok(B, H, W, C, O, k, stride, pad):
+    """can dkd_conv_igemm_bf16 run this geometry (C % 64 == 0, O % 8 == 0, ...)?"""
+    return bool(_size("dkd_conv_igemm_bf16_supported", B, H, W, C, O, k, stride, pad))
+
+
+def conv_igemm16(x16, w16, k, stride, pad, epi=EPI_BF16):
+    """implicit-GEMM convolution under the policy: x16 [B,H,W,C] bf16 NHWC, w16 [O, k*k*C] bf16 in (ky,kx,c) order ->
+    [B*Ho*Wo, O], bf16 (EPI_BF16) or the rounded result held in fp32 (EPI_F32); no im2col rows in HBM"""
+    _chk16(x16, "x16"), _chk16(w16, "w16")
+    B, H, W, C = x16.shape
+    O = w16.shape[0]
+    if w16.shape[1] != k * k * C or epi not in (EPI_BF16, EPI_F32):
+        raise _lib.DkdError(f"conv_igemm16: weight is {tuple(w16.shape)}, expected [O, {k * k * C}]; epi {epi}")
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    out = torch.empty((B * Ho * Wo, O), dtype=torch.float32 if epi == EPI_F32 else BF16, device=x16.device)
+    wsb = _size("dkd_conv_igemm_bf16_workspace_bytes", B, H, W, C, O, k, stride, pad)
+    ws = workspace(wsb, x16.device) if wsb else None
+    check(_lib.binding().dkd_conv_igemm_bf16(_p(x16), _p(w16), _p(out), _p(ws), B, H, W, C, O, k, stride, pad, epi, _stream()),
+          "dkd_conv_igemm_bf16", (B, H, W, C, O, k, stride, pad, epi))
+    return out
+
+
 def cast_bf16(x, out_cols=None):
     """fp32 [..., C] -> bf16 [rows, out_cols] (round to nearest even; zero K-padding up to out_cols)"""
     _chk(x, "x")
