@@ -71,6 +71,8 @@ def test_every_kernel_is_bit_reproducible_beside_the_bf16_teacher():
         "transpose": lambda: [ops.transpose(h4)],
         "patchify nchw 14 / nhwc 2": lambda: [ops.patchify_nchw(img, 14), ops.patchify_nhwc(x3, 2)],
         "im2col 3x3 / col2im": lambda: [ops.im2col_nhwc(x3, 3, 1, 1), ops.col2im_nhwc(col3, B, 14, 14, 512, 3, 1, 1)],
+        "implicit-GEMM conv fwd / wgrad (fp32), fwd (bf16)": lambda: [ops.conv_igemm_fwd(x3, w3i, 3, 1, 1), ops.conv_igemm_wgrad(x3, dz3i, 3, 1, 1),
+                                                                  ops.conv_igemm16(x3_16, w3i_16, 3, 1, 1)],
         "dwconv3 fwd / dgrad / wgrad": lambda: [ops.dwconv3(x3, wt3, 2), ops.dwconv3(x3, wt3, 1, dgrad_shape=(14, 14)), ops.dwconv3_wgrad(x3, x3, 1)],
         "maxpool3 fwd / bwd": lambda: list(ops.maxpool3(x3)) + [ops.maxpool3_bwd(mp_y, mp_arg, 14, 14)],
         "avgpool2 fwd / bwd": lambda: [ops.avgpool2(x4), ops.avgpool2(ap_y, backward_hw=(7, 7))],
@@ -121,6 +123,8 @@ def test_every_kernel_is_bit_reproducible_beside_the_bf16_teacher():
     s16, u16, dctm = b16(s), b16(u12), r(16, 16)
     part49 = r(448, 49 * 1024)
     dy16, wt7_128, col3 = r(B, 16, 16, 1024), r(49, 128), r(B * 196, 9 * 512)
+    w3i, dz3i = r(256, 9 * 512), r(B * 196, 256)
+    x3_16, w3i_16 = x3.bfloat16(), w3i.bfloat16()
     ap_y = ops.avgpool2(x4)
     w1, w2 = r(4096, 1024) * 0.02, r(1024, 4096) * 0.02
     bad = []
