@@ -904,6 +904,50 @@ class DepthwiseBN16Fn(Function):
         return dx, ret(o_w, dw, p_w), ret(o_g, dg, p_g), ret(o_b, db, p_b), None, None, None, None, None
 
 
+class SqueezeExcite16Fn(Function):
+    """torchvision.ops.SqueezeExcitation (MobileNetV3, models/backbones/mobilenet_v3.py:10) under the policy, on 16-bit values held in
+    fp32 tensors.  What autocast makes of it: adaptive_avg_pool2d runs in the input's dtype (fp32 mean, one rounding), fc1 / fc2 are
+    conv2d - 16-bit operands, 16-bit result rnd(acc + bias) -, ReLU / Hardsigmoid / the scaling product are 16-bit element-wise ops
+    (one rounding each).  Backward: every gradient tensor is 16 bit - d(scale) = rnd(sum_hw rnd(dy x)) (mul's backward rounds the
+    product tensor before sum_to_size adds it up), Hardsigmoid's and the pool's backward round once, and the two gradients that meet
+    at x (through the product and through the pool) are added in 16 bit."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = _c(x)
+        B, H, W, C = x.shape
+        S = w1.shape[0]
+        pooled16 = ops.cast_bf16(ops.colreduce(x.view(B * H * W, C), groups=B, scale=1.0 / (H * W)))     # [B, C]; the cast is the rounding
+        w1_16, w2_16 = _w16_2d(w1, S, C), _w16_2d(w2, C, S)
+        h16 = ops.gemm_bf16(pooled16, w1_16, bias=_w16(b1), epi=ops.EPI_BF16_RELU)
+        z16 = ops.gemm_bf16(h16, w2_16, bias=_w16(b2))
+        z = ops.cast_f32(z16)
+        s = ops.round_bf16_(ops.hardsigmoid(z))
+        ctx.save_for_backward(x, pooled16, h16, z, s, w1_16, w2_16)
+        ctx.params = (w1, b1, w2, b2)
+        return ops.round_bf16_(ops.group_affine(x, B, mul=s))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pooled16, h16, z, s, w1_16, w2_16 = ctx.saved_tensors
+        B, H, W, C = x.shape
+        rows = B * H * W
+        p_w1, p_b1, p_w2, p_b2 = ctx.params
+        g = _round16(dy)
+        # (the product of two 16-bit values is exact in fp32: rounding it gives mul's 16-bit product tensor)
+        prod = ops.round_bf16_(ops.group_affine(g.view(rows, C), rows, mul=x.view(rows, C)))
+        ds = ops.round_bf16_(ops.colreduce(prod, groups=B))
+        dz16 = ops.cast_bf16(ops.hardsigmoid(z, ds))
+        dh16 = ops.relu_bwd16(ops.gemm_bf16(dz16, w2_16, b_layout=1), h16)
+        dw2, db2 = wgrad16(dz16, h16, p_w2, p_b2, reshape=lambda t: t.reshape(p_w2.shape))
+        dw1, db1 = wgrad16(dh16, pooled16, p_w1, p_b1, reshape=lambda t: t.reshape(p_w1.shape))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dpool = ops.cast_f32(ops.scale16(ops.gemm_bf16(dh16, w1_16, b_layout=1), 1.0 / (H * W)))   # the pool's backward, rounded
+            dx = ops.round_bf16_(ops.group_affine(ops.round_bf16_(ops.group_affine(g, B, mul=s)), B, add=dpool))
+        return dx, dw1, db1, dw2, db2
+
+
 class AvgPool3_16Fn(Function):
     """nn.AvgPool2d(3, stride, 1) on a 16-bit tensor: rnd(fp32 average); backward likewise"""
 

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 
 NONE, RELU, HSWISH = 0, 1, 4  # activation codes of the BatchNorm epilogue kernels (include/dkd_hip.h)
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01
@@ -73,11 +74,12 @@ class ConvNormActivation(nn.Sequential):
         if self.training:
             bn.num_batches_tracked += 1
         state = (bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        a16 = getattr(self, "autocast16", False)
         if self.depthwise:
-            return Fn.DepthwiseBNFn.apply(x, conv.weight, bn.weight, bn.bias, state, conv.stride[0], self.training, self.act,
-                                          conv.dilation[0])
-        return Fn.ConvBNActFn.apply(x, conv.weight, bn.weight, bn.bias, state, conv.kernel_size[0], conv.stride[0], self.act,
-                                    self.training, src_nchw)
+            return (Fn16.DepthwiseBN16Fn if a16 else Fn.DepthwiseBNFn).apply(x, conv.weight, bn.weight, bn.bias, state, conv.stride[0],
+                                                                           self.training, self.act, conv.dilation[0])
+        return (Fn16.ConvBNAct16Fn if a16 else Fn.ConvBNActFn).apply(x, conv.weight, bn.weight, bn.bias, state, conv.kernel_size[0],
+                                                                    conv.stride[0], self.act, self.training, src_nchw)
 
 
 class SqueezeExcitation(nn.Module):
@@ -89,7 +91,8 @@ class SqueezeExcitation(nn.Module):
         self.fc2 = nn.Conv2d(squeeze, channels, 1)
 
     def forward(self, x):
-        return Fn.SqueezeExciteFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        fn = Fn16.SqueezeExcite16Fn if getattr(self, "autocast16", False) else Fn.SqueezeExciteFn
+        return fn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
 class InvertedResidual(nn.Module):
@@ -110,7 +113,7 @@ class InvertedResidual(nn.Module):
 
     def forward(self, x):
         y = self.block(x)
-        return Fn.AddFn.apply(y, x) if self.use_res_connect else y
+        return (Fn16.Add16Fn if getattr(self, "autocast16", False) else Fn.AddFn).apply(y, x) if self.use_res_connect else y
 
 
 class D2MobileNetV3(nn.Module):
@@ -145,12 +148,24 @@ class D2MobileNetV3(nn.Module):
                                      {"res2": 4, "res3": 8, "res4": 16, "res5": 32})  # mobilenet_v3.py:50-53 (metadata as is)
         self._out_features = out_features
 
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the reference's default precision=16 policy (train.py:263) - dense and depthwise
+        convolutions on bf16 operands with 16-bit results, BatchNorm / ReLU / Hardswish / squeeze-excitation / the residual add on
+        16-bit values held in fp32 tensors (functional16.py)"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        for m in self.modules():
+            m.autocast16 = precision == "bf16_autocast"
+        return self
+
     def forward_features_nhwc(self, x):
         outs = {}
+        a16 = getattr(self, "autocast16", False)
         for idx, layer in enumerate(self.features):
             x = layer(x, src_nchw=True) if idx == 0 else layer(x)
             if idx in self.layer2res:
-                outs[self.layer2res[idx]] = x
+                outs[self.layer2res[idx]] = Fn16.RoundGradFn.apply(x) if a16 else x
         return outs
 
     def forward(self, x):

@@ -310,7 +310,7 @@ class ModelWrapper(nn.Module):
         if not hasattr(backbone, "set_precision"):
             if precision in (None, "fp32"):
                 return self
-            raise NotImplementedError(f"{type(backbone).__name__} has no mixed-precision path (ConvNeXt-V2, Swin, STDC, ResNet, PResNet, MobileNetV2 and DarkNet students have one)")
+            raise NotImplementedError(f"{type(backbone).__name__} has no mixed-precision path (ConvNeXt-V2, Swin, STDC, ResNet, PResNet, MobileNetV2, MobileNetV3 and DarkNet students have one)")
         backbone.set_precision(precision or "fp32")
         return self
 

@@ -198,7 +198,43 @@ def test_stdc_cat_bottleneck_under_the_policy_vs_torch_autocast():
         assert not bad, bad
 
 
-@pytest.mark.parametrize("family", ["resnet", "stdc", "presnet", "mobilenet_v2", "darknet"])
+@pytest.mark.parametrize("C,S,H", [(96, 24, 14), (576, 144, 7), (16, 8, 28)])
+def test_squeeze_excitation_under_the_policy_vs_torch_autocast(C, S, H):
+    """MobileNetV3's SqueezeExcitation (torchvision; mobilenet_v3.py:10) fed the oracle's own 16-bit input: output, input gradient and
+    the four parameter gradients against torch.autocast on the oracle, each held to a fraction of the policy's own distance from
+    fp32 (pool -> fc1 -> ReLU -> fc2 -> Hardsigmoid -> scale: six roundings forward, eight backward)"""
+    from oracle import mobilenet_v3_oracle as mo
+    from dinov2_distillation_amd import functional16 as F16
+    g = torch.Generator().manual_seed(C + S)
+    B = 4
+    p = {"fc1.weight": torch.randn(S, C, 1, 1, generator=g) * C ** -0.5, "fc1.bias": 0.3 * torch.randn(S, generator=g),
+         "fc2.weight": torch.randn(C, S, 1, 1, generator=g) * S ** -0.5, "fc2.bias": 0.3 * torch.randn(C, generator=g)}
+    x = r16(torch.randn(B, C, H, H, generator=g))
+    ct = torch.randn(B, C, H, H, generator=g)
+    x16, x32 = x.bfloat16().requires_grad_(True), x.clone().requires_grad_(True)
+    q16, o16 = _run_oracle(lambda q: mo.squeeze_excitation(q, "", x16), p, True)
+    q32, o32 = _run_oracle(lambda q: mo.squeeze_excitation(q, "", x32), p, False)
+    assert o16.dtype == torch.bfloat16
+    (o16.float() * ct).sum().backward()
+    (o32 * ct).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    prm = {k: v.clone().cuda().requires_grad_(True) for k, v in p.items()}
+    out = F16.SqueezeExcite16Fn.apply(xg, prm["fc1.weight"], prm["fc1.bias"], prm["fc2.weight"], prm["fc2.bias"])
+    out.backward(ct.permute(0, 2, 3, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out, r16(out))
+    pairs = [("out", out.permute(0, 3, 1, 2), o16, o32), ("dx", xg.grad.permute(0, 3, 1, 2), x16.grad, x32.grad)]
+    pairs += [("d" + k, prm[k].grad, q16[k].grad, q32[k].grad) for k in p]
+    bad = []
+    for name, ours, a16, a32 in pairs:
+        e, noise = rel(ours, a16), rel(a16, a32)
+        print(f"  {name}: ours vs autocast {e:.2e}; autocast vs fp32 {noise:.2e}")
+        if e >= max(0.5 * noise, 5e-4):
+            bad.append((name, e, noise))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("family", ["resnet", "stdc", "presnet", "mobilenet_v2", "darknet", "mobilenet_v3"])
 def test_whole_backbone_and_step_under_the_policy(family):
     """the whole backbone (stem from the fp32 NCHW image, max pool, every stage) against the autocast oracle at the policy's own
     distance from fp32, and one full distillation step of the BASELINE pair (configs[2]: vitb14 -> resnet_50; configs[0]:
@@ -220,6 +256,10 @@ def test_whole_backbone_and_step_under_the_policy(family):
         from oracle import mobilenet_v2_oracle as mo
         w = ModelWrapper("mobilenet_v2", [8, 8], ["res4", "res5"])
         ofn = lambda xin: (lambda q: mo.forward(q, xin))
+    elif family == "mobilenet_v3":   # (torchvision's MobileNetV3: Hardswish behind BatchNorm, 5 x 5 depthwise, squeeze-excitation)
+        from oracle import mobilenet_v3_oracle as m3
+        w = ModelWrapper("mobilenet_v3_small", [8, 8], ["res4", "res5"])
+        ofn = lambda xin: (lambda q: m3.forward(q, xin, "small"))
     elif family == "presnet":   # (ResNet-vd, not a BASELINE config: the same nodes plus the average-pool "d" shortcut)
         from oracle import presnet_oracle as po
         w = ModelWrapper("presnet_50", [8, 8], ["res4", "res5"])
@@ -246,7 +286,8 @@ def test_whole_backbone_and_step_under_the_policy(family):
     pair = {"resnet": dict(teacher="dinov2_vitb14", student="resnet_50"), "stdc": dict(teacher="dinov2_vits14", student="stdc_2"),
             "presnet": dict(teacher="dinov2_vits14", student="presnet_50"),
             "mobilenet_v2": dict(teacher="dinov2_vits14", student="mobilenet_v2"),
-            "darknet": dict(teacher="dinov2_vits14", student="darknet_s")}[family]
+            "darknet": dict(teacher="dinov2_vits14", student="darknet_s"),
+            "mobilenet_v3": dict(teacher="dinov2_vits14", student="mobilenet_v3_small")}[family]
     xb = torch.randn(4, 3, 224, 224, generator=g).cuda()
     l32 = float(DistillationStepper(device="cuda:0", **pair).step(xb).detach())
     st = DistillationStepper(device="cuda:0", precision="bf16_autocast", **pair)
