@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
 
 int check(const dkd_attn16_args* g, bool bwd) {
     if (!g || !g->q || !g->k || !g->v || !g->m || !g->linv || g->B <= 0 || g->H <= 0 || g->Nq <= 0 || g->Nk <= 0) return DKD_ERR_BAD_ARG;
-    if (g->hd != 64 && g->hd != 48 && g->hd != 32 && g->hd != 24 && g->hd != 16) return DKD_ERR_UNSUPPORTED;
+    if ((g->hd & 7) || g->hd < 16 || g->hd > 64) return DKD_ERR_UNSUPPORTED;  // 8-wide chunks of a 32- or 64-wide tile (MiT: 40)
     if (g->H > 65535 || g->B > 65535) return DKD_ERR_UNSUPPORTED;
     const long w = (long)g->H * g->hd;
     if ((g->ldq & 7) || (g->ldkv & 7) || g->ldq < w || g->ldkv < w) return DKD_ERR_ALIGN;

@@ -1010,6 +1010,157 @@ class Add16Fn(Function):
         return g, g
 
 
+# ---- MiT (SegFormer) under the policy: fp32 residual stream (patch-embed LayerNorm returns fp32), every Linear / conv 16-bit ------
+class Linear16Fn(Function):
+    """nn.Linear under autocast on a bf16 input: y16 = rnd(x16 W^T + b).  residual (fp32): the fp32 stream's add rides in the epilogue,
+    out fp32 = residual + y16; its gradient passes through, the Linear's 16-bit output sees it rounded"""
+
+    @staticmethod
+    def forward(ctx, x16, w, b, residual):
+        x16 = _c(x16)
+        N, K = w.shape[0], x16.shape[-1]
+        x2, w16 = x16.reshape(-1, K), _w16(w)
+        b16 = None if b is None else _w16(b)
+        if residual is None:
+            y = ops.gemm_bf16(x2, w16, bias=b16)
+        else:
+            y = ops.gemm_bf16(x2, w16, epi=ops.EPI_F32_RESID, bias=b16, residual=_c(residual).reshape(-1, N))
+        ctx.save_for_backward(x2, w16)
+        ctx.params, ctx.has_res, ctx.xshape = (w, b), residual is not None, tuple(x16.shape)
+        return y.reshape(*x16.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w16 = ctx.saved_tensors
+        dy = _c(dy)
+        d2 = dy.reshape(-1, dy.shape[-1])
+        d16 = ops.cast_bf16(d2) if ctx.has_res else d2
+        dx = ops.gemm_bf16(d16, w16, b_layout=1).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw, db = wgrad16(d16, x2, ctx.params[0], ctx.params[1])
+        return dx, dw, db, (dy if ctx.has_res else None)
+
+
+class CrossAttn16Fn(Function):
+    """softmax(rnd(rnd(q k^T) scale)) v on bf16 q [B, N, D] and packed kv [B, Nk, 2 D] (mit.py:155-160 under autocast: both matmuls
+    16-bit, the scaling a 16-bit product, softmax fp32, its output cast down for attn @ v); flash kernels, nothing materialised"""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        q, kv = _c(q), _c(kv)
+        B, N, D = q.shape
+        Nk = kv.shape[1]
+        hd = D // heads
+        if hd > 64:   # (MiT-b1 ... b5, third stage: 80) no flash kernel: the materialised path on contiguous copies of k and v
+            k, v = kv[..., :D].contiguous().view(B * Nk, D), kv[..., D:].contiguous().view(B * Nk, D)
+            o, S, P = ops.attention16_forward(q.view(B * N, D), k, v, B, heads, N, Nk, hd, scale)
+            ctx.save_for_backward(q, k, v, S, P)
+            ctx.meta = (heads, scale, Nk)
+            return o.view(B, N, D)
+        o, stats = ops.attention16_cross(q.view(B * N, D), kv, B, heads, N, Nk, hd, scale)
+        ctx.save_for_backward(q, kv, *stats)
+        ctx.meta = (heads, scale, Nk)
+        return o.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, do):
+        heads, scale, Nk = ctx.meta
+        if len(ctx.saved_tensors) == 5:
+            q, k, v, S, P = ctx.saved_tensors
+            B, N, D = q.shape
+            dq, dk, dv = ops.attention16_backward(_c(do).view(B * N, D), q.view(B * N, D), k, v, S, P, B, heads, N, Nk, D // heads, scale)
+            return dq.view(B, N, D), torch.cat([dk.view(B, Nk, D), dv.view(B, Nk, D)], dim=2), None, None
+        q, kv, m, linv = ctx.saved_tensors
+        B, N, D = q.shape
+        dq, dkv = ops.attention16_cross(q.view(B * N, D), kv, B, heads, N, Nk, D // heads, scale, dO=_c(do).view(B * N, D), stats=(m, linv))
+        return dq.view(B, N, D), dkv.view(B, Nk, 2 * D), None, None
+
+
+class DWConvBiasGelu16Fn(Function):
+    """gelu(depthwise 3 x 3 + bias) of MiT's Mix-FFN (mit.py:22-34, 70-77) on a bf16 NHWC map under autocast: the conv is a 16-bit op
+    (16-bit taps and bias, fp32 accumulation, ONE rounding of acc + bias), GELU a 16-bit element-wise op"""
+
+    @staticmethod
+    def forward(ctx, u16, w, b):
+        from .functional import _ones_zeros
+        u16 = _c(u16)
+        C = u16.shape[3]
+        wt = _prepared(w, ("dwtaps16", 3), 1, C, 9, 1, (9, C))               # tap-major, 16-bit values
+        z = ops.dwconv3(ops.cast_f32(u16), wt, 1).reshape(-1, C)
+        one, zero = _ones_zeros(C, u16.device)
+        pre16 = ops.cast_bf16(ops.bn_act_pos_fwd(z, zero, one, one, _rounded(b), None, relu=0))   # rnd(acc + bias)
+        ctx.save_for_backward(u16, wt, pre16)
+        ctx.wshape = tuple(w.shape)
+        ctx.params = (w, b)
+        return ops.gelu16(pre16).reshape(u16.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        u16, wt, pre16 = ctx.saved_tensors
+        C = u16.shape[3]
+        p_w, p_b = ctx.params
+        o_w, o_b = direct(p_w, p_b)
+        dpre16 = ops.gelu16(pre16, _c(dy).reshape(-1, C))
+        db = ops.colreduce16(dpre16, ops.RED_SUM, out=None if o_b is None else o_b.view(1, C), round_out=True).reshape(C)
+        dz4 = ops.cast_f32(dpre16).reshape(u16.shape)
+        dx = ops.cast_bf16(ops.dwconv3(dz4, wt, 1, dgrad_shape=u16.shape[1:3])).reshape(u16.shape) if ctx.needs_input_grad[0] else None
+        dw = ops.round_bf16_(ops.transpose(ops.dwconv3_wgrad(ops.cast_f32(u16), dz4, 1),
+                                           out=None if o_w is None else o_w.view(C, 9))).reshape(ctx.wshape)
+        return dx, ret(o_w, dw, p_w), ret(o_b, db, p_b)
+
+
+class ConvBias16Fn(Function):
+    """conv(k, stride, pad k // 2) + bias under autocast (MiT ``OverlapPatchEmbed.proj``, mit.py:237-243): the fp32 input (the NCHW
+    image, or the previous stage's fp32 LayerNorm output as NHWC) is rounded by the conv's cast, im2col runs on the bf16 copy, the
+    result is bf16 rnd(acc + bias).  The input's gradient comes back as fp32 holding 16-bit values (ONE rounding after col2im)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, stride, src_nchw):
+        x = _c(x)
+        O, pad = w.shape[0], k // 2
+        if src_nchw:
+            B, Cin, H, W = x.shape
+            rows = ops.im2col_nchw(x, k, stride, pad)
+            Kp = (rows.shape[1] + 7) // 8 * 8
+            rows16 = ops.cast_bf16(rows, Kp)
+            kk = Cin * k * k
+            w16 = _cached(w, ("conv16 nchw", Kp), lambda: ops.cast_bf16(w.detach().reshape(O, kk), Kp))
+        else:
+            B, H, W, Cin = x.shape
+            if Cin % 8:
+                raise NotImplementedError("the 16-bit overlapping patch embed needs a channel count that is a multiple of 8")
+            x16 = ops.cast_bf16(x)
+            rows16 = ops.im2col_nhwc(x16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
+            w16 = _prepared(w, "conv16", O, Cin, k * k, 2, (O, k * k * Cin))   # [O][ky][kx][c]
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        y16 = ops.gemm_bf16(rows16, w16, bias=_w16(b))
+        ctx.save_for_backward(rows16, w16)
+        ctx.meta = (k, stride, pad, src_nchw, tuple(x.shape), tuple(w.shape))
+        ctx.params = (w, b)
+        return y16.reshape(B, Ho, Wo, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows16, w16 = ctx.saved_tensors
+        k, stride, pad, src_nchw, xshape, wshape = ctx.meta
+        O = wshape[0]
+        dy16 = _c(dy).reshape(-1, O)
+        p_w, p_b = ctx.params
+        dx = None
+        if src_nchw:
+            kk = xshape[1] * k * k
+            dw, db = wgrad16(dy16, rows16, p_w, p_b, transform=lambda t: p_w.grad.view(O, kk).copy_(t[:, :kk]),
+                             reshape=lambda t: t[:, :kk].reshape(wshape))
+        else:
+            B, H, W, Cin = xshape
+            dw, db = wgrad16(dy16, rows16, p_w, p_b,
+                             transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
+                             reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
+            if ctx.needs_input_grad[0]:   # the taps' products stay fp32 until col2im has summed them: ONE rounding
+                drows = ops.gemm_bf16(dy16, w16, b_layout=1, epi=ops.EPI_F32_RAW)
+                dx = ops.round_bf16_(ops.col2im_nhwc(drows, B, H, W, Cin, k, stride, pad))
+        return dx, dw, db, None, None, None
+
+
 class ToBf16Fn(Function):
     """fp32 tensor holding 16-bit values -> the same values as bf16 in HBM (exact); the 16-bit gradient comes back as fp32 holding it"""
 

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import functional16 as Fn16
 from .. import ops
 
 
@@ -25,6 +26,8 @@ class _Linear(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
     def forward(self, x, act=ops.ACT_NONE, residual=None):
+        if getattr(self, "autocast16", False):   # x bf16; with a residual the fp32 stream's add rides in the epilogue
+            return Fn16.Linear16Fn.apply(x, self.weight, self.bias, residual)
         return Fn.linear(x, self.weight, self.bias, act, residual)
 
 
@@ -43,7 +46,9 @@ class _LayerNorm(nn.Module):
         super().__init__()
         self.weight, self.bias, self.eps = nn.Parameter(torch.ones(dim)), nn.Parameter(torch.zeros(dim)), eps
 
-    def forward(self, x):
+    def forward(self, x, out16=False):
+        if getattr(self, "autocast16", False):   # nn.LayerNorm is on autocast's fp32 list; out16: the consumer Linear's input cast
+            return Fn16.LayerNorm16Fn.apply(x, self.weight, self.bias, self.eps, out16, True)
         return Fn.layer_norm(x, self.weight, self.bias, self.eps)
 
 
@@ -63,7 +68,8 @@ class Mlp(nn.Module):
     def forward(self, x, H, W, residual):
         B, N, _ = x.shape
         h = self.fc1(x)
-        h = Fn.DWConvBiasGeluFn.apply(h.reshape(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias)
+        fn = Fn16.DWConvBiasGelu16Fn if getattr(self, "autocast16", False) else Fn.DWConvBiasGeluFn
+        h = fn.apply(h.reshape(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias)
         return self.fc2(h.reshape(B, N, -1), residual=residual)
 
 
@@ -81,6 +87,16 @@ class Attention(nn.Module):
 
     def forward(self, x, H, W, residual):
         B, N, C = x.shape
+        if getattr(self, "autocast16", False):
+            # x: norm1's fp32 output.  Its two consumers (q, and sr / kv) each cast it down: two cast nodes, so that their 16-bit
+            # gradients are added in fp32 as autograd does at the fp32 tensor
+            q = self.q(Fn16.ToBf16Fn.apply(x))
+            x16 = Fn16.ToBf16Fn.apply(x)
+            if self.sr_ratio > 1:
+                r = Fn16.PatchConv16Fn.apply(x16.reshape(B, H, W, C), self.sr.weight, self.sr.bias, self.sr_ratio, False)
+                x16 = self.norm(r.reshape(B, -1, C), out16=True)
+            o = Fn16.CrossAttn16Fn.apply(q, self.kv(x16), self.num_heads, self.scale)
+            return self.proj(o, residual=residual)
         q = self.q(x)
         if self.sr_ratio > 1:
             r = Fn.PatchConvFn.apply(x.reshape(B, H, W, C), self.sr.weight, self.sr.bias, self.sr_ratio, False)
@@ -96,8 +112,9 @@ class TransformerBlock(nn.Module):
         self.norm2, self.mlp = _LayerNorm(dim), Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, H, W):
+        a16 = getattr(self, "autocast16", False)
         x = self.attn(self.norm1(x), H, W, residual=x)     # x + attn(norm1(x)): the residual rides in proj's epilogue
-        return self.mlp(self.norm2(x), H, W, residual=x)
+        return self.mlp(self.norm2(x, out16=True) if a16 else self.norm2(x), H, W, residual=x)
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -107,7 +124,8 @@ class OverlapPatchEmbed(nn.Module):
         self.patch_size, self.stride = patch_size, stride
 
     def forward(self, x, src_nchw):
-        y = Fn.ConvBiasFn.apply(x, self.proj.weight, self.proj.bias, self.patch_size, self.stride, src_nchw)
+        fn = Fn16.ConvBias16Fn if getattr(self, "autocast16", False) else Fn.ConvBiasFn
+        y = fn.apply(x, self.proj.weight, self.proj.bias, self.patch_size, self.stride, src_nchw)
         B, H, W, C = y.shape
         return self.norm(y.reshape(B, H * W, C)), H, W
 
@@ -127,6 +145,17 @@ class MultiscaleImageTransformer(nn.Module):
             self.add_module(f"norm{i + 1}", _LayerNorm(embed_dims[i]))
         self._out_features = out_features or ["res2", "res3", "res4", "res5"]
         self._out_feature_channels = {f"res{i + 2}": embed_dims[i] for i in range(4)}
+
+    def set_precision(self, precision):
+        """"fp32" (exact) or "bf16_autocast": the reference's default precision=16 policy (train.py:263) - every Linear, the
+        overlapping patch embeds, the spatial-reduction conv, Mix-FFN's depthwise conv and both attention matmuls on bf16 operands
+        with 16-bit results, LayerNorm / softmax / the residual stream fp32 (functional16.py)"""
+        if precision not in ("fp32", "bf16_autocast"):
+            raise ValueError(f"unknown student precision {precision!r}")
+        self.precision = precision
+        for m in self.modules():
+            m.autocast16 = precision == "bf16_autocast"
+        return self
 
     def forward_features_nhwc(self, x):
         outs = {}

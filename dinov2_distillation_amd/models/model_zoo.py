@@ -304,13 +304,13 @@ class ModelWrapper(nn.Module):
 
     def set_precision(self, precision):
         """"fp32" (default, exact) or "bf16_autocast": the backbone under the reference's default precision=16 policy (functional16.py):
-        ConvNeXt-V2, Swin and ResNet with bf16 activations in HBM, STDC / PResNet / MobileNetV2 / DarkNet with 16-bit values in fp32 tensors.  MobileNetV3 and
-        MiT have no mixed-precision path."""
+        ConvNeXt-V2, Swin and ResNet with bf16 activations in HBM, STDC / PResNet / MobileNetV2 / MobileNetV3 / DarkNet with 16-bit values in
+        fp32 tensors, MiT with an fp32 residual stream and bf16 Linear / conv / attention tensors."""
         backbone = self.model.model
         if not hasattr(backbone, "set_precision"):
             if precision in (None, "fp32"):
                 return self
-            raise NotImplementedError(f"{type(backbone).__name__} has no mixed-precision path (ConvNeXt-V2, Swin, STDC, ResNet, PResNet, MobileNetV2, MobileNetV3 and DarkNet students have one)")
+            raise NotImplementedError(f"{type(backbone).__name__} has no mixed-precision path (every native student family has one; the timm wrappers do not exist here)")
         backbone.set_precision(precision or "fp32")
         return self
 

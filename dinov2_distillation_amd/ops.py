@@ -1390,6 +1390,34 @@ def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, l
     return O, S, P
 
 
+def attention16_cross(q, kv, B, H, Nq, Nk, hd, c1, dO=None, stats=None):
+    """the policy's attention with the keys / values packed side by side: q [B*Nq, D] bf16, kv [B*Nk, 2 D] bf16 = [k | v] (MiT's
+    spatial-reduction attention, models/backbones/mit.py:128-165), flash form (attention16_forward's roundings, c2 = 1).
+    Forward (dO None) -> O [B*Nq, D], (m, linv);  backward (dO, stats from the forward) -> dq [B*Nq, D], dkv [B*Nk, 2 D]"""
+    _chk16(q, "q"), _chk16(kv, "kv"), _chk16(dO, "dO")
+    D = H * hd
+    if hd % 8 or not 16 <= hd <= 64:
+        raise NotImplementedError(f"attention16_cross: head dim {hd} has no flash kernel (multiples of 8 from 16 to 64)")
+    kv2 = kv.view(B * Nk, 2 * D)
+    a = _attn16_train_args(q, kv2, kv2[:, D:], B, H, Nq, Nk, hd, c1, 1.0, False, D)
+    a.ldkv = 2 * D
+    if dO is None:
+        O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
+        m = torch.empty((B * H * Nq,), dtype=torch.float32, device=q.device)
+        linv = torch.empty_like(m)
+        a.o, a.ldo, a.m, a.linv = _p(O), D, _p(m), _p(linv)
+        check(_lib.binding().dkd_attn16_train_fwd(_lib.ref(a), _stream()), "dkd_attn16_train_fwd", (B, H, Nq, Nk, hd))
+        return O, (m, linv)
+    m, linv = stats
+    dq = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
+    dkv = torch.empty((B * Nk, 2 * D), dtype=BF16, device=q.device)
+    delta = torch.empty_like(m)
+    a.m, a.linv, a.delta, a.d_o, a.lddo = _p(m), _p(linv), _p(delta), _p(dO), D
+    a.dq, a.dk, a.dv, a.lddq, a.lddkv = _p(dq), _p(dkv), _p(dkv[:, D:]), D, 2 * D
+    check(_lib.binding().dkd_attn16_train_bwd(_lib.ref(a), _stream()), "dkd_attn16_train_bwd", (B, H, Nq, Nk, hd))
+    return dq, dkv
+
+
 def attention16_backward(dO, q, k, v, S, P, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, ld=None, out=None):
     """-> dq, dk, dv (bf16), every matmul result and every scalar product rounded as autograd's 16-bit backward does.
     ld: q / k / v are column slices with that row pitch; out = (dq, dk, dv) column slices (same pitch) to write into.

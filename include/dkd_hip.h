@@ -286,7 +286,7 @@ int dkd_scale_bf16(const void* x, float s, void* out, long n, void* stream);
  * q / k / v bf16 [B*N, ld] column slices (element (b, token, head, d) at x[(b*N + token)*ld + head*hd + d]: the fused qkv Linear's
  * 16-bit output), o bf16 [B*N, ldo].  S = rnd(q k^T) * scale, softmax fp32 (online), probabilities rounded to bf16 for the second
  * matmul, fp32 accumulation, one rounding at the store.  Forward only; hd == 64; ld % 8 == 0, ldo % 4 == 0. */
-/* The SAME policy attention with gradients, flash-style (csrc/attention16_train.hip; hd in {16, 24, 32, 48, 64}): no [B*H, Nq, Nk]
+/* The SAME policy attention with gradients, flash-style (csrc/attention16_train.hip; hd a multiple of 8 in [16, 64]): no [B*H, Nq, Nk]
  * tensors in HBM.  The
  * roundings are those of dkd_attn16_softmax_* around the batched dkd_gemm_bf16 calls (eager attention under autocast and autograd's
  * backward through it): S = rnd(q k^T), T = rnd(rnd(S c1) c2), P = rnd(softmax_fp32(T)) with the final row max / sum (two key sweeps),
