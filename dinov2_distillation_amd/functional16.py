@@ -121,24 +121,33 @@ def _rounded(t):
     return _prepared(t, "rounded", 1, 1, t.numel(), 1, tuple(t.shape))
 
 
-def wgrad16(dy16, x16, w, b, transform=None, reshape=None):
+def wgrad16(dy16, x16, w, b, transform=None, reshape=None, make_x16=None):
     """dW = rnd(dy16^T x16) and db = rnd(sum_rows dy16), as fp32 master gradients - ONE launch (+ its K-slab fold): the bias
     gradient is the row sum of the weight-gradient GEMM's [rows][N_out] operand and rides on the matrix cores (dkd_hip.h,
     dkd_gemm_bf16_args.rowsum).  In-place on the weight-gradient stream when the arena allows it (ops.can_async), else returned
-    to autograd."""
+    to autograd.  make_x16: x16 is the SOURCE of the [rows, K] operand and make_x16(x16) builds it (im2col of a conv whose forward ran
+    as an implicit GEMM) - on the weight-gradient stream too, off the main chain."""
+    if make_x16 is not None and not ops.can_async(w, b):
+        x16, make_x16 = make_x16(x16), None
     N, K = dy16.shape[-1], x16.shape[-1]
     if ops.can_async(w, b):
         side = ops.wgrad_stream(dy16.device)
         ops.claim(w, b)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            if make_x16 is not None:
+                src = x16
+                x16 = make_x16(src)      # (allocated under the side stream: no cross-stream lifetime to record)
+                src.record_stream(side)
+                K = x16.shape[-1]
             rs = None if b is None else b.grad.view(-1)
             if transform is None:
                 ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, out=w.grad.view(N, K), ws_slot=3, rowsum=rs)
             else:
                 transform(ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, ws_slot=3, rowsum=rs))
         dy16.record_stream(side)
-        x16.record_stream(side)
+        if make_x16 is None:
+            x16.record_stream(side)
         ops.grad_done(w, b)
         return None, None
     db = None if b is None else torch.empty(N, dtype=F32, device=dy16.device)
@@ -793,14 +802,12 @@ class ConvBNAct16Fn(Function):
         # sum of their 16-bit gradients: nothing to round)
         dz16, dg, db = ops.bn_bwd16(_c(dy).reshape(-1, O), z16, mean, rstd, bn_w, bn_b, relu, dgamma_out=o_g, dbeta_out=o_b)
         B, H, W, Cin = xshape
-        x16 = None
-        if ctx.igemm:   # the forward ran implicit: the weight gradient's patches are built now (and freed after its launch)
-            x16 = rows16
-            rows16 = ops.im2col_nhwc(x16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
-        if k == 1:
+        # the forward ran implicit: the weight gradient's patches are built now, on the weight-gradient stream, and freed after its launch
+        mk = (lambda x16: ops.im2col_nhwc(x16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)) if ctx.igemm else None
+        if k == 1 and mk is None:
             dw, _ = wgrad16(dz16, rows16, p_w, None, reshape=lambda t: t.reshape(wshape))
         else:
-            dw, _ = wgrad16(dz16, rows16, p_w, None,
+            dw, _ = wgrad16(dz16, rows16, p_w, None, make_x16=mk,
                             transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
                             reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
         dx = None
@@ -840,12 +847,12 @@ class ConvBNAct16Fn(Function):
                             reshape=lambda t: t[:, :kk].reshape(wshape))
         else:
             B, H, W, Cin = xshape
-            if ctx.igemm:   # the forward ran implicit: the weight gradient's patches are built now (and freed after its launch)
-                rows16 = ops.im2col_nhwc(rows16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)
-            if k == 1:
+            # the forward ran implicit: the weight gradient's patches are built now, on the weight-gradient stream
+            mk = (lambda x16: ops.im2col_nhwc(x16.view(F32).reshape(B, H, W, Cin // 2), k, stride, pad).view(BF16)) if ctx.igemm else None
+            if k == 1 and mk is None:
                 dw, _ = wgrad16(dz16, rows16, p_w, None, reshape=lambda t: t.reshape(wshape))
             else:
-                dw, _ = wgrad16(dz16, rows16, p_w, None,
+                dw, _ = wgrad16(dz16, rows16, p_w, None, make_x16=mk,
                                 transform=lambda t: ops.transpose(t.reshape(O, k * k, Cin), out=p_w.grad.view(O, Cin, k * k)),
                                 reshape=lambda t: ops.transpose(t.reshape(O, k * k, Cin)).reshape(wshape))
             if ctx.needs_input_grad[0]:

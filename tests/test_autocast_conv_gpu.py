@@ -361,7 +361,7 @@ def test_whole_backbone_and_step_under_the_policy(family):
     elif family == "mit":   # (SegFormer's Mix Transformer: fp32 residual stream, 16-bit Linears / convs / attention)
         from oracle import mit_oracle as mi
         w = ModelWrapper("mit_b0", [8, 8], ["res4", "res5"])
-        ofn = lambda xin: (lambda q: mi.forward(q, xin, [2, 2, 2, 2], sr_ratios=(8, 4, 2, 1), policy=torch.is_autocast_cpu_enabled()))
+        ofn = lambda xin: (lambda q: mi.forward(q, xin, [2, 2, 2, 2], sr_ratios=(8, 4, 2, 1), policy=torch.is_autocast_enabled("cpu")))
     elif family == "presnet":   # (ResNet-vd, not a BASELINE config: the same nodes plus the average-pool "d" shortcut)
         from oracle import presnet_oracle as po
         w = ModelWrapper("presnet_50", [8, 8], ["res4", "res5"])
