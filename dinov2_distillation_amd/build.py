@@ -49,11 +49,30 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+# AddressSanitizer build of the HOST side ("ASan host build"): the launchers' argument validation, launch planning and
+# workspace arithmetic instrumented; device code is compiled as usual (GPU ASan needs xnack+, not available on this pool).  Lives
+# under build/asan (never shipped); tests/test_abi_cpu.py runs every launcher through it.
+ASAN_OBJ = os.path.join(ROOT, "build", "asan")
+ASAN_LIB = os.path.join(ASAN_OBJ, "libdkd_hip_asan.so")
+ASAN_FLAGS = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-Wno-option-ignored"]
+
+
+def asan_runtime():
+    """the clang ASan runtime to LD_PRELOAD into an uninstrumented python"""
+    r = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = r.stdout.strip()
+    if os.path.isabs(p) and os.path.exists(p):
+        return p
+    import glob
+    c = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return c[0] if c else None
+
+
+def _compile(src, force, asan=False):
+    obj = os.path.join(ASAN_OBJ if asan else OBJ, os.path.basename(src)[:-4] + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _newest_header()):
         return obj, False
-    cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *(ASAN_FLAGS if asan else []), *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -79,5 +98,23 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_asan(force=False, verbose=True):
+    os.makedirs(ASAN_OBJ, exist_ok=True)
+    srcs = sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force, asan=True), srcs))
+    if any(ch for _, ch in res) or not os.path.exists(ASAN_LIB) or force:
+        cmd = [_hipcc(), "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", f"--offload-arch={ARCH}", "-o", ASAN_LIB, *[o for o, _ in res]]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[dkd build] linked {ASAN_LIB}")
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--asan" in sys.argv:
+        build_asan(force="--force" in sys.argv)
+    else:
+        build(force="--force" in sys.argv)

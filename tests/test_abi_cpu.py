@@ -3,6 +3,7 @@ argument structs match the C layout, and the product path refuses to run without
 import ctypes
 import os
 import subprocess
+import sys
 
 import pytest
 import torch
@@ -127,3 +128,29 @@ def test_binding_helpers_match_the_selected_binding():
     assert [f for f, _ in _lib._STRUCT_DEFS["dkd_gemm_args"]][:2] == ["A", "lda"] and a.M == 3
     b = _lib.binding()
     assert b.dkd_abi_version() == _lib.DEFINES["DKD_ABI_VERSION"]
+
+
+def _sweep(libpath, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_sweep.py"), libpath], capture_output=True, text=True, env=e, timeout=600)
+    return r.returncode, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_every_launcher_refuses_null_arguments(lib):
+    """all ~100 launchers called with NULL pointers / zero sizes answer DKD_ERR_* (nothing launched, nothing dereferenced), and with
+    plausible sizes and fake device addresses run their host side to the launch without a crash (tests/abi_sweep.py)"""
+    rc, out = _sweep(_lib.LIB_PATH)
+    assert rc == 0 and "OK " in out, out
+
+
+def test_host_side_under_address_sanitizer():
+    """SURVEY 5 "ASan host build": the same sweep against libdkd_hip_asan.so (host code of every .hip instrumented with
+    -fsanitize=address; build/asan, cached) with the clang ASan runtime preloaded into the interpreter - no report, exit 0"""
+    from dinov2_distillation_amd import build
+    rt = build.asan_runtime()
+    if rt is None:
+        pytest.skip("no clang ASan runtime in this toolchain")
+    asan_lib = build.build_asan(verbose=False)
+    rc, out = _sweep(asan_lib, {"LD_PRELOAD": rt, "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1"})
+    assert rc == 0 and "OK " in out and "AddressSanitizer" not in out, out
