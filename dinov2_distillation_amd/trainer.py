@@ -13,7 +13,7 @@ from .train import DistillationModule
 class DistillationStepper:
     def __init__(self, teacher="dinov2_vits14", student="convnext_tiny", crop=224, device="cuda", heads=(16, 24),
                  clip=1.0, lr=1e-3, seed=1, bucket_bytes=32 << 20, teacher_precision=None, accumulate_grad_batches=1,
-                 student_precision=None, projector_precision=None, precision=None):
+                 student_precision=None, projector_precision=None, precision=None, max_inflight_steps=3):
         if precision is not None:  # one switch for the whole step: "bf16_autocast" = the reference's default precision=16 policy
             teacher_precision = teacher_precision or precision
             student_precision = student_precision or precision
@@ -40,6 +40,7 @@ class DistillationStepper:
         self.clip = clip
         self.step_idx = 0
         self.accumulate, self.micro = int(accumulate_grad_batches), 0  # train.py:269
+        self.max_inflight, self._inflight = int(max_inflight_steps), []   # host run-ahead bound (see _throttle); 0 = unbounded
 
     # ---- hipGraph replay of the whole step -----------------------------------------------------------------------------
     # Every launch of the step is capture-safe (no allocation or synchronisation inside the library, side streams fork from and
@@ -86,6 +87,20 @@ class DistillationStepper:
         self.optimizer.step(clip_grad_norm=self.clip)
         return loss.detach()
 
+    def _throttle(self):
+        """keep the host at most max_inflight_steps steps ahead of the GPU.  The step is enqueued 2-3x faster than it runs, and an
+        unbounded run-ahead makes the caching allocator grow for dozens of steps (blocks handed to the side streams are reusable only
+        once their events have completed): measured on BASELINE configs[2] under the policy, 20-30 GiB of new hipMalloc segments and
+        single steps of 2 s inside a timed loop (NOTES 9.20).  Waiting on the step before last costs nothing while the GPU is the
+        bottleneck - the previous step is still queued in full - and bounds the footprint to the steps in flight."""
+        if self.max_inflight <= 0:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight.append(ev)
+        if len(self._inflight) > self.max_inflight:
+            self._inflight.pop(0).synchronize()
+
     def step(self, batch):
         """one micro-batch.  With accumulate_grad_batches = n (train.py:269) the gradients of n consecutive calls add up in the
         arena (loss scaled by 1/n as Lightning does), the exchange and the optimiser run on every n-th call."""
@@ -106,4 +121,5 @@ class DistillationStepper:
             self.optimizer.step(clip_grad_norm=self.clip)
             self.step_idx += 1
         self.module.sync_logged()  # the packed metric all-reduce (one per micro-batch) has long finished: join it
+        self._throttle()
         return loss

@@ -30,17 +30,26 @@ def run(idx, precision, steps, warmup):
     losses = [st.step(x).detach() for _ in range(warmup)]   # (no host sync inside the warm-up: the caching allocator has to reach the
     torch.cuda.synchronize()                                # footprint of the un-synchronised timed loop, where the host runs ahead)
     losses = [float(v) for v in losses]
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
+    host = []
     for _ in range(steps):
+        h0 = time.perf_counter()
         loss = st.step(x)
+        host.append((time.perf_counter() - h0) * 1e3)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    ms1 = torch.cuda.memory_stats()
+    # a slow timed loop with device allocations in it is the caching allocator still growing (hipMalloc synchronises), not the step
+    grow = {"device_allocs_in_timed_loop": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+            "reserved_gib_growth": round((ms1["reserved_bytes.all.current"] - ms0["reserved_bytes.all.current"]) / 2 ** 30, 2),
+            "host_ms_per_step_max": round(max(host), 1)}
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     del st
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     return dict(config=idx, precision=precision or "fp32", batch=B, ms_per_step=round(ms, 2), images_per_s=round(B / ms * 1e3, 1),
-                first_losses=[round(v, 5) for v in losses], last_loss=round(float(loss.detach()), 5), peak_gib=round(peak, 2))
+                first_losses=[round(v, 5) for v in losses], last_loss=round(float(loss.detach()), 5), peak_gib=round(peak, 2), **grow)
 
 
 def main():
