@@ -556,7 +556,9 @@ struct DmaStager {
 // as a few dozen short slabs in the first round they cost about one tile's worth of work spread over the chip.
 // SPREAD: the next tile's DMA pieces are issued between the k-blocks' MFMAs (A in front of the first, B in front of the last k-block)
 // instead of all in front of the tile's first fragment read - the order that won on every shape of the bf16 ring kernel.
-template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0, bool PEEL = false, bool SPREAD = false>
+// PRIO (tuning variants 112 / 113, DKD_TUNING builds): s_setprio around the MFMA block (1) or around fragment reads + MFMA block (2) - the
+// wave that has its fragments wins the issue arbitration against the co-resident waves' address arithmetic and DMA issue.
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0, bool PEEL = false, bool SPREAD = false, int PRIO = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda,
                                                                     const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                     int M, int N, int K, int kchunk, Epilogue epi,
@@ -612,10 +614,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
         const float* As = smem + cur * (A_SZ + B_SZ);
         float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
         const bool more = kt + 1 < nk && !(knock & 2);
+        if (PRIO >= 3) __builtin_amdgcn_s_setprio(1);   // (3 / 4: the data-movement instructions win the arbitration, the MFMAs yield)
         if (more && !SPREAD) {  // every wave passed the barrier: nobody reads the other buffer any more
             da.issue(An, tid);
             if (!(knock & 4)) db.issue(An + A_SZ, tid);
         }
+        if (PRIO == 4) __builtin_amdgcn_s_setprio(0);
         if (do_rowsum) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rs += DA::at(As, kk, tid);
@@ -623,6 +627,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
 #pragma unroll
         for (int kb = 0; kb < BK / 16; ++kb) {
             float4 a[TM], b[TN];
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = DA::frag(As, (wm * TM + i) * 16, kb, g, i16);
 #pragma unroll
@@ -631,6 +636,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
                 if (kb == 0) da.issue(An, tid);
                 if (kb == BK / 16 - 1) db.issue(An + A_SZ, tid);
             }
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+            if (PRIO == 3) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -640,6 +647,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
                 }
+            if (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(0);
+            if (PRIO == 3 && kb + 1 < BK / 16) __builtin_amdgcn_s_setprio(1);   // the next k-block's fragment reads
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt + 1 have landed
         if (!(knock & 8)) __syncthreads();
@@ -1077,7 +1086,7 @@ static bool dma_ok(const dkd_gemm_args* g, int kchunk) {
     if (g->rowsum && g->a_layout == 0) return false;
     return true;
 }
-template <int WM, int WN, int TM, int TN, int BK, int KNOCK = 0, bool SPREAD = false>
+template <int WM, int WN, int TM, int TN, int BK, int KNOCK = 0, bool SPREAD = false, int PRIO = 0>
 int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
     if (!dma_ok<BK>(g, kchunk)) return DKD_ERR_UNSUPPORTED;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -1085,7 +1094,7 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     float* ws = splits > 1 ? g->workspace : nullptr;
     const int vec = epilogue_vec_ok(g);
 #define DKD_GEMM_LAUNCH3(AKC, BKC)                                                                                          \
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK, false, SPREAD>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK, false, SPREAD, PRIO>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
                        g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec, 0, 0)
     if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH3(true, true);
     else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH3(true, false);
@@ -1361,7 +1370,7 @@ static void cfg_tile(int cfg, int* bm, int* bn) {
         case 56: *bm = 96; *bn = 64; break;
         case 102: case 104: *bm = 128; *bn = 64; break;
         case 103: *bm = 64; *bn = 128; break;
-        case 44: case 100: case 101: case 111: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
+        case 44: case 100: case 101: case 111: case 112: case 113: case 114: case 115: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
         default: *bm = 64; *bn = 128; break;  // 3, 5
     }
@@ -1479,6 +1488,12 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
         case 100: return launch_dma<2, 2, 2, 2, 16>(g, epi, splits, kchunk, st);     // 64 x 64, LDS-DMA staging, BK 16
         case 101: return launch_dma<2, 2, 2, 2, 32>(g, epi, splits, kchunk, st);     // 64 x 64, BK 32
         case 111: return launch_dma<2, 2, 2, 2, 32, 0, true>(g, epi, splits, kchunk, st);  // ... with the DMA issue spread over the k-blocks
+#ifdef DKD_TUNING  // s_setprio around the MFMA block / fragment reads + MFMA block (scripts/tune_v2.py 101,112,113)
+        case 112: return launch_dma<2, 2, 2, 2, 32, 0, false, 1>(g, epi, splits, kchunk, st);
+        case 113: return launch_dma<2, 2, 2, 2, 32, 0, false, 2>(g, epi, splits, kchunk, st);
+        case 114: return launch_dma<2, 2, 2, 2, 32, 0, false, 3>(g, epi, splits, kchunk, st);
+        case 115: return launch_dma<2, 2, 2, 2, 32, 0, false, 4>(g, epi, splits, kchunk, st);
+#endif
 #ifdef DKD_TUNING  // VERDICT r02 item 3a, re-measured in round 3 (scripts/tune_v2.py 0,102,103,104): one B tile under two M-tiles
         case 102: return launch_dma<2, 2, 4, 2, 32>(g, epi, splits, kchunk, st);     // 128 x 64, 4 waves of 64 x 32
         case 103: return launch_dma<2, 2, 2, 4, 32>(g, epi, splits, kchunk, st);     // 64 x 128, 4 waves of 32 x 64
