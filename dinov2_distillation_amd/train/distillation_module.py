@@ -200,7 +200,24 @@ class DistillationModule(_Base):
         teacher_features.record_stream(main)
         return {"student": student_features, "teacher": teacher_features}
 
+    def _bound_run_ahead(self, batch):
+        """Lightning branch: keep the host at most ``cfg.train.max_inflight_steps`` (default 3, 0 = unbounded) training steps ahead of
+        the GPU - Lightning's loop synchronises only when it reads a logged value, and an unbounded run-ahead keeps the caching allocator
+        growing for dozens of steps (NOTES 9.20).  The plain-module branch is bounded by trainer.DistillationStepper itself."""
+        if _Base is nn.Module or not batch.is_cuda:
+            return
+        n = int(self.cfg.train.get("max_inflight_steps", 3)) if hasattr(self.cfg, "train") else 3
+        if n <= 0:
+            return
+        q = self.__dict__.setdefault("_inflight_steps", [])
+        ev = torch.cuda.Event()
+        ev.record()
+        q.append(ev)
+        if len(q) > n:
+            q.pop(0).synchronize()
+
     def training_step(self, batch, batch_idx):
+        self._bound_run_ahead(batch)
         losses = self._compute_losses(self._extract_features(batch))
         self._log_training_metrics(losses)
         return losses["loss"]
