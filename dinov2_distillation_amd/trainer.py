@@ -1,5 +1,7 @@
 """Minimal step driver for the hot path (what Lightning's fit loop does around ``training_step`` in the reference:
 zero_grad -> training_step -> backward (+ DDP exchange) -> clip -> optimizer.step; train.py:256-288)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -40,7 +42,8 @@ class DistillationStepper:
         self.clip = clip
         self.step_idx = 0
         self.accumulate, self.micro = int(accumulate_grad_batches), 0  # train.py:269
-        self.max_inflight, self._inflight = int(max_inflight_steps), []   # host run-ahead bound (see _throttle); 0 = unbounded
+        # host run-ahead bound (see _throttle); 0 = unbounded; DKD_MAX_INFLIGHT overrides the argument (A/B runs of bench.py)
+        self.max_inflight, self._inflight = int(os.environ.get("DKD_MAX_INFLIGHT", max_inflight_steps)), []
 
     # ---- hipGraph replay of the whole step -----------------------------------------------------------------------------
     # Every launch of the step is capture-safe (no allocation or synchronisation inside the library, side streams fork from and
