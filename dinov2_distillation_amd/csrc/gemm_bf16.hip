@@ -410,14 +410,15 @@ int conv16_plan(int B, int H, int W, int C, int O, int k, int stride, int pad, C
     if ((long)H + 2 * pad < k || (long)W + 2 * pad < k) return DKD_ERR_BAD_ARG;
     const long Ho = ((long)H + 2 * pad - k) / stride + 1, Wo = ((long)W + 2 * pad - k) / stride + 1;
     const long pix = (long)B * Ho * Wo, kk = (long)k * k * C;
-    // a 64-deep k-tile inside one tap; 16-byte output pieces; exact float pixel decomposition; 32-bit byte offsets
-    if ((C % 64) || (O % 8) || pix >= (1L << 24) || kk >= (1L << 24) || (long)B * H * W * C * 2 >= (1L << 32) ||
+    // a 64- (or 32-) deep k-tile inside one tap; 16-byte output pieces; exact float pixel decomposition; 32-bit byte offsets
+    if ((C % 32) || (O % 8) || pix >= (1L << 24) || kk >= (1L << 24) || (long)B * H * W * C * 2 >= (1L << 32) ||
         (long)H * W * C * 2 >= (1L << 31))
         return DKD_ERR_UNSUPPORTED;
     pl->Ho = (int)Ho, pl->Wo = (int)Wo, pl->M = (int)pix, pl->N = O, pl->K = (int)kk;
     int slabs = bf16_slabs(pl->M, pl->N, pl->K), kchunk = pl->K;
+    const int bk = (C % 64) ? 32 : 64;   // the ring configuration dkd_bf16_ring_launch_conv takes
     if (slabs > 1) {
-        kchunk = ((pl->K + slabs - 1) / slabs + 63) / 64 * 64;
+        kchunk = ((pl->K + slabs - 1) / slabs + bk - 1) / bk * bk;
         slabs = dkd_cdiv(pl->K, kchunk);
     }
     pl->slabs = slabs, pl->kchunk = kchunk;

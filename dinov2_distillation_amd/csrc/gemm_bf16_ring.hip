@@ -416,12 +416,19 @@ bool dkd_bf16_ring_ok(const dkd_gemm_bf16_args* g, int kchunk, int bk) {
     return true;
 }
 
-// the gathered-A (implicit-GEMM convolution) instantiations: configuration 10 (128 x 128 x 64, two stages, spread DMA issue), NT layout
+// the gathered-A (implicit-GEMM convolution) instantiations, NT layout: configuration 10 (128 x 128 x 64, two stages, spread DMA issue)
+// when C % 64 == 0, else configuration 6 (BK 32, three stages: C % 32 == 0 - STDC's and DarkNet's 32-channel convs)
 int dkd_bf16_ring_launch_conv(const dkd_gemm_bf16_args* g, const Conv16Geom& cg, int epi, int slabs, int kchunk, hipStream_t st) {
-    if ((cg.C % 64) || (g->K % 64) || (kchunk % 64) || g->a_layout != 0 || g->b_layout != 0 || g->batch > 1) return DKD_ERR_UNSUPPORTED;
+    const int bk = (cg.C % 64) ? 32 : 64;
+    if ((cg.C % bk) || (g->K % bk) || (kchunk % bk) || g->a_layout != 0 || g->b_layout != 0 || g->batch > 1) return DKD_ERR_UNSUPPORTED;
     const dim3 grid(dkd_cdiv(g->M, 128) * dkd_cdiv(g->N, 128), slabs, 1), block(256);
-#define DKD_RING_CONV(E) \
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<2, 2, 2, 64, 2, E, true, true, false, 0, true, Conv16Geom>), grid, block, 0, st, *g, kchunk, cg)
+#define DKD_RING_CONV(E)                                                                                                            \
+    do {                                                                                                                            \
+        if (bk == 64)                                                                                                               \
+            hipLaunchKernelGGL((gemm_bf16_ring_kernel<2, 2, 2, 64, 2, E, true, true, false, 0, true, Conv16Geom>), grid, block, 0, st, *g, kchunk, cg); \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gemm_bf16_ring_kernel<2, 2, 2, 32, 3, E, true, true, false, 0, false, Conv16Geom>), grid, block, 0, st, *g, kchunk, cg); \
+    } while (0)
     switch (epi) {
         case DKD_BF16_EPI_BF16: DKD_RING_CONV(DKD_BF16_EPI_BF16); break;
         case DKD_BF16_EPI_F32: DKD_RING_CONV(DKD_BF16_EPI_F32); break;

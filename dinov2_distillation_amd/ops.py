@@ -1037,7 +1037,7 @@ def gemm_bf16(a, w, *, epi=EPI_BF16, bias=None, colscale=None, residual=None, re
 
 
 def conv_igemm16_ok(B, H, W, C, O, k, stride, pad):
-    """can dkd_conv_igemm_bf16 run this geometry (C % 64 == 0, O % 8 == 0, ...)?"""
+    """can dkd_conv_igemm_bf16 run this geometry (C % 32 == 0, O % 8 == 0, ...)?"""
     return bool(_size("dkd_conv_igemm_bf16_supported", B, H, W, C, O, k, stride, pad))
 
 

@@ -494,7 +494,7 @@ int dkd_conv_igemm_f32(const float* x, const float* d, float* out, const float* 
 long dkd_conv_igemm_f32_workspace_bytes(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode);
 int dkd_conv_igemm_f32_supported(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode);
 /* The same convolution on bf16 NHWC under the autocast policy (x16, w16 [O][k*k*C] bf16; the A operand of the LDS-DMA ring kernel of
- * dkd_gemm_bf16 is gathered; C % 64 == 0, O % 8 == 0).  epi: DKD_BF16_EPI_BF16 (out bf16 = rnd(acc)) or DKD_BF16_EPI_F32 (out f32 =
+ * dkd_gemm_bf16 is gathered; C % 32 == 0, O % 8 == 0).  epi: DKD_BF16_EPI_BF16 (out bf16 = rnd(acc)) or DKD_BF16_EPI_F32 (out f32 =
  * rnd(acc): the 16-bit result held in fp32).  Forward, and - as the forward of the flipped kernel, x16 = dy - the stride-1 input gradient,
  * whose taps are summed in the fp32 accumulators before the ONE rounding conv backward applies (this replaces the un-rounded
  * DKD_BF16_EPI_F32_RAW products + col2im).  The weight gradient keeps dkd_gemm_bf16 on im2col rows of the bf16 copy. */

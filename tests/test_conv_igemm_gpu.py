@@ -125,6 +125,8 @@ CASES16 = [  # B, H, W, C, O, k, stride, pad
     (3, 16, 16, 128, 64, 1, 2, 0),     # strided 1 x 1
     (8, 14, 14, 256, 256, 3, 1, 1),
     (2, 7, 7, 512, 512, 3, 1, 1),      # K = 4608 on 4 tiles: K-slabs + fold
+    (2, 28, 28, 32, 64, 3, 1, 1),      # C = 32 (STDC, DarkNet): the 32-deep ring configuration, K = 288
+    (4, 14, 14, 96, 96, 3, 2, 1),      # C = 96: 32-deep tiles, three per tap
 ]
 
 
@@ -167,10 +169,10 @@ def test_igemm16_forward_and_dgrad(ops, B, H, W, C, O, k, s, p):
 
 
 def test_igemm16_refuses_what_it_cannot_tile(ops):
-    assert not ops.conv_igemm16_ok(2, 8, 8, 32, 64, 3, 1, 1)      # a 64-deep k-tile would straddle two taps
+    assert not ops.conv_igemm16_ok(2, 8, 8, 48, 64, 3, 1, 1)      # a 32-deep k-tile would straddle two taps
     assert not ops.conv_igemm16_ok(2, 8, 8, 64, 60, 3, 1, 1)      # 16-byte output pieces
     with pytest.raises(Exception, match="UNSUPPORTED|status -3"):
-        ops.conv_igemm16(torch.randn(2, 8, 8, 32, device="cuda").bfloat16(), torch.randn(64, 9 * 32, device="cuda").bfloat16(), 3, 1, 1)
+        ops.conv_igemm16(torch.randn(2, 8, 8, 48, device="cuda").bfloat16(), torch.randn(64, 9 * 48, device="cuda").bfloat16(), 3, 1, 1)
 
 
 def test_conv_bn_act16_node_implicit_vs_materialised(ops):
