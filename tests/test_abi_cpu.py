@@ -154,3 +154,30 @@ def test_host_side_under_address_sanitizer():
     asan_lib = build.build_asan(verbose=False)
     rc, out = _sweep(asan_lib, {"LD_PRELOAD": rt, "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1"})
     assert rc == 0 and "OK " in out and "AddressSanitizer" not in out, out
+
+
+def test_implicit_gemm_convolution_planning_queries(lib):
+    """the host-side plan of dkd_conv_igemm_f32 / _bf16 (pure functions of the geometry, no GPU): what is accepted, what is refused
+    and when K-slab workspaces are asked for"""
+    for fn in (lib.dkd_conv_igemm_f32_supported, lib.dkd_conv_igemm_bf16_supported):
+        fn.restype = ctypes.c_int
+    for fn in (lib.dkd_conv_igemm_f32_workspace_bytes, lib.dkd_conv_igemm_bf16_workspace_bytes):
+        fn.restype = ctypes.c_long
+    f32, b16 = lib.dkd_conv_igemm_f32_supported, lib.dkd_conv_igemm_bf16_supported
+    # ResNet-50 at bs 128 (BASELINE configs[2]): every 3 x 3 conv, forward and weight gradient
+    for (hw, c) in ((56, 64), (28, 128), (14, 256), (7, 512)):
+        assert f32(128, hw, hw, c, c, 3, 1, 1, 0) == 1 and f32(128, hw, hw, c, c, 3, 1, 1, 1) == 1 and b16(128, hw, hw, c, c, 3, 1, 1) == 1
+    assert f32(128, 56, 56, 128, 128, 3, 2, 1, 0) == 1 and f32(128, 56, 56, 256, 512, 1, 2, 0, 0) == 1      # stride 2, strided 1 x 1
+    assert f32(2, 8, 8, 24, 64, 3, 1, 1, 0) == 0 and b16(2, 8, 8, 48, 64, 3, 1, 1) == 0                    # a k-tile would straddle taps
+    assert b16(2, 28, 28, 32, 64, 3, 1, 1) == 1 and b16(2, 8, 8, 64, 60, 3, 1, 1) == 0                     # C = 32 ring; 16-byte outputs
+    assert f32(2, 224, 224, 3, 64, 7, 2, 3, 0) == 0                                                        # the RGB stem
+    assert f32(2, 9, 9, 64, 64, 3, 1, 1, 0) == 1 and f32(2, 9, 9, 64, 64, 3, 1, 1, 1) == 0                 # 162 pixels: no whole k-tiles
+    assert f32(0, 8, 8, 64, 64, 3, 1, 1, 0) == 0 and f32(2, 2, 2, 64, 64, 7, 1, 1, 0) == 0                 # bad arguments
+    assert f32(1024, 224, 224, 64, 64, 3, 1, 1, 0) == 0                                                    # 2^24 pixels and more
+    # many output tiles: no K-slabs; few tiles and a long reduction: slabs (forward of the last stage at bs 2, every weight gradient)
+    assert lib.dkd_conv_igemm_f32_workspace_bytes(128, 56, 56, 64, 64, 3, 1, 1, 0) == 0
+    assert lib.dkd_conv_igemm_f32_workspace_bytes(2, 7, 7, 512, 512, 3, 1, 1, 0) > 0
+    ws = lib.dkd_conv_igemm_f32_workspace_bytes(128, 14, 14, 256, 256, 3, 1, 1, 1)
+    assert ws > 0 and ws % (256 * 9 * 256 * 4) == 0                                                        # whole [O, 9 C] slabs
+    assert lib.dkd_conv_igemm_bf16_workspace_bytes(128, 56, 56, 64, 64, 3, 1, 1) == 0
+    assert lib.dkd_conv_igemm_bf16_workspace_bytes(2, 7, 7, 512, 512, 3, 1, 1) > 0
