@@ -558,7 +558,12 @@ struct DmaStager {
 // instead of all in front of the tile's first fragment read - the order that won on every shape of the bf16 ring kernel.
 // PRIO (tuning variants 112 / 113, DKD_TUNING builds): s_setprio around the MFMA block (1) or around fragment reads + MFMA block (2) - the
 // wave that has its fragments wins the issue arbitration against the co-resident waves' address arithmetic and DMA issue.
-template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0, bool PEEL = false, bool SPREAD = false, int PRIO = 0>
+// PIPE (tuning variants 120-122, DKD_TUNING builds; UNVERIFIED beyond scripts/tune_v2.py's cross-check): the k-blocks' fragments are
+// double-buffered in registers (those of k-block kb + 1 are read under the MFMAs of kb) and the four k-steps of a block run
+// outermost over the wave's TM x TN accumulators (consecutive MFMAs never share an accumulator) - the schedule of the bf16 ring
+// kernel, meant for 128 x 128 tiles of 4 waves x (64 x 64): half the L2 -> LDS staging bytes per FLOP of the 64 x 64 tile.
+template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int KNOCK = 0, bool PEEL = false, bool SPREAD = false, int PRIO = 0,
+          bool PIPE = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda,
                                                                     const float* __restrict__ B, long ldb, float* C, long ldc,
                                                                     int M, int N, int K, int kchunk, Epilogue epi,
@@ -624,6 +629,43 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rs += DA::at(As, kk, tid);
         }
+        if constexpr (PIPE) {
+            float4 a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = DA::frag(As, (wm * TM + i) * 16, 0, g, i16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = DB::frag(As + A_SZ, (wn * TN + j) * 16, 0, g, i16);
+#pragma unroll
+            for (int kb = 0; kb < BK / 16; ++kb) {
+                const int c = kb & 1, n = c ^ 1;
+                if (kb + 1 < BK / 16) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[n][i] = DA::frag(As, (wm * TM + i) * 16, kb + 1, g, i16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[n][j] = DB::frag(As + A_SZ, (wn * TN + j) * 16, kb + 1, g, i16);
+                }
+                if (SPREAD && more) {
+                    if (kb == 0) da.issue(An, tid);
+                    if (kb == BK / 16 - 1) db.issue(An + A_SZ, tid);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][j].x, a[c][i].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][j].y, a[c][i].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][j].z, a[c][i].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][j].w, a[c][i].w, acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kb = 0; kb < BK / 16; ++kb) {
             float4 a[TM], b[TN];
@@ -649,6 +691,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_dma_kernel(const float* 
                 }
             if (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(0);
             if (PRIO == 3 && kb + 1 < BK / 16) __builtin_amdgcn_s_setprio(1);   // the next k-block's fragment reads
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt + 1 have landed
         if (!(knock & 8)) __syncthreads();
@@ -1086,7 +1129,7 @@ static bool dma_ok(const dkd_gemm_args* g, int kchunk) {
     if (g->rowsum && g->a_layout == 0) return false;
     return true;
 }
-template <int WM, int WN, int TM, int TN, int BK, int KNOCK = 0, bool SPREAD = false, int PRIO = 0>
+template <int WM, int WN, int TM, int TN, int BK, int KNOCK = 0, bool SPREAD = false, int PRIO = 0, bool PIPE = false>
 int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, hipStream_t st) {
     if (!dma_ok<BK>(g, kchunk)) return DKD_ERR_UNSUPPORTED;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -1094,7 +1137,7 @@ int launch_dma(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchu
     float* ws = splits > 1 ? g->workspace : nullptr;
     const int vec = epilogue_vec_ok(g);
 #define DKD_GEMM_LAUNCH3(AKC, BKC)                                                                                          \
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK, false, SPREAD, PRIO>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, TM, TN, BK, AKC, BKC, KNOCK, false, SPREAD, PRIO, PIPE>), grid, block, 0, st, g->A, g->lda, g->B, g->ldb, g->C, \
                        g->ldc, g->M, g->N, g->K, kchunk, epi, ws, g->rowsum, vec, 0, 0)
     if (g->a_layout == 0 && g->b_layout == 0) DKD_GEMM_LAUNCH3(true, true);
     else if (g->a_layout == 0 && g->b_layout == 1) DKD_GEMM_LAUNCH3(true, false);
@@ -1364,13 +1407,13 @@ static int pick_cfg(int M, int N, int K, int a_layout, int b_layout, int variant
 }
 static void cfg_tile(int cfg, int* bm, int* bn) {
     switch (cfg) {
-        case 1: case CFG_128x128_8W: *bm = 128; *bn = 128; break;
+        case 1: case CFG_128x128_8W: case 120: case 121: *bm = 128; *bn = 128; break;
         case CFG_128x96_4W: *bm = 128; *bn = 96; break;
         case 43: case 55: *bm = 64; *bn = 96; break;
         case 56: *bm = 96; *bn = 64; break;
         case 102: case 104: *bm = 128; *bn = 64; break;
         case 103: *bm = 64; *bn = 128; break;
-        case 44: case 100: case 101: case 111: case 112: case 113: case 114: case 115: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
+        case 44: case 100: case 101: case 111: case 112: case 113: case 114: case 115: case 122: case 130: case 131: case 132: case 133: case 134: *bm = 64; *bn = 64; break;
         case 52: *bm = 32; *bn = 64; break;
         default: *bm = 64; *bn = 128; break;  // 3, 5
     }
@@ -1491,6 +1534,10 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
 #ifdef DKD_TUNING  // s_setprio around the MFMA block / fragment reads + MFMA block (scripts/tune_v2.py 101,112,113)
         case 112: return launch_dma<2, 2, 2, 2, 32, 0, false, 1>(g, epi, splits, kchunk, st);
         case 113: return launch_dma<2, 2, 2, 2, 32, 0, false, 2>(g, epi, splits, kchunk, st);
+        // register-pipelined fragments, k-step-outermost MFMA order: 128 x 128 (4 waves of 64 x 64), spread DMA issue; 64 x 64 for reference
+        case 120: return launch_dma<2, 2, 4, 4, 32, 0, true, 0, true>(g, epi, splits, kchunk, st);
+        case 121: return launch_dma<2, 2, 4, 4, 32, 0, false, 0, true>(g, epi, splits, kchunk, st);
+        case 122: return launch_dma<2, 2, 2, 2, 32, 0, false, 0, true>(g, epi, splits, kchunk, st);
         case 114: return launch_dma<2, 2, 2, 2, 32, 0, false, 3>(g, epi, splits, kchunk, st);
         case 115: return launch_dma<2, 2, 2, 2, 32, 0, false, 4>(g, epi, splits, kchunk, st);
 #endif
