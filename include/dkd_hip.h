@@ -67,7 +67,8 @@ typedef struct dkd_gemm_args {
     float alpha;
     int32_t variant; /* 0 = automatic tile/schedule choice (the only value product code passes).  >0 pins a kernel for A/B
                         runs: 1-5 (32x32x2 family), 21-23 (bf16x3 tiles), 43/44/52/55/56 (16x16x4 family), 100/101 (LDS-DMA);
-                        130-134 are timing-only knock-outs that exist only in a -DDKD_TUNING build (else DKD_ERR_UNSUPPORTED);
+                        102-104 / 111-115 / 120-122 (larger tiles, DMA issue order, wave priority, register-pipelined fragments: measured and not kept,
+                        NOTES 9.21) and the timing-only knock-outs 130-134 exist only in a -DDKD_TUNING build (else DKD_ERR_UNSUPPORTED / BAD_ARG);
                         anything else: DKD_ERR_BAD_ARG */
     int32_t precision; /* DKD_PREC_F32 (exact fp32 MFMA, default), DKD_PREC_BF16X3 (3-way bf16 split of each fp32 operand,
                           6 MFMA products, fp32 accumulate: fp32-level accuracy) or DKD_PREC_BF16 (operands rounded to bf16
