@@ -17,43 +17,9 @@
 #include <cstdlib>
 #include "common.h"
 #include "dkd_hip.h"
+#include "gemm_f32_common.h"
 
 namespace {
-
-struct Epilogue {
-    const float* bias;
-    const float* colscale;
-    const float* residual;
-    float* preact;
-    long ldr;
-    int res_mod;
-    int act;
-    int row_grp, row_grp_stride, row_off;
-    float alpha;
-    int order;  // tile order experiment (DKD_TILE_ORDER, scripts/pmc_tile_order.sh): 0 = xcd_remap (shipped)
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == DKD_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == DKD_ACT_GELU) return gelu_f(v);
-    return v;
-}
-
-__device__ __forceinline__ void epilogue_store(const Epilogue& e, float* C, long ldc, int m, int n,
-                                               float acc) {
-    float v = acc * e.alpha;
-    if (e.bias) v += e.bias[n];
-    long orow = m;
-    if (e.row_grp > 0) orow = (long)(m / e.row_grp) * e.row_grp_stride + (m % e.row_grp) + e.row_off;
-    if (e.preact) e.preact[orow * ldc + n] = v;
-    v = apply_act(v, e.act);
-    if (e.colscale) v *= e.colscale[n];
-    if (e.residual) {
-        const long rr = e.res_mod > 0 ? (long)(m % e.res_mod) : orow;
-        v += e.residual[rr * e.ldr + n];
-    }
-    C[orow * ldc + n] = v;
-}
 
 // ---- tile staging -------------------------------------------------------------------------------
 // EXT = tile extent along the non-reduction index (BM or BN); KC = source is contiguous along k.
@@ -102,12 +68,6 @@ struct Stager {
     }
 };
 
-// XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of
-// logical tiles (bn fastest) -> the tiles that share an A row-panel hit the same L2.  Bijective for any grid.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk / 8, r = nblk % 8, x = bid % 8, j = bid / 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
 
 // DKD_TILE_ORDER experiment: 1 = the launch order itself (column tile fastest, consecutive tiles on different XCDs);
 // 2 = xcd_remap over row-panel PAIRS (the two row panels of a pair alternate, so 12 tiles share two A panels and each B tile twice)
@@ -323,33 +283,6 @@ struct Stager2 {
     }
 };
 
-__device__ __forceinline__ void epilogue_store4(const Epilogue& e, float* C, long ldc, int m, int n, int N, f32x4 acc, bool vec) {
-    if (!vec) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < N) epilogue_store(e, C, ldc, m, n + r, acc[r]);
-        return;
-    }
-    float4 v = make_float4(acc[0] * e.alpha, acc[1] * e.alpha, acc[2] * e.alpha, acc[3] * e.alpha);
-    if (e.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    long orow = m;
-    if (e.row_grp > 0) orow = (long)(m / e.row_grp) * e.row_grp_stride + (m % e.row_grp) + e.row_off;
-    if (e.preact) *reinterpret_cast<float4*>(e.preact + orow * ldc + n) = v;
-    v.x = apply_act(v.x, e.act); v.y = apply_act(v.y, e.act); v.z = apply_act(v.z, e.act); v.w = apply_act(v.w, e.act);
-    if (e.colscale) {
-        const float4 c = *reinterpret_cast<const float4*>(e.colscale + n);
-        v.x *= c.x; v.y *= c.y; v.z *= c.z; v.w *= c.w;
-    }
-    if (e.residual) {
-        const long rr = e.res_mod > 0 ? (long)(m % e.res_mod) : orow;
-        const float4 r = *reinterpret_cast<const float4*>(e.residual + rr * e.ldr + n);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
-    *reinterpret_cast<float4*>(C + orow * ldc + n) = v;
-}
 
 template <int WM, int WN, int TM, int TN, int BK, bool A_KC, bool B_KC, int PF = 2, bool EDGE = true>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_v2_kernel(const float* __restrict__ A, long lda,
@@ -1380,6 +1313,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvGeom cg, const 
 
 }  // namespace
 
+int dkd_f32_splitk_reduce(const dkd_gemm_args* g, const Epilogue& epi, int splits, hipStream_t st) { return launch_splitk_reduce(g, epi, splits, st); }
+
 // ---- automatic configuration --------------------------------------------------------------------------------------
 // Measured on MI355X (scripts/tune_v2.py over every GEMM shape of the config-[1] step, gpurun_out/tune_v2_*.log): the v2
 // family (16x16x4 MFMA, K-contiguous LDS rows, float4 epilogue) beats the 32x32x2 family on every shape, and within it SMALL
@@ -1456,6 +1391,13 @@ extern "C" long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, 
     return 0;
 }
 
+// what a DKD_PREC_BF16X3 launch of this shape needs: the split-precision kernels (gemm_x3.hip) plan their own K-slabs, and a shape
+// they do not take falls through to the paths above
+extern "C" long dkd_gemm_x3_workspace_bytes(int M, int N, int K, int a_layout, int b_layout) {
+    const long x3 = dkd_x3_workspace_bytes(M, N, K, a_layout, b_layout), f32 = dkd_gemm_f32_workspace_bytes(M, N, K, a_layout, b_layout);
+    return f32 > x3 ? f32 : x3;
+}
+
 extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || !g->A || !g->B || !g->C) return DKD_ERR_BAD_ARG;
     // float4 staging: contiguous extent of each operand and its leading dimension must be multiples of 4
@@ -1477,6 +1419,11 @@ extern "C" int dkd_gemm_f32(const dkd_gemm_args* g, void* stream) {
     epi.alpha = g->alpha;
     static const int tile_order_env = getenv("DKD_TILE_ORDER") ? atoi(getenv("DKD_TILE_ORDER")) : 0;
     epi.order = tile_order_env;
+    if (g->precision == DKD_PREC_BF16X3 && (g->variant == 0 || (g->variant >= 31 && g->variant <= 49))) {
+        // the LDS-DMA ring kernels of gemm_x3.hip (every layout of the step); ragged reductions fall through to the older paths
+        const int rc = dkd_x3_launch(g, epi, (hipStream_t)stream);
+        if (rc != DKD_ERR_UNSUPPORTED) return rc;
+    }
     if ((g->precision == DKD_PREC_BF16 || g->precision == DKD_PREC_BF16X3) && g->a_layout == 1 && g->b_layout == 1 && !g->rowsum &&
         g->variant == 0) {
         const int max_sp = auto_splits(g->M, g->N, g->K, 1, 1);  // the workspace was sized for this many slabs

@@ -1,0 +1,604 @@
+// bf16x3 split-precision GEMM on the bf16 matrix cores, LDS-DMA ring (dkd_gemm_args.precision = DKD_PREC_BF16X3).
+//
+// fp32 operands in HBM, fp32 result: every operand value x is split into three bf16 terms x = hi + mid + lo (round-to-nearest at
+// every level: 8 + 8 + 8 significant bits and their signs cover the 24-bit significand, the split is exact) and the product keeps the
+// six largest cross terms
+//     a b ~= a_hi b_hi + (a_hi b_mid + a_mid b_hi) + (a_mid b_mid + a_hi b_lo + a_lo b_hi)         dropped: <= 2^-25 |a| |b|
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - below the rounding of an fp32 product, measured 5e-7 ... 8e-7 of the fp64
+// result where the exact v_mfma_f32_16x16x4_f32 kernel (gemm_f32.hip) sits at 1e-6 - at 16 / 6 = 2.7x the fp32 matrix rate.  The
+// arithmetic class of the reference's own fp32 mode: torch.set_float32_matmul_precision('high') (/root/reference/train.py:304).
+// Same contract, layouts and fused epilogue as dkd_gemm_f32 (forward NT, dgrad NN, weight gradient TN with K-slabs).
+//
+// Pipeline (the schedule of gemm_bf16_ring.hip on fp32 operand tiles):
+//   * fp32 tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a ring of NS stages, a
+//     counted s_waitcnt vmcnt retires the tile that is read next, ONE s_barrier per k-tile publishes it and frees the stage that is
+//     overwritten next; the k-loop is unrolled over the ring so every LDS address is lane base + immediate;
+//   * K-contiguous operand: [rows][BK] fp32 image, the 16-byte chunk index XOR-ed with (row / rows-per-256-B) on the SOURCE address
+//     (an LDS-DMA image is lane-linear) - conflict-free ds_read_b128 under gfx950's 16-lane service groups; M / N-contiguous operand
+//     (dgrad's weight, both operands of a weight gradient): the tile as it lies, [BK][cols], read by ds_read_b32 with 32 consecutive
+//     columns per half-wave (conflict-free as it stands);
+//   * each lane's fragment (8 consecutive k of its row, fp32) is split into the three bf16 fragments IN REGISTERS - 5.5 VALU
+//     instructions per value (v_cvt_pk_bf16_f32, shift / mask back, v_sub_f32) beside 6 MFMAs per fragment pair: the wave tile
+//     (64 x 64 ... 64 x 128) sets how many VALU issue slots a matrix instruction has to cover, the tuning axis of this kernel;
+//   * LDS-transposed epilogue (whole 128 ... 384-byte runs per output row) into the shared fp32 epilogue of dkd_gemm_f32.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "dkd_hip.h"
+#include "gemm_f32_common.h"
+
+namespace {
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One fp32 operand's share of a ring stage: BX rows (m or n) x BK k.
+template <int BX, int BK, bool KC, int NW>
+struct RingF {
+    static constexpr int BYTES = BX * BK * 4, PIECES = BYTES / 1024, PPW = PIECES / NW;
+    static_assert(BYTES % 1024 == 0 && PIECES % NW == 0 && PPW >= 1, "an operand tile must split into whole 1 KiB pieces per wave");
+    static_assert(BK == 16 || BK == 32, "k-tile of 16 or 32");
+    static constexpr int CPR = BK / 4;   // K-contiguous image: 16-byte chunks per row
+    static constexpr int RP = 64 / BK;   //                     rows per 256-byte bank period
+    static constexpr int CPK = BX / 4;   // M / N-contiguous image: chunks per k-row
+    const char* base;                    // wave-uniform, advanced by `step` per k-tile
+    unsigned off[PPW];                   // per lane, fixed for the whole launch
+    long step;
+
+    static __device__ __forceinline__ int swz(int row) { return (row / RP) & (CPR - 1); }
+
+    __device__ __forceinline__ void init(const float* __restrict__ P, long ld, int x0, int xmax, int k0, int wid, int lane) {
+        step = KC ? (long)BK * 4 : (long)BK * ld * 4;
+        base = reinterpret_cast<const char*>(KC ? P + (long)x0 * ld + k0 : P + (long)k0 * ld + x0);
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int idx = (wid + p * NW) * 64 + lane;
+            if (KC) {
+                const int row = idx / CPR, slot = idx % CPR;
+                const int chunk = slot ^ swz(row);
+                off[p] = (unsigned)(((long)(min(x0 + row, xmax - 1) - x0) * ld + 4 * chunk) * 4);
+            } else {
+                const int krow = idx / CPK, slot = idx % CPK;
+                off[p] = (unsigned)(((long)krow * ld + (min(x0 + 4 * slot, xmax - 4) - x0)) * 4);
+            }
+        }
+    }
+    template <int P0, int P1>
+    __device__ __forceinline__ void issue_part(char* __restrict__ S, int wid) {
+#pragma unroll
+        for (int p = P0; p < P1; ++p)
+            if (p < PPW)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (unsigned long)off[p]), (lds_void_t*)(S + (wid + p * NW) * 1024), 16, 0, 0);
+    }
+    __device__ __forceinline__ void advance() { base += step; }
+    __device__ __forceinline__ void issue(char* __restrict__ S, int wid) {
+        issue_part<0, PPW>(S, wid);
+        advance();
+    }
+    // the lane's part of every fragment address of this operand (computed once per launch)
+    static __device__ __forceinline__ int lane_base(int lane) {
+        const int l31 = lane & 31, half = lane >> 5;
+        if (KC) return l31 * (BK * 4) + 16 * ((2 * half) ^ swz(l31));  // rows r0 + l31 with r0 % 32 == 0: swz(r0 + l31) = swz(l31) ^ swz(r0)
+        return (8 * half * BX + l31) * 4;
+    }
+    // fragment = 8 consecutive k (16 ks + 8 half ...) of row r0 + l31; lb = lane_base
+    static __device__ __forceinline__ void frag(const char* __restrict__ S, int lb, int r0, int ks, float (&v)[8]) {
+        if (KC) {
+            // chunk (4 ks + 2 half + e) ^ swz(row): the lane part is in lb, the tile part (r0, ks) is an XOR of address bits 4 .. 6
+            const int x = 16 * ((4 * ks) ^ swz(r0));  // swz(r0 + l31) = swz(r0) ^ swz(l31) for r0 % 32 == 0 (no carry into the masked bits)
+            const float4 lo = *reinterpret_cast<const float4*>(S + r0 * (BK * 4) + (lb ^ x));
+            const float4 hi = *reinterpret_cast<const float4*>(S + r0 * (BK * 4) + (lb ^ x ^ 16));
+            v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+        } else {
+            const float* p = reinterpret_cast<const float*>(S + lb) + (16 * ks) * BX + r0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[j * BX];
+        }
+    }
+};
+
+// x = h + m + l.  Two values at a time, so that one v_cvt_pk_bf16_f32 rounds a pair: 3 conversions, 2 + 2 shift / mask operations
+// back to fp32 and 4 subtractions per pair = 5.5 VALU instructions per value (written element by element hipcc converts every value
+// on its own: 10 per value, measured 2.3x the matrix time).  TRUNC: the terms cut instead of rounded (v_and / v_perm_b32 only, no
+// conversion instruction): still an exact split (8 + 8 + 8 significant bits), the dropped cross terms are then <= 2^-21 |a| |b| and
+// one-signed - a relative scaling of the result by at most 1 + 5e-7.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned as_u(float f) { return __builtin_bit_cast(unsigned, f); }
+template <bool TRUNC>
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 hp, mp, lp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = x[2 * e], x1 = x[2 * e + 1];
+        if (TRUNC) {
+            const float r0 = x0 - as_f(as_u(x0) & 0xffff0000u), r1 = x1 - as_f(as_u(x1) & 0xffff0000u);
+            const float s0 = r0 - as_f(as_u(r0) & 0xffff0000u), s1 = r1 - as_f(as_u(r1) & 0xffff0000u);
+            hp[e] = __builtin_amdgcn_perm(as_u(x1), as_u(x0), 0x07060302u);  // {x1.hi16, x0.hi16}
+            mp[e] = __builtin_amdgcn_perm(as_u(r1), as_u(r0), 0x07060302u);
+            lp[e] = __builtin_amdgcn_perm(as_u(s1), as_u(s0), 0x07060302u);
+        } else {
+            const unsigned hh = cvt2(x0, x1);
+            const float r0 = x0 - as_f(hh << 16), r1 = x1 - as_f(hh & 0xffff0000u);
+            const unsigned mm = cvt2(r0, r1);
+            const float s0 = r0 - as_f(mm << 16), s1 = r1 - as_f(mm & 0xffff0000u);
+            hp[e] = hh;
+            mp[e] = mm;
+            lp[e] = cvt2(s0, s1);
+        }
+    }
+    h = __builtin_bit_cast(bf16x8, hp);
+    m = __builtin_bit_cast(bf16x8, mp);
+    l = __builtin_bit_cast(bf16x8, lp);
+}
+
+// WGM x WGN waves, each a (32 TM) x (32 TN) tile; BM = 32 TM WGM, BN = 32 TN WGN; k-tile BK; NS ring stages.
+// PIPE: software pipeline over the k-blocks (16 k each).  A wave is in-order: with the split in front of its MFMAs a k-block costs
+// [8 DMA issues] + [176 VALU] + [24 MFMA] one after the other and the matrix pipe is fed 40-50 % of the time whatever the co-resident
+// waves do (measured: 110-117 TF/s fp32-equivalent, the VALU count hardly matters).  Here the fragments of k-block n + 1 are read and
+// split into a second register set WHILE the MFMAs of k-block n run from the first (sched_group_barrier pins the interleave: one MFMA,
+// then its share of the next block's VALU work), and the tile hand-over (counted wait, barrier, next DMA issue) sits between two
+// such phases - so each phase is one branch-free scheduling region.  Two stages (the parity of the register sets is then static).
+// ROWSUM (weight-gradient layout): every wave also sums the A fragments it reads anyway (exact fp32; 8 adds per fragment) and the waves
+// of the first column tile store the bias gradient.
+// KNOCK (only in a -DDKD_TUNING build; timing experiments whose RESULTS ARE WRONG): 1 = no split (the raw bits as fragments),
+// 2 = no MFMAs, 4 = no DMA inside the k-loop, 8 = no barrier.
+template <int TM, int TN>
+struct Planes {
+    bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+};
+
+template <int WGM, int WGN, int TM, int TN, int BK, int NS, bool A_KC, bool B_KC, int OCC, bool TRUNC, bool PIPE, bool ROWSUM, int KNOCK>
+__global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                                           long ldb, float* C, long ldc, int M, int N, int K, int kchunk,
+                                                                           Epilogue epi, float* __restrict__ ws, float* __restrict__ rowsum,
+                                                                           int vec_ok) {
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NW = WGM * WGN, KB = BK / 16;
+    using RA = RingF<BM, BK, A_KC, NW>;
+    using RB = RingF<BN, BK, B_KC, NW>;
+    constexpr int STAGE = RA::BYTES + RB::BYTES, PW = RA::PPW + RB::PPW;
+    static_assert(NS >= 2 && NS <= 4, "2 .. 4 stages");
+    static_assert(!PIPE || NS == 2, "the pipelined schedule is written for two stages");
+    static_assert((NS - 1) * PW < 64, "vmcnt range");
+    static_assert(!ROWSUM || !A_KC, "row sums of the [K][M] operand");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WGN, wn = wid % WGN, half = lane >> 5, l31 = lane & 31;
+    const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+    const int bm0 = (tile / nbn) * BM, bn0 = (tile % nbn) * BN;
+    const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg) / BK;  // (the host only sends whole k-tiles here)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float rs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+
+    RA ra;
+    RB rb;
+    ra.init(A, lda, bm0, M, kbeg, wid, lane);
+    rb.init(B, ldb, bn0, N, kbeg, wid, lane);
+    const int lba = RA::lane_base(lane), lbb = RB::lane_base(lane);
+
+    // fragments of k-block ks of the tile in stage st -> three bf16 planes each
+    // live: the tile exists (the pipelined schedule reads one k-block past the end, stale LDS: never multiplied, never summed)
+    auto load_split = [&](int st, int ks, Planes<TM, TN>& P, bool live) {
+        const char* As = smem + st * STAGE;
+        const char* Bs = As + RA::BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[8];
+            RA::frag(As, lba, wm * (32 * TM) + i * 32, ks, v);
+            if (ROWSUM) {
+                const float sv = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                rs[i] += live ? sv : 0.f;  // (a select, not a branch: the phase stays one scheduling region)
+            }
+            if (KNOCK & 1) {
+                u32x4 t = {as_u(v[0]), as_u(v[1]), as_u(v[2]), as_u(v[3])}, u = {as_u(v[4]), as_u(v[5]), as_u(v[6]), as_u(v[7])};
+                P.ah[i] = __builtin_bit_cast(bf16x8, t), P.am[i] = __builtin_bit_cast(bf16x8, u), P.al[i] = P.ah[i];
+            } else {
+                split8<TRUNC>(v, P.ah[i], P.am[i], P.al[i]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float v[8];
+            RB::frag(Bs, lbb, wn * (32 * TN) + j * 32, ks, v);
+            if (KNOCK & 17) {
+                u32x4 t = {as_u(v[0]), as_u(v[1]), as_u(v[2]), as_u(v[3])}, u = {as_u(v[4]), as_u(v[5]), as_u(v[6]), as_u(v[7])};
+                P.bh[j] = __builtin_bit_cast(bf16x8, t), P.bm[j] = __builtin_bit_cast(bf16x8, u), P.bl[j] = P.bh[j];
+            } else {
+                split8<TRUNC>(v, P.bh[j], P.bm[j], P.bl[j]);
+            }
+        }
+    };
+    auto mma = [&](const Planes<TM, TN>& P) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {  // D^T: rows = n, lanes = m; smallest cross terms first
+                if (KNOCK & 2) {
+                    asm volatile("" ::"v"(P.ah[i]), "v"(P.am[i]), "v"(P.al[i]), "v"(P.bh[j]), "v"(P.bm[j]), "v"(P.bl[j]));
+                    continue;
+                }
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bh[j], P.al[i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bl[j], P.ah[i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bm[j], P.am[i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bh[j], P.am[i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bm[j], P.ah[i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bh[j], P.ah[i], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
+
+    if constexpr (PIPE) {
+        // one phase = the MFMAs of the current k-block from one register set + the reads and the split of the next into the other
+        constexpr int NMMA = 6 * TM * TN, NREAD = (A_KC ? 2 : 8) * TM + (B_KC ? 2 : 8) * TN;
+        constexpr int NVALU = 44 * (TM + TN) + (ROWSUM ? 8 * TM : 0);
+        constexpr int LEAD = NMMA >= 8 ? 2 : 1, PER = (NVALU + NMMA - LEAD - 1) / (NMMA - LEAD);
+        auto interleave = [&]() {  // reads first, LEAD MFMAs over their latency, then one MFMA : PER VALU
+            if (KNOCK & 3) return;
+            __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
+#pragma unroll
+            for (int q = 0; q < NMMA - LEAD; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        };
+        // the freshly split planes are pinned at the end of their phase: without it the split (pure register arithmetic whose first
+        // use is the NEXT phase's MFMAs) sinks below the hand-over's barrier into the block of its use and the phase runs its MFMAs bare
+        auto pin = [&](Planes<TM, TN>& P) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(P.ah[i]), "+v"(P.am[i]), "+v"(P.al[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(P.bh[j]), "+v"(P.bm[j]), "+v"(P.bl[j]));
+        };
+        Planes<TM, TN> P0, P1;
+        if (nk > 0) {
+            ra.issue(smem, wid);
+            rb.issue(smem + RA::BYTES, wid);
+        }
+        if (nk > 1) {
+            ra.issue(smem + STAGE, wid);
+            rb.issue(smem + STAGE + RA::BYTES, wid);
+            wait_vm<PW>();
+        } else {
+            wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        load_split(0, 0, P0, nk > 0);
+        for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int kt = kt0 + st;
+                if (kt >= nk) break;
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const bool even = ((st * KB + ks) & 1) == 0;  // (static after unrolling: 2 KB phases per trip)
+                    if (ks + 1 < KB) {
+                        if (even) { load_split(st, ks + 1, P1, true); mma(P0); } else { load_split(st, ks + 1, P0, true); mma(P1); }
+                        interleave();
+                        if (even) pin(P1); else pin(P0);
+                    } else {
+                        // hand-over: tile kt + 1 has landed in the other stage; behind the barrier nobody reads tile kt's stage any
+                        // more (its last fragments went into registers in the previous phase): tile kt + 2 may land there
+                        __builtin_amdgcn_sched_barrier(0);
+                        wait_vm<0>();
+                        if (!(KNOCK & 8)) __builtin_amdgcn_s_barrier();
+                        if (kt + 2 < nk && !(KNOCK & 4)) {
+                            ra.issue(smem + st * STAGE, wid);
+                            rb.issue(smem + st * STAGE + RA::BYTES, wid);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // (past the last tile this reads stale LDS into a register set that is never multiplied)
+                        {
+                            const bool live = kt + 1 < nk;
+                            if (even) { load_split(st ^ 1, 0, P1, live); mma(P0); } else { load_split(st ^ 1, 0, P0, live); mma(P1); }
+                        }
+                        interleave();
+                        if (even) pin(P1); else pin(P0);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) {
+                ra.issue(smem + s * STAGE, wid);
+                rb.issue(smem + s * STAGE + RA::BYTES, wid);
+            }
+        for (int kt0 = 0; kt0 < nk; kt0 += NS) {
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {  // stage of tile kt: a compile-time constant, so are all LDS offsets below
+                const int kt = kt0 + st;
+                if (kt >= nk) break;
+                // tiles kt .. min(nk, kt + NS - 1) - 1 are in flight: retire tile kt, leave the younger ones
+                const int younger = min(nk - 1 - kt, NS - 2);
+                if (younger >= 2) wait_vm<(NS > 3 ? 2 : 0) * PW>();
+                else if (younger == 1) wait_vm<(NS > 2 ? 1 : 0) * PW>();
+                else wait_vm<0>();
+                if (!(KNOCK & 8)) __builtin_amdgcn_s_barrier();  // tile kt is visible to every wave; nobody reads stage (kt - 1) % NS any more
+                const int sn = st == 0 ? NS - 1 : st - 1;  // == (kt + NS - 1) % NS
+                if (kt + NS - 1 < nk && !(KNOCK & 4)) {
+                    ra.issue(smem + sn * STAGE, wid);
+                    rb.issue(smem + sn * STAGE + RA::BYTES, wid);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    Planes<TM, TN> P;
+                    load_split(st, ks, P, true);
+                    mma(P);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue.  The accumulators hold D^T: lane (l31, half) owns output row m and, per register quad q of tile j, the columns
+    // 32 j + 8 q + 4 half + (0..3).  Each 32 x (32 TN) slab of the wave goes through a per-wave LDS tile (fp32, rows of 32 TN + 4
+    // floats: conflict-free b128 stores) and comes back row-contiguous: whole 128 (TN) byte runs per output row and instruction
+    // for the residual loads and the stores.  LDS operations of one wave execute in order: no barrier between a wave's own stores
+    // and loads; the one barrier in front frees the ring stages.
+    const bool partial = ws != nullptr;
+    if (ROWSUM && rowsum != nullptr && bn0 == 0 && wn == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s = rs[i] + __shfl_xor(rs[i], 32, 64);  // the two k-halves of the row
+            const int m = bm0 + wm * (32 * TM) + i * 32 + l31;
+            if (half == 0 && m < M) {
+                if (partial) ws[(long)gridDim.y * M * N + (long)blockIdx.y * M + m] = s;
+                else rowsum[m] = s * epi.alpha;
+            }
+        }
+    }
+    constexpr int TP = 32 * TN + 4, Q = 8 * TN;  // floats per LDS row; float4 per output row of the slab
+    __syncthreads();
+    float* T = reinterpret_cast<float*>(smem) + wid * (32 * TP);
+    float* out = partial ? ws + (long)blockIdx.y * M * N : C;
+    const bool vec = vec_ok != 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mt0 = bm0 + wm * (32 * TM) + i * 32, nt0 = bn0 + wn * (32 * TN);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(T + l31 * TP + 32 * j + 8 * q + 4 * half) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if (vec) {
+#pragma unroll
+            for (int p = 0; p < (32 * Q) / 64; ++p) {
+                const int idx = p * 64 + lane, r = idx / Q, c = 4 * (idx % Q);
+                const int m = mt0 + r, n = nt0 + c;
+                const float4 q4 = *reinterpret_cast<const float4*>(T + r * TP + c);
+                if (m < M && n < N) {
+                    if (partial) *reinterpret_cast<float4*>(out + (long)m * N + n) = q4;
+                    else epilogue_store4(epi, C, ldc, m, n, N, f32x4{q4.x, q4.y, q4.z, q4.w}, true);
+                }
+            }
+        } else {  // ragged N / unaligned epilogue operands: element by element, not unrolled (code size)
+#pragma unroll 1
+            for (int p = 0; p < (32 * Q) / 64; ++p) {
+                const int idx = p * 64 + lane, r = idx / Q, c = 4 * (idx % Q);
+                const int m = mt0 + r, n = nt0 + c;
+                const float4 q4 = *reinterpret_cast<const float4*>(T + r * TP + c);
+                if (m < M && n < N) {
+                    const float v[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll 1
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) {
+                            if (partial) out[(long)m * N + n + e] = v[e];
+                            else epilogue_store(epi, C, ldc, m, n + e, v[e]);
+                        }
+                }
+            }
+        }
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, int NS, int OCC = 1, bool TRUNC = false, bool PIPE = false, int KNOCK = 0>
+struct X3Cfg {
+    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NW = WGM * WGN;
+    static constexpr int RING = NS * (BM + BN) * BK * 4, EPI = NW * 32 * (32 * TN + 4) * 4;
+    static constexpr int LDS = RING > EPI ? RING : EPI;
+
+    template <bool AKC, bool BKC, bool RSUM>
+    static int launch_layout(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
+        auto kern = gemm_x3_ring_kernel<WGM, WGN, TM, TN, BK, NS, AKC, BKC, OCC, TRUNC, PIPE, RSUM, KNOCK>;
+        static bool attr_done = false;  // (one flag per instantiation; a benign race: the attribute call is idempotent)
+        if (!attr_done && LDS > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr_done = true;
+        const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(NW * 64);
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc, g->M, g->N, g->K, kchunk, epi,
+                           splits > 1 ? g->workspace : (float*)nullptr, g->rowsum, vec);
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
+    static int launch(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
+        if (g->a_layout == 0 && g->b_layout == 0) return launch_layout<true, true, false>(g, epi, splits, kchunk, vec, st);
+        if (g->a_layout == 0 && g->b_layout == 1) return launch_layout<true, false, false>(g, epi, splits, kchunk, vec, st);
+        if (g->a_layout == 1 && g->b_layout == 1)
+            return g->rowsum ? launch_layout<false, false, true>(g, epi, splits, kchunk, vec, st)
+                             : launch_layout<false, false, false>(g, epi, splits, kchunk, vec, st);
+        return DKD_ERR_UNSUPPORTED;
+    }
+};
+
+// configurations (variant 30 + c pins one for A/B runs; 0 = automatic).  P = software-pipelined k-blocks
+//   1: 128 x 128, 4 waves of 64 x 64, BK 32, 2 stages, P (64 KB of LDS: two workgroups per CU)
+//   3: 128 x 128, 2 waves of 64 x 128, BK 32, 2 stages, P (64 KB; 5.5 instead of 7.3 split instructions per MFMA, one wave per SIMD)
+//   4: 128 x 128, 4 waves of 64 x 64, BK 16, 3 stages, not pipelined (48 KB: three per CU)
+//   8: 128 x 128, 4 waves of 64 x 64, BK 16, 2 stages, P (32 KB; reductions that are a multiple of 16 only)
+//   9: 64 x 128, 2 waves of 64 x 64, BK 32, 2 stages, P (48 KB: three per CU)
+//   10: as 1, not pipelined
+//   11-15 (-DDKD_TUNING only): knock-outs of 1 - no split, no MFMAs, no DMA in the loop, no barrier, no split of B
+// Measured (scripts/tune_x3.py over the 39 GEMM shapes of the configs[1] step, profiles/r04_x3_*): per-step GEMM time 35.0 ms exact ->
+// 28.6 (1 everywhere) -> 27 ms with the choice below; also built and dropped: 128 x 192 / 128 x 256 / 256 x 128 tiles (64 x 96 ... 128 x 64
+// per wave: one workgroup per CU, nothing covers a wave's LDS and barrier waits: 37-94 TF/s), the truncating split (same speed).
+typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true> Cfg1;
+typedef X3Cfg<2, 1, 2, 4, 32, 2, 1, false, true> Cfg3;
+typedef X3Cfg<2, 2, 2, 2, 16, 3, 2> Cfg4;
+typedef X3Cfg<2, 2, 2, 2, 16, 2, 2, false, true> Cfg8;
+typedef X3Cfg<1, 2, 2, 2, 32, 2, 2, false, true> Cfg9;
+typedef X3Cfg<2, 2, 2, 2, 32, 2, 2> Cfg10;
+#ifdef DKD_TUNING
+typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true, 1> Cfg11;
+typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true, 2> Cfg12;
+typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true, 4> Cfg13;
+typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true, 8> Cfg14;
+typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, true, true, 16> Cfg15;
+constexpr int NCFG = 15;
+#else
+constexpr int NCFG = 10;
+#endif
+
+bool cfg_exists(int cfg) { return cfg == 1 || cfg == 3 || cfg == 4 || (cfg >= 8 && cfg <= NCFG); }
+
+void cfg_dims(int cfg, int* bm, int* bn, int* bk, int* per_cu) {
+    switch (cfg) {
+        case 3: *bm = Cfg3::BM, *bn = Cfg3::BN, *bk = 32, *per_cu = 2; break;
+        case 4: *bm = Cfg4::BM, *bn = Cfg4::BN, *bk = 16, *per_cu = 3; break;
+        case 8: *bm = Cfg8::BM, *bn = Cfg8::BN, *bk = 16, *per_cu = 2; break;
+        case 9: *bm = Cfg9::BM, *bn = Cfg9::BN, *bk = 32, *per_cu = 3; break;
+        default: *bm = Cfg1::BM, *bn = Cfg1::BN, *bk = 32, *per_cu = 2; break;
+    }
+}
+
+int env_cfg() {
+    static const int c = getenv("DKD_X3_CFG") ? atoi(getenv("DKD_X3_CFG")) : 0;
+    return c;
+}
+
+int pick_cfg(int M, int N, int K, int a_layout, int b_layout, int variant) {
+    if (variant > 30 && cfg_exists(variant - 30)) return variant - 30;
+    if (cfg_exists(env_cfg())) return env_cfg();
+    if (K % 32) return 8;
+    if (K < 256) return 4;  // (one or two k-tiles of 32 would be all prologue)
+    const long t128 = (long)dkd_cdiv(M, 128) * dkd_cdiv(N, 128);
+    // weight gradients and the few-tile shapes: long reductions in K-slabs, where the 64 x 128 wave tile's lower split cost shows
+    if ((a_layout == 1 && b_layout == 1) || t128 < 256) return 3;
+    // 128 x 128 (two per CU) or 64 x 128 (three per CU): whichever fills the chip's rounds better (M = 16384, N = 384: 384 of 512 against
+    // 768 of 768 slots; M = 64 * 257: 387 of 512 against 771 of 1536), the larger tile at a tie
+    const long t64 = (long)dkd_cdiv(M, 64) * dkd_cdiv(N, 128);
+    const double e1 = (double)t128 / (double)((t128 + 511) / 512 * 512), e9 = (double)t64 / (double)((t64 + 767) / 768 * 768);
+    return (K >= 1024 && e9 > e1 + 0.1) ? 9 : 1;
+}
+
+// K-slabs only when the output grid alone leaves most of the chip idle (weight gradients; the few-tile long-K forward shapes)
+int pick_splits(int M, int N, int K, int cfg) {
+    int bm, bn, bk, per_cu;
+    cfg_dims(cfg, &bm, &bn, &bk, &per_cu);
+    const long tiles = (long)dkd_cdiv(M, bm) * dkd_cdiv(N, bn), slots = 256L * per_cu;
+    if (tiles * 4 > slots * 3 || K < 512) return 1;
+    long want = slots / tiles, maxk = K / 256;
+    if (want > maxk) want = maxk;
+    if (want > 128) want = 128;
+    return want < 1 ? 1 : (int)want;
+}
+
+int plan(int M, int N, int K, int cfg, int* kchunk) {
+    int bm, bn, bk, per_cu;
+    cfg_dims(cfg, &bm, &bn, &bk, &per_cu);
+    int splits = pick_splits(M, N, K, cfg);
+    *kchunk = K;
+    if (splits > 1) {
+        *kchunk = ((K + splits - 1) / splits + bk - 1) / bk * bk;
+        splits = (K + *kchunk - 1) / *kchunk;
+    }
+    return splits;
+}
+
+bool x3_ok(int M, int N, int K, int a_layout, int b_layout) {
+    // whole 16-deep k-blocks; reductions under 96 stay on the exact kernel (nothing to amortise the split over: those launches are bound
+    // by their output traffic either way)
+    if ((K % 16) || K < 96) return false;
+    if (a_layout == 1 && b_layout == 0) return false;
+    if (a_layout == 1 && ((M & 3) || M < 4)) return false;
+    if (b_layout == 1 && ((N & 3) || N < 4)) return false;
+    return true;
+}
+
+int epilogue_vec_ok_x3(const dkd_gemm_args* g) {
+    int vec = (g->N % 4 == 0) && (g->ldc % 4 == 0) && dkd_aligned16(g->C);
+    if (g->bias && !dkd_aligned16(g->bias)) vec = 0;
+    if (g->colscale && !dkd_aligned16(g->colscale)) vec = 0;
+    if (g->preact && !dkd_aligned16(g->preact)) vec = 0;
+    if (g->residual && (!dkd_aligned16(g->residual) || (g->ldr % 4))) vec = 0;
+    return vec;
+}
+}  // namespace
+
+long dkd_x3_workspace_bytes(int M, int N, int K, int a_layout, int b_layout) {
+    if (!x3_ok(M, N, K, a_layout, b_layout)) return 0;
+    long best = 0;
+    for (int cfg = 1; cfg <= NCFG; ++cfg) {  // (any configuration the launcher may take for this shape, pinned ones included)
+        if (!cfg_exists(cfg)) continue;
+        int bm, bn, bk, per_cu, kchunk;
+        cfg_dims(cfg, &bm, &bn, &bk, &per_cu);
+        if (K % bk) continue;
+        const int splits = plan(M, N, K, cfg, &kchunk);
+        const long b = splits > 1 ? (long)splits * ((long)M * N + M) * (long)sizeof(float) : 0;
+        if (b > best) best = b;
+    }
+    return best;
+}
+
+int dkd_x3_launch(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st) {
+    if (!x3_ok(g->M, g->N, g->K, g->a_layout, g->b_layout)) return DKD_ERR_UNSUPPORTED;
+    if (g->rowsum && g->a_layout == 0) return DKD_ERR_UNSUPPORTED;
+    const int cfg = pick_cfg(g->M, g->N, g->K, g->a_layout, g->b_layout, g->variant);
+    int bm, bn, bk, per_cu, kchunk;
+    cfg_dims(cfg, &bm, &bn, &bk, &per_cu);
+    if (g->K % bk) return DKD_ERR_UNSUPPORTED;
+    int splits = plan(g->M, g->N, g->K, cfg, &kchunk);
+    if (splits > 1 && (!g->workspace || !dkd_aligned16(g->workspace))) {
+        splits = 1;
+        kchunk = g->K;
+    }
+    const int vec = epilogue_vec_ok_x3(g);
+    int rc;
+    switch (cfg) {
+        case 1: rc = Cfg1::launch(g, epi, splits, kchunk, vec, st); break;
+        case 3: rc = Cfg3::launch(g, epi, splits, kchunk, vec, st); break;
+        case 4: rc = Cfg4::launch(g, epi, splits, kchunk, vec, st); break;
+        case 8: rc = Cfg8::launch(g, epi, splits, kchunk, vec, st); break;
+        case 9: rc = Cfg9::launch(g, epi, splits, kchunk, vec, st); break;
+        case 10: rc = Cfg10::launch(g, epi, splits, kchunk, vec, st); break;
+#ifdef DKD_TUNING
+        case 11: rc = Cfg11::launch(g, epi, splits, kchunk, vec, st); break;
+        case 12: rc = Cfg12::launch(g, epi, splits, kchunk, vec, st); break;
+        case 13: rc = Cfg13::launch(g, epi, splits, kchunk, vec, st); break;
+        case 14: rc = Cfg14::launch(g, epi, splits, kchunk, vec, st); break;
+        case 15: rc = Cfg15::launch(g, epi, splits, kchunk, vec, st); break;
+#endif
+        default: return DKD_ERR_BAD_ARG;
+    }
+    if (rc != DKD_OK) return rc;
+    if (splits > 1) return dkd_f32_splitk_reduce(g, epi, splits, st);
+    return DKD_OK;
+}

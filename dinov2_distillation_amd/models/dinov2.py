@@ -75,7 +75,7 @@ class Block(nn.Module):
         one chain must be complete before the other chain can even enqueue a read (once per block and precision change;
         inside a hipGraph capture the copies exist already from the warm-up steps)."""
         prec = ops.GEMM_PRECISION if self.precision is None else self.precision
-        if prec == ops.PREC_F32:
+        if prec != ops.PREC_BF16:  # (exact fp32 and the split-precision kernels read the weight as it lies)
             return None
         p = self.prepared()
         if "t_" + name not in p:

@@ -86,10 +86,11 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
         out = torch.empty((out_rows, N), dtype=torch.float32, device=a.device)
     _chk(out, "out")
     ldc = N if ldc is None else ldc
-    wsb = _size("dkd_gemm_f32_workspace_bytes", M, N, K, a_layout, b_layout)
+    prec = GEMM_PRECISION if precision is None else precision
+    wsb = _size("dkd_gemm_x3_workspace_bytes" if prec == PREC_BF16X3 else "dkd_gemm_f32_workspace_bytes", M, N, K, a_layout, b_layout)
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     check(_GEMM32(A=_p(a2), lda=lda, B=_p(b2), ldb=ldb, C=_p(out), ldc=ldc, bias=_p(bias), colscale=_p(colscale), residual=_p(residual),
-                  preact=_p(preact), workspace=_p(ws), rowsum=_p(rowsum), precision=GEMM_PRECISION if precision is None else precision,
+                  preact=_p(preact), workspace=_p(ws), rowsum=_p(rowsum), precision=prec,
                   ldr=(N if ldr is None else ldr), a_layout=a_layout, b_layout=b_layout, M=M, N=N, K=K, act=act, res_mod=res_mod,
                   alpha=alpha, variant=variant, row_grp=rg, row_grp_stride=rgs, row_off=ro),
           "dkd_gemm_f32", (M, N, K, a_layout, b_layout))
@@ -115,7 +116,7 @@ def dgrad(dy, w, **kw):
     """dx = dy @ w for w stored [N_out, K_in] (the KN operand of dkd_gemm_f32).  In the bf16 modes the (small) weight is
     transposed first (or its cached transpose ``w_t`` is used) so the launch becomes NT and takes the bf16 MFMA kernel."""
     prec = GEMM_PRECISION if kw.get("precision") is None else kw["precision"]
-    if prec in (PREC_BF16X3, PREC_BF16):
+    if prec == PREC_BF16:  # (the split-precision kernels of gemm_x3.hip read the weight as it lies)
         wt = kw.pop("w_t", None)
         return gemm(dy, transpose(w.reshape(-1, w.shape[-1])) if wt is None else wt, **kw)
     kw.pop("w_t", None)
@@ -127,7 +128,7 @@ def linear_wgrad(dy, x, with_bias_grad=False):
     if not with_bias_grad:
         return gemm(dy, x, a_layout=1, b_layout=1)
     db = torch.empty(dy.shape[-1], dtype=torch.float32, device=dy.device)
-    if GEMM_PRECISION != PREC_F32:  # the bf16 weight-gradient kernels have no fused row sum
+    if GEMM_PRECISION == PREC_BF16:  # the plain-bf16 weight-gradient kernel has no fused row sum
         colreduce(dy.reshape(-1, dy.shape[-1]), RED_SUM, out=db.view(1, -1))
         return gemm(dy, x, a_layout=1, b_layout=1), db
     return gemm(dy, x, a_layout=1, b_layout=1, rowsum=db), db
@@ -271,7 +272,7 @@ def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True, compute=None):
     with torch.cuda.stream(side):
         N, K = dy2.shape[-1], x2.shape[-1]
         rs = b.grad.view(-1) if b is not None else None
-        if rs is not None and GEMM_PRECISION != PREC_F32:  # the bf16 weight-gradient kernels have no fused row sum
+        if rs is not None and GEMM_PRECISION == PREC_BF16:  # the plain-bf16 weight-gradient kernel has no fused row sum
             colreduce(dy2, RED_SUM, out=rs.view(1, -1))
             rs = None
         if compute is not None:    # the caller's own weight-gradient launch (implicit-GEMM convolution), raw [N, K] result

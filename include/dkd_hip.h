@@ -78,6 +78,9 @@ typedef struct dkd_gemm_args {
 int dkd_gemm_f32(const dkd_gemm_args* args, void* stream);
 int dkd_gemm_f32_splits(int M, int N, int K);
 long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout);
+/* workspace of a DKD_PREC_BF16X3 launch of this shape (>= dkd_gemm_f32_workspace_bytes: the LDS-DMA ring kernels of csrc/gemm_x3.hip
+ * plan their own K-slabs; the precision the reference's fp32 mode runs its matmuls in, train.py:304) */
+long dkd_gemm_x3_workspace_bytes(int M, int N, int K, int a_layout, int b_layout);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of token-major rows (one wavefront per row, C <= 2048, C % 4 == 0).

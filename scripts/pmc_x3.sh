@@ -1,0 +1,28 @@
+#!/bin/bash
+# SQ counter passes over scripts/one_gemm_x3.py (one counter group per run); prints per-kernel averages.   pmc_x3.sh M N K al bl variants
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/pmc_x3; mkdir -p $R/gpurun_out/pmc_x3
+rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u > $R/gpurun_out/pmc_x3/sq_counters.txt
+i=0
+for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM SQ_INSTS_SALU" \
+         "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES SQ_VALU_MFMA_COEXEC_CYCLES"; do
+  i=$((i+1)); D=$R/gpurun_out/pmc_x3/g$i
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python3 $R/scripts/one_gemm_x3.py "$@" > $D.log 2>&1 || { tail -3 $D.log; echo "group $i failed: $C"; }
+done
+cd $R && python3 - <<'PY'
+import csv,glob,collections,re
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_x3/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"]
+        if "gemm" not in k: continue
+        m=re.search(r"gemm_x3_ring_kernel<([^>]*)>",k)
+        k=("x3<"+m.group(1).replace(" ","")+">") if m else k.split("(")[0][-60:]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,d in agg.items():
+    print(k)
+    for c,v in sorted(d.items()): print("    %-32s %14.0f" % (c, sum(v)/len(v)))
+PY

@@ -1,0 +1,70 @@
+"""A/B of the bf16x3 LDS-DMA ring kernels (gemm_x3.hip, variants 31..) against the exact fp32 kernel and the older register-staged bf16x3
+kernel, per GEMM shape of the configs[1] step; error of each against an fp64 product of the same operands.
+    python scripts/tune_x3.py [f,31,32,...]   (f = exact fp32, o = old bf16x3 kernel, a = automatic x3 choice, NN = x3 variant)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dinov2_distillation_amd import ops
+from tune_v2_shapes import shapes
+
+arms = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f", "a", "31", "32"]
+only = sys.argv[2] if len(sys.argv) > 2 else None  # "nt" / "nn" / "tn"
+
+
+def arm_kw(a):
+    if a == "f":
+        return dict(precision=ops.PREC_F32, variant=0)
+    if a == "o":
+        return dict(precision=ops.PREC_BF16X3, variant=20)  # (anything outside 0 / 31..39 keeps the older paths)
+    if a == "a":
+        return dict(precision=ops.PREC_BF16X3, variant=0)
+    return dict(precision=ops.PREC_BF16X3, variant=int(a))
+
+
+tot = {a: 0.0 for a in arms}
+flop = 0.0
+for M, N, K, al, bl, cnt in shapes:
+    lay = {(0, 0): "nt", (0, 1): "nn", (1, 1): "tn"}[(al, bl)]
+    if only and lay != only:
+        continue
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K) if al == 0 else (K, M), generator=g).cuda()
+    b = torch.randn((N, K) if bl == 0 else (K, N), generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    ad, bd = a.double(), b.double()
+    ref = (ad if al == 0 else ad.t()) @ (bd.t() if bl == 0 else bd)
+    if al == 0:
+        ref = ref + bias.double() + res.double()
+    del ad, bd
+    line = "M=%6d N=%5d K=%6d %s x%2d |" % (M, N, K, lay, cnt)
+    kws, outs = {}, {}
+    for arm in arms:
+        out = torch.empty(M, N, device="cuda")
+        kw = dict(a_layout=al, b_layout=bl, out=out, **arm_kw(arm))
+        if al == 0:
+            kw.update(bias=bias, residual=res)
+        try:
+            for _ in range(2): ops.gemm(a, b, **kw)
+        except Exception as e:
+            line += " %s: %s |" % (arm, str(e)[-30:])
+            continue
+        kws[arm], outs[arm] = kw, out
+    torch.cuda.synchronize()
+    samples = {v: [] for v in kws}
+    for rnd in range(7):  # interleaved rounds: clock / thermal drift hits every arm alike; report the median
+        for v in (list(kws) if rnd % 2 == 0 else list(kws)[::-1]):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3): ops.gemm(a, b, **kws[v])
+            e1.record(); torch.cuda.synchronize()
+            samples[v].append(e0.elapsed_time(e1) * 1e3 / 3)
+    for v in kws:
+        us = sorted(samples[v])[len(samples[v]) // 2]
+        err = ((outs[v].double() - ref).abs().max() / ref.abs().max()).item()
+        tot[v] += cnt * us
+        line += " %s %6.1fus %5.1fTF %.0e |" % (v, us, 2.0 * M * N * K / us / 1e6, err)
+    flop += cnt * 2.0 * M * N * K
+    print(line, flush=True)
+print("per-step totals (ms):", {v: round(t / 1e3, 2) for v, t in tot.items()},
+      "TF/s:", {v: round(flop / t / 1e6, 1) for v, t in tot.items() if t > 0})

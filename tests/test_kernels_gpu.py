@@ -85,14 +85,15 @@ def test_gemm_peeled_last_tile_row(ops, N, K):
     xd, wd, bd, csd, resd = dev(x), dev(w), dev(b), dev(cs), dev(res)
     ref_pre = (x.double() @ w.double().t() + b.double())
     pre = torch.empty(M, N, device="cuda")
-    out = ops.gemm(xd, wd, bias=bd, act=ops.ACT_GELU, colscale=csd, residual=resd, preact=pre)
+    f32 = dict(precision=ops.PREC_F32)  # (the peel belongs to the exact kernel, whatever DKD_GEMM_PRECISION says)
+    out = ops.gemm(xd, wd, bias=bd, act=ops.ACT_GELU, colscale=csd, residual=resd, preact=pre, **f32)
     close(pre, ref_pre, "preact", rtol=2e-5)
     close(out, F.gelu(ref_pre) * cs + res, "bias + gelu + colscale + residual", rtol=2e-5)
     close(out[-64:], (F.gelu(ref_pre) * cs + res)[-64:], "the peeled rows", rtol=2e-5)
-    out2 = ops.gemm(xd, wd, bias=bd, act=ops.ACT_GELU, colscale=csd, residual=resd)
+    out2 = ops.gemm(xd, wd, bias=bd, act=ops.ACT_GELU, colscale=csd, residual=resd, **f32)
     assert torch.equal(out, out2)
-    plain = ops.gemm(xd, wd)
-    whole = ops.gemm(xd[:-64], wd)   # 256 tile rows: no peel
+    plain = ops.gemm(xd, wd, **f32)
+    whole = ops.gemm(xd[:-64], wd, **f32)   # 256 tile rows: no peel
     assert torch.equal(plain[:-64], whole)
     close(plain[-64:], (x[-64:].double() @ w.double().t()), "peeled rows, no epilogue", rtol=2e-5)
 
@@ -442,6 +443,74 @@ def test_patchify_ragged_edge_is_zero_padded(ops):
     rows = ops.patchify_nchw(dev(x), 4)
     assert rows.shape == (2 * 22 * 23, 48)
     close(ops.gemm(rows, dev(w.reshape(8, 48))), ref, "ragged patch-embed", rtol=2e-5)
+
+
+X3_VARIANTS = (0, 31, 33, 34, 38, 39, 40)  # automatic choice + every shipped configuration of csrc/gemm_x3.hip
+
+
+@pytest.mark.parametrize("variant", X3_VARIANTS)
+def test_gemm_x3_layouts_and_epilogues(ops, variant):
+    """the split-precision LDS-DMA ring kernels (csrc/gemm_x3.hip; the arithmetic class of the reference's fp32 mode, train.py:304):
+    forward / dgrad / wgrad layouts with ragged M and N edges (clamped rows, the element-wise epilogue), every fused epilogue term,
+    K-slabs and the fused bias gradient, against an fp64 product of the same operands at fp32 round-off level"""
+    P3 = ops.PREC_BF16X3
+    g = torch.Generator().manual_seed(100 + variant)
+    for M, N, K in ((1000, 200, 768), (771, 388, 160), (4096, 384, 1536), (130, 1536, 384)):  # forward: y[M, N] = x[M, K] w[N, K]^T
+        x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        close(ops.gemm(dev(x), dev(w), precision=P3, variant=variant), x.double() @ w.double().t(), f"NT {M} {N} {K}", rtol=5e-6)
+    for M, N, K in ((1000, 768, 200), (771, 160, 388), (4096, 1536, 384)):  # dgrad: dx[M, K] = dy[M, N] w[N, K] (reduction N: whole k-tiles)
+        dy, w = torch.randn(M, N, generator=g), torch.randn(N, K, generator=g)
+        close(ops.gemm(dev(dy), dev(w), b_layout=1, precision=P3, variant=variant), dy.double() @ w.double(), f"NN {M} {N} {K}", rtol=5e-6)
+    for M, N, K in ((4096, 200, 768), (1024, 388, 156), (16384, 96, 384)):  # wgrad: dW[N, K] = dy[M, N]^T x[M, K] (reduction M, K-slabs)
+        dy, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+        close(ops.gemm(dev(dy), dev(x), a_layout=1, b_layout=1, precision=P3, variant=variant), dy.double().t() @ x.double(),
+              f"TN {M} {N} {K}", rtol=5e-6)
+    # every epilogue term, aligned (float4 path) and with a ragged N (element-wise path)
+    for M, N, K in ((514, 384, 96), (514, 198, 96)):
+        g = torch.Generator().manual_seed(7 + N)
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        cs, res = torch.rand(N, generator=g) + 0.5, torch.randn(M, N, generator=g)
+        ref_pre = x.double() @ w.double().t() + b.double()
+        pre = torch.empty(M, N, device="cuda")
+        out = ops.gemm(dev(x), dev(w), bias=dev(b), act=ops.ACT_GELU, colscale=dev(cs), residual=dev(res), preact=pre, precision=P3,
+                       variant=variant)
+        close(pre, ref_pre, "x3 preact", rtol=5e-6)
+        close(out, F.gelu(ref_pre) * cs.double() + res.double(), "x3 bias+gelu+colscale+residual", rtol=5e-6)
+        c = dev(res.clone())
+        ops.gemm(dev(x), dev(w), out=c, residual=c, alpha=0.5, act=ops.ACT_RELU, precision=P3, variant=variant)
+        close(c, torch.relu(0.5 * (x.double() @ w.double().t())) + res.double(), "x3 alpha + relu + accumulate", rtol=5e-6)
+    # row remap (CLS slot) + periodic residual (position table)
+    g = torch.Generator().manual_seed(11)
+    Bn, P2, N, K = 2, 257, 384, 96
+    x2, w, b = torch.randn(Bn * P2, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    pos = torch.randn(P2 + 1, N, generator=g)
+    outb = torch.zeros(Bn * (P2 + 1), N, device="cuda")
+    ops.gemm(dev(x2), dev(w), bias=dev(b), out=outb, residual=dev(pos)[1:], res_mod=P2, row_map=(P2, P2 + 1, 1, Bn * (P2 + 1)), precision=P3,
+             variant=variant)
+    ref = torch.zeros(Bn, P2 + 1, N, dtype=torch.float64)
+    ref[:, 1:] = (x2.double() @ w.double().t() + b.double()).reshape(Bn, P2, N) + pos[1:].double()
+    close(outb, ref.reshape(-1, N), "x3 row remap + periodic residual", rtol=5e-6)
+
+
+@pytest.mark.parametrize("variant", X3_VARIANTS)
+@pytest.mark.parametrize("rows,n_out,k_in", [(1024, 136, 264), (16384, 200, 136), (50176, 192, 768), (21904, 384, 96)])
+def test_gemm_x3_wgrad_with_fused_bias_gradient(ops, variant, rows, n_out, k_in):
+    """dW = dy^T x and db = column sums of dy from ONE split-precision launch (the row sums ride on the fragments the waves hold in
+    fp32), without and with K-slabs (rows = 16 * 1369: the reduction of a P = 37 projector, a multiple of 16 but not of 32);
+    bit-reproducible"""
+    if rows % 32 and variant not in (0, 34, 38):
+        pytest.skip("a pinned 32-deep configuration needs whole k-tiles")
+    g = torch.Generator().manual_seed(rows + n_out)
+    dy, x = torch.randn(rows, n_out, generator=g) * 0.1, torch.randn(rows, k_in, generator=g)
+    dyd, xd = dev(dy), dev(x)
+    outs = []
+    for _ in range(2):
+        db = torch.empty(n_out, device="cuda")
+        dw = ops.gemm(dyd, xd, a_layout=1, b_layout=1, rowsum=db, precision=ops.PREC_BF16X3, variant=variant)
+        outs.append((dw, db))
+    close(outs[0][0], dy.double().t() @ x.double(), f"x3 wgrad {rows}", rtol=5e-6)
+    close(outs[0][1], dy.double().sum(0), f"x3 bias grad {rows}", rtol=5e-6)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("M,N,K", [(384, 1536, 12544), (96, 384, 4100), (200, 136, 1000)])
