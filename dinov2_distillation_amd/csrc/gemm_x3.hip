@@ -116,27 +116,40 @@ __device__ __forceinline__ unsigned cvt2(float a, float b) {
 }
 __device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned as_u(float f) { return __builtin_bit_cast(unsigned, f); }
+// Level by level over the fragment's four pairs (four independent chains between two dependent instructions): written pair by pair
+// the 11 instructions of a pair are one dependency chain and every one of them waits for its predecessor (SQ_WAIT_INST_ANY 33 %).
 template <bool TRUNC>
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
     u32x4 hp, mp, lp;
+    float r[8], s[8];
+    if (TRUNC) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x0 = x[2 * e], x1 = x[2 * e + 1];
-        if (TRUNC) {
-            const float r0 = x0 - as_f(as_u(x0) & 0xffff0000u), r1 = x1 - as_f(as_u(x1) & 0xffff0000u);
-            const float s0 = r0 - as_f(as_u(r0) & 0xffff0000u), s1 = r1 - as_f(as_u(r1) & 0xffff0000u);
-            hp[e] = __builtin_amdgcn_perm(as_u(x1), as_u(x0), 0x07060302u);  // {x1.hi16, x0.hi16}
-            mp[e] = __builtin_amdgcn_perm(as_u(r1), as_u(r0), 0x07060302u);
-            lp[e] = __builtin_amdgcn_perm(as_u(s1), as_u(s0), 0x07060302u);
-        } else {
-            const unsigned hh = cvt2(x0, x1);
-            const float r0 = x0 - as_f(hh << 16), r1 = x1 - as_f(hh & 0xffff0000u);
-            const unsigned mm = cvt2(r0, r1);
-            const float s0 = r0 - as_f(mm << 16), s1 = r1 - as_f(mm & 0xffff0000u);
-            hp[e] = hh;
-            mp[e] = mm;
-            lp[e] = cvt2(s0, s1);
+        for (int e = 0; e < 4; ++e) hp[e] = __builtin_amdgcn_perm(as_u(x[2 * e + 1]), as_u(x[2 * e]), 0x07060302u);  // {x1.hi16, x0.hi16}
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = x[e] - as_f(as_u(x[e]) & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mp[e] = __builtin_amdgcn_perm(as_u(r[2 * e + 1]), as_u(r[2 * e]), 0x07060302u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = r[e] - as_f(as_u(r[e]) & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lp[e] = __builtin_amdgcn_perm(as_u(s[2 * e + 1]), as_u(s[2 * e]), 0x07060302u);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hp[e] = cvt2(x[2 * e], x[2 * e + 1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[2 * e] = x[2 * e] - as_f(hp[e] << 16);
+            r[2 * e + 1] = x[2 * e + 1] - as_f(hp[e] & 0xffff0000u);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mp[e] = cvt2(r[2 * e], r[2 * e + 1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s[2 * e] = r[2 * e] - as_f(mp[e] << 16);
+            s[2 * e + 1] = r[2 * e + 1] - as_f(mp[e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lp[e] = cvt2(s[2 * e], s[2 * e + 1]);
     }
     h = __builtin_bit_cast(bf16x8, hp);
     m = __builtin_bit_cast(bf16x8, mp);
@@ -454,17 +467,19 @@ struct X3Cfg {
 //   3: 128 x 128, 2 waves of 64 x 128, BK 32, 2 stages, P (64 KB; 5.5 instead of 7.3 split instructions per MFMA, one wave per SIMD)
 //   4: 128 x 128, 4 waves of 64 x 64, BK 16, 3 stages, not pipelined (48 KB: three per CU)
 //   8: 128 x 128, 4 waves of 64 x 64, BK 16, 2 stages, P (32 KB; reductions that are a multiple of 16 only)
-//   9: 64 x 128, 2 waves of 64 x 64, BK 32, 2 stages, P (48 KB: three per CU)
 //   10: as 1, not pipelined
 //   11-15 (-DDKD_TUNING only): knock-outs of 1 - no split, no MFMAs, no DMA in the loop, no barrier, no split of B
 // Measured (scripts/tune_x3.py over the 39 GEMM shapes of the configs[1] step, profiles/r04_x3_*): per-step GEMM time 35.0 ms exact ->
-// 28.6 (1 everywhere) -> 27 ms with the choice below; also built and dropped: 128 x 192 / 128 x 256 / 256 x 128 tiles (64 x 96 ... 128 x 64
-// per wave: one workgroup per CU, nothing covers a wave's LDS and barrier waits: 37-94 TF/s), the truncating split (same speed).
+// 28.6 (1 everywhere) -> 27.5 ms with the choice below (0.765 of the exact kernel on every box).  Built, measured and dropped: 128 x 192 /
+// 128 x 256 / 256 x 128 tiles (64 x 96 ... 128 x 64 per wave: one workgroup per CU, nothing covers a wave's LDS and barrier waits:
+// 37-94 TF/s), 64 x 128 tiles of two waves (three per CU: 103 TF/s), registers capped for three / four workgroups per CU (114 TF/s;
+// 64 with spills), the truncating split (same speed), no split of B at all (a knock-out: +8 % - operand planes prepared in HBM would
+// not pay).  Where the time goes (profiles/r04_x3_pmc.md): a wave spends 52 % of its cycles issuing (VALU: 4 cycles each whatever the
+// co-resident waves do), 33 % stalled at issue, 15 % at waits; the matrix pipe is busy 40 % of the kernel.
 typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true> Cfg1;
 typedef X3Cfg<2, 1, 2, 4, 32, 2, 1, false, true> Cfg3;
 typedef X3Cfg<2, 2, 2, 2, 16, 3, 2> Cfg4;
 typedef X3Cfg<2, 2, 2, 2, 16, 2, 2, false, true> Cfg8;
-typedef X3Cfg<1, 2, 2, 2, 32, 2, 2, false, true> Cfg9;
 typedef X3Cfg<2, 2, 2, 2, 32, 2, 2> Cfg10;
 #ifdef DKD_TUNING
 typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true, 1> Cfg11;
@@ -477,14 +492,13 @@ constexpr int NCFG = 15;
 constexpr int NCFG = 10;
 #endif
 
-bool cfg_exists(int cfg) { return cfg == 1 || cfg == 3 || cfg == 4 || (cfg >= 8 && cfg <= NCFG); }
+bool cfg_exists(int cfg) { return cfg == 1 || cfg == 3 || cfg == 4 || cfg == 8 || (cfg >= 10 && cfg <= NCFG); }
 
 void cfg_dims(int cfg, int* bm, int* bn, int* bk, int* per_cu) {
     switch (cfg) {
         case 3: *bm = Cfg3::BM, *bn = Cfg3::BN, *bk = 32, *per_cu = 2; break;
         case 4: *bm = Cfg4::BM, *bn = Cfg4::BN, *bk = 16, *per_cu = 3; break;
         case 8: *bm = Cfg8::BM, *bn = Cfg8::BN, *bk = 16, *per_cu = 2; break;
-        case 9: *bm = Cfg9::BM, *bn = Cfg9::BN, *bk = 32, *per_cu = 3; break;
         default: *bm = Cfg1::BM, *bn = Cfg1::BN, *bk = 32, *per_cu = 2; break;
     }
 }
@@ -502,11 +516,11 @@ int pick_cfg(int M, int N, int K, int a_layout, int b_layout, int variant) {
     const long t128 = (long)dkd_cdiv(M, 128) * dkd_cdiv(N, 128);
     // weight gradients and the few-tile shapes: long reductions in K-slabs, where the 64 x 128 wave tile's lower split cost shows
     if ((a_layout == 1 && b_layout == 1) || t128 < 256) return 3;
-    // 128 x 128 (two per CU) or 64 x 128 (three per CU): whichever fills the chip's rounds better (M = 16384, N = 384: 384 of 512 against
-    // 768 of 768 slots; M = 64 * 257: 387 of 512 against 771 of 1536), the larger tile at a tie
-    const long t64 = (long)dkd_cdiv(M, 64) * dkd_cdiv(N, 128);
-    const double e1 = (double)t128 / (double)((t128 + 511) / 512 * 512), e9 = (double)t64 / (double)((t64 + 767) / 768 * 768);
-    return (K >= 1024 && e9 > e1 + 0.1) ? 9 : 1;
+    // three column tiles under a long reduction (the N = 384 Linears): the 16-deep three-stage ring fits three workgroups per CU and
+    // fills the 294 ... 387 tiles' single round better (measured 121 against 132 us at M = 12544, level at M = 16384 and 16448 ... 153
+    // against 138 us: the frozen teacher's 64 * 257 rows stay on configuration 1)
+    if (N <= 384 && K >= 1024 && t128 * 4 <= 3 * 512 && (M % 128) == 0) return 4;
+    return 1;
 }
 
 // K-slabs only when the output grid alone leaves most of the chip idle (weight gradients; the few-tile long-K forward shapes)
@@ -587,7 +601,6 @@ int dkd_x3_launch(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st) {
         case 3: rc = Cfg3::launch(g, epi, splits, kchunk, vec, st); break;
         case 4: rc = Cfg4::launch(g, epi, splits, kchunk, vec, st); break;
         case 8: rc = Cfg8::launch(g, epi, splits, kchunk, vec, st); break;
-        case 9: rc = Cfg9::launch(g, epi, splits, kchunk, vec, st); break;
         case 10: rc = Cfg10::launch(g, epi, splits, kchunk, vec, st); break;
 #ifdef DKD_TUNING
         case 11: rc = Cfg11::launch(g, epi, splits, kchunk, vec, st); break;

@@ -180,8 +180,10 @@ class PackedMetrics:
     """The step's scalar metrics as ONE vector in ONE all-reduce (rank mean), issued on a side stream so that it never sits
     between two kernels of the compute stream.  ``values()`` (after ``wait()``) -> {name: 0-d tensor}."""
 
-    def __init__(self, keys, vec, handle, side):
-        self.keys, self.vec, self.handle, self.side = keys, vec, handle, side
+    _verified = set()   # key-set signatures already found equal on every rank (a run logs the same names every step)
+
+    def __init__(self, keys, vec, handle, side, sig=None):
+        self.keys, self.vec, self.handle, self.side, self.sig = keys, vec, handle, side, sig
 
     def wait(self):
         """make the CURRENT stream (and, for gloo, the host) wait for the exchange; idempotent"""
@@ -192,8 +194,20 @@ class PackedMetrics:
                 torch.cuda.current_stream().wait_stream(self.side)
         return self
 
+    def check_keys(self):
+        """the ranks packed the same names (count and hash ride in the last two slots): one host read, once per key set"""
+        if self.sig is None or (self.sig, len(self.keys)) in PackedMetrics._verified:
+            return
+        got = self.vec[len(self.keys):].tolist()
+        tol = 0.25 / max(dist.get_world_size(), 1)
+        if any(abs(g - w) > tol for g, w in zip(got, self.sig)):
+            raise RuntimeError(f"allreduce_metrics: the ranks log different metric names (this rank: {self.keys}); a packed exchange "
+                               "needs the same key set on every rank")
+        PackedMetrics._verified.add((self.sig, len(self.keys)))
+
     def values(self):
         self.wait()
+        self.check_keys()
         return {k: self.vec[i] for i, k in enumerate(self.keys)}
 
 
@@ -207,10 +221,20 @@ def allreduce_metrics_async(values, process_group=None, side=None, force=False):
     if not values or not dist.is_initialized() or (dist.get_world_size(process_group) == 1 and not force):
         return None  # (force: run the collective in a one-rank group too - lets a one-GPU box drive the RCCL path)
     keys = sorted(values)
-    first = next(v for v in values.values() if torch.is_tensor(v))
-    vec = torch.stack([(values[k].detach().float() if torch.is_tensor(values[k])
-                        else torch.tensor(float(values[k]), device=first.device)).reshape(()) for k in keys])
+    first = next((v for v in values.values() if torch.is_tensor(v)), None)
+    if first is not None:
+        dev = first.device
+    else:  # only Python numbers: the current HIP device under RCCL, the host under gloo
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(process_group) == "nccl" else torch.device("cpu")
     world = dist.get_world_size(process_group)
+    # the sorted key set defines the layout of the packed vector: a rank that logs a different set would have other ranks' entries
+    # averaged into the wrong names without a sound (the reference's one-collective-per-name logging would have failed instead).  Two
+    # extra slots carry the count and a hash of the names; equal on every rank <=> their rank mean equals the local value.
+    import zlib
+    sig = (float(len(keys)), float(zlib.crc32("\0".join(keys).encode()) % 4093))
+    vec = torch.stack([(values[k].detach().float().to(dev) if torch.is_tensor(values[k])
+                        else torch.tensor(float(values[k]), device=dev)).reshape(()) for k in keys]
+                      + [torch.tensor(v, device=dev) for v in sig])
     if vec.is_cuda:
         if side is None:
             side = _METRIC_STREAMS.get(vec.device.index)
@@ -225,7 +249,7 @@ def allreduce_metrics_async(values, process_group=None, side=None, force=False):
         side = None
         vec.div_(world)
         handle = dist.all_reduce(vec, group=process_group, async_op=True)
-    return PackedMetrics(keys, vec, handle, side)
+    return PackedMetrics(keys, vec, handle, side, sig)
 
 
 def allreduce_metrics(values, process_group=None):

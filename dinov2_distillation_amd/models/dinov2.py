@@ -28,6 +28,7 @@ PATCH, POS_GRID = 14, 37
 FLASH16 = os.environ.get("DKD_FLASH16", "1") != "0"
 # the autocast teacher's forward as one hipGraph launch after two eager calls per input shape (VisionTransformer._forward_tokens_autocast_graph)
 TEACHER_GRAPH = os.environ.get("DKD_TEACHER_GRAPH", "1") != "0"
+TEACHER_GRAPH_SHAPES = 4   # input shapes that keep a captured graph (and its private memory pool) alive at a time
 
 
 def _tn(*shape, gen):
@@ -264,7 +265,12 @@ class VisionTransformer(nn.Module):
         key = (tuple(x.shape), x.device.index)
         ent = self._tgraph.get(key)
         if ent is None or ent["stamp"] != stamp:
+            self._tgraph.pop(key, None)
+            while len(self._tgraph) >= TEACHER_GRAPH_SHAPES:  # (each entry owns a private-pool graph: last / partial batches, the
+                self._tgraph.pop(next(iter(self._tgraph)))    #  validation batch size ... the oldest shape goes first)
             ent = self._tgraph[key] = {"calls": 0, "stamp": stamp}
+        else:
+            self._tgraph[key] = self._tgraph.pop(key)  # most recently used last
         if "graph" not in ent:
             ent["calls"] += 1
             if ent["calls"] <= 2:
@@ -283,7 +289,10 @@ class VisionTransformer(nn.Module):
             ent.update(graph=g, inp=static_in, out=static_out)
         ent["inp"].copy_(x)
         ent["graph"].replay()
-        return ent["out"]
+        # a COPY of the static output: the next replay of this shape overwrites that buffer without any autograd version bump, and a
+        # caller may keep teacher features across calls (validation collection, two forwards before one backward, KDLossFn's saved
+        # tensors).  One device-to-device copy of [B, P*P, D] next to ~90 launches.
+        return ent["out"].clone()
 
     def forward_tokens(self, x):
         """-> final-norm patch tokens [B, P*P, D], dense (CLS dropped by the norm kernel's row gather)."""

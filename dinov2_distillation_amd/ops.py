@@ -18,7 +18,10 @@ RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM, RED_GELUSQ, RED_DOTGELU_SU
 _ws = {}
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {None: None, "f32": PREC_F32, "fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
-GEMM_PRECISION = PRECISIONS.get(os.environ.get("DKD_GEMM_PRECISION", "f32").lower(), PREC_F32)  # process-wide default
+# process-wide default of the fp32-operand GEMMs: the bf16x3 split (csrc/gemm_x3.hip: fp32-level accuracy - 5e-7 ... 2e-6 of an fp64 product,
+# the exact kernel's own distance - at 0.77 of its time; the arithmetic class the reference's fp32 mode runs its matmuls in, train.py:304
+# torch.set_float32_matmul_precision('high')).  DKD_GEMM_PRECISION=f32: the exact v_mfma_f32_16x16x4_f32 kernels everywhere.
+GEMM_PRECISION = PRECISIONS.get(os.environ.get("DKD_GEMM_PRECISION", "bf16x3").lower(), PREC_BF16X3)
 
 
 _stream = _lib.stream  # the launch stream argument (ctypes binding: the current HIP stream; torch binding: taken inside the op)
@@ -171,7 +174,10 @@ def shadow16(w):
         return None
     if opt.flat_p16 is None:
         opt.enable_shadow16()
-    if w._version != ent[4] or ent[5] is None:
+    # the version counter catches in-place edits through torch; `p.data = t` re-seats the storage without one, so the parameter must
+    # still BE its arena view.  (An in-place edit through `.data` - p.data.copy_ / mul_, EMA or checkpoint code - bumps nothing and
+    # changes no pointer: such code has to call FusedAdamW.refresh_shadow16() afterwards; the load paths of this package do.)
+    if w._version != ent[4] or ent[5] is None or w.data_ptr() != opt.flat_p.data_ptr() + 4 * ent[2]:
         SHADOW_DIRTY = True
         return None
     return ent[5]

@@ -128,6 +128,14 @@ class FusedAdamW(torch.optim.Optimizer):
         torch.cuda.current_stream().synchronize()  # built once, read from every stream (teacher / chain / weight-gradient streams)
         self._validate_shadow()
 
+    def refresh_shadow16(self):
+        """re-derive the bf16 shadow from the fp32 parameters as they are now.  For code that edits parameters through ``.data``
+        (p.data.copy_ / mul_: checkpoint loading, EMA) - such writes bump no version counter, so the shadow cannot notice them; the
+        optimiser's own step rewrites it anyway.  No-op while no shadow exists."""
+        if self.flat_p16 is not None:
+            self.enable_shadow16()
+        ops.WEIGHT_EPOCH += 1  # cached 16-bit copies of derived parameters (functional16) are stale too
+
     def _validate_shadow(self):
         for p, off, n in self.layout:
             ent = ops._SHADOW.get(id(p))

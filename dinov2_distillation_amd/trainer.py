@@ -69,6 +69,11 @@ class DistillationStepper:
         ops.CAPTURE_SERIAL += 1
         with torch.cuda.graph(self.graph):
             self.static_loss = self._step_body(self.static_batch)
+        # optimizer.step() ran its HOST bookkeeping during the capture pass, but the captured kernel (and its device-side step
+        # increment, optim._hyper[:, 5]) has not executed: take that pass back, or state_dict() exports a step counter one ahead of
+        # the device and a resumed run applies the bias correction of step t + 1
+        self.optimizer._steps -= 1
+        self.optimizer._step_t -= 1.0
         return self
 
     def step_graph(self, batch):

@@ -66,14 +66,16 @@ typedef struct dkd_gemm_args {
     int32_t row_grp, row_grp_stride, row_off;
     float alpha;
     int32_t variant; /* 0 = automatic tile/schedule choice (the only value product code passes).  >0 pins a kernel for A/B
-                        runs: 1-5 (32x32x2 family), 21-23 (bf16x3 tiles), 43/44/52/55/56 (16x16x4 family), 100/101 (LDS-DMA);
+                        runs: 1-5 (32x32x2 family), 21-23 (register-staged bf16x3 tiles), 31/33/34/38/40 (bf16x3 LDS-DMA ring configurations,
+                        csrc/gemm_x3.hip; 41-45: its knock-outs, -DDKD_TUNING only), 43/44/52/55/56 (16x16x4 family), 100/101 (LDS-DMA);
                         102-104 / 111-115 / 120-122 (larger tiles, DMA issue order, wave priority, register-pipelined fragments: measured and not kept,
                         NOTES 9.21) and the timing-only knock-outs 130-134 exist only in a -DDKD_TUNING build (else DKD_ERR_UNSUPPORTED / BAD_ARG);
                         anything else: DKD_ERR_BAD_ARG */
-    int32_t precision; /* DKD_PREC_F32 (exact fp32 MFMA, default), DKD_PREC_BF16X3 (3-way bf16 split of each fp32 operand,
-                          6 MFMA products, fp32 accumulate: fp32-level accuracy) or DKD_PREC_BF16 (operands rounded to bf16
-                          while staged, fp32 accumulate: the frozen teacher's opt-in mode).  Both bf16 modes exist for the NT
-                          layout only; other layouts silently use the exact path */
+    int32_t precision; /* DKD_PREC_F32 (exact fp32 MFMA), DKD_PREC_BF16X3 (3-way bf16 split of each fp32 operand, 6 MFMA products, fp32
+                          accumulate: fp32-level accuracy; csrc/gemm_x3.hip, every layout incl. the fused bias gradient; what the Python
+                          side passes by default) or DKD_PREC_BF16 (operands rounded to bf16 while staged, fp32 accumulate: the frozen
+                          teacher's opt-in mode, NT / TN layouts).  A shape a mode does not take (reduction not a multiple of 16, or under
+                          96: nothing to amortise the split over) silently runs on the exact path */
 } dkd_gemm_args;
 int dkd_gemm_f32(const dkd_gemm_args* args, void* stream);
 int dkd_gemm_f32_splits(int M, int N, int K);

@@ -12,7 +12,27 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dinov2_distillation_amd import _lib  # noqa: E402  (header parser only: no torch import happens here)
 
+# Pass 2 hands FAKE device addresses to real launchers: with a GPU in reach those launches would run and fault.  The sweep must never see
+# one: the caller hides the devices (tests/test_abi_cpu.py sets HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES in the child's environment); this
+# is the second lock - hide them here too, before the HIP runtime is loaded, and skip pass 2 if a device is visible all the same.
+os.environ["HIP_VISIBLE_DEVICES"] = "-1"
+os.environ["ROCR_VISIBLE_DEVICES"] = ""
 lib = ctypes.CDLL(sys.argv[1])
+
+
+def _visible_devices():
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            hip = ctypes.CDLL(name)
+        except OSError:
+            continue
+        n = ctypes.c_int(0)
+        rc = hip.hipGetDeviceCount(ctypes.byref(n))
+        return n.value if rc == 0 else 0
+    return 0
+
+
+GPU_IN_REACH = _visible_devices() > 0
 FAKE = 0x7F0000001000   # aligned, unmapped: the host side must never read through a device pointer
 INTS = {"B": 2, "H": 14, "W": 14, "C": 64, "O": 64, "k": 3, "stride": 1, "pad": 1, "M": 256, "N": 128, "K": 128, "rows": 256, "cols": 128,
         "groups": 2, "Hi": 14, "Wi": 14, "Ho": 16, "Wo": 16, "hd": 32, "Nq": 64, "Nk": 64, "heads": 2, "lda": 128, "ldb": 128, "ldc": 128,
@@ -29,6 +49,9 @@ def value(name, ty, real):
 
 n_calls = 0
 for real in (False, True):
+    if real and GPU_IN_REACH:
+        print("SKIP pass 2: a GPU is visible to this process (fake device addresses must never reach one)")
+        break
     for name, (restype, args) in _lib._FUNC_DEFS.items():
         launcher = any(a == "stream" for a, _ in args)
         if not launcher and not real:

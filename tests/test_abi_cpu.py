@@ -133,6 +133,10 @@ def test_binding_helpers_match_the_selected_binding():
 def _sweep(libpath, env=None):
     e = dict(os.environ)
     e.update(env or {})
+    # pass 2 of the sweep calls real launchers with fake device addresses: it must not be able to reach a GPU (on a GPU box a plain
+    # `pytest tests` runs this file too)
+    e["HIP_VISIBLE_DEVICES"] = "-1"
+    e["ROCR_VISIBLE_DEVICES"] = ""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_sweep.py"), libpath], capture_output=True, text=True, env=e, timeout=600)
     return r.returncode, r.stdout[-2000:] + r.stderr[-4000:]
 
