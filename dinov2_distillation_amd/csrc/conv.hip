@@ -206,6 +206,133 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const TI* __restrict
     }
 }
 
+// wgrad, LDS-tiled: x and dy are read ONCE (the kernel above streams both once per tap row: 4.4 - 4.8x their bytes at the memory
+// side, 0.06 - 0.15 of the HBM roofline).  One workgroup = one image, one chunk of 32 channels, one chunk of output rows; the input rows
+// slide through a ring of eight LDS slots (a row is staged once - converted once if it is bf16 - and read by the seven tap rows that
+// need it), the dy row through a double buffer; one barrier per row.  Lane = (tap row i, channel quad), wave = x segment: every
+// thread keeps the 7 float4 sums of its tap row for its segment, the input row sliding through a 7-wide register window; the segments
+// are added through LDS at the end.  Columns -3 .. -1 and W .. W+2 of every slot are zero for good, rows outside the image are staged as
+// zeros.  Same partial layout as above: part[b * ny + yc][tap][c].
+constexpr int DW_CC = 32;  // channels per workgroup (8 quads x 7 tap rows = 56 of a wave's 64 lanes)
+template <typename TI, typename TD, int XS>
+__global__ __launch_bounds__(XS * 64) void dwconv7_wgrad_lds_kernel(const TI* __restrict__ in, const TD* __restrict__ dout,
+                                                                     float* __restrict__ part, int H, int W, int C, int RY) {
+    extern __shared__ __attribute__((aligned(16))) float4 dw_smem[];
+    const int WP = (W + 6) | 1, cq = C >> 2;  // slot pitch in pixels, odd: the tap rows of a 16-lane read group then sit in both
+    float4* ring = dw_smem;                   // 128-byte halves of the bank period.  [8][WP][8]
+    float4* dyb = dw_smem + 8 * WP * 8;       // [2][W][8]
+    const int tid = threadIdx.x, lane = tid & 63, seg = __builtin_amdgcn_readfirstlane(tid >> 6), c4l = lane & 7, ti = lane >> 3;
+    const int cc = blockIdx.x, yc = blockIdx.y, b = blockIdx.z, ny = gridDim.y;
+    const int y0 = yc * RY, y1 = min(H, y0 + RY);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long img = (long)b * H * W * cq + cc * 8;  // float4 index of (b, 0, 0, first quad of this chunk)
+    constexpr int NT = XS * 64;
+    // zero the pad columns of every slot once
+    for (int q = tid; q < 8 * 6 * 8; q += NT) {
+        const int slot = q / 48, r = q % 48, col = r / 8, c = r % 8;
+        ring[(slot * WP + (col < 3 ? col : W + col)) * 8 + c] = zero;
+    }
+    const int items = W * 8;                       // float4 of one row of this channel chunk
+    constexpr int MAXI = 2;                        // staged items per thread and tensor (the launcher checks W * 8 <= MAXI * NT)
+    float4 rin[MAXI], rdy[MAXI];
+    auto load_row = [&](int r, float4 (&v)[MAXI]) {  // input row r -> registers (zeros outside the image)
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const int q = tid + k * NT;
+            v[k] = (q < items && r >= 0 && r < H) ? ld4(in, img + ((long)r * W + q / 8) * cq + (q & 7)) : zero;
+        }
+    };
+    auto store_row = [&](int r, const float4 (&v)[MAXI]) {
+        float4* S = ring + ((r + 3) & 7) * WP * 8;
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const int q = tid + k * NT;
+            if (q < items) S[(3 + q / 8) * 8 + (q & 7)] = v[k];
+        }
+    };
+    auto load_in = [&](int r) { load_row(r, rin); };
+    auto store_in = [&](int r) { store_row(r, rin); };
+    auto load_dy = [&](int y) {
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const int q = tid + k * NT;
+            rdy[k] = (q < items && y < y1) ? ld4(dout, img + ((long)y * W + q / 8) * cq + (q & 7)) : zero;
+        }
+    };
+    auto store_dy = [&](int y) {
+        float4* S = dyb + (y & 1) * W * 8;
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const int q = tid + k * NT;
+            if (q < items) S[q] = rdy[k];
+        }
+    };
+    // prologue: rows y0 - 3 .. y0 + 2 into the ring; row y0 + 3 and dy row y0 wait in registers for the first barrier
+    {
+        float4 pre[6][MAXI];  // (all six rows in flight together: one memory round trip, not six)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) load_row(y0 - 3 + k, pre[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) store_row(y0 - 3 + k, pre[k]);
+    }
+    load_in(y0 + 3);
+    load_dy(y0);
+    float4 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = zero;
+    const int xw = (W + XS - 1) / XS, xs0 = seg * xw, xs1 = min(W, xs0 + xw);
+    for (int y = y0; y < y1; ++y) {
+        store_in(y + 3);   // slot of row y - 5: nobody reads it any more (a slow thread is at most in row y - 1: rows y - 4 .. y + 2)
+        store_dy(y);
+        __syncthreads();
+        load_in(y + 4);    // in flight under this row's arithmetic
+        load_dy(y + 1);
+        if (ti < 7) {
+            const float4* S = ring + ((y + ti) & 7) * WP * 8 + c4l;   // input row y + ti - 3, padded column index = x + j
+            const float4* D = dyb + (y & 1) * W * 8 + c4l;
+            // seven positions per trip (the segments are 7 or 14 wide at every ConvNeXt stage): a 13-wide window, six register moves per
+            // seven positions instead of six per position; a ragged tail multiplies zeros (dy) with clamped (in-row) window reads
+            float4 win[13];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) win[j] = S[(xs0 + j) * 8];
+            for (int x = xs0; x < xs1; x += 7) {
+                float4 d[7];
+#pragma unroll
+                for (int p = 0; p < 7; ++p) {
+                    win[6 + p] = S[min(x + p + 6, W + 5) * 8];   // (a ragged tail re-reads the last, zeroed, pad column)
+                    const float4 dv = D[min(x + p, xs1 - 1) * 8];   // (always an LDS read; the select is on the value)
+                    d[p] = (x + p < xs1) ? dv : zero;
+                }
+#pragma unroll
+                for (int p = 0; p < 7; ++p)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) fma4(acc[j], d[p], win[p + j]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) win[j] = win[7 + j];
+            }
+        }
+    }
+    // add the x segments (fixed order) and store the chunk's 49 x 32 partial sums
+    __syncthreads();
+    float4* R = dw_smem;  // [XS][7][64] (the ring is free)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) R[(seg * 7 + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (seg == 0 && ti < 7) {
+        float4* p = reinterpret_cast<float4*>(part + ((long)(b * ny + yc) * 49 + ti * 7) * C) + cc * 8 + c4l;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            float4 v = acc[j];
+#pragma unroll
+            for (int s2 = 1; s2 < XS; ++s2) {
+                const float4 o = R[(s2 * 7 + j) * 64 + lane];
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            p[(long)j * cq] = v;
+        }
+    }
+}
+
 // ---- patchify -------------------------------------------------------------------------------------------------
 // NCHW image -> rows [(b,py,px)][(c,ky,kx)]  (matches conv weight [O][c][ky][kx] flattened); V floats per access.
 template <int V>
@@ -394,30 +521,53 @@ extern "C" int dkd_dwconv7_fwd_io(const void* in_bf16, const float* w_tap_major,
     return rc;
 }
 
-static int dw_ry(int H) { return H >= 28 ? 4 : (H >= 14 ? 2 : 1); }
+// row chunks per image: two for the 56 x 56 stage (its 32-channel chunks alone leave the chip a third empty), one otherwise; a chunk
+// re-reads six halo rows of x
+static int dw_ry(int H) { return H >= 56 ? (H + 1) / 2 : H; }
 extern "C" long dkd_dwconv7_wgrad_f32_parts(int B, int H) { return (long)B * ((H + dw_ry(H) - 1) / dw_ry(H)); }
 
-extern "C" int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* partials, int B, int H, int W, int C,
-                                     void* stream) {
-    if (!in || !dout || !partials || B <= 0) return DKD_ERR_BAD_ARG;
-    const int RY = dw_ry(H);
+template <typename TI, typename TD>
+static int launch_dwconv7_wgrad(const TI* in, const TD* dout, float* partials, int B, int H, int W, int C, void* stream) {
+    if (!in || !dout || !partials || B <= 0 || H <= 0 || W <= 0) return DKD_ERR_BAD_ARG;
+    const int RY = dw_ry(H), ny = (H + RY - 1) / RY;
     if (C & 3) return DKD_ERR_ALIGN;
-    const long total = (long)B * ((H + RY - 1) / RY) * 7 * (C / 4);
-    hipLaunchKernelGGL((dwconv7_wgrad_kernel<float, float>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, dout,
-                       partials, B, H, W, C, RY);
+    hipStream_t st = (hipStream_t)stream;
+    static const bool old_kernel = getenv("DKD_DWCONV7_WGRAD_OLD") != nullptr;  // A/B: the one-thread-per-tap-row kernel
+    const int XS = W >= 28 ? 4 : (W >= 14 ? 2 : 1);
+    size_t lds = ((size_t)8 * ((W + 6) | 1) * 8 + (size_t)2 * W * 8) * sizeof(float4);   // ring + dy double buffer ...
+    if (lds < (size_t)XS * 7 * 64 * sizeof(float4)) lds = (size_t)XS * 7 * 64 * sizeof(float4);  // ... re-used by the segment sums
+    // whole 32-channel chunks, a row of the chunk within two staged float4 per thread, the ring within the CU's LDS
+    if (!old_kernel && C % DW_CC == 0 && W * 8 <= 2 * XS * 64 && lds <= 150 * 1024 && B <= 65535) {
+        const dim3 grid(C / DW_CC, ny, B);
+#define DKD_DW_WG(XSV)                                                                                                             \
+    do {                                                                                                                           \
+        auto kern = dwconv7_wgrad_lds_kernel<TI, TD, XSV>;                                                                         \
+        if (lds > 64 * 1024) {                                                                                                     \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                                    \
+        }                                                                                                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(XSV * 64), lds, st, in, dout, partials, H, W, C, RY);                                  \
+    } while (0)
+        if (XS == 4) DKD_DW_WG(4);
+        else if (XS == 2) DKD_DW_WG(2);
+        else DKD_DW_WG(1);
+#undef DKD_DW_WG
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
+    const long total = (long)B * ny * 7 * (C / 4);
+    hipLaunchKernelGGL((dwconv7_wgrad_kernel<TI, TD>), dim3(blocks_for(total)), dim3(256), 0, st, in, dout, partials, B, H, W, C, RY);
     DKD_LAUNCH_CHECK();
     return DKD_OK;
 }
 
+extern "C" int dkd_dwconv7_wgrad_f32(const float* in, const float* dout, float* partials, int B, int H, int W, int C,
+                                     void* stream) {
+    return launch_dwconv7_wgrad(in, dout, partials, B, H, W, C, stream);
+}
+
 extern "C" int dkd_dwconv7_wgrad_bf16(const void* in, const void* dout, float* partials, int B, int H, int W, int C, void* stream) {
-    if (!in || !dout || !partials || B <= 0) return DKD_ERR_BAD_ARG;
-    const int RY = dw_ry(H);
-    if (C & 3) return DKD_ERR_ALIGN;
-    const long total = (long)B * ((H + RY - 1) / RY) * 7 * (C / 4);
-    hipLaunchKernelGGL((dwconv7_wgrad_kernel<__bf16, __bf16>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const __bf16*>(in), reinterpret_cast<const __bf16*>(dout), partials, B, H, W, C, RY);
-    DKD_LAUNCH_CHECK();
-    return DKD_OK;
+    return launch_dwconv7_wgrad(reinterpret_cast<const __bf16*>(in), reinterpret_cast<const __bf16*>(dout), partials, B, H, W, C, stream);
 }
 
 extern "C" int dkd_patchify_nchw_f32(const float* img, float* out, int B, int Cin, int H, int W, int k, void* stream) {
