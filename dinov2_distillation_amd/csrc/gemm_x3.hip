@@ -473,7 +473,7 @@ struct X3Cfg {
 // 28.6 (1 everywhere) -> 27.5 ms with the choice below (0.765 of the exact kernel on every box).  Built, measured and dropped: 128 x 192 /
 // 128 x 256 / 256 x 128 tiles (64 x 96 ... 128 x 64 per wave: one workgroup per CU, nothing covers a wave's LDS and barrier waits:
 // 37-94 TF/s), 64 x 128 tiles of two waves (three per CU: 103 TF/s), registers capped for three / four workgroups per CU (114 TF/s;
-// 64 with spills), the truncating split (same speed), no split of B at all (a knock-out: +8 % - operand planes prepared in HBM would
+// 64 with spills), four 16-deep stages (three tiles of look-ahead: 109 TF/s), the truncating split (same speed), no split of B at all (a knock-out: +8 % - operand planes prepared in HBM would
 // not pay).  Where the time goes (profiles/r04_x3_pmc.md): a wave spends 52 % of its cycles issuing (VALU: 4 cycles each whatever the
 // co-resident waves do), 33 % stalled at issue, 15 % at waits; the matrix pipe is busy 40 % of the kernel.
 typedef X3Cfg<2, 2, 2, 2, 32, 2, 2, false, true> Cfg1;

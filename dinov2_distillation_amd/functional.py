@@ -241,8 +241,7 @@ class ConvNeXtBlockFn(Function):
             with torch.cuda.stream(side):
                 ops.dwconv7_wgrad_cw(x, dd, out=o_dww.view(C, 49))   # partial sums folded straight into the [C, 49] parameter layout
                 ops.colreduce(dd.reshape(M, C), ops.RED_SUM, out=o_dwb.view(1, C))
-            x.record_stream(side)
-            dd.record_stream(side)
+            ops.side_hold(side, x, dd)
             ddw = ddb = None
             dx = ops.dwconv7(dd, wt, None, add=dout, flip=True)
         else:

@@ -138,16 +138,14 @@ def wgrad16(dy16, x16, w, b, transform=None, reshape=None, make_x16=None):
             if make_x16 is not None:
                 src = x16
                 x16 = make_x16(src)      # (allocated under the side stream: no cross-stream lifetime to record)
-                src.record_stream(side)
+                ops.side_hold(side, src)
                 K = x16.shape[-1]
             rs = None if b is None else b.grad.view(-1)
             if transform is None:
                 ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, out=w.grad.view(N, K), ws_slot=3, rowsum=rs)
             else:
                 transform(ops.gemm_bf16(dy16, x16, a_layout=1, b_layout=1, epi=ops.EPI_F32, ws_slot=3, rowsum=rs))
-        dy16.record_stream(side)
-        if make_x16 is None:
-            x16.record_stream(side)
+        ops.side_hold(side, dy16, x16 if make_x16 is None else None)
         ops.grad_done(w, b)
         return None, None
     db = None if b is None else torch.empty(N, dtype=F32, device=dy16.device)
@@ -183,7 +181,7 @@ def wgrad16_many(items):
         for t in it[:2]:
             if id(t) not in seen:
                 seen.add(id(t))
-                t.record_stream(side)
+                ops.side_hold(side, t)
     ops.grad_done(*params)
     return [(None, None)] * len(items)
 

@@ -212,6 +212,46 @@ def wgrad_join():
     for s in producer_streams():
         if s != cur:
             cur.wait_stream(s)
+    _release_held(cur.device.index)
+
+
+# ---- lifetime of tensors handed to a side stream ---------------------------------------------------------------------------------
+# A block that its owner frees while a side stream still reads it must not be re-used early.  `Tensor.record_stream` leaves that to the
+# caching allocator: the block comes back only once an event recorded at the free has completed - and with the host a step or two ahead of
+# the GPU it looks busy at the next step's allocation, so the allocator keeps calling hipMalloc (100-200 new segments and GiBs of growth
+# inside a timed loop, reserved = 2.8x the peak, NOTES 9.20).  Here the operands are simply kept alive until the main stream has JOINED the
+# side streams (wgrad_join, in front of every optimiser step): their blocks are then freed in main-stream order, the allocator sees the
+# same free lists at every step start, and a steady-state step allocates nothing from the device.  DKD_SIDE_LIFETIME=record: the old way.
+SIDE_LIFETIME_HOLD = os.environ.get("DKD_SIDE_LIFETIME", "hold") != "record"
+HOLD_BYTES_MAX = int(float(os.environ.get("DKD_HOLD_GIB", "24")) * (1 << 30))  # a backward pass that never joins: join and release here
+_held = {}        # device index -> [tensors]
+_held_bytes = {}  # device index -> bytes
+
+
+def _release_held(idx):
+    lst = _held.get(idx)
+    if lst:
+        lst.clear()
+        _held_bytes[idx] = 0
+
+
+def side_hold(side, *tensors):
+    """these tensors were just handed to kernels on `side` (enqueued already): keep them from being re-used under those kernels"""
+    if not SIDE_LIFETIME_HOLD or torch.cuda.is_current_stream_capturing():
+        for t in tensors:  # (inside a hipGraph capture the private pool's own bookkeeping does it)
+            if t is not None:
+                t.record_stream(side)
+        return
+    idx = side.device.index
+    lst = _held.setdefault(idx, [])
+    n = _held_bytes.get(idx, 0)
+    for t in tensors:
+        if t is not None:
+            lst.append(t)
+            n += t.numel() * t.element_size()
+    _held_bytes[idx] = n
+    if n > HOLD_BYTES_MAX:  # nobody joins (a backward pass without an optimiser step ...): do it here
+        wgrad_join()
 
 
 def add_grad_listener(fn):
@@ -287,8 +327,7 @@ def wgrad_into(dy2, x2, w, b=None, transform=None, fork=True, compute=None):
             gemm(dy2, x2, a_layout=1, b_layout=1, out=w.grad.view(N, K), rowsum=rs, ws_slot=3)
         else:
             transform(gemm(dy2, x2, a_layout=1, b_layout=1, rowsum=rs, ws_slot=3))
-    dy2.record_stream(side)  # (also during graph capture: the private pool recycles freed blocks inside one capture)
-    x2.record_stream(side)
+    side_hold(side, dy2, x2)
     for p_ in (w, b):
         if p_ is not None:
             for fn in _grad_listeners:

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..losses import ScaleKD
 
 try:  # pragma: no cover - lightning is not installed in the build image
@@ -137,19 +138,19 @@ class DistillationModule(_Base):
                     tok_f = self._forward_specific_stage(tok_f, layer_name)
                 frequency_loss, frequency_similarity = (loss_fn.get_freq_loss if last else loss_fn.get_spat_loss)(tok_f, teacher)
             if two:
-                x.record_stream(side)
+                ops.side_hold(side, x)
             spatial_query, frequency_query = tok_s, tok_f
             parts.append((name, spatial_loss, frequency_loss, spatial_similarity, frequency_similarity))
             if last:
                 break
         if two:
-            teacher.record_stream(side)
+            ops.side_hold(side, teacher)
             main.wait_stream(side)
         loss_dict = {}
         if two:
             for _, _, frequency_loss, _, frequency_similarity in parts:
                 for t in (frequency_loss, frequency_similarity):
-                    t.record_stream(main)
+                    ops.side_hold(main, t)
         if teacher.is_cuda:
             # the same arithmetic as the scalar expressions below in one autograd node (functional.LossCombineFn): 4 launches
             # forward / 1 backward instead of ~13 one-element kernels each way at the forward -> backward hand-over
@@ -197,7 +198,7 @@ class DistillationModule(_Base):
             teacher_features = self.teacher(batch)[key]
         student_features = self.student(batch)
         main.wait_stream(side)
-        teacher_features.record_stream(main)
+        ops.side_hold(main, teacher_features)
         return {"student": student_features, "teacher": teacher_features}
 
     def _bound_run_ahead(self, batch):
