@@ -1,0 +1,18 @@
+"""Is the bf16x3 GEMM's error biased?  Signed mean and RMS error of x3 / exact fp32 against fp64, operands of one sign (every product
+positive: a truncating accumulate shows as a negative mean error) and of both signs."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dinov2_distillation_amd import ops
+g = torch.Generator().manual_seed(0)
+for name, mk in (("positive operands", lambda *s: torch.rand(*s, generator=g) + 0.5), ("signed operands", lambda *s: torch.randn(*s, generator=g))):
+    for M, N, K in ((4096, 384, 1536), (4096, 1536, 384), (2048, 384, 12544)):
+        a, b = mk(M, K).cuda(), mk(N, K).cuda()
+        ref = a.double() @ b.double().t()
+        line = "%-18s M=%5d N=%5d K=%6d |" % (name, M, N, K)
+        for pname, prec, var in (("exact", ops.PREC_F32, 0), ("x3 auto", ops.PREC_BF16X3, 0), ("x3 cfg1", ops.PREC_BF16X3, 31), ("x3 cfg4", ops.PREC_BF16X3, 34)):
+            o = ops.gemm(a, b, precision=prec, variant=var).double()
+            d = o - ref
+            scale = ref.abs().mean()
+            line += " %s: mean %+.2e rms %.2e max %.2e |" % (pname, float(d.mean() / scale), float(d.pow(2).mean().sqrt() / scale), float(d.abs().max() / ref.abs().max()))
+        print(line, flush=True)

@@ -375,8 +375,8 @@ def test_whole_backbone_and_step_under_the_policy(family):
         _perturb_bn(dict(net.named_parameters()), g)
     p = {k: v.detach().clone() for k, v in net.state_dict().items()}
     x = torch.randn(4, 3, 128, 128, generator=g)
-    _, o16 = _run_oracle(ofn(x), p, True)
-    _, o32 = _run_oracle(ofn(x), p, False)
+    q16, o16 = _run_oracle(ofn(x), p, True)
+    q32, o32 = _run_oracle(ofn(x), p, False)
     w.set_precision("bf16_autocast")
     w.cuda().train()
     feats = net.forward_features_nhwc(x.cuda())
@@ -384,6 +384,23 @@ def test_whole_backbone_and_step_under_the_policy(family):
         e, noise = rel(feats[k].permute(0, 3, 1, 2), o16[k]), rel(o16[k], o32[k])
         print(f"{family} {k}: ours vs autocast oracle {e:.2e}; autocast vs fp32 {noise:.2e}")
         assert (family == "mit" or torch.equal(feats[k], r16(feats[k]))) and noise > 1e-3 and e < 1.3 * noise   # (MiT: fp32 LayerNorm output)
+    # ... and the gradients of the whole backbone for one cotangent on res4 and res5 (the step check below is
+    # property-only): every parameter gradient, concatenated, against the autocast oracle's at the policy's own distance from fp32
+    cot = {k: torch.randn(o32[k].shape, generator=g) for k in ("res4", "res5")}
+    sum((o16[k].float() * cot[k]).sum() for k in cot).backward()
+    sum((o32[k] * cot[k]).sum() for k in cot).backward()
+    sum((feats[k].float() * cot[k].permute(0, 2, 3, 1).cuda()).sum() for k in cot).backward()
+    from dinov2_distillation_amd import ops
+    ops.wgrad_join()
+    torch.cuda.synchronize()
+    ours = {k: v.grad.detach().cpu().double() for k, v in net.named_parameters() if v.grad is not None}
+    names = [k for k in sorted(ours) if k in q16 and q16[k].grad is not None and q32[k].grad is not None
+             and q32[k].grad.abs().max() > 1e-6 * max(float(v.grad.abs().max()) for v in q32.values() if getattr(v, "grad", None) is not None)]
+    cat = lambda d: torch.cat([(d[k] if isinstance(d[k], torch.Tensor) and not d[k].requires_grad else d[k].grad).double().reshape(-1) for k in names])
+    g_ours, g16, g32 = cat(ours), cat(q16), cat(q32)
+    e_g, noise_g = float((g_ours - g16).norm() / g16.norm()), float((g16 - g32).norm() / g32.norm())
+    print(f"{family} parameter gradients ({len(names)} tensors): ours vs autocast oracle {e_g:.2e}; autocast vs fp32 {noise_g:.2e}")
+    assert len(names) > 10 and noise_g > 1e-3 and e_g < 1.3 * noise_g
     del w, net, feats
     pair = {"resnet": dict(teacher="dinov2_vitb14", student="resnet_50"), "stdc": dict(teacher="dinov2_vits14", student="stdc_2"),
             "presnet": dict(teacher="dinov2_vits14", student="presnet_50"),
