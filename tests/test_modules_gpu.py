@@ -1270,6 +1270,9 @@ def test_hipgraph_replay_of_the_step_matches_eager():
         if use_graph:
             snap = st.optimizer.arena.clone()
             st.capture(xs[0])             # (capture warms up with real steps: restore the state afterwards)
+            # the capture pass runs the optimiser's host bookkeeping but not its kernel - the host counter that
+            # state_dict() exports must equal the device-side step counter right after capture() (two executed warm-up steps)
+            assert st.optimizer._steps == 2 and float(st.optimizer._hyper[0, 5]) == 2.0
             st.optimizer.arena.copy_(snap)
             st.optimizer._hyper[:, 5] = 0.0
         for i, x in enumerate(xs):
@@ -1281,10 +1284,11 @@ def test_hipgraph_replay_of_the_step_matches_eager():
             losses.append(float((st.step_graph(x) if use_graph else st.step(x)).detach()))
         if use_graph:
             # the exported optimiser state counts the replays too (it advanced only in the host-side step(), so a
-            # checkpoint taken after N replays resumed N steps short): 3 host-side steps inside capture() (two warm-ups and the
-            # captured body) + one per replay; the device counter was zeroed above and counts the replays alone
+            # checkpoint taken after N replays resumed N steps short): the two executed warm-up steps of capture() + one per replay
+            # (the capture pass itself executes nothing and is not counted); the device counter was zeroed above and counts the
+            # replays alone
             sd = st.optimizer.state_dict()
-            assert float(sd["state"][0]["step"]) == 3 + len(xs) and st.optimizer._steps == 3 + len(xs)
+            assert float(sd["state"][0]["step"]) == 2 + len(xs) and st.optimizer._steps == 2 + len(xs)
             assert float(st.optimizer._hyper[0, 5]) == len(xs)
         return losses, st.optimizer.flat_p.clone()
 
