@@ -223,7 +223,7 @@ def wgrad_join():
 # side streams (wgrad_join, in front of every optimiser step): their blocks are then freed in main-stream order, the allocator sees the
 # same free lists at every step start, and a steady-state step allocates nothing from the device.  DKD_SIDE_LIFETIME=record: the old way.
 SIDE_LIFETIME_HOLD = os.environ.get("DKD_SIDE_LIFETIME", "hold") != "record"
-HOLD_BYTES_MAX = int(float(os.environ.get("DKD_HOLD_GIB", "24")) * (1 << 30))  # a backward pass that never joins: join and release here
+HOLD_BYTES_MAX = int(float(os.environ.get("DKD_HOLD_GIB", "64")) * (1 << 30))  # a backward pass that never joins: join and release here
 _held = {}        # device index -> [tensors]
 _held_bytes = {}  # device index -> bytes
 
