@@ -1548,6 +1548,24 @@ extern "C" long dkd_conv_igemm_f32_workspace_bytes(int B, int H, int W, int C, i
     return pl.splits > 1 ? (long)pl.splits * pl.M * pl.N * (long)sizeof(float) : 0;
 }
 
+// the forward / stride-1 input-gradient form on the bf16x3 split-precision ring kernel (csrc/gemm_x3.hip, gathered A operand); same
+// arguments, workspace and result as mode 0 below.  DKD_ERR_UNSUPPORTED: the geometry stays on the exact kernel (the caller falls back).
+extern "C" int dkd_conv_igemm_x3_supported(int B, int H, int W, int C, int O, int k, int stride, int pad) {
+    ConvPlan pl;
+    if (conv_igemm_plan(B, H, W, C, O, k, stride, pad, 0, &pl) != DKD_OK) return 0;
+    return dkd_x3_conv_ok(B, H, W, C, O, k, pl.Ho, pl.Wo) ? 1 : 0;
+}
+
+extern "C" int dkd_conv_igemm_x3(const float* x, const float* w, float* out, const float* bias, float* workspace, int B, int H, int W, int C,
+                                 int O, int k, int stride, int pad, void* stream) {
+    if (!x || !w || !out) return DKD_ERR_BAD_ARG;
+    ConvPlan pl;
+    const int rc = conv_igemm_plan(B, H, W, C, O, k, stride, pad, 0, &pl);
+    if (rc != DKD_OK) return rc;
+    if (!dkd_aligned16(x) || !dkd_aligned16(w) || !dkd_aligned16(out)) return DKD_ERR_ALIGN;
+    return dkd_x3_conv_forward(x, w, out, bias, workspace, pl.splits, B, H, W, C, O, k, stride, pad, pl.Ho, pl.Wo, (hipStream_t)stream);
+}
+
 extern "C" int dkd_conv_igemm_f32(const float* x, const float* d, float* out, const float* bias, float* workspace, int B, int H,
                                   int W, int C, int O, int k, int stride, int pad, int mode, void* stream) {
     if (!x || !d || !out) return DKD_ERR_BAD_ARG;

@@ -85,3 +85,6 @@ int dkd_f32_splitk_reduce(const dkd_gemm_args* g, const Epilogue& epi, int split
 // gemm_x3.hip: the bf16x3 split-precision kernels (LDS-DMA ring); DKD_ERR_UNSUPPORTED = take another path
 int dkd_x3_launch(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st);
 long dkd_x3_workspace_bytes(int M, int N, int K, int a_layout, int b_layout);
+bool dkd_x3_conv_ok(int B, int H, int W, int C, int O, int k, int Ho, int Wo);
+int dkd_x3_conv_forward(const float* x, const float* w, float* out, const float* bias, float* workspace, int max_splits, int B, int H, int W,
+                        int C, int O, int k, int stride, int pad, int Ho, int Wo, hipStream_t st);

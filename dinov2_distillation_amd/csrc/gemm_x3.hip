@@ -104,6 +104,73 @@ struct RingF {
     }
 };
 
+// Implicit-GEMM convolution (resnet.py:258-289, stdc.py:8-24): the A operand's share of the ring, gathered.  The same lane-linear
+// K-contiguous fp32 image as RingF<.., true, ..> (fragment reads and split are shared), but the lane that owns (row, chunk) fetches 4
+// channels of "its" output pixel's current tap - x[b, oy s + ky - p, ox s + kx - p, c0 + 4 chunk ..] - or 16 bytes of a zero page when the
+// tap falls into the padding.  C % BK == 0 keeps a k-tile inside one tap: the tap walk (c0, kx, ky) is wave-uniform scalar arithmetic.
+struct NoConvX3 {};
+struct ConvGeomX3 {
+    const float* x;
+    int H, W, C, kw, s, p, Ho, Wo;
+    float inv_wo, inv_howo;
+};
+__device__ __attribute__((aligned(16))) float conv_zero_x3[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void divmod_x3(int n, int d, float inv, int& q, int& r) {  // exact for 0 <= n < 2^24
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
+template <int BX, int BK, int NW>
+struct ConvRingF {
+    using Dense = RingF<BX, BK, true, NW>;
+    static constexpr int BYTES = Dense::BYTES, PPW = Dense::PPW, CPR = Dense::CPR;
+    ConvGeomX3 cg;
+    unsigned boff[PPW];   // byte offset of the lane's image + its 16-byte chunk
+    int iy0[PPW], ix0[PPW];
+    int c0, ky, kx;       // wave-uniform: where the next k-tile starts
+
+    __device__ __forceinline__ void init(const ConvGeomX3& geom, int x0, int xmax, int k0, int wid, int lane) {
+        cg = geom;
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int idx = (wid + p * NW) * 64 + lane;
+            const int row = idx / CPR, slot = idx % CPR;
+            const int chunk = slot ^ Dense::swz(row);
+            int b, rem, oy, ox;
+            divmod_x3(min(x0 + row, xmax - 1), cg.Ho * cg.Wo, cg.inv_howo, b, rem);
+            divmod_x3(rem, cg.Wo, cg.inv_wo, oy, ox);
+            boff[p] = (unsigned)(((long)b * cg.H * cg.W * cg.C + 4 * chunk) * 4);
+            iy0[p] = oy * cg.s - cg.p;
+            ix0[p] = ox * cg.s - cg.p;
+        }
+        const int tap = k0 / cg.C;
+        c0 = k0 - tap * cg.C;
+        ky = tap / cg.kw;
+        kx = tap - ky * cg.kw;
+    }
+    __device__ __forceinline__ void issue(char* __restrict__ S, int wid) {
+        const char* xb = reinterpret_cast<const char*>(cg.x);
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int y = iy0[p] + ky, xx = ix0[p] + kx;
+            const bool ok = (unsigned)y < (unsigned)cg.H && (unsigned)xx < (unsigned)cg.W;
+            const char* src = ok ? xb + ((unsigned long)boff[p] + (unsigned long)(unsigned)(((y * cg.W + xx) * cg.C + c0) * 4))
+                                 : reinterpret_cast<const char*>(conv_zero_x3);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(S + (wid + p * NW) * 1024), 16, 0, 0);
+        }
+        c0 += BK;
+        if (c0 >= cg.C) {
+            c0 = 0;
+            if (++kx == cg.kw) { kx = 0; ++ky; }
+        }
+    }
+    static __device__ __forceinline__ int lane_base(int lane) { return Dense::lane_base(lane); }
+    static __device__ __forceinline__ void frag(const char* __restrict__ S, int lb, int r0, int ks, float (&v)[8]) { Dense::frag(S, lb, r0, ks, v); }
+};
+
 // x = h + m + l.  Two values at a time, so that one v_cvt_pk_bf16_f32 rounds a pair: 3 conversions, 2 + 2 shift / mask operations
 // back to fp32 and 4 subtractions per pair = 5.5 VALU instructions per value (written element by element hipcc converts every value
 // on its own: 10 per value, measured 2.3x the matrix time).  TRUNC: the terms cut instead of rounded (v_and / v_perm_b32 only, no
@@ -172,13 +239,17 @@ struct Planes {
     bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 };
 
-template <int WGM, int WGN, int TM, int TN, int BK, int NS, bool A_KC, bool B_KC, int OCC, bool TRUNC, bool PIPE, bool ROWSUM, int KNOCK>
+// CG = ConvGeomX3: the A operand is gathered from an NHWC image (implicit-GEMM convolution, see ConvRingF); NoConvX3: dense operands.
+template <int WGM, int WGN, int TM, int TN, int BK, int NS, bool A_KC, bool B_KC, int OCC, bool TRUNC, bool PIPE, bool ROWSUM, int KNOCK,
+          class CG = NoConvX3>
 __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                                            long ldb, float* C, long ldc, int M, int N, int K, int kchunk,
                                                                            Epilogue epi, float* __restrict__ ws, float* __restrict__ rowsum,
-                                                                           int vec_ok) {
+                                                                           int vec_ok, CG cgeom) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NW = WGM * WGN, KB = BK / 16;
-    using RA = RingF<BM, BK, A_KC, NW>;
+    constexpr bool CONV = !std::is_same<CG, NoConvX3>::value;
+    static_assert(!CONV || A_KC, "the gathered operand is K-contiguous");
+    using RA = typename std::conditional<CONV, ConvRingF<BM, BK, NW>, RingF<BM, BK, A_KC, NW>>::type;
     using RB = RingF<BN, BK, B_KC, NW>;
     constexpr int STAGE = RA::BYTES + RB::BYTES, PW = RA::PPW + RB::PPW;
     static_assert(NS >= 2 && NS <= 4, "2 .. 4 stages");
@@ -207,7 +278,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const 
 
     RA ra;
     RB rb;
-    ra.init(A, lda, bm0, M, kbeg, wid, lane);
+    if constexpr (CONV) ra.init(cgeom, bm0, M, kbeg, wid, lane);
+    else ra.init(A, lda, bm0, M, kbeg, wid, lane);
     rb.init(B, ldb, bn0, N, kbeg, wid, lane);
     const int lba = RA::lane_base(lane), lbb = RB::lane_base(lane);
 
@@ -448,7 +520,20 @@ struct X3Cfg {
         attr_done = true;
         const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(NW * 64);
         hipLaunchKernelGGL(kern, grid, block, LDS, st, g->A, g->lda, g->B, g->ldb, g->C, g->ldc, g->M, g->N, g->K, kchunk, epi,
-                           splits > 1 ? g->workspace : (float*)nullptr, g->rowsum, vec);
+                           splits > 1 ? g->workspace : (float*)nullptr, g->rowsum, vec, NoConvX3{});
+        DKD_LAUNCH_CHECK();
+        return DKD_OK;
+    }
+    // the gathered-A form (implicit-GEMM convolution): NT layout only
+    static int launch_conv(const dkd_gemm_args* g, const ConvGeomX3& cg, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
+        auto kern = gemm_x3_ring_kernel<WGM, WGN, TM, TN, BK, NS, true, true, OCC, TRUNC, PIPE, false, KNOCK, ConvGeomX3>;
+        if (LDS > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+        }
+        const dim3 grid(dkd_cdiv(g->M, BM) * dkd_cdiv(g->N, BN), splits), block(NW * 64);
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, (const float*)nullptr, 0L, g->B, g->ldb, g->C, g->ldc, g->M, g->N, g->K, kchunk, epi,
+                           splits > 1 ? g->workspace : (float*)nullptr, (float*)nullptr, vec, cg);
         DKD_LAUNCH_CHECK();
         return DKD_OK;
     }
@@ -613,5 +698,47 @@ int dkd_x3_launch(const dkd_gemm_args* g, const Epilogue& epi, hipStream_t st) {
     }
     if (rc != DKD_OK) return rc;
     if (splits > 1) return dkd_f32_splitk_reduce(g, epi, splits, st);
+    return DKD_OK;
+}
+
+// Implicit-GEMM convolution forward (and, with the flipped kernel, the stride-1 input gradient) on the split-precision ring kernel:
+// out[(b,oy,ox)][o] = sum_(ky,kx,c) x[b, oy s + ky - p, ox s + kx - p, c] w[o][(ky,kx,c)] (+ bias).  max_splits: the K-slabs the caller's
+// workspace was sized for (dkd_conv_igemm_f32_workspace_bytes).  DKD_ERR_UNSUPPORTED: take the exact kernel.
+bool dkd_x3_conv_ok(int B, int H, int W, int C, int O, int k, int Ho, int Wo) {
+    const long pix = (long)B * Ho * Wo, kk = (long)k * k * C;
+    // a 32-deep k-tile inside one tap; float4 columns; exact float pixel decomposition; 32-bit byte offsets inside one image
+    if ((C % 32) || (O % 4) || pix >= (1L << 24) || (long)H * W * C * 4 >= (1L << 31) || kk >= (1L << 24) || kk < 96) return false;
+    // only where the 128 x 128 tiles fill the chip: measured (scripts/time_configs.py, DKD_CONV_X3 A/B) configs[2] (bs 128) 147.3 -> 145.1 ms
+    // with this kernel, configs[0] (bs 2: 49 ... 196 tiles per conv) 17-19 -> 22 ms - small convolutions stay on the 64 x 64 exact kernel
+    return (long)dkd_cdiv(pix, 128) * dkd_cdiv(O, 128) >= 384;
+}
+
+int dkd_x3_conv_forward(const float* x, const float* w, float* out, const float* bias, float* workspace, int max_splits, int B, int H, int W,
+                        int C, int O, int k, int stride, int pad, int Ho, int Wo, hipStream_t st) {
+    const long pix = (long)B * Ho * Wo, kk = (long)k * k * C;
+    if (!dkd_x3_conv_ok(B, H, W, C, O, k, Ho, Wo)) return DKD_ERR_UNSUPPORTED;
+    dkd_gemm_args g = {};
+    g.B = w, g.ldb = kk, g.C = out, g.ldc = O, g.M = (int)pix, g.N = O, g.K = (int)kk, g.bias = bias, g.alpha = 1.f, g.workspace = workspace;
+    Epilogue epi = {};
+    epi.bias = bias;
+    epi.alpha = 1.f;
+    int kchunk;
+    int splits = plan(g.M, g.N, g.K, 1, &kchunk);
+    if (splits > max_splits || !workspace || !dkd_aligned16(workspace)) {
+        splits = max_splits > 1 && workspace && dkd_aligned16(workspace) ? max_splits : 1;
+        kchunk = g.K;
+        if (splits > 1) {
+            kchunk = ((g.K + splits - 1) / splits + 31) / 32 * 32;
+            splits = (g.K + kchunk - 1) / kchunk;
+        }
+    }
+    ConvGeomX3 cg;
+    cg.x = x, cg.H = H, cg.W = W, cg.C = C, cg.kw = k, cg.s = stride, cg.p = pad, cg.Ho = Ho, cg.Wo = Wo;
+    cg.inv_wo = 1.f / (float)Wo;
+    cg.inv_howo = 1.f / (float)(Ho * Wo);
+    const int vec = epilogue_vec_ok_x3(&g);
+    const int rc = Cfg1::launch_conv(&g, cg, epi, splits, kchunk, vec, st);
+    if (rc != DKD_OK) return rc;
+    if (splits > 1) return dkd_f32_splitk_reduce(&g, epi, splits, st);
     return DKD_OK;
 }

@@ -719,6 +719,9 @@ def col2im_nhwc(drows, B, H, W, C, k, stride, pad):
     return dx
 
 
+CONV_X3 = os.environ.get("DKD_CONV_X3", "1") != "0"   # A/B: k x k convolutions on the exact fp32 implicit-GEMM kernel in every GEMM mode
+
+
 def conv_igemm_ok(B, H, W, C, O, k, stride, pad, mode=0):
     """can dkd_conv_igemm_f32 run this geometry (C % 32 == 0, O % 4 == 0, ...; the weight gradient, mode 1, also needs a whole
     number of 32-pixel k-tiles)?  A pure function of the integers, asked once per shape."""
@@ -738,6 +741,11 @@ def conv_igemm_fwd(x, w2, k, stride, pad, bias=None, out=None):
     _chk(out, "out")
     wsb = _size("dkd_conv_igemm_f32_workspace_bytes", B, H, W, C, O, k, stride, pad, 0)
     ws = workspace(wsb, x.device) if wsb else None
+    if GEMM_PRECISION == PREC_BF16X3 and CONV_X3 and _size("dkd_conv_igemm_x3_supported", B, H, W, C, O, k, stride, pad):
+        # the split-precision kernel with the gathered operand (what it does not take stays on the exact kernel)
+        check(_lib.binding().dkd_conv_igemm_x3(_p(x), _p(w2), _p(out), _p(bias), _p(ws), B, H, W, C, O, k, stride, pad, _stream()),
+              "dkd_conv_igemm_x3", (B, H, W, C, O, k, stride, pad))
+        return out
     check(_lib.binding().dkd_conv_igemm_f32(_p(x), _p(w2), _p(out), _p(bias), _p(ws), B, H, W, C, O, k, stride, pad, 0, _stream()),
           "dkd_conv_igemm_f32", (B, H, W, C, O, k, stride, pad))
     return out

@@ -497,6 +497,12 @@ int dkd_im2col_nchw_f32(const float* img, float* rows, int B, int Cin, int H, in
  * the caller keeps the materialised path). */
 int dkd_conv_igemm_f32(const float* x, const float* d, float* out, const float* bias, float* workspace, int B, int H, int W, int C,
                        int O, int k, int stride, int pad, int mode, void* stream);
+/* mode 0 on the bf16x3 split-precision kernel (fp32-level accuracy, DKD_PREC_BF16X3's arithmetic; the Python side's default): same
+ * arguments and workspace.  dkd_conv_igemm_x3_supported: 1 when the geometry is handled (else the call returns DKD_ERR_UNSUPPORTED:
+ * it stays on dkd_conv_igemm_f32) */
+int dkd_conv_igemm_x3(const float* x, const float* w, float* out, const float* bias, float* workspace, int B, int H, int W, int C, int O,
+                      int k, int stride, int pad, void* stream);
+int dkd_conv_igemm_x3_supported(int B, int H, int W, int C, int O, int k, int stride, int pad);
 long dkd_conv_igemm_f32_workspace_bytes(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode);
 int dkd_conv_igemm_f32_supported(int B, int H, int W, int C, int O, int k, int stride, int pad, int mode);
 /* The same convolution on bf16 NHWC under the autocast policy (x16, w16 [O][k*k*C] bf16; the A operand of the LDS-DMA ring kernel of

@@ -43,6 +43,31 @@ def w2_of(w, k):
     return w.permute(0, 2, 3, 1).reshape(O, k * k * C).contiguous()
 
 
+@pytest.mark.parametrize("B,H,W,C,O,k,s,p", [(64, 56, 56, 64, 64, 3, 1, 1),     # ResNet layer1's 3 x 3 at bs 64: 1568 tiles
+                                             (64, 57, 57, 64, 128, 3, 2, 1),    # stride 2, odd image, ragged last row tile
+                                             (40, 40, 40, 32, 96, 5, 1, 2)])    # 5 x 5, 32 channels (a tap per k-tile), ragged N tile
+def test_igemm_x3_forward_and_stride1_dgrad(ops, monkeypatch, B, H, W, C, O, k, s, p):
+    """the split-precision form of the implicit-GEMM convolution (csrc/gemm_x3.hip, gathered A operand; taken for chip-filling
+    geometries in the default GEMM mode): forward with bias and - stride 1 - the input gradient through the flipped kernel, against
+    fp64 convolutions at fp32 round-off level"""
+    monkeypatch.setattr(ops, "GEMM_PRECISION", ops.PREC_BF16X3)
+    from dinov2_distillation_amd import _lib
+    assert _lib.load().dkd_conv_igemm_x3_supported(B, H, W, C, O, k, s, p) == 1
+    g = torch.Generator().manual_seed(B + H + C + O + k)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(O, C, k, k, generator=g) / (k * C ** 0.5)
+    bias = torch.randn(O, generator=g)
+    y_ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=s, padding=p)
+    Ho, Wo = y_ref.shape[2:]
+    z = ops.conv_igemm_fwd(x.cuda(), w2_of(w, k).cuda(), k, s, p, bias=bias.cuda())
+    close(z.view(B, Ho, Wo, O), y_ref.permute(0, 2, 3, 1), "x3 forward + bias", rtol=5e-6)
+    if s == 1:
+        dy = torch.randn(B, Ho, Wo, O, generator=g)
+        dx_ref = torch.nn.grad.conv2d_input((B, C, H, W), w.double(), dy.double().permute(0, 3, 1, 2), stride=1, padding=p)
+        dx = ops.conv_igemm_dgrad(dy.cuda(), w.cuda(), (B, H, W, C), k, p)
+        close(dx, dx_ref.permute(0, 2, 3, 1), "x3 stride-1 input gradient", rtol=5e-6)
+
+
 @pytest.mark.parametrize("B,H,W,C,O,k,s,p", CASES)
 def test_igemm_forward_dgrad_wgrad(ops, B, H, W, C, O, k, s, p):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + C + O + k)
