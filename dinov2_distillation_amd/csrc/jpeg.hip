@@ -1,0 +1,342 @@
+// Baseline JPEG decode on the GPU: the reference's `Image.open(img_path).convert('RGB')` (/root/reference/datasets/CustomDataset.py:64),
+// i.e. what Pillow's libjpeg-turbo does for a baseline file, bit for bit (tests/test_jpeg_gpu.py compares with Pillow itself):
+//   jpeg_entropy_idct_kernel   one wave per entropy-coded segment (a whole image, or one restart interval of it): the 64 lanes stage
+//                              the byte stream into an LDS ring 1 KiB at a time and remove the 0xFF00 stuffing with a wave prefix sum;
+//                              lane 0 runs the sequential Huffman decode of one MCU into LDS; 8 lanes per block then dequantise and
+//                              run libjpeg's "islow" integer inverse DCT (column pass, row pass) and store 8-pixel rows of the
+//                              component planes
+//   jpeg_rgb_kernel            one thread per pixel: libjpeg's "fancy" (triangle) h2v1 / h2v2 chroma upsampling evaluated at the
+//                              pixel, then the 16-bit fixed-point YCbCr -> RGB of jdcolor.c; writes packed RGB, the layout
+//                              dkd_aug_resize reads
+// Integer work end to end; the Huffman stage is latency-bound by construction (one lane), images / restart intervals run side by side.
+#include "common.h"
+#include "dkd_hip.h"
+
+namespace {
+
+constexpr int RING = 4096;        // bytes of unstuffed stream held in LDS
+constexpr int LUT_BITS = 9;
+constexpr int TBL_BYTES = DKD_JPEG_TABLE_BYTES;   // per image: 4 x 64 u16 quantisers (natural order), 4 x (16 counts + 256 values)
+constexpr int HUFF0 = 512;
+constexpr int HUFF_STRIDE = 272;
+
+__constant__ unsigned char kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                                          41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                          30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Lds {
+    unsigned int ring[RING / 4];            // byte k of the stream sits at byte address k ^ 3: aligned words read MSB first
+    unsigned short lut[4][1 << LUT_BITS];   // (code length << 8) | symbol for codes of at most LUT_BITS bits, else 0
+    int maxcode[4][18];                     // largest code of each length, -1: none
+    int valoff[4][18];                      // index of a length's first value minus its first code
+    unsigned char tbl[TBL_BYTES];
+    short coef[6][64];
+    int ws[6][64];
+    unsigned char zz[64];
+};
+
+// the even / odd butterflies of jidctint.c (Loeffler, Ligtenberg, Moschytz; CONST_BITS 13)
+__device__ __forceinline__ void idct8(const int x[8], int o[8]) {
+    int z2 = x[2], z3 = x[6];
+    int z1 = (z2 + z3) * 4433;
+    const int tmp2 = z1 + z3 * (-15137), tmp3 = z1 + z2 * 6270;
+    const int tmp0 = (x[0] + x[4]) * 8192, tmp1 = (x[0] - x[4]) * 8192;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int t0 = x[7], t1 = x[5], t2 = x[3], t3 = x[1];
+    z1 = t0 + t3;
+    z2 = t1 + t2;
+    z3 = t0 + t2;
+    int z4 = t1 + t3;
+    const int z5 = (z3 + z4) * 9633;
+    t0 *= 2446;
+    t1 *= 16819;
+    t2 *= 25172;
+    t3 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 = z3 * (-16069) + z5;
+    z4 = z4 * (-3196) + z5;
+    t0 += z1 + z3;
+    t1 += z2 + z4;
+    t2 += z2 + z3;
+    t3 += z1 + z4;
+    o[0] = tmp10 + t3, o[7] = tmp10 - t3, o[1] = tmp11 + t2, o[6] = tmp11 - t2;
+    o[2] = tmp12 + t1, o[5] = tmp12 - t1, o[3] = tmp13 + t0, o[4] = tmp13 - t0;
+}
+
+__device__ __forceinline__ unsigned range_limit(int v) {   // libjpeg's range_limit table indexed with & RANGE_MASK
+    v &= 1023;
+    return v < 128 ? v + 128 : (v < 512 ? 255 : (v < 896 ? 0 : v - 896));
+}
+
+struct BitReader {
+    unsigned long long acc;   // unread bits, MSB first
+    int n;                    // how many of them are valid
+    int rp;                   // next ring word
+    __device__ __forceinline__ void fill(const unsigned int* ring) {
+        if (n < 32) {
+            acc |= (unsigned long long)ring[rp & (RING / 4 - 1)] << (32 - n);
+            n += 32;
+            ++rp;
+        }
+    }
+    __device__ __forceinline__ unsigned peek(int k) const { return (unsigned)(acc >> (64 - k)); }
+    __device__ __forceinline__ void skip(int k) {
+        acc <<= k;
+        n -= k;
+    }
+    __device__ __forceinline__ int receive_extend(int s) {   // s in 1..15
+        const int v = (int)peek(s);
+        skip(s);
+        return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    }
+};
+
+__device__ __forceinline__ int huff_symbol(BitReader& br, const Lds& L, int t) {
+    br.fill(L.ring);
+    const unsigned e = L.lut[t][br.peek(LUT_BITS)];
+    if (e) {
+        br.skip(e >> 8);
+        return e & 255;
+    }
+    const int code16 = (int)br.peek(16);
+    for (int l = LUT_BITS + 1; l <= 16; ++l) {
+        const int c = code16 >> (16 - l);
+        if (c <= L.maxcode[t][l]) {
+            br.skip(l);
+            return L.tbl[HUFF0 + t * HUFF_STRIDE + 16 + ((c + L.valoff[t][l]) & 255)];
+        }
+    }
+    br.skip(16);   // not a code of this table (corrupt stream): libjpeg substitutes a zero symbol as well
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned char* __restrict__ bytes, const int* __restrict__ seg_meta,
+                                                               const int* __restrict__ img_meta, const unsigned char* __restrict__ tables,
+                                                               unsigned char* __restrict__ planes) {
+    __shared__ Lds L;
+    const int lane = threadIdx.x;
+    const int* sm = seg_meta + (long)blockIdx.x * DKD_JPEG_SEG_INTS;
+    const int img = sm[0];
+    const long s0 = (long)(unsigned)sm[1], s_end = s0 + sm[2];
+    const int mcu0 = sm[3], n_mcu = sm[4];
+    const int* im = img_meta + (long)img * DKD_JPEG_IMG_INTS;
+    const int nc = im[2], h0 = im[3], v0 = im[4], mcux = im[5];
+    const int sel = im[15];
+    const int nblk0 = h0 * v0, nblk = nblk0 + (nc == 3 ? 2 : 0);
+
+    // ---- tables: the image's quantisers and Huffman specifications into LDS, then the 9-bit look-ahead tables -------------------
+    {
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(tables + (long)im[14] * TBL_BYTES);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(L.tbl);
+        for (int i = lane; i < TBL_BYTES / 4; i += 64) dst[i] = src[i];
+        unsigned int* lz = reinterpret_cast<unsigned int*>(&L.lut[0][0]);
+        for (int i = lane; i < 4 * (1 << LUT_BITS) / 2; i += 64) lz[i] = 0;
+        unsigned int* cz = reinterpret_cast<unsigned int*>(&L.coef[0][0]);
+        for (int i = lane; i < 6 * 64 / 2; i += 64) cz[i] = 0;
+        L.zz[lane] = kZigzag[lane];
+    }
+    __syncthreads();
+    for (int t = 0; t < 4; ++t) {
+        const unsigned char* bits = L.tbl + HUFF0 + t * HUFF_STRIDE;
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {   // every lane walks the 16 lengths; each fills the look-ahead entries of its own symbols
+            const int cnt = bits[l - 1];
+            if (lane == 0) {
+                L.maxcode[t][l] = cnt ? code + cnt - 1 : -1;
+                L.valoff[t][l] = k - code;
+            }
+            if (l <= LUT_BITS)
+                for (int j = lane; j < cnt; j += 64) {
+                    const unsigned short e = (unsigned short)((l << 8) | bits[16 + k + j]);
+                    const int first = (code + j) << (LUT_BITS - l);
+                    for (int f = 0; f < (1 << (LUT_BITS - l)); ++f) L.lut[t][(first + f) & ((1 << LUT_BITS) - 1)] = e;
+                }
+            code = (code + cnt) << 1;
+            k += cnt;
+        }
+    }
+    __syncthreads();
+
+    // ---- the stream --------------------------------------------------------------------------------------------------------------
+    const long a0 = s0 & ~15L;
+    int chunk = 0;         // next 1 KiB piece of the source
+    int wpos = 0;          // bytes staged so far
+    unsigned prev_last = 0;
+    BitReader br{0ull, 0, 0};
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+
+    for (int m = 0; m < n_mcu; ++m) {
+        // stage until at least 2 KiB lie ahead of the reader (an MCU of six blocks cannot take more than 1.3 KiB); behind the end of the
+        // segment the stream continues with zero bytes, as libjpeg's does
+        int rbytes = __builtin_amdgcn_readfirstlane(br.rp) * 4;
+        while (wpos - rbytes < 2048) {
+            const long p = a0 + (long)chunk * 1024 + lane * 16;
+            const bool beyond = a0 + (long)chunk * 1024 >= s_end;
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (!beyond && p < s_end) w = *reinterpret_cast<const uint4*>(bytes + p);
+            const unsigned wv[4] = {w.x, w.y, w.z, w.w};
+            unsigned up = __shfl_up(wv[3] >> 24, 1);
+            if (lane == 0) up = prev_last;
+            prev_last = __shfl(wv[3] >> 24, 63);
+            unsigned keep = 0, prev = up;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned b = (wv[j >> 2] >> (8 * (j & 3))) & 255;
+                const bool valid = beyond || (p + j >= s0 && p + j < s_end);
+                if (valid && !(b == 0 && prev == 0xFF && !beyond)) keep |= 1u << j;
+                prev = b;
+            }
+            const int cnt = __popc(keep);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            int at = wpos + incl - cnt;
+            unsigned char* rb = reinterpret_cast<unsigned char*>(L.ring);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (keep & (1u << j)) {
+                    rb[(at & (RING - 1)) ^ 3] = (unsigned char)((wv[j >> 2] >> (8 * (j & 3))) & 255);
+                    ++at;
+                }
+            wpos += __shfl(incl, 63);
+            ++chunk;
+        }
+        __syncthreads();
+
+        if (lane == 0) {
+            int bi = 0;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                if (ci >= nc) break;
+                const int td = (sel >> (6 + 2 * ci)) & 1, ta = 2 + ((sel >> (7 + 2 * ci)) & 1);
+                const int reps = ci == 0 ? nblk0 : 1;
+                int pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
+                for (int r = 0; r < reps; ++r, ++bi) {
+                    short* blk = L.coef[bi];
+                    int s = huff_symbol(br, L, td) & 15;
+                    if (s) pred += br.receive_extend(s);
+                    blk[0] = (short)pred;
+                    int k = 1;
+                    while (k < 64) {
+                        const int rs = huff_symbol(br, L, ta);
+                        s = rs & 15;
+                        if (!s) {
+                            if ((rs >> 4) != 15) break;
+                            k += 16;
+                            continue;
+                        }
+                        k += rs >> 4;
+                        const int v = br.receive_extend(s);
+                        if (k > 63) break;
+                        blk[L.zz[k]] = (short)v;
+                        ++k;
+                    }
+                }
+                if (ci == 0) pred0 = pred; else if (ci == 1) pred1 = pred; else pred2 = pred;
+            }
+        }
+        __syncthreads();
+
+        // ---- dequantise + inverse DCT: lane = 8 * block + column, then 8 * block + row --------------------------------------------
+        const int b = lane >> 3, c = lane & 7;
+        const int comp = b < nblk0 ? 0 : b - nblk0 + 1;
+        if (b < nblk) {
+            const unsigned short* q = reinterpret_cast<const unsigned short*>(L.tbl) + 64 * ((sel >> (2 * comp)) & 3);
+            int x[8], o[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x[r] = (int)L.coef[b][r * 8 + c] * (int)q[r * 8 + c];
+                L.coef[b][r * 8 + c] = 0;
+            }
+            idct8(x, o);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) L.ws[b][r * 8 + c] = (o[r] + (1 << 10)) >> 11;
+        }
+        __syncthreads();
+        if (b < nblk) {
+            int x[8], o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = L.ws[b][c * 8 + j];
+            idct8(x, o);
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo |= range_limit((o[j] + (1 << 17)) >> 18) << (8 * j);
+                hi |= range_limit((o[j + 4] + (1 << 17)) >> 18) << (8 * j);
+            }
+            const int mi = mcu0 + m, my = mi / mcux, mx = mi - my * mcux;
+            const int brow = comp == 0 ? my * v0 + b / h0 : my, bcol = comp == 0 ? mx * h0 + b % h0 : mx;
+            unsigned char* dst = planes + (long)im[7 + comp] * 16 + (long)(brow * 8 + c) * im[10 + comp] + bcol * 8;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void jpeg_rgb_kernel(const unsigned char* __restrict__ planes, const int* __restrict__ img_meta,
+                                                       unsigned char* __restrict__ rgb) {
+    const int* im = img_meta + (long)blockIdx.y * DKD_JPEG_IMG_INTS;
+    const int W = im[0], H = im[1], nc = im[2], h0 = im[3], v0 = im[4];
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)W * H) return;
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    const int Y = planes[(long)im[7] * 16 + (long)y * im[10] + x];
+    int r = Y, g = Y, bl = Y;
+    if (nc == 3) {
+        const int cw = (W + h0 - 1) / h0, ch = (H + v0 - 1) / v0;
+        int cc[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned char* pl = planes + (long)im[8 + k] * 16;
+            const int st = im[11 + k];
+            if (h0 == 1) {
+                cc[k] = pl[(long)y * st + x];
+            } else if (cw <= 2) {   // jdsample.c uses the triangle filter only for downsampled_width > 2
+                cc[k] = pl[(long)(y / v0) * st + (x >> 1)];
+            } else if (v0 == 1) {
+                const int cx = x >> 1, t = 3 * pl[(long)y * st + cx];
+                if (x & 1) cc[k] = cx == cw - 1 ? pl[(long)y * st + cx] : (t + pl[(long)y * st + cx + 1] + 2) >> 2;
+                else cc[k] = cx == 0 ? pl[(long)y * st] : (t + pl[(long)y * st + cx - 1] + 1) >> 2;
+            } else {
+                const int cx = x >> 1, cy = y >> 1;
+                const int oy = (y & 1) ? min(cy + 1, ch - 1) : max(cy - 1, 0);
+                const unsigned char *r0 = pl + (long)cy * st, *r1 = pl + (long)oy * st;
+                const int s = 3 * r0[cx] + r1[cx];
+                if (x & 1) cc[k] = cx == cw - 1 ? (4 * s + 7) >> 4 : (3 * s + 3 * r0[cx + 1] + r1[cx + 1] + 7) >> 4;
+                else cc[k] = cx == 0 ? (4 * s + 8) >> 4 : (3 * s + 3 * r0[cx - 1] + r1[cx - 1] + 8) >> 4;
+            }
+        }
+        const int cb = cc[0] - 128, cr = cc[1] - 128;
+        r = Y + ((91881 * cr + 32768) >> 16);
+        g = Y + ((-22554 * cb - 46802 * cr + 32768) >> 16);
+        bl = Y + ((116130 * cb + 32768) >> 16);
+        r = min(max(r, 0), 255), g = min(max(g, 0), 255), bl = min(max(bl, 0), 255);
+    }
+    unsigned char* o = rgb + (long)im[13] * 16 + p * 3;
+    o[0] = (unsigned char)r, o[1] = (unsigned char)g, o[2] = (unsigned char)bl;
+}
+
+}  // namespace
+
+extern "C" int dkd_jpeg_decode_planes(const void* bytes, const int* seg_meta, int n_seg, const int* img_meta, const void* tables,
+                                      void* planes, void* stream) {
+    if (!bytes || !seg_meta || !img_meta || !tables || !planes || n_seg <= 0) return DKD_ERR_BAD_ARG;
+    if (!dkd_aligned16(bytes) || !dkd_aligned16(planes) || (((uintptr_t)tables) & 3)) return DKD_ERR_ALIGN;
+    hipLaunchKernelGGL(jpeg_entropy_idct_kernel, dim3(n_seg), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)bytes, seg_meta,
+                       img_meta, (const unsigned char*)tables, (unsigned char*)planes);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}
+
+extern "C" int dkd_jpeg_planes_to_rgb(const void* planes, const int* img_meta, int n_img, int max_pixels, void* rgb, void* stream) {
+    if (!planes || !img_meta || !rgb || n_img <= 0 || max_pixels <= 0) return DKD_ERR_BAD_ARG;
+    if (!dkd_aligned16(planes) || !dkd_aligned16(rgb)) return DKD_ERR_ALIGN;
+    if (n_img > 65535) return DKD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(jpeg_rgb_kernel, dim3(dkd_cdiv(max_pixels, 256), n_img), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)planes, img_meta, (unsigned char*)rgb);
+    DKD_LAUNCH_CHECK();
+    return DKD_OK;
+}

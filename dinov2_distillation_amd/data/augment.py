@@ -267,37 +267,49 @@ class DataAugmentationDINOGpu:
         return [make_plan(generator, h, w, self.size, self.scale) for h, w in shapes]
 
     def __call__(self, images, generator=None, plans=None, return_stages=False):
-        """images: list of uint8 [H, W, 3] tensors / arrays (CPU).  plans: reuse decisions (tests); default: draw them."""
+        """images: list of uint8 [H, W, 3] tensors / arrays (CPU), or a data.jpeg.DecodedBatch (packed RGB already on the GPU).
+        plans: reuse decisions (tests); default: draw them."""
         S, dev = self.size, self.device
         if dev.type != "cuda":
             raise _lib.DkdError("DataAugmentationDINOGpu needs an MI355X (the pixel pipeline has no CPU path)")
-        imgs = [torch.as_tensor(np.ascontiguousarray(im)) for im in images]
-        for im in imgs:
-            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
-                raise _lib.DkdError(f"expected uint8 [H, W, 3] RGB images, got {im.dtype} {tuple(im.shape)}")
-        B = len(imgs)
+        on_device = hasattr(images, "packed")
+        if on_device:
+            shapes, offs = list(images.shapes), np.asarray(images.offsets, np.int64)
+            if images.packed.device != dev:
+                raise _lib.DkdError(f"the decoded batch lives on {images.packed.device}, the pipeline on {dev}")
+        else:
+            imgs = [torch.as_tensor(np.ascontiguousarray(im)) for im in images]
+            for im in imgs:
+                if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+                    raise _lib.DkdError(f"expected uint8 [H, W, 3] RGB images, got {im.dtype} {tuple(im.shape)}")
+            shapes = [(im.shape[0], im.shape[1]) for im in imgs]
+        B = len(shapes)
         if plans is None:
             gen = generator if generator is not None else torch.default_generator
-            plans = self.plan([(im.shape[0], im.shape[1]) for im in imgs], gen)
+            plans = self.plan(shapes, gen)
         self.last_plans = plans
-        # pack the images and the per-image parameter arrays (host), one H2D copy each
-        sizes = [im.numel() for im in imgs]
-        offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
-        packed, copied = self._staging(int(offs[-1]))
-        packed_np = packed.numpy()  # (numpy's memcpy into the pinned pages: 10x faster than 64 torch slice assignments)
-        for im, o, n in zip(imgs, offs[:-1], sizes):
-            packed_np[int(o):int(o) + n] = im.numpy().reshape(-1)
+        if on_device:
+            src = images.packed
+        else:
+            # pack the images (host), one H2D copy
+            sizes = [im.numel() for im in imgs]
+            offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in sizes])]).astype(np.int64)
+            packed, copied = self._staging(int(offs[-1]))
+            packed_np = packed.numpy()  # (numpy's memcpy into the pinned pages: 10x faster than 64 torch slice assignments)
+            for im, o, n in zip(imgs, offs[:-1], sizes):
+                packed_np[int(o):int(o) + n] = im.numpy().reshape(-1)
+            src = packed.to(dev, non_blocking=True)
+            copied.record(torch.cuda.current_stream(dev))  # the host may rewrite this slot once the DMA above has run
         # Pillow's coefficient tables: tabulated on the device (dkd_aug_coeffs, the same double-precision operations as
         # resample_coeffs below; the host version costs ~25 ms per batch of 64 in numpy and is kept as the test's reference)
         crop_w, crop_h = [p["crop"][3] for p in plans], [p["crop"][2] for p in plans]
         ksz = lambda v: int(math.ceil(2.0 * max(1.0, max(v) / S))) * 2 + 1
         kh_n, kv_n = ksz(crop_w), ksz(crop_h)
         meta = np.zeros((B, 10), np.int32)
-        for b, (im, p) in enumerate(zip(imgs, plans)):
+        for b, (hw, p) in enumerate(zip(shapes, plans)):
             i, j, h, w = p["crop"]
             lo = int(offs[b]) & 0xFFFFFFFF
-            meta[b] = [lo - (1 << 32) if lo >= (1 << 31) else lo, int(offs[b]) >> 32, im.shape[0], im.shape[1], i, j, h, w,
-                       int(p["flip"]), 0]
+            meta[b] = [lo - (1 << 32) if lo >= (1 << 31) else lo, int(offs[b]) >> 32, hw[0], hw[1], i, j, h, w, int(p["flip"]), 0]
         max_h = max(p["crop"][2] for p in plans)
         n_ops = len(plans[0]["ops"])
         opc = np.zeros((n_ops, B), np.int32)
@@ -307,8 +319,6 @@ class DataAugmentationDINOGpu:
                 opc[r, b], fpar[r, b] = _op_params(op, mag, S)
         erase = np.array([p["erase"] if p["erase"] is not None else (0, 0, 0, 0) for p in plans], np.int32)
         up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
-        src = packed.to(dev, non_blocking=True)
-        copied.record(torch.cuda.current_stream(dev))  # the host may rewrite this slot once the DMA above has run
         meta_d, opc_d, fpar_d, erase_d, sizes_d = (up(a) for a in (meta, opc, fpar, erase, np.array(crop_w + crop_h, np.int32)))
         lib = _lib.binding()
         P, st = _lib.ptr, _lib.stream

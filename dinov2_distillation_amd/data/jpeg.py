@@ -1,0 +1,263 @@
+"""Image decode on the GPU - the first call of the reference's sample loader, ``Image.open(img_path).convert('RGB')``
+(/root/reference/datasets/CustomDataset.py:64), for baseline JPEG files.
+
+    dec = JpegDecoderGpu()
+    batch = dec.decode([open(p, "rb").read() for p in paths])    # DecodedBatch: packed RGB on the GPU, bit-exact with Pillow
+    x = DataAugmentationDINOGpu(...)(batch, generator)           # consumed where it lies (no host round trip)
+    batch.images()                                               # or: a list of uint8 [H, W, 3] views
+
+The host only walks the marker segments of each file (SOF / DQT / DHT / DRI / SOS, and the restart markers of the entropy-coded
+data) and copies the file bytes up; Huffman decoding, dequantisation, the inverse DCT, chroma upsampling and the colour conversion
+run in csrc/jpeg.hip (dkd_jpeg_decode_planes, dkd_jpeg_planes_to_rgb - include/dkd_hip.h).  Supported: what Pillow writes by
+default and what ImageNet-style datasets overwhelmingly hold - SOF0 / SOF1, 8 bit, one interleaved scan, grayscale or YCbCr with
+4:4:4, 4:2:2 or 4:2:0 sampling, restart intervals.  Anything else (progressive, CMYK, other sampling factors, several scans, a
+file that is not a JPEG at all) raises ``UnsupportedJpeg`` - or, with ``host_fallback=True``, is decoded by Pillow on the host and
+copied into its slot of the batch, counted in ``JpegDecoderGpu.stats``.
+"""
+import io
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+IMG_INTS, SEG_INTS, TABLE_BYTES = (_lib.DEFINES[k] for k in ("DKD_JPEG_IMG_INTS", "DKD_JPEG_SEG_INTS", "DKD_JPEG_TABLE_BYTES"))
+_ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
+                    62, 63])
+_SOF_OTHER = frozenset((0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF))
+
+
+class UnsupportedJpeg(_lib.DkdError):
+    pass
+
+
+class JpegHeader:
+    """what the kernels need to know about one file"""
+    __slots__ = ("width", "height", "ncomp", "h0", "v0", "mcux", "mcuy", "selectors", "tables", "segments")
+
+
+def _align16(n):
+    return (n + 15) // 16 * 16
+
+
+def parse_jpeg(data):
+    """bytes -> JpegHeader; segments = [(byte offset, length, first MCU, MCU count)] relative to the start of the file"""
+    n = len(data)
+    if n < 4 or data[0] != 0xFF or data[1] != 0xD8:
+        raise UnsupportedJpeg("not a JPEG file")
+    tables = np.zeros(TABLE_BYTES, np.uint8)
+    quant = tables[:512].view(np.uint16).reshape(4, 64)
+    have_q, have_h = set(), set()
+    comps, restart, adobe = None, 0, None
+    pos = 2
+    while True:
+        if pos + 4 > n:
+            raise UnsupportedJpeg("no scan in the file")
+        if data[pos] != 0xFF:
+            raise UnsupportedJpeg("marker expected")
+        m = data[pos + 1]
+        if m == 0xFF:           # fill byte
+            pos += 1
+            continue
+        if m == 0x01 or 0xD0 <= m <= 0xD7:
+            pos += 2
+            continue
+        if m == 0xD9:
+            raise UnsupportedJpeg("no scan in the file")
+        ln = (data[pos + 2] << 8) | data[pos + 3]
+        seg = data[pos + 4:pos + 2 + ln]
+        if len(seg) != ln - 2:
+            raise UnsupportedJpeg("truncated header")
+        if m == 0xDB:
+            p = 0
+            while p < len(seg):
+                pq, tq = seg[p] >> 4, seg[p] & 15
+                if tq > 3:
+                    raise UnsupportedJpeg("quantiser index")
+                if pq:
+                    vals = np.frombuffer(seg, ">u2", 64, p + 1)
+                    p += 129
+                else:
+                    vals = np.frombuffer(seg, np.uint8, 64, p + 1)
+                    p += 65
+                quant[tq, _ZIGZAG] = vals
+                have_q.add(tq)
+        elif m == 0xC4:
+            p = 0
+            while p < len(seg):
+                tc, th = seg[p] >> 4, seg[p] & 15
+                if tc > 1 or th > 1:
+                    raise UnsupportedJpeg("more than two Huffman tables per class")
+                nv = sum(seg[p + 1:p + 17])
+                if nv > 256 or p + 17 + nv > len(seg):
+                    raise UnsupportedJpeg("bad Huffman table")
+                base = 512 + (2 * tc + th) * 272
+                tables[base:base + 272] = 0
+                tables[base:base + 17 + nv - 1] = np.frombuffer(seg, np.uint8, 16 + nv, p + 1)
+                have_h.add((tc, th))
+                p += 17 + nv
+        elif m in (0xC0, 0xC1):
+            if seg[0] != 8:
+                raise UnsupportedJpeg("sample precision")
+            height, width, nc = (seg[1] << 8) | seg[2], (seg[3] << 8) | seg[4], seg[5]
+            comps = [(seg[6 + 3 * i], seg[7 + 3 * i] >> 4, seg[7 + 3 * i] & 15, seg[8 + 3 * i]) for i in range(nc)]
+        elif m in _SOF_OTHER:
+            raise UnsupportedJpeg("not a baseline JPEG (SOF%d)" % (m - 0xC0))
+        elif m == 0xDD:
+            restart = (seg[0] << 8) | seg[1]
+        elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
+            adobe = seg[11]
+        elif m == 0xDA:
+            break
+        pos += 2 + ln
+    if comps is None or width == 0 or height == 0:
+        raise UnsupportedJpeg("no frame header")
+    nc = len(comps)
+    if nc not in (1, 3) or (nc == 3 and adobe == 0):
+        raise UnsupportedJpeg("colour space (components: %d)" % nc)   # CMYK / YCCK / Adobe RGB
+    if nc == 3:
+        ids = [c[0] for c in comps]
+        if ids == [ord("R"), ord("G"), ord("B")] and adobe is None:
+            raise UnsupportedJpeg("RGB component ids")
+        if (comps[1][1], comps[1][2], comps[2][1], comps[2][2]) != (1, 1, 1, 1) or (comps[0][1], comps[0][2]) not in ((1, 1), (2, 1), (2, 2)):
+            raise UnsupportedJpeg("sampling factors")
+    ns = seg[0]
+    if ns != nc or len(seg) < 1 + 2 * ns + 3:
+        raise UnsupportedJpeg("component-wise scans")
+    sel = 0
+    for i in range(ns):
+        if seg[1 + 2 * i] != comps[i][0]:
+            raise UnsupportedJpeg("scan component order")
+        td, ta = seg[2 + 2 * i] >> 4, seg[2 + 2 * i] & 15
+        if td > 1 or ta > 1 or (0, td) not in have_h or (1, ta) not in have_h or comps[i][3] not in have_q:
+            raise UnsupportedJpeg("table selectors")
+        sel |= comps[i][3] << (2 * i) | td << (6 + 2 * i) | ta << (7 + 2 * i)
+    h = JpegHeader()
+    h.width, h.height, h.ncomp = width, height, nc
+    h.h0, h.v0 = (comps[0][1], comps[0][2]) if nc == 3 else (1, 1)   # a single component is never interleaved: 8x8 MCUs
+    h.mcux, h.mcuy = -(-width // (8 * h.h0)), -(-height // (8 * h.v0))
+    h.selectors, h.tables = sel, tables
+    # the entropy-coded data: up to the first marker that is not a restart marker
+    ecs = pos + 2 + ln
+    a = np.frombuffer(data, np.uint8, n - ecs, ecs)
+    ff = np.flatnonzero(a[:-1] == 0xFF)
+    ff = ff[a[ff + 1] != 0]
+    is_rst = (a[ff + 1] & 0xF8) == 0xD0
+    ends = np.flatnonzero(~is_rst)
+    if len(ends) == 0:
+        raise UnsupportedJpeg("truncated file (no marker behind the scan)")
+    end, rst = int(ff[ends[0]]), ff[:ends[0]]
+    total = h.mcux * h.mcuy
+    if restart:
+        if len(rst) != -(-total // restart) - 1:
+            raise UnsupportedJpeg("restart markers do not match the restart interval")
+        starts = np.concatenate([[0], rst + 2])
+        stops = np.concatenate([rst, [end]])
+        h.segments = [(ecs + int(s), int(e - s), i * restart, min(restart, total - i * restart))
+                      for i, (s, e) in enumerate(zip(starts, stops))]
+    else:
+        if len(rst):
+            raise UnsupportedJpeg("restart markers without a restart interval")
+        h.segments = [(ecs, end, 0, total)]
+    return h
+
+
+class DecodedBatch:
+    """packed RGB images on the GPU: image b is ``packed[offsets[b] : offsets[b] + 3 * H * W]`` viewed as [H, W, 3]"""
+
+    def __init__(self, packed, offsets, shapes):
+        self.packed, self.offsets, self.shapes = packed, offsets, shapes
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def images(self):
+        return [self.packed[int(o):int(o) + 3 * h * w].view(h, w, 3) for o, (h, w) in zip(self.offsets, self.shapes)]
+
+
+class JpegDecoderGpu:
+    PINNED_SLOTS = 3
+
+    def __init__(self, device="cuda", host_fallback=False):
+        self.device = torch.device(device)
+        self.host_fallback = host_fallback
+        self.stats = dict(images=0, host_decoded=0, segments=0)
+        self._ring, self._slot = [None] * self.PINNED_SLOTS, 0
+
+    def _staging(self, nbytes):
+        i = self._slot
+        self._slot = (i + 1) % self.PINNED_SLOTS
+        ent = self._ring[i]
+        if ent is not None:
+            ent[1].synchronize()
+        if ent is None or ent[0].numel() < nbytes:
+            ent = self._ring[i] = [torch.empty(nbytes * 5 // 4, dtype=torch.uint8, pin_memory=True), torch.cuda.Event()]
+        return ent[0][:nbytes], ent[1]
+
+    def decode(self, files):
+        """files: list of bytes objects (whole JPEG files) -> DecodedBatch"""
+        dev = self.device
+        if dev.type != "cuda":
+            raise _lib.DkdError("JpegDecoderGpu needs an MI355X (the decoder has no CPU path)")
+        B = len(files)
+        heads, host = [], {}
+        for b, f in enumerate(files):
+            try:
+                heads.append(parse_jpeg(f))
+            except UnsupportedJpeg:
+                if not self.host_fallback:
+                    raise
+                from PIL import Image
+                host[b] = np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))
+                heads.append(None)
+        shapes = [(h.height, h.width) if h is not None else host[b].shape[:2] for b, h in enumerate(heads)]
+        rgb_offs = np.concatenate([[0], np.cumsum([_align16(3 * hh * ww) for hh, ww in shapes])]).astype(np.int64)
+        if int(rgb_offs[-1]) >= (1 << 35):
+            raise _lib.DkdError("batch too large for one decode call")
+        rgb = torch.empty(int(rgb_offs[-1]), dtype=torch.uint8, device=dev)
+        gpu = [b for b, h in enumerate(heads) if h is not None]
+        if gpu:
+            file_offs, o = {}, 0
+            for b in gpu:
+                file_offs[b] = o
+                o += _align16(len(files[b]))
+            if o + 16 >= (1 << 31):
+                raise _lib.DkdError("batch too large for one decode call")
+            packed, copied = self._staging(o + 16)
+            pk = packed.numpy()
+            img_meta = np.zeros((len(gpu), IMG_INTS), np.int32)
+            tables = np.zeros((len(gpu), TABLE_BYTES), np.uint8)
+            segs, plane_off, max_px = [], 0, 1
+            for i, b in enumerate(gpu):
+                h, f = heads[b], files[b]
+                pk[file_offs[b]:file_offs[b] + len(f)] = np.frombuffer(f, np.uint8)
+                m = img_meta[i]
+                m[:7] = (h.width, h.height, h.ncomp, h.h0, h.v0, h.mcux, h.mcuy)
+                for c in range(h.ncomp):
+                    hs, vs = (h.h0, h.v0) if c == 0 else (1, 1)
+                    m[7 + c], m[10 + c] = plane_off // 16, h.mcux * hs * 8
+                    plane_off += _align16(h.mcux * hs * 8 * h.mcuy * vs * 8)
+                m[13], m[14], m[15] = rgb_offs[b] // 16, i, h.selectors
+                tables[i] = h.tables
+                segs.extend((i, file_offs[b] + s, ln, m0, nm, 0) for s, ln, m0, nm in h.segments)
+                max_px = max(max_px, h.width * h.height)
+            if plane_off >= (1 << 35):
+                raise _lib.DkdError("batch too large for one decode call")
+            seg_meta = np.asarray(segs, np.int32)
+            up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+            src = packed.to(dev, non_blocking=True)
+            copied.record(torch.cuda.current_stream(dev))
+            img_d, seg_d, tab_d = up(img_meta), up(seg_meta), up(tables)
+            planes = torch.empty(plane_off, dtype=torch.uint8, device=dev)
+            lib = _lib.binding()
+            P, st = _lib.ptr, _lib.stream
+            _lib.check(lib.dkd_jpeg_decode_planes(P(src), P(seg_d), len(segs), P(img_d), P(tab_d), P(planes), st()), "dkd_jpeg_decode_planes")
+            _lib.check(lib.dkd_jpeg_planes_to_rgb(P(planes), P(img_d), len(gpu), max_px, P(rgb), st()), "dkd_jpeg_planes_to_rgb")
+            self.stats["segments"] += len(segs)
+        for b, arr in host.items():
+            n = arr.size
+            rgb[int(rgb_offs[b]):int(rgb_offs[b]) + n].copy_(torch.from_numpy(np.ascontiguousarray(arr)).view(-1))
+        self.stats["images"] += B
+        self.stats["host_decoded"] += len(host)
+        return DecodedBatch(rgb, rgb_offs[:-1].copy(), [tuple(int(v) for v in s) for s in shapes])

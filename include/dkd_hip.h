@@ -371,6 +371,30 @@ int dkd_aug_finish(const void* img, const int* erase, float* out, int B, int S, 
                    float std1, float std2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Image decode of the input pipeline: datasets/CustomDataset.py:64 ``Image.open(img_path).convert('RGB')`` for
+ * baseline JPEG files (SOF0 / SOF1, 8 bit, one interleaved scan, grayscale or YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling), bit-exact
+ * with Pillow's libjpeg-turbo: Huffman decode, dequantisation, the "islow" integer inverse DCT, "fancy" chroma upsampling and the
+ * fixed-point YCbCr -> RGB.  The host (dinov2_distillation_amd/data/jpeg.py) only parses the marker segments.
+ *   bytes:  the files of the batch, each starting on a 16-byte boundary, >= 16 bytes of padding behind the last one.
+ *   img_meta int32 [B, DKD_JPEG_IMG_INTS] = {width, height, components (1 | 3), h0, v0 (luma sampling factors), MCUs per row, MCU rows,
+ *     plane offset / 16 of component 0, 1, 2, plane row stride of component 0, 1, 2 (multiples of 8: whole blocks), RGB offset / 16,
+ *     index of the image's table block, selectors = tq0 | tq1 << 2 | tq2 << 4 | td0 << 6 | ta0 << 7 | td1 << 8 | ta1 << 9 |
+ *     td2 << 10 | ta2 << 11 (quantiser 0..3, DC / AC Huffman table 0..1 of each component)}.
+ *   tables uint8 [*, DKD_JPEG_TABLE_BYTES]: 4 quantisers as uint16 [64] in natural (row-major) order, then the Huffman specifications
+ *     DC0, DC1, AC0, AC1, each 16 code-length counts followed by 256 value slots.
+ *   seg_meta int32 [n_seg, DKD_JPEG_SEG_INTS] = {image, byte offset of the entropy-coded segment, its length without the marker
+ *     behind it, first MCU, MCU count, 0}: one per image, or one per restart interval.
+ *   dkd_jpeg_decode_planes: one wavefront per segment -> the component planes (uint8, padded to whole MCUs).
+ *   dkd_jpeg_planes_to_rgb: planes -> packed RGB [H, W, 3] per image at RGB offset (the layout dkd_aug_resize reads);
+ *     max_pixels = the largest width * height of the batch. */
+#define DKD_JPEG_IMG_INTS 16
+#define DKD_JPEG_SEG_INTS 6
+#define DKD_JPEG_TABLE_BYTES 1600
+int dkd_jpeg_decode_planes(const void* bytes, const int* seg_meta, int n_seg, const int* img_meta, const void* tables, void* planes,
+                           void* stream);
+int dkd_jpeg_planes_to_rgb(const void* planes, const int* img_meta, int n_img, int max_pixels, void* rgb, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * ScaleKD loss tail (losses/scalekd.py:67-92 get_spat_loss, :95-127 get_freq_loss).  S, T: token-major [rows, D].
  * out2[0] = alpha/B * sum |s^ - t^|^2, out2[1] = mean cosine.  mean_s/mean_t: NULL (spatial) or [B, D] spatial
  * means (frequency variant == DCT / zero DC / IDCT).  bwd writes d loss / d (centred) S scaled by *grad_out

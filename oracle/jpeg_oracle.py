@@ -1,0 +1,307 @@
+"""CPU restatement of baseline JPEG decoding as Pillow / libjpeg-turbo performs it for the reference's
+`Image.open(path).convert('RGB')` (/root/reference/datasets/CustomDataset.py:64) - TEST INFRASTRUCTURE ONLY (the product decodes on the
+GPU: dinov2_distillation_amd/data/jpeg.py + csrc/jpeg.hip; nothing in the package imports this file).
+
+Pinned: tests/test_jpeg_cpu.py compares this restatement bit for bit with Pillow's own decoder (the reference's decoder) on files
+encoded here (4:4:4 / 4:2:2 / 4:2:0, grayscale, odd sizes, restart intervals, qualities 30-100).
+
+The algorithm is libjpeg's (IJG release 6b API, which libjpeg-turbo implements bit-exactly in its SIMD paths), restated from its published
+description:
+  * marker parsing, Huffman entropy decoding of a baseline (SOF0 / SOF1, 8-bit, one interleaved scan) stream     (jdmarker.c, jdhuff.c)
+  * dequantisation + the "islow" integer inverse DCT (Loeffler-Ligtenberg-Moschytz, 13-bit constants, two passes)   (jidctint.c)
+  * "fancy" (triangle-filter) chroma upsampling h2v1 / h2v2                                                        (jdsample.c)
+  * YCbCr -> RGB with 16-bit fixed-point tables                                                                    (jdcolor.c)
+"""
+import numpy as np
+
+ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42,
+                   49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+
+
+class Unsupported(Exception):
+    pass
+
+
+def parse(data):
+    """-> dict(width, height, comps=[(id, h, v, tq)], qt={id: int32[64] natural order}, dc={id: (bits, vals)}, ac=..., scan=[(comp index, td, ta)],
+    restart_interval, ecs=bytes of the entropy-coded segment)"""
+    d = memoryview(data)
+    if d[0] != 0xFF or d[1] != 0xD8:
+        raise Unsupported("not a JPEG")
+    pos = 2
+    info = dict(qt={}, dc={}, ac={}, restart_interval=0, comps=None)
+    while True:
+        if d[pos] != 0xFF:
+            raise Unsupported("marker expected")
+        while d[pos + 1] == 0xFF:
+            pos += 1
+        m = d[pos + 1]
+        pos += 2
+        if m == 0xD9:
+            raise Unsupported("no scan")
+        seglen = (d[pos] << 8) | d[pos + 1]
+        seg = bytes(d[pos + 2:pos + seglen])
+        if m == 0xDB:
+            p = 0
+            while p < len(seg):
+                pq, tq = seg[p] >> 4, seg[p] & 15
+                p += 1
+                if pq:
+                    vals = [(seg[p + 2 * i] << 8) | seg[p + 2 * i + 1] for i in range(64)]
+                    p += 128
+                else:
+                    vals = list(seg[p:p + 64])
+                    p += 64
+                q = np.zeros(64, np.int32)
+                q[ZIGZAG] = vals
+                info["qt"][tq] = q
+        elif m in (0xC0, 0xC1):
+            if seg[0] != 8:
+                raise Unsupported("precision")
+            info["height"], info["width"] = (seg[1] << 8) | seg[2], (seg[3] << 8) | seg[4]
+            n = seg[5]
+            info["comps"] = [(seg[6 + 3 * i], seg[7 + 3 * i] >> 4, seg[7 + 3 * i] & 15, seg[8 + 3 * i]) for i in range(n)]
+        elif m in (0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
+            raise Unsupported("not baseline")
+        elif m == 0xC4:
+            p = 0
+            while p < len(seg):
+                tc, th = seg[p] >> 4, seg[p] & 15
+                bits = list(seg[p + 1:p + 17])
+                nv = sum(bits)
+                vals = list(seg[p + 17:p + 17 + nv])
+                p += 17 + nv
+                info["ac" if tc else "dc"][th] = (bits, vals)
+        elif m == 0xDD:
+            info["restart_interval"] = (seg[0] << 8) | seg[1]
+        elif m == 0xEE and seg[:5] == b"Adobe":
+            info["adobe_transform"] = seg[11]
+        elif m == 0xDA:
+            ns = seg[0]
+            ids = [c[0] for c in info["comps"]]
+            info["scan"] = [(ids.index(seg[1 + 2 * i]), seg[2 + 2 * i] >> 4, seg[2 + 2 * i] & 15) for i in range(ns)]
+            if ns != len(info["comps"]):
+                raise Unsupported("non-interleaved scans")
+            info["ecs"] = bytes(d[pos + seglen:])
+            break
+        pos += seglen
+    nc = len(info["comps"])
+    if nc not in (1, 3) or info.get("adobe_transform", 1) == 0:
+        raise Unsupported("colour space")
+    if nc == 3:
+        (_, h0, v0, _), (_, h1, v1, _), (_, h2, v2, _) = info["comps"]
+        if (h1, v1, h2, v2) != (1, 1, 1, 1) or (h0, v0) not in ((1, 1), (2, 1), (2, 2)):
+            raise Unsupported("sampling factors")
+    return info
+
+
+def _huff_tables(bits, vals):
+    """canonical code tables: maxcode[l] (-1: no code of that length), valptr[l], mincode[l]"""
+    code, k = 0, 0
+    mincode, maxcode, valptr = [0] * 17, [-1] * 18, [0] * 17
+    for l in range(1, 17):
+        valptr[l] = k
+        mincode[l] = code
+        code += bits[l - 1]
+        k += bits[l - 1]
+        maxcode[l] = code - 1 if bits[l - 1] else -1
+        code <<= 1
+    return mincode, maxcode, valptr, vals
+
+
+class _Bits:
+    def __init__(self, data):
+        self.d, self.p, self.acc, self.n = data, 0, 0, 0
+
+    def bit(self):
+        if self.n == 0:
+            b = self.d[self.p] if self.p < len(self.d) else 0
+            self.p += 1
+            if b == 0xFF:
+                nxt = self.d[self.p] if self.p < len(self.d) else 0
+                if nxt == 0:
+                    self.p += 1
+                else:           # a marker: feed zeros (as libjpeg does past the end of a segment)
+                    self.p -= 1
+                    b = 0
+            self.acc, self.n = b, 8
+        self.n -= 1
+        return (self.acc >> self.n) & 1
+
+    def bits(self, k):
+        v = 0
+        for _ in range(k):
+            v = (v << 1) | self.bit()
+        return v
+
+    def restart(self):
+        """skip to just behind the next RSTn marker"""
+        self.n = 0
+        while not (self.d[self.p] == 0xFF and 0xD0 <= self.d[self.p + 1] <= 0xD7):
+            self.p += 1
+        self.p += 2
+
+
+def _decode_sym(br, tab):
+    mincode, maxcode, valptr, vals = tab
+    code = 0
+    for l in range(1, 17):
+        code = (code << 1) | br.bit()
+        if maxcode[l] >= 0 and code <= maxcode[l]:
+            return vals[valptr[l] + code - mincode[l]]
+    return 0
+
+
+def _extend(v, s):
+    return v if s == 0 or v >= (1 << (s - 1)) else v - (1 << s) + 1
+
+
+def entropy_decode(info):
+    """-> list per component of int16 [blocks_h, blocks_w, 64] (natural order, quantised)"""
+    comps = info["comps"]
+    hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+    mcux, mcuy = -(-info["width"] // (8 * hmax)), -(-info["height"] // (8 * vmax))
+    coef = [np.zeros((mcuy * c[2], mcux * c[1], 64), np.int16) for c in comps]
+    dct = {k: _huff_tables(*v) for k, v in info["dc"].items()}
+    act = {k: _huff_tables(*v) for k, v in info["ac"].items()}
+    br = _Bits(info["ecs"])
+    pred = [0] * len(comps)
+    ri, count = info["restart_interval"], 0
+    for my in range(mcuy):
+        for mx in range(mcux):
+            if ri and count and count % ri == 0:
+                br.restart()
+                pred = [0] * len(comps)
+            count += 1
+            for ci, td, ta in info["scan"]:
+                _, h, v, _ = comps[ci]
+                for by in range(v):
+                    for bx in range(h):
+                        blk = coef[ci][my * v + by, mx * h + bx]
+                        s = _decode_sym(br, dct[td])
+                        pred[ci] += _extend(br.bits(s), s)
+                        blk[0] = pred[ci]
+                        k = 1
+                        while k < 64:
+                            rs = _decode_sym(br, act[ta])
+                            r, s = rs >> 4, rs & 15
+                            if s == 0:
+                                if r != 15:
+                                    break
+                                k += 16
+                                continue
+                            k += r
+                            blk[ZIGZAG[k]] = _extend(br.bits(s), s)
+                            k += 1
+    return coef
+
+
+C = dict(F0_298=2446, F0_390=3196, F0_541=4433, F0_765=6270, F0_899=7373, F1_175=9633, F1_501=12299, F1_847=15137, F1_961=16069,
+         F2_053=16819, F2_562=20995, F3_072=25172)
+
+
+def _idct_1d(x0, x1, x2, x3, x4, x5, x6, x7, shift_dc):
+    """the LLM butterfly of jidctint.c on int64 arrays; returns the eight (un-descaled) outputs"""
+    z2, z3 = x2, x6
+    z1 = (z2 + z3) * C["F0_541"]
+    tmp2 = z1 + z3 * (-C["F1_847"])
+    tmp3 = z1 + z2 * C["F0_765"]
+    tmp0 = (x0 + x4) << 13
+    tmp1 = (x0 - x4) << 13
+    tmp10, tmp13, tmp11, tmp12 = tmp0 + tmp3, tmp0 - tmp3, tmp1 + tmp2, tmp1 - tmp2
+    t0, t1, t2, t3 = x7, x5, x3, x1
+    z1, z2, z3, z4 = t0 + t3, t1 + t2, t0 + t2, t1 + t3
+    z5 = (z3 + z4) * C["F1_175"]
+    t0, t1, t2, t3 = t0 * C["F0_298"], t1 * C["F2_053"], t2 * C["F3_072"], t3 * C["F1_501"]
+    z1, z2, z3, z4 = z1 * (-C["F0_899"]), z2 * (-C["F2_562"]), z3 * (-C["F1_961"]) + z5, z4 * (-C["F0_390"]) + z5
+    t0, t1, t2, t3 = t0 + z1 + z3, t1 + z2 + z4, t2 + z2 + z3, t3 + z1 + z4
+    return (tmp10 + t3, tmp11 + t2, tmp12 + t1, tmp13 + t0, tmp13 - t0, tmp12 - t1, tmp11 - t2, tmp10 - t3)
+
+
+def _range_limit(x):
+    v = x & 1023
+    return np.where(v < 128, v + 128, np.where(v < 512, 255, np.where(v < 896, 0, v - 896))).astype(np.uint8)
+
+
+def idct_islow(coef, qt):
+    """coef int16 [..., 64] natural order, qt int32[64] -> uint8 [..., 8, 8]"""
+    x = (coef.astype(np.int64) * qt.astype(np.int64)).reshape(*coef.shape[:-1], 8, 8)   # [row][col]
+    cols = _idct_1d(*[x[..., r, :] for r in range(8)], None)
+    ws = np.stack([(c + (1 << 10)) >> 11 for c in cols], axis=-2)   # pass 1 over columns: DESCALE by CONST_BITS - PASS1_BITS
+    rows = _idct_1d(*[ws[..., :, c] for c in range(8)], None)
+    out = np.stack([(r + (1 << 17)) >> 18 for r in rows], axis=-1)  # pass 2 over rows: DESCALE by CONST_BITS + PASS1_BITS + 3
+    return _range_limit(out)
+
+
+def planes(info, coef):
+    """-> list per component of uint8 [blocks_h * 8, blocks_w * 8]"""
+    out = []
+    for (cid, h, v, tq), c in zip(info["comps"], coef):
+        px = idct_islow(c, info["qt"][tq])              # [bh, bw, 8, 8]
+        out.append(px.transpose(0, 2, 1, 3).reshape(c.shape[0] * 8, c.shape[1] * 8))
+    return out
+
+
+def _h2v1_fancy(row):
+    """uint8 [.., w] -> [.., 2w] (jdsample.c h2v1_fancy_upsample)"""
+    x = row.astype(np.int32)
+    w = x.shape[-1]
+    out = np.empty(x.shape[:-1] + (2 * w,), np.int32)
+    left = np.concatenate([x[..., :1], x[..., :-1]], axis=-1)
+    right = np.concatenate([x[..., 1:], x[..., -1:]], axis=-1)
+    out[..., 0::2] = (3 * x + left + 1) >> 2
+    out[..., 1::2] = (3 * x + right + 2) >> 2
+    out[..., 0] = x[..., 0]
+    out[..., -1] = x[..., -1]
+    return out.astype(np.uint8)
+
+
+def _h2v2_fancy(p):
+    """uint8 [h, w] -> [2h, 2w] (jdsample.c h2v2_fancy_upsample; the rows above the first / below the last are the edge rows themselves)"""
+    x = p.astype(np.int32)
+    h, w = x.shape
+    up = np.concatenate([x[:1], x[:-1]], axis=0)
+    dn = np.concatenate([x[1:], x[-1:]], axis=0)
+    out = np.empty((2 * h, 2 * w), np.int32)
+    for v, other in ((0, up), (1, dn)):
+        s = 3 * x + other                                   # column sums of the two contributing rows
+        last = np.concatenate([s[:, :1], s[:, :-1]], axis=1)
+        nxt = np.concatenate([s[:, 1:], s[:, -1:]], axis=1)
+        even = (3 * s + last + 8) >> 4
+        odd = (3 * s + nxt + 7) >> 4
+        even[:, 0] = (4 * s[:, 0] + 8) >> 4
+        odd[:, -1] = (4 * s[:, -1] + 7) >> 4
+        out[v::2, 0::2] = even
+        out[v::2, 1::2] = odd
+    return out.astype(np.uint8)
+
+
+def to_rgb(info, pl):
+    """component planes -> uint8 [H, W, 3]"""
+    H, W = info["height"], info["width"]
+    if len(pl) == 1:
+        return np.repeat(pl[0][:H, :W, None], 3, axis=2)
+    (_, h0, v0, _) = info["comps"][0]
+    y = pl[0]
+    cw, ch = -(-W // h0), -(-H // v0)                       # downsampled_width / height of the chroma components
+    chroma = []
+    for c in pl[1:]:
+        c = c[:ch, :cw]
+        if cw <= 2:                                         # jdsample.c: the triangle filter needs downsampled_width > 2, else replication
+            c = np.repeat(np.repeat(c, h0, axis=1), v0, axis=0)
+        elif (h0, v0) == (2, 2):
+            c = _h2v2_fancy(c)
+        elif (h0, v0) == (2, 1):
+            c = _h2v1_fancy(c)
+        chroma.append(c[:H, :W].astype(np.int32))
+    yy, cb, cr = y[:H, :W].astype(np.int32), chroma[0] - 128, chroma[1] - 128
+    r = yy + ((91881 * cr + 32768) >> 16)
+    g = yy + ((-22554 * cb - 46802 * cr + 32768) >> 16)
+    b = yy + ((116130 * cb + 32768) >> 16)
+    return np.clip(np.stack([r, g, b], axis=2), 0, 255).astype(np.uint8)
+
+
+def decode(data):
+    """JPEG bytes -> uint8 [H, W, 3], as PIL.Image.open(...).convert('RGB')"""
+    info = parse(data)
+    return to_rgb(info, planes(info, entropy_decode(info)))

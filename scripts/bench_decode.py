@@ -60,3 +60,54 @@ print(f"  Image.open(...).convert('RGB')           {r_full:7.1f} images/s per co
 print(f"  ... with draft('RGB', (320, 320)) first   {r_draft:7.1f} images/s per core")
 for name, need in (("fp32 step (bench.py value)", 1784.0), ("whole step under the autocast policy", 3228.0)):
     print(f"  {name}: {need:.0f} images/s -> {need / r_full:.1f} decode cores")
+
+# ---- the same files through the GPU decoder (csrc/jpeg.hip) ----------------------------------------------------------------------
+try:
+    import torch
+    have_gpu = torch.cuda.is_available()
+except Exception:
+    have_gpu = False
+if have_gpu:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dinov2_distillation_amd.data.jpeg import JpegDecoderGpu, parse_jpeg
+    batch = (files * 2)[:64]
+    for f, im in zip(batch[:4], JpegDecoderGpu().decode(batch[:4]).images()):
+        assert np.array_equal(im.cpu().numpy(), np.asarray(Image.open(io.BytesIO(f)).convert("RGB")))
+    t0 = time.perf_counter()
+    for f in batch:
+        parse_jpeg(f)
+    t_parse = (time.perf_counter() - t0) / len(batch)
+    print(f"GPU decode, batch of {len(batch)} (bit-exact with Pillow on the first four):")
+    print(f"  host side, marker walk only               {t_parse * 1e6:7.1f} us per file on one core")
+    for label, fs in (("no restart markers: one wavefront per image", batch),):
+        dec = JpegDecoderGpu()
+        dec.decode(fs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n, t0 = 0, time.perf_counter()
+        e0.record()
+        while time.perf_counter() - t0 < secs:
+            dec.decode(fs)
+            n += 1
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n
+        print(f"  {label}: {wall * 1e3:6.2f} ms per batch end to end ({len(fs) / wall:7.0f} images/s; GPU timeline "
+              f"{e0.elapsed_time(e1) / n:6.2f} ms per batch)")
+    # the same pictures re-encoded with one restart interval per MCU row: one wavefront per row
+    rows = []
+    for f in batch:
+        buf = io.BytesIO()
+        Image.open(io.BytesIO(f)).save(buf, format="JPEG", quality=90, restart_marker_rows=1)
+        rows.append(buf.getvalue())
+    dec = JpegDecoderGpu()
+    dec.decode(rows)
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < secs:
+        dec.decode(rows)
+        n += 1
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n
+    print(f"  one restart interval per MCU row ({dec.stats['segments'] // dec.stats['images']} wavefronts per image): {wall * 1e3:6.2f} ms per batch "
+          f"({len(rows) / wall:7.0f} images/s)")

@@ -1,0 +1,64 @@
+"""JPEG files for the decoder tests, encoded here with Pillow (data only): synthetic pictures of different sizes, every chroma
+sampling the decoder supports, grayscale, qualities 30..100, optimised (per-file) Huffman tables, restart intervals."""
+import io
+
+import numpy as np
+from PIL import Image
+
+
+def picture(seed, h, w, gray=False, noise=25.0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([127 + 120 * np.sin(xx / 7.0 + yy / 13.0 + seed), 127 + 120 * np.cos(xx / 5.0 - seed),
+                     127 + 100 * np.sin(yy / 3.0 + xx / 11.0)], 2)
+    base += rng.normal(0, noise, base.shape)
+    a = np.clip(base, 0, 255).astype(np.uint8)
+    return Image.fromarray(a[..., 0] if gray else a)
+
+
+def encode(img, **kw):
+    b = io.BytesIO()
+    img.save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def pillow_rgb(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def cases(sizes=((8, 8), (16, 16), (17, 23), (33, 47), (64, 48), (50, 75), (1, 1), (3, 100), (100, 3), (9, 4), (2, 2), (40, 6)),
+          qualities=(30, 75, 95, 100), restarts=(0, 1, 3)):
+    """-> [(name, file bytes)]"""
+    out = []
+    for i, (h, w) in enumerate(sizes):
+        for ss in (0, 1, 2, "gray"):
+            for q in qualities:
+                for ri in restarts:
+                    kw = dict(quality=q)
+                    if ss != "gray":
+                        kw["subsampling"] = ss
+                    if ri:
+                        kw["restart_marker_blocks"] = ri
+                    out.append((f"{h}x{w}_ss{ss}_q{q}_ri{ri}", encode(picture(i, h, w, ss == "gray"), **kw)))
+    return out
+
+
+def special_cases():
+    """optimised Huffman tables (codes up to 16 bits), hard content (long codes, many stuffed bytes), one-row restart intervals"""
+    out = []
+    for i, (h, w, noise) in enumerate(((120, 160, 25.0), (97, 131, 90.0), (64, 64, 200.0))):
+        for ss in (0, 1, 2, "gray"):
+            kw = {} if ss == "gray" else dict(subsampling=ss)
+            img = picture(20 + i, h, w, ss == "gray", noise)
+            out.append((f"opt_{h}x{w}_ss{ss}", encode(img, quality=92, optimize=True, **kw)))
+            out.append((f"rows_{h}x{w}_ss{ss}", encode(img, quality=85, restart_marker_rows=1, **kw)))
+            out.append((f"q100_{h}x{w}_ss{ss}", encode(img, quality=100, **kw)))
+    return out
+
+
+def unsupported_cases():
+    img = picture(3, 40, 56)
+    png = io.BytesIO()
+    img.save(png, "PNG")
+    return [("progressive", encode(img, quality=80, progressive=True)), ("cmyk", encode(img.convert("CMYK"), quality=80)),
+            ("png", png.getvalue()), ("rgb_adobe", encode(img, quality=80, keep_rgb=True))]

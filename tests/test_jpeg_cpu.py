@@ -1,0 +1,93 @@
+"""Image decode (datasets/CustomDataset.py:64), CPU side:
+  * oracle/jpeg_oracle.py - the restatement of libjpeg's baseline decode the GPU tests check against - is pinned bit for bit
+    against Pillow's decoder (the reference's) on files encoded here and against the committed fixtures;
+  * the host half of the product (data/jpeg.py parse_jpeg): header fields, segment bookkeeping, what it refuses."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import jpeg_cases as J
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_oracle_matches_pillow_bit_for_bit():
+    from oracle import jpeg_oracle as O
+    n = 0
+    for name, data in J.cases(sizes=((8, 8), (17, 23), (33, 47), (1, 1), (3, 100), (100, 3), (9, 4), (40, 6)), qualities=(30, 95, 100),
+                              restarts=(0, 3)):
+        got, ref = O.decode(data), J.pillow_rgb(data)
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+        n += 1
+    assert n == 8 * 4 * 3 * 2
+    for name, data in J.special_cases():     # optimised Huffman tables, one-row restart intervals, quality 100 on noise
+        assert np.array_equal(O.decode(data), J.pillow_rgb(data)), name
+
+
+def test_oracle_matches_the_committed_fixtures():
+    from oracle import jpeg_oracle as O
+    fx = np.load(os.path.join(HERE, "golden", "jpeg_fixtures.npz"))
+    names = [k[5:] for k in fx.files if k.startswith("file_")]
+    assert len(names) >= 40
+    for name in names:
+        assert np.array_equal(O.decode(fx["file_" + name].tobytes()), fx["rgb_" + name]), name
+
+
+def test_oracle_refuses_what_it_does_not_restate():
+    from oracle import jpeg_oracle as O
+    for name, data in J.unsupported_cases():
+        with pytest.raises(O.Unsupported):
+            O.decode(data)
+
+
+def test_parse_jpeg_headers_and_segments():
+    from PIL import Image
+    from dinov2_distillation_amd.data.jpeg import parse_jpeg
+    for name, data in J.cases(sizes=((17, 23), (64, 48), (100, 3)), qualities=(75,), restarts=(0, 1, 3)) + J.special_cases():
+        h = parse_jpeg(data)
+        im = Image.open(io.BytesIO(data))
+        assert (h.width, h.height) == im.size and h.ncomp == (1 if im.mode == "L" else 3), name
+        total = h.mcux * h.mcuy
+        assert h.mcux * 8 * h.h0 >= h.width > (h.mcux - 1) * 8 * h.h0 and h.mcuy * 8 * h.v0 >= h.height > (h.mcuy - 1) * 8 * h.v0
+        # segments tile the MCUs in order, lie inside the file, do not contain a marker and end in front of one
+        nxt = 0
+        for off, ln, m0, nm in h.segments:
+            assert m0 == nxt and nm > 0 and 0 < off and off + ln + 2 <= len(data)
+            nxt += nm
+            seg = np.frombuffer(data, np.uint8, ln, off)
+            ff = np.flatnonzero(seg[:-1] == 0xFF)
+            assert (seg[ff + 1] == 0).all() and data[off + ln] == 0xFF and data[off + ln + 1] != 0
+        assert nxt == total
+        if "_ri" in name:
+            ri = int(name.rsplit("_ri", 1)[1])
+            assert len(h.segments) == (-(-total // ri) if ri else 1)
+        # the table block: quantisers in natural order, Huffman counts consistent with the value lists
+        q = h.tables[:512].view(np.uint16).reshape(4, 64)
+        for c in range(h.ncomp):
+            tq = (h.selectors >> (2 * c)) & 3
+            assert q[tq].min() >= 1
+            assert np.array_equal(q[tq], np.asarray(im.quantization[tq]))    # (Pillow de-zigzags its tables too)
+        for t in range(4):
+            spec = h.tables[512 + 272 * t:512 + 272 * (t + 1)]
+            assert int(spec[:16].sum()) <= 256
+
+
+def test_parse_jpeg_refuses_other_formats():
+    from dinov2_distillation_amd.data.jpeg import UnsupportedJpeg, parse_jpeg
+    for name, data in J.unsupported_cases():
+        with pytest.raises(UnsupportedJpeg):
+            parse_jpeg(data)
+    good = J.encode(J.picture(1, 24, 24), quality=80)
+    with pytest.raises(UnsupportedJpeg):
+        parse_jpeg(good[:len(good) // 2])     # truncated: no marker behind the scan
+    with pytest.raises(UnsupportedJpeg):
+        parse_jpeg(b"")
+
+
+def test_decoder_needs_the_gpu():
+    from dinov2_distillation_amd import _lib
+    from dinov2_distillation_amd.data.jpeg import JpegDecoderGpu
+    with pytest.raises(_lib.DkdError):
+        JpegDecoderGpu(device="cpu").decode([J.encode(J.picture(1, 8, 8))])

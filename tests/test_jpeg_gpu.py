@@ -1,0 +1,86 @@
+"""Image decode on the GPU (csrc/jpeg.hip + data/jpeg.py) against Pillow's decoder - the reference's
+``Image.open(img_path).convert('RGB')``, datasets/CustomDataset.py:64: every byte of every image equal, on files of all supported
+samplings / sizes / qualities / restart intervals / Huffman tables in batches of mixed shapes, against the committed fixtures and
+against oracle/jpeg_oracle.py; then the decoded batch fed to the augmentation pipeline where it lies."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import jpeg_cases as J
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _decode_and_compare(named, expect=None, chunk=48):
+    from dinov2_distillation_amd.data.jpeg import JpegDecoderGpu
+    dec = JpegDecoderGpu()
+    for s in range(0, len(named), chunk):
+        part = named[s:s + chunk]
+        batch = dec.decode([d for _, d in part])
+        imgs = batch.images()
+        assert len(imgs) == len(part)
+        for (name, data), im in zip(part, imgs):
+            ref = expect[name] if expect is not None else J.pillow_rgb(data)
+            got = im.cpu().numpy()
+            assert got.shape == ref.shape, (name, got.shape, ref.shape)
+            if not np.array_equal(got, ref):
+                d = np.abs(got.astype(int) - ref.astype(int))
+                raise AssertionError(f"{name}: {int((d > 0).sum())} bytes differ (max {int(d.max())}), first at {np.argwhere(d > 0)[0].tolist()}")
+    assert dec.stats["host_decoded"] == 0
+    return dec
+
+
+def test_every_sampling_size_quality_and_restart_interval_matches_pillow():
+    named = J.cases()
+    assert len(named) == 12 * 4 * 4 * 3
+    rng = np.random.default_rng(0)
+    order = rng.permutation(len(named))       # batches of mixed shapes and samplings
+    dec = _decode_and_compare([named[i] for i in order])
+    assert dec.stats["images"] == len(named) and dec.stats["segments"] > len(named)
+
+
+def test_optimised_tables_long_codes_and_row_restarts():
+    _decode_and_compare(J.special_cases(), chunk=12)
+
+
+def test_committed_fixtures_and_the_oracle():
+    from oracle import jpeg_oracle as O
+    fx = np.load(os.path.join(HERE, "golden", "jpeg_fixtures.npz"))
+    names = [k[5:] for k in fx.files if k.startswith("file_")]
+    named = [(n, fx["file_" + n].tobytes()) for n in names]
+    _decode_and_compare(named, expect={n: fx["rgb_" + n] for n in names})
+    _decode_and_compare(named[:12], expect={n: O.decode(d) for n, d in named[:12]})
+
+
+def test_photograph_sized_batch():
+    """the dataset's shape of work: 64 files of ~500 x 375, 4:2:0, quality 90, no restart markers (one wavefront each)"""
+    named = [(f"photo{i}", J.encode(J.picture(100 + i, 375 + (i % 5) * 8, 500 - (i % 7) * 16, noise=12.0), quality=90))
+             for i in range(64)]
+    _decode_and_compare(named, chunk=64)
+
+
+def test_other_formats_raise_or_take_the_counted_host_route():
+    from dinov2_distillation_amd.data.jpeg import JpegDecoderGpu, UnsupportedJpeg
+    good = [(f"ok{i}", J.encode(J.picture(i, 40 + i, 60 - i), quality=85)) for i in range(3)]
+    odd = J.unsupported_cases()
+    with pytest.raises(UnsupportedJpeg):
+        JpegDecoderGpu().decode([d for _, d in good + odd])
+    dec = JpegDecoderGpu(host_fallback=True)
+    mixed = [good[0], odd[0], good[1], odd[1], odd[2], good[2], odd[3]]
+    for (name, data), im in zip(mixed, dec.decode([d for _, d in mixed]).images()):
+        assert np.array_equal(im.cpu().numpy(), J.pillow_rgb(data)), name
+    assert dec.stats == dict(images=7, host_decoded=4, segments=3)
+
+
+def test_decoded_batch_feeds_the_augmentation_pipeline_in_place():
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu
+    from dinov2_distillation_amd.data.jpeg import JpegDecoderGpu
+    files = [J.encode(J.picture(40 + i, 90 + 7 * i, 120 - 5 * i), quality=88, subsampling=i % 3) for i in range(6)]
+    batch = JpegDecoderGpu().decode(files)
+    aug = DataAugmentationDINOGpu((0.08, 1.0), 224)
+    a = aug(batch, generator=torch.Generator().manual_seed(5))
+    b = aug([J.pillow_rgb(f) for f in files], generator=torch.Generator().manual_seed(5))
+    assert a.shape == (6, 3, 224, 224) and torch.equal(a, b)
