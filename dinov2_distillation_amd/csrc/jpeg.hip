@@ -2,7 +2,7 @@
 // i.e. what Pillow's libjpeg-turbo does for a baseline file, bit for bit (tests/test_jpeg_gpu.py compares with Pillow itself):
 //   jpeg_entropy_idct_kernel   one wave per entropy-coded segment (a whole image, or one restart interval of it): the 64 lanes stage
 //                              the byte stream into an LDS ring 1 KiB at a time and remove the 0xFF00 stuffing with a wave prefix sum;
-//                              lane 0 runs the sequential Huffman decode of one MCU into LDS; 8 lanes per block then dequantise and
+//                              the sequential Huffman decode of one MCU runs on the scalar unit (wave-uniform state) into LDS; 8 lanes per block then dequantise and
 //                              run libjpeg's "islow" integer inverse DCT (column pass, row pass) and store 8-pixel rows of the
 //                              component planes
 //   jpeg_rgb_kernel            one thread per pixel: libjpeg's "fancy" (triangle) h2v1 / h2v2 chroma upsampling evaluated at the
@@ -20,20 +20,23 @@ constexpr int TBL_BYTES = DKD_JPEG_TABLE_BYTES;   // per image: 4 x 64 u16 quant
 constexpr int HUFF0 = 512;
 constexpr int HUFF_STRIDE = 272;
 
-__constant__ unsigned char kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
-                                          41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                          30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+// position in the zigzag scan of the coefficient at row-major index i
+__constant__ unsigned char kScanPos[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                                           41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                                           46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
 struct Lds {
     unsigned int ring[RING / 4];            // byte k of the stream sits at byte address k ^ 3: aligned words read MSB first
-    unsigned short lut[4][1 << LUT_BITS];   // (code length << 8) | symbol for codes of at most LUT_BITS bits, else 0
+    unsigned int lut[4][1 << LUT_BITS];     // what the next LUT_BITS bits of the stream decode to (below); 0: a longer code
     int maxcode[4][18];                     // largest code of each length, -1: none
     int valoff[4][18];                      // index of a length's first value minus its first code
     unsigned char tbl[TBL_BYTES];
-    short coef[6][64];
+    short coef[6][64];                      // in zigzag (stream) order
     int ws[6][64];
-    unsigned char zz[64];
 };
+// look-ahead entry: bits 0-4 = stream bits it consumes, 5-8 = zero run, 9-12 = magnitude category still to be read from the stream,
+// bit 13 = the coefficient itself is in bits 16-31 (code and magnitude bits both fit into the window: nothing more to read)
+constexpr unsigned LUT_HAS_VALUE = 1u << 13;
 
 // the even / odd butterflies of jidctint.c (Loeffler, Ligtenberg, Moschytz; CONST_BITS 13)
 __device__ __forceinline__ void idct8(const int x[8], int o[8]) {
@@ -69,15 +72,24 @@ __device__ __forceinline__ unsigned range_limit(int v) {   // libjpeg's range_li
     return v < 128 ? v + 128 : (v < 512 ? 255 : (v < 896 ? 0 : v - 896));
 }
 
+// The entropy decode is ONE sequential chain per segment.  It runs on the scalar unit: every lane executes it with identical (wave-
+// uniform) state, values that come back from LDS are pinned to SGPRs with readfirstlane, so shifts, compares and branches are SALU
+// instructions and scalar branches instead of vector code under a one-lane EXEC mask (which the compiler brackets with EXEC save /
+// restore sequences at every if - measured 1.9x slower).
+__device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 struct BitReader {
     unsigned long long acc;   // unread bits, MSB first
     int n;                    // how many of them are valid
-    int rp;                   // next ring word
+    int rp;                   // ring word held in `next`
+    unsigned next;            // fetched one refill ahead, so that the LDS latency is off the decode chain
     __device__ __forceinline__ void fill(const unsigned int* ring) {
         if (n < 32) {
-            acc |= (unsigned long long)ring[rp & (RING / 4 - 1)] << (32 - n);
+            acc |= (unsigned long long)uni(next) << (32 - n);
             n += 32;
             ++rp;
+            next = ring[rp & (RING / 4 - 1)];   // (stays in its VGPR until the next refill: the wait lands there, not here)
         }
     }
     __device__ __forceinline__ unsigned peek(int k) const { return (unsigned)(acc >> (64 - k)); }
@@ -92,23 +104,36 @@ struct BitReader {
     }
 };
 
-__device__ __forceinline__ int huff_symbol(BitReader& br, const Lds& L, int t) {
+// one Huffman symbol and, for a non-zero magnitude category, the value behind it: -> run in *run, category in *cat (0: no value)
+__device__ __forceinline__ int huff_value(BitReader& br, const Lds& L, int t, int* run, int* cat) {
     br.fill(L.ring);
-    const unsigned e = L.lut[t][br.peek(LUT_BITS)];
+    const unsigned e = uni(L.lut[t][br.peek(LUT_BITS)]);
+    int sym;
     if (e) {
-        br.skip(e >> 8);
-        return e & 255;
-    }
-    const int code16 = (int)br.peek(16);
-    for (int l = LUT_BITS + 1; l <= 16; ++l) {
-        const int c = code16 >> (16 - l);
-        if (c <= L.maxcode[t][l]) {
-            br.skip(l);
-            return L.tbl[HUFF0 + t * HUFF_STRIDE + 16 + ((c + L.valoff[t][l]) & 255)];
+        br.skip(e & 31);
+        *run = (e >> 5) & 15;
+        if (e & LUT_HAS_VALUE) {
+            *cat = 1;
+            return (int)e >> 16;
         }
+        sym = (e >> 9) & 15;
+    } else {
+        const int code16 = (int)br.peek(16);
+        sym = 0;
+        int l = LUT_BITS + 1;
+        for (; l <= 16; ++l) {
+            const int c = code16 >> (16 - l);
+            if (c <= uni(L.maxcode[t][l])) {
+                sym = uni((int)L.tbl[HUFF0 + t * HUFF_STRIDE + 16 + ((c + uni(L.valoff[t][l])) & 255)]);
+                break;
+            }
+        }
+        br.skip(l > 16 ? 16 : l);   // (no code of this table - a corrupt stream: a zero symbol, as libjpeg substitutes)
+        *run = sym >> 4;
+        sym &= 15;
     }
-    br.skip(16);   // not a code of this table (corrupt stream): libjpeg substitutes a zero symbol as well
-    return 0;
+    *cat = sym;
+    return sym ? br.receive_extend(sym) : 0;
 }
 
 __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned char* __restrict__ bytes, const int* __restrict__ seg_meta,
@@ -130,46 +155,63 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
         const unsigned int* src = reinterpret_cast<const unsigned int*>(tables + (long)im[14] * TBL_BYTES);
         unsigned int* dst = reinterpret_cast<unsigned int*>(L.tbl);
         for (int i = lane; i < TBL_BYTES / 4; i += 64) dst[i] = src[i];
-        unsigned int* lz = reinterpret_cast<unsigned int*>(&L.lut[0][0]);
-        for (int i = lane; i < 4 * (1 << LUT_BITS) / 2; i += 64) lz[i] = 0;
         unsigned int* cz = reinterpret_cast<unsigned int*>(&L.coef[0][0]);
         for (int i = lane; i < 6 * 64 / 2; i += 64) cz[i] = 0;
-        L.zz[lane] = kZigzag[lane];
     }
     __syncthreads();
     for (int t = 0; t < 4; ++t) {
         const unsigned char* bits = L.tbl + HUFF0 + t * HUFF_STRIDE;
+        int maxc[LUT_BITS + 1], voff[LUT_BITS + 1];
         int code = 0, k = 0;
-        for (int l = 1; l <= 16; ++l) {   // every lane walks the 16 lengths; each fills the look-ahead entries of its own symbols
+#pragma unroll
+        for (int l = 1; l <= 16; ++l) {
             const int cnt = bits[l - 1];
+            if (l <= LUT_BITS) maxc[l] = cnt ? code + cnt - 1 : -1, voff[l] = k - code;
             if (lane == 0) {
                 L.maxcode[t][l] = cnt ? code + cnt - 1 : -1;
                 L.valoff[t][l] = k - code;
             }
-            if (l <= LUT_BITS)
-                for (int j = lane; j < cnt; j += 64) {
-                    const unsigned short e = (unsigned short)((l << 8) | bits[16 + k + j]);
-                    const int first = (code + j) << (LUT_BITS - l);
-                    for (int f = 0; f < (1 << (LUT_BITS - l)); ++f) L.lut[t][(first + f) & ((1 << LUT_BITS) - 1)] = e;
-                }
             code = (code + cnt) << 1;
             k += cnt;
         }
+        // every lane decodes 8 of the 512 possible windows
+        for (int w = lane; w < (1 << LUT_BITS); w += 64) {
+            unsigned e = 0;
+#pragma unroll
+            for (int l = 1; l <= LUT_BITS; ++l) {
+                const int c = w >> (LUT_BITS - l);
+                if (e == 0 && c <= maxc[l]) {
+                    const int sym = bits[16 + ((c + voff[l]) & 255)];
+                    const int run = t >= 2 ? sym >> 4 : 0, cat = sym & 15;
+                    if (cat && l + cat <= LUT_BITS) {
+                        int v = (w >> (LUT_BITS - l - cat)) & ((1 << cat) - 1);
+                        if (v < (1 << (cat - 1))) v += 1 - (1 << cat);
+                        e = (unsigned)(l + cat) | run << 5 | LUT_HAS_VALUE | (unsigned)v << 16;
+                    } else {
+                        e = (unsigned)l | run << 5 | cat << 9;
+                    }
+                }
+            }
+            L.lut[t][w] = e;
+        }
     }
     __syncthreads();
+    int scan[8];   // where the eight coefficients of this lane's column sit in the zigzag scan
+#pragma unroll
+    for (int r = 0; r < 8; ++r) scan[r] = kScanPos[r * 8 + (lane & 7)];
 
     // ---- the stream --------------------------------------------------------------------------------------------------------------
     const long a0 = s0 & ~15L;
     int chunk = 0;         // next 1 KiB piece of the source
     int wpos = 0;          // bytes staged so far
     unsigned prev_last = 0;
-    BitReader br{0ull, 0, 0};
+    BitReader br{0ull, 0, 0, 0u};
     int pred0 = 0, pred1 = 0, pred2 = 0;
 
     for (int m = 0; m < n_mcu; ++m) {
         // stage until at least 2 KiB lie ahead of the reader (an MCU of six blocks cannot take more than 1.3 KiB); behind the end of the
         // segment the stream continues with zero bytes, as libjpeg's does
-        int rbytes = __builtin_amdgcn_readfirstlane(br.rp) * 4;
+        int rbytes = br.rp * 4;
         while (wpos - rbytes < 2048) {
             const long p = a0 + (long)chunk * 1024 + lane * 16;
             const bool beyond = a0 + (long)chunk * 1024 >= s_end;
@@ -207,7 +249,8 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
         }
         __syncthreads();
 
-        if (lane == 0) {
+        {   // (all lanes, uniformly: see BitReader)
+            if (m == 0) br.next = L.ring[0];
             int bi = 0;
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
@@ -217,22 +260,20 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
                 int pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
                 for (int r = 0; r < reps; ++r, ++bi) {
                     short* blk = L.coef[bi];
-                    int s = huff_symbol(br, L, td) & 15;
-                    if (s) pred += br.receive_extend(s);
+                    int run, cat;
+                    pred += huff_value(br, L, td, &run, &cat);
                     blk[0] = (short)pred;
                     int k = 1;
                     while (k < 64) {
-                        const int rs = huff_symbol(br, L, ta);
-                        s = rs & 15;
-                        if (!s) {
-                            if ((rs >> 4) != 15) break;
-                            k += 16;
+                        const int v = huff_value(br, L, ta, &run, &cat);
+                        if (!cat) {
+                            if (run != 15) break;   // end of block
+                            k += 16;                // sixteen zeros
                             continue;
                         }
-                        k += rs >> 4;
-                        const int v = br.receive_extend(s);
+                        k += run;
                         if (k > 63) break;
-                        blk[L.zz[k]] = (short)v;
+                        blk[k] = (short)v;
                         ++k;
                     }
                 }
@@ -249,8 +290,8 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
             int x[8], o[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                x[r] = (int)L.coef[b][r * 8 + c] * (int)q[r * 8 + c];
-                L.coef[b][r * 8 + c] = 0;
+                x[r] = (int)L.coef[b][scan[r]] * (int)q[r * 8 + c];
+                L.coef[b][scan[r]] = 0;
             }
             idct8(x, o);
 #pragma unroll

@@ -275,7 +275,7 @@ class DataAugmentationDINOGpu:
         on_device = hasattr(images, "packed")
         if on_device:
             shapes, offs = list(images.shapes), np.asarray(images.offsets, np.int64)
-            if images.packed.device != dev:
+            if images.packed.device.type != dev.type or (dev.index is not None and images.packed.device.index != dev.index):
                 raise _lib.DkdError(f"the decoded batch lives on {images.packed.device}, the pipeline on {dev}")
         else:
             imgs = [torch.as_tensor(np.ascontiguousarray(im)) for im in images]

@@ -257,7 +257,7 @@ class JpegDecoderGpu:
             self.stats["segments"] += len(segs)
         for b, arr in host.items():
             n = arr.size
-            rgb[int(rgb_offs[b]):int(rgb_offs[b]) + n].copy_(torch.from_numpy(np.ascontiguousarray(arr)).view(-1))
+            rgb[int(rgb_offs[b]):int(rgb_offs[b]) + n].copy_(torch.from_numpy(np.array(arr)).view(-1))
         self.stats["images"] += B
         self.stats["host_decoded"] += len(host)
         return DecodedBatch(rgb, rgb_offs[:-1].copy(), [tuple(int(v) for v in s) for s in shapes])
