@@ -2,7 +2,8 @@
 // i.e. what Pillow's libjpeg-turbo does for a baseline file, bit for bit (tests/test_jpeg_gpu.py compares with Pillow itself):
 //   jpeg_entropy_idct_kernel   one wave per entropy-coded segment (a whole image, or one restart interval of it): the 64 lanes stage
 //                              the byte stream into an LDS ring 1 KiB at a time and remove the 0xFF00 stuffing with a wave prefix sum;
-//                              the sequential Huffman decode of one MCU runs on the scalar unit (wave-uniform state) into LDS; 8 lanes per block then dequantise and
+//                              all lanes look up, speculatively, the symbol that would start at each of the next 64 bit offsets and the scalar unit follows
+//                              the chain of symbols through them (Huffman decode of one MCU into LDS); 8 lanes per block then dequantise and
 //                              run libjpeg's "islow" integer inverse DCT (column pass, row pass) and store 8-pixel rows of the
 //                              component planes
 //   jpeg_rgb_kernel            one thread per pixel: libjpeg's "fancy" (triangle) h2v1 / h2v2 chroma upsampling evaluated at the
@@ -34,9 +35,14 @@ struct Lds {
     short coef[6][64];                      // in zigzag (stream) order
     int ws[6][64];
 };
-// look-ahead entry: bits 0-4 = stream bits it consumes, 5-8 = zero run, 9-12 = magnitude category still to be read from the stream,
-// bit 13 = the coefficient itself is in bits 16-31 (code and magnitude bits both fit into the window: nothing more to read)
-constexpr unsigned LUT_HAS_VALUE = 1u << 13;
+// A look-ahead entry says what the LUT_BITS bits of a window decode to when a symbol of that table starts at its first bit:
+//   bits 0-4   stream bits the symbol takes, its magnitude bits included (NEED: the code alone)
+//   bits 5-11  how far it advances the coefficient index: zero run + 1 for a coefficient, 1 for a DC difference, 16 for a run of
+//              sixteen zeros, 64 for the end of block (and for SLOW: either ends the walk)
+//   bit 12     VALUE: the coefficient is in bits 16-31          bit 13  SLOW: the code is longer than the window
+//   bit 14     NEED: the magnitude bits did not fit the window; bits 16-19 hold their count (resolved per lane from its 32 bits)
+constexpr unsigned F_VALUE = 1u << 12, F_SLOW = 1u << 13, F_NEED = 1u << 14;
+constexpr unsigned F_END = 64u << 5;
 
 // the even / odd butterflies of jidctint.c (Loeffler, Ligtenberg, Moschytz; CONST_BITS 13)
 __device__ __forceinline__ void idct8(const int x[8], int o[8]) {
@@ -72,68 +78,41 @@ __device__ __forceinline__ unsigned range_limit(int v) {   // libjpeg's range_li
     return v < 128 ? v + 128 : (v < 512 ? 255 : (v < 896 ? 0 : v - 896));
 }
 
-// The entropy decode is ONE sequential chain per segment.  It runs on the scalar unit: every lane executes it with identical (wave-
-// uniform) state, values that come back from LDS are pinned to SGPRs with readfirstlane, so shifts, compares and branches are SALU
-// instructions and scalar branches instead of vector code under a one-lane EXEC mask (which the compiler brackets with EXEC save /
-// restore sequences at every if - measured 1.9x slower).
+// The entropy decode is ONE sequential chain per segment: where a symbol starts is known only once the one before it is decoded.
+// The wave cuts the chain's cost in two parts.  (1) All 64 lanes decode speculatively: lane i takes the 32 stream bits that start i
+// bits behind the read position and looks up the symbol that WOULD start there (one LDS gather per table, the magnitude bits
+// resolved in the lane).  (2) The scalar unit then only follows the chain through the lanes - readlane the entry at the current
+// offset, add its length, writelane the coefficient index it lands on - about a dozen SALU instructions per symbol with no memory
+// access, until the block ends or the 64 offsets are used up; the lanes the chain touched then store their coefficients together.
+// (One lane doing all of it under a one-lane EXEC mask took ~600 cycles per symbol; wave-uniform scalar code with one LDS
+// round trip per symbol ~480.)
 __device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-struct BitReader {
-    unsigned long long acc;   // unread bits, MSB first
-    int n;                    // how many of them are valid
-    int rp;                   // ring word held in `next`
-    unsigned next;            // fetched one refill ahead, so that the LDS latency is off the decode chain
-    __device__ __forceinline__ void fill(const unsigned int* ring) {
-        if (n < 32) {
-            acc |= (unsigned long long)uni(next) << (32 - n);
-            n += 32;
-            ++rp;
-            next = ring[rp & (RING / 4 - 1)];   // (stays in its VGPR until the next refill: the wait lands there, not here)
-        }
-    }
-    __device__ __forceinline__ unsigned peek(int k) const { return (unsigned)(acc >> (64 - k)); }
-    __device__ __forceinline__ void skip(int k) {
-        acc <<= k;
-        n -= k;
-    }
-    __device__ __forceinline__ int receive_extend(int s) {   // s in 1..15
-        const int v = (int)peek(s);
-        skip(s);
-        return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
-    }
-};
+// lane `lane` of v = the scalar s (this compiler has no builtin for v_writelane_b32; on gfx9 the lane select goes through M0 because a
+// VOP3 instruction may read one SGPR only)
+__device__ __forceinline__ void writelane(int& v, int s, int lane) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(s), "s"(lane));   // (M0 has no other user in this file)
+}
+__device__ __forceinline__ int extend(unsigned v, int cat) { return (int)v < (1 << (cat - 1)) ? (int)v - (1 << cat) + 1 : (int)v; }
 
-// one Huffman symbol and, for a non-zero magnitude category, the value behind it: -> run in *run, category in *cat (0: no value)
-__device__ __forceinline__ int huff_value(BitReader& br, const Lds& L, int t, int* run, int* cat) {
-    br.fill(L.ring);
-    const unsigned e = uni(L.lut[t][br.peek(LUT_BITS)]);
-    int sym;
-    if (e) {
-        br.skip(e & 31);
-        *run = (e >> 5) & 15;
-        if (e & LUT_HAS_VALUE) {
-            *cat = 1;
-            return (int)e >> 16;
+// a symbol whose code is longer than the look-ahead window, decoded from the 32 stream bits `win` by the canonical search (scalar):
+// -> entry in the look-ahead format with the value resolved
+__device__ __forceinline__ unsigned slow_symbol(const Lds& L, int t, unsigned win) {
+    const int code16 = (int)(win >> 16);
+    int sym = 0, l = LUT_BITS + 1;
+    for (; l <= 16; ++l) {
+        const int c = code16 >> (16 - l);
+        if (c <= uni(L.maxcode[t][l])) {
+            sym = uni((int)L.tbl[HUFF0 + t * HUFF_STRIDE + 16 + ((c + uni(L.valoff[t][l])) & 255)]);
+            break;
         }
-        sym = (e >> 9) & 15;
-    } else {
-        const int code16 = (int)br.peek(16);
-        sym = 0;
-        int l = LUT_BITS + 1;
-        for (; l <= 16; ++l) {
-            const int c = code16 >> (16 - l);
-            if (c <= uni(L.maxcode[t][l])) {
-                sym = uni((int)L.tbl[HUFF0 + t * HUFF_STRIDE + 16 + ((c + uni(L.valoff[t][l])) & 255)]);
-                break;
-            }
-        }
-        br.skip(l > 16 ? 16 : l);   // (no code of this table - a corrupt stream: a zero symbol, as libjpeg substitutes)
-        *run = sym >> 4;
-        sym &= 15;
     }
-    *cat = sym;
-    return sym ? br.receive_extend(sym) : 0;
+    if (l > 16) l = 16, sym = 0;   // (no code of this table - a corrupt stream: a zero symbol, as libjpeg substitutes)
+    const int run = t >= 2 ? sym >> 4 : 0, cat = sym & 15;
+    if (!cat) return t < 2 ? (unsigned)l | 1u << 5 | F_VALUE : (unsigned)l | (run == 15 ? 16u << 5 : F_END);
+    const unsigned v = (win << l) >> (32 - cat);
+    return (unsigned)(l + cat) | (unsigned)(run + 1) << 5 | F_VALUE | (unsigned)extend(v, cat) << 16;
 }
 
 __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned char* __restrict__ bytes, const int* __restrict__ seg_meta,
@@ -176,20 +155,20 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
         }
         // every lane decodes 8 of the 512 possible windows
         for (int w = lane; w < (1 << LUT_BITS); w += 64) {
-            unsigned e = 0;
+            unsigned e = F_SLOW | F_END;
 #pragma unroll
             for (int l = 1; l <= LUT_BITS; ++l) {
                 const int c = w >> (LUT_BITS - l);
-                if (e == 0 && c <= maxc[l]) {
+                if ((e & F_SLOW) && c <= maxc[l]) {
                     const int sym = bits[16 + ((c + voff[l]) & 255)];
                     const int run = t >= 2 ? sym >> 4 : 0, cat = sym & 15;
-                    if (cat && l + cat <= LUT_BITS) {
-                        int v = (w >> (LUT_BITS - l - cat)) & ((1 << cat) - 1);
-                        if (v < (1 << (cat - 1))) v += 1 - (1 << cat);
-                        e = (unsigned)(l + cat) | run << 5 | LUT_HAS_VALUE | (unsigned)v << 16;
-                    } else {
-                        e = (unsigned)l | run << 5 | cat << 9;
-                    }
+                    if (!cat)
+                        e = t < 2 ? (unsigned)l | 1u << 5 | F_VALUE : (unsigned)l | (run == 15 ? 16u << 5 : F_END);
+                    else if (l + cat <= LUT_BITS)
+                        e = (unsigned)(l + cat) | (unsigned)(run + 1) << 5 | F_VALUE |
+                            (unsigned)extend((w >> (LUT_BITS - l - cat)) & ((1 << cat) - 1), cat) << 16;
+                    else
+                        e = (unsigned)l | (unsigned)(run + 1) << 5 | F_NEED | (unsigned)cat << 16;
                 }
             }
             L.lut[t][w] = e;
@@ -205,13 +184,13 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
     int chunk = 0;         // next 1 KiB piece of the source
     int wpos = 0;          // bytes staged so far
     unsigned prev_last = 0;
-    BitReader br{0ull, 0, 0, 0u};
+    int pos = 0;           // bits of the (unstuffed) stream consumed so far
     int pred0 = 0, pred1 = 0, pred2 = 0;
 
     for (int m = 0; m < n_mcu; ++m) {
         // stage until at least 2 KiB lie ahead of the reader (an MCU of six blocks cannot take more than 1.3 KiB); behind the end of the
         // segment the stream continues with zero bytes, as libjpeg's does
-        int rbytes = br.rp * 4;
+        const int rbytes = pos >> 3;
         while (wpos - rbytes < 2048) {
             const long p = a0 + (long)chunk * 1024 + lane * 16;
             const bool beyond = a0 + (long)chunk * 1024 >= s_end;
@@ -249,36 +228,70 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
         }
         __syncthreads();
 
-        {   // (all lanes, uniformly: see BitReader)
-            if (m == 0) br.next = L.ring[0];
-            int bi = 0;
+        int bi = 0;
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                if (ci >= nc) break;
-                const int td = (sel >> (6 + 2 * ci)) & 1, ta = 2 + ((sel >> (7 + 2 * ci)) & 1);
-                const int reps = ci == 0 ? nblk0 : 1;
-                int pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
-                for (int r = 0; r < reps; ++r, ++bi) {
-                    short* blk = L.coef[bi];
-                    int run, cat;
-                    pred += huff_value(br, L, td, &run, &cat);
-                    blk[0] = (short)pred;
-                    int k = 1;
-                    while (k < 64) {
-                        const int v = huff_value(br, L, ta, &run, &cat);
-                        if (!cat) {
-                            if (run != 15) break;   // end of block
-                            k += 16;                // sixteen zeros
-                            continue;
+        for (int ci = 0; ci < 3; ++ci) {
+            if (ci >= nc) break;
+            const int td = (sel >> (6 + 2 * ci)) & 1, ta = 2 + ((sel >> (7 + 2 * ci)) & 1);
+            const int reps = ci == 0 ? nblk0 : 1;
+            int pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
+            for (int r = 0; r < reps; ++r, ++bi) {
+                short* blk = L.coef[bi];
+                int k = 0;   // next coefficient index; 0: the block's DC difference comes first
+                while (k < 64) {
+                    // (1) every lane: the 32 bits that start `lane` bits behind the read position, and what they decode to
+                    const int p = pos + lane;
+                    const unsigned w0 = L.ring[(p >> 5) & (RING / 4 - 1)], w1 = L.ring[((p >> 5) + 1) & (RING / 4 - 1)];
+                    const unsigned win = (unsigned)((((unsigned long long)w0 << 32 | w1) << (p & 31)) >> 32);
+                    unsigned f = L.lut[ta][win >> (32 - LUT_BITS)];
+                    if (k == 0) {
+                        const unsigned fd = L.lut[td][win >> (32 - LUT_BITS)];
+                        if (lane == 0) f = fd;
+                    }
+                    if (f & F_NEED) {
+                        const int l = f & 31, cat = (f >> 16) & 15;
+                        f = (f & 0xFE0u) | (unsigned)(l + cat) | F_VALUE | (unsigned)extend((win << l) >> (32 - cat), cat) << 16;
+                    }
+                    // (2) the scalar unit follows the chain
+                    const int k0 = k;
+                    int off = 0, kk = -1;   // kk: the coefficient index the chain reaches a lane with, -1: not on the chain
+                    unsigned e;
+                    do {
+                        e = __builtin_amdgcn_readlane(f, off);
+                        writelane(kk, k, off);
+                        k += (e >> 5) & 127;
+                        off += e & 31;
+                    } while ((k | off) < 64);
+                    const bool slow = (e & F_SLOW) != 0;   // the walk ended on a long code (which advanced `off` by nothing)
+                    // (3) the lanes on the chain store their coefficients
+                    int dc = 0;
+                    if (k0 == 0) {
+                        const unsigned e0 = __builtin_amdgcn_readlane(f, 0);
+                        if (!(e0 & F_SLOW)) {
+                            pred += (int)e0 >> 16;
+                            dc = pred;
                         }
-                        k += run;
-                        if (k > 63) break;
-                        blk[k] = (short)v;
-                        ++k;
+                    }
+                    if (kk >= 0 && (f & F_VALUE)) {
+                        const int at = kk + (int)((f >> 5) & 127) - 1;
+                        if (at <= 63) blk[at] = (short)(k0 == 0 && lane == 0 ? dc : (int)f >> 16);
+                    }
+                    pos += off;
+                    if (slow) {
+                        k -= 64;
+                        const unsigned es = slow_symbol(L, k == 0 ? td : ta, __builtin_amdgcn_readlane(win, off));
+                        if (es & F_VALUE) {
+                            int v = (int)es >> 16;
+                            if (k == 0) v = pred += v;
+                            const int at = k + (int)((es >> 5) & 127) - 1;
+                            if (at <= 63) blk[at] = (short)v;
+                        }
+                        k += (es >> 5) & 127;
+                        pos += es & 31;
                     }
                 }
-                if (ci == 0) pred0 = pred; else if (ci == 1) pred1 = pred; else pred2 = pred;
             }
+            if (ci == 0) pred0 = pred; else if (ci == 1) pred1 = pred; else pred2 = pred;
         }
         __syncthreads();
 

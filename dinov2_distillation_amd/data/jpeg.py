@@ -261,3 +261,36 @@ class JpegDecoderGpu:
         self.stats["images"] += B
         self.stats["host_decoded"] += len(host)
         return DecodedBatch(rgb, rgb_offs[:-1].copy(), [tuple(int(v) for v in s) for s in shapes])
+
+
+class CustomDatasetFiles:
+    """/root/reference/datasets/CustomDataset.py:18-69 ``CustomDataset`` without its two per-sample host calls (decode, transform): the
+    same directory walk and extension filter, ``__getitem__`` returns the FILE (bytes).  Collate with ``list`` and hand the batch to
+    ``GpuInputPipeline``."""
+
+    def __init__(self, img_dirs):
+        import os
+        if isinstance(img_dirs, str):
+            img_dirs = [img_dirs]
+        self.images = [os.path.join(d, n) for d in img_dirs for n in os.listdir(d) if n.endswith((".jpg", ".png", ".jpeg"))]
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, idx):
+        with open(self.images[idx], "rb") as f:
+            return f.read()
+
+
+class GpuInputPipeline:
+    """files of one batch -> the normalised float32 [B, 3, S, S] batch on the GPU: decode (csrc/jpeg.hip) + ``DataAugmentationDINOGpu``
+    (csrc/augment.hip) without a host round trip in between.  The reference's dataset also lists .png files
+    (datasets/CustomDataset.py:44): those, and JPEG flavours the kernels do not cover, are decoded by Pillow on the host when
+    ``host_fallback`` is set (the default here; ``decoder.stats`` counts them)."""
+
+    def __init__(self, aug, host_fallback=True):
+        self.aug = aug
+        self.decoder = JpegDecoderGpu(aug.device, host_fallback=host_fallback)
+
+    def __call__(self, files, generator=None, plans=None):
+        return self.aug(self.decoder.decode(files), generator=generator, plans=plans)

@@ -91,3 +91,21 @@ def test_decoder_needs_the_gpu():
     from dinov2_distillation_amd.data.jpeg import JpegDecoderGpu
     with pytest.raises(_lib.DkdError):
         JpegDecoderGpu(device="cpu").decode([J.encode(J.picture(1, 8, 8))])
+
+
+def test_dataset_lists_what_the_reference_lists(tmp_path):
+    """datasets/CustomDataset.py:41-45: every directory, os.listdir order, the three extensions; items are the files' bytes"""
+    import os
+    from dinov2_distillation_amd.data import CustomDatasetFiles
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(), b.mkdir()
+    blobs = {}
+    for d, names in ((a, ("x.jpg", "y.jpeg", "z.png", "skip.txt", "UPPER.JPG")), (b, ("w.jpg",))):
+        for i, n in enumerate(names):
+            blobs[str(d / n)] = J.encode(J.picture(i, 16, 16), quality=70)
+            (d / n).write_bytes(blobs[str(d / n)])
+    ds = CustomDatasetFiles([str(a), str(b)])
+    expect = [os.path.join(str(d), n) for d in (a, b) for n in os.listdir(d) if n.endswith((".jpg", ".png", ".jpeg"))]
+    assert ds.images == expect and len(ds) == 4
+    assert all(ds[i] == blobs[p] for i, p in enumerate(ds.images))
+    assert CustomDatasetFiles(str(b)).images == [str(b / "w.jpg")]

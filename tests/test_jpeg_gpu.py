@@ -84,3 +84,20 @@ def test_decoded_batch_feeds_the_augmentation_pipeline_in_place():
     a = aug(batch, generator=torch.Generator().manual_seed(5))
     b = aug([J.pillow_rgb(f) for f in files], generator=torch.Generator().manual_seed(5))
     assert a.shape == (6, 3, 224, 224) and torch.equal(a, b)
+
+
+def test_input_pipeline_from_files_with_a_png_in_the_batch():
+    import io
+    from PIL import Image
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu, GpuInputPipeline
+    files = [J.encode(J.picture(60 + i, 70 + 9 * i, 100 - 3 * i), quality=90) for i in range(5)]
+    png = io.BytesIO()
+    J.picture(9, 64, 80).save(png, "PNG")
+    files.insert(2, png.getvalue())
+    aug = DataAugmentationDINOGpu((0.08, 1.0), 224)
+    pipe = GpuInputPipeline(aug)
+    a = pipe(files, generator=torch.Generator().manual_seed(11))
+    b = aug([np.asarray(Image.open(io.BytesIO(f)).convert("RGB")) for f in files], generator=torch.Generator().manual_seed(11))
+    assert torch.equal(a, b) and pipe.decoder.stats["host_decoded"] == 1
+    with pytest.raises(Exception):
+        GpuInputPipeline(aug, host_fallback=False)(files)
