@@ -37,12 +37,15 @@ struct Lds {
 };
 // A look-ahead entry says what the LUT_BITS bits of a window decode to when a symbol of that table starts at its first bit:
 //   bits 0-4   stream bits the symbol takes, its magnitude bits included (NEED: the code alone)
-//   bits 5-11  how far it advances the coefficient index: zero run + 1 for a coefficient, 1 for a DC difference, 16 for a run of
+//   bits 8-14  how far it advances the coefficient index: zero run + 1 for a coefficient, 1 for a DC difference, 16 for a run of
 //              sixteen zeros, 64 for the end of block (and for SLOW: either ends the walk)
-//   bit 12     VALUE: the coefficient is in bits 16-31          bit 13  SLOW: the code is longer than the window
-//   bit 14     NEED: the magnitude bits did not fit the window; bits 16-19 hold their count (resolved per lane from its 32 bits)
-constexpr unsigned F_VALUE = 1u << 12, F_SLOW = 1u << 13, F_NEED = 1u << 14;
-constexpr unsigned F_END = 64u << 5;
+//   bit 15     VALUE: the coefficient is in bits 16-31.  Without it: bits 16-19 = NEED, the count of magnitude bits that did not fit
+//              the window (resolved per lane from its 32 bits), bit 20 = SLOW, the code is longer than the window
+// (bits 5-7 stay zero: the chain walk adds bits 0-14 of an entry to {bit offset | coefficient index << 8} in one scalar add)
+constexpr unsigned F_VALUE = 1u << 15, F_SLOW = 1u << 20, F_STEP = 0x7F1Fu;
+constexpr unsigned F_END = 64u << 8;
+__device__ __forceinline__ unsigned f_step(int bits, int inc) { return (unsigned)bits | (unsigned)inc << 8; }
+__device__ __forceinline__ unsigned f_coef(int bits, int inc, int v) { return f_step(bits, inc) | F_VALUE | (unsigned)v << 16; }
 
 // the even / odd butterflies of jidctint.c (Loeffler, Ligtenberg, Moschytz; CONST_BITS 13)
 __device__ __forceinline__ void idct8(const int x[8], int o[8]) {
@@ -110,9 +113,8 @@ __device__ __forceinline__ unsigned slow_symbol(const Lds& L, int t, unsigned wi
     }
     if (l > 16) l = 16, sym = 0;   // (no code of this table - a corrupt stream: a zero symbol, as libjpeg substitutes)
     const int run = t >= 2 ? sym >> 4 : 0, cat = sym & 15;
-    if (!cat) return t < 2 ? (unsigned)l | 1u << 5 | F_VALUE : (unsigned)l | (run == 15 ? 16u << 5 : F_END);
-    const unsigned v = (win << l) >> (32 - cat);
-    return (unsigned)(l + cat) | (unsigned)(run + 1) << 5 | F_VALUE | (unsigned)extend(v, cat) << 16;
+    if (!cat) return t < 2 ? f_coef(l, 1, 0) : f_step(l, run == 15 ? 16 : 64);
+    return f_coef(l + cat, run + 1, extend((win << l) >> (32 - cat), cat));
 }
 
 __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned char* __restrict__ bytes, const int* __restrict__ seg_meta,
@@ -159,16 +161,15 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
 #pragma unroll
             for (int l = 1; l <= LUT_BITS; ++l) {
                 const int c = w >> (LUT_BITS - l);
-                if ((e & F_SLOW) && c <= maxc[l]) {
+                if (e == (F_SLOW | F_END) && c <= maxc[l]) {
                     const int sym = bits[16 + ((c + voff[l]) & 255)];
                     const int run = t >= 2 ? sym >> 4 : 0, cat = sym & 15;
                     if (!cat)
-                        e = t < 2 ? (unsigned)l | 1u << 5 | F_VALUE : (unsigned)l | (run == 15 ? 16u << 5 : F_END);
+                        e = t < 2 ? f_coef(l, 1, 0) : f_step(l, run == 15 ? 16 : 64);
                     else if (l + cat <= LUT_BITS)
-                        e = (unsigned)(l + cat) | (unsigned)(run + 1) << 5 | F_VALUE |
-                            (unsigned)extend((w >> (LUT_BITS - l - cat)) & ((1 << cat) - 1), cat) << 16;
+                        e = f_coef(l + cat, run + 1, extend((w >> (LUT_BITS - l - cat)) & ((1 << cat) - 1), cat));
                     else
-                        e = (unsigned)l | (unsigned)(run + 1) << 5 | F_NEED | (unsigned)cat << 16;
+                        e = f_step(l, run + 1) | (unsigned)cat << 16;
                 }
             }
             L.lut[t][w] = e;
@@ -248,32 +249,33 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
                         const unsigned fd = L.lut[td][win >> (32 - LUT_BITS)];
                         if (lane == 0) f = fd;
                     }
-                    if (f & F_NEED) {
+                    if (!(f & F_VALUE) && (f & 0xF0000u)) {
                         const int l = f & 31, cat = (f >> 16) & 15;
-                        f = (f & 0xFE0u) | (unsigned)(l + cat) | F_VALUE | (unsigned)extend((win << l) >> (32 - cat), cat) << 16;
+                        f = f_coef(l + cat, (f >> 8) & 127, extend((win << l) >> (32 - cat), cat));
                     }
-                    // (2) the scalar unit follows the chain
+                    // (2) the scalar unit follows the chain; st = bit offset | coefficient index << 8
                     const int k0 = k;
-                    int off = 0, kk = -1;   // kk: the coefficient index the chain reaches a lane with, -1: not on the chain
+                    int st = k << 8, reached = -1;   // reached: the state the chain arrives at a lane with, -1: not on the chain
                     unsigned e;
                     do {
-                        e = __builtin_amdgcn_readlane(f, off);
-                        writelane(kk, k, off);
-                        k += (e >> 5) & 127;
-                        off += e & 31;
-                    } while ((k | off) < 64);
-                    const bool slow = (e & F_SLOW) != 0;   // the walk ended on a long code (which advanced `off` by nothing)
+                        e = __builtin_amdgcn_readlane(f, st & 63);
+                        writelane(reached, st, st);   // (the lane select reads its low six bits)
+                        st += e & F_STEP;
+                    } while (!(st & 0xC0C0));
+                    const int off = st & 255;
+                    k = st >> 8;
+                    const bool slow = (e & (F_VALUE | F_SLOW)) == F_SLOW;   // the walk ended on a long code (which advanced the offset by nothing)
                     // (3) the lanes on the chain store their coefficients
                     int dc = 0;
                     if (k0 == 0) {
                         const unsigned e0 = __builtin_amdgcn_readlane(f, 0);
-                        if (!(e0 & F_SLOW)) {
+                        if (e0 & F_VALUE) {
                             pred += (int)e0 >> 16;
                             dc = pred;
                         }
                     }
-                    if (kk >= 0 && (f & F_VALUE)) {
-                        const int at = kk + (int)((f >> 5) & 127) - 1;
+                    if (reached >= 0 && (f & F_VALUE)) {
+                        const int at = (reached >> 8) + (int)((f >> 8) & 127) - 1;
                         if (at <= 63) blk[at] = (short)(k0 == 0 && lane == 0 ? dc : (int)f >> 16);
                     }
                     pos += off;
@@ -283,10 +285,10 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
                         if (es & F_VALUE) {
                             int v = (int)es >> 16;
                             if (k == 0) v = pred += v;
-                            const int at = k + (int)((es >> 5) & 127) - 1;
+                            const int at = k + (int)((es >> 8) & 127) - 1;
                             if (at <= 63) blk[at] = (short)v;
                         }
-                        k += (es >> 5) & 127;
+                        k += (es >> 8) & 127;
                         pos += es & 31;
                     }
                 }
