@@ -1,5 +1,6 @@
 // The 16-bit policy's attention WITH gradients, flash-style on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), head dims 16 / 24 /
-// 32 (tiles padded to 32: HDP = 32) and 48 / 64 (HDP = 64): the
+// 32 (tiles padded to 32: HDP = 32), 40 / 48 / 64 (HDP = 64) and 72 / 80 / 96 (HDP = 96: the 16-head projector on 1536 channels, MiT's
+// 80-wide third stage): the
 // ScaleKD projectors' cross attention (losses/scalekd.py:308-313) and the frozen DINOv2 blocks re-used on student tokens
 // (train/distillation_module.py:176-177) under the reference's default precision=16 (train.py:263 == torch autocast).
 //
@@ -16,8 +17,9 @@
 // STREAMED set arrives as 64-row tiles in LDS (LDS-DMA, two stages, one barrier per tile) and lands on the accumulator registers
 // - which, packed to bf16 eight at a time, are the B operand of the second product, whose A operand is the streamed tile read
 // transposed (ds_read_b64_tr_b16).  One LDS image serves both read forms: rows of 2 HDP bytes whose 16-byte chunk index is XOR-ed
-// with the row's position in its 256-byte bank period group ((row / 2) % 8 for 128-byte rows, (row / 4) % 4 for 64-byte rows); chunks
-// past the real head dim (24 in a 32-wide tile) are never loaded and stay zero.
+// with the row's position in its 256-byte bank period group ((row / 2) % 8 for 128-byte rows, (row / 4) % 4 for 64-byte rows; 192-byte
+// rows start 48 banks apart - a period of four rows - and XOR (row / 4) % 4 into the low two bits of the chunk index, which stays inside
+// its group of four of the 12 chunks); chunks past the real head dim (24 in a 32-wide tile) are never loaded and stay zero.
 #include <cmath>
 
 #include "common.h"
@@ -37,9 +39,9 @@ __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" :
 
 template <int HDP>
 struct Geo {
-    static constexpr int ROWB = HDP * 2, TILE = TR * ROWB, CPR = HDP / 8, RPP = 1024 / ROWB, PIECES = TILE / 1024, PPW = PIECES / NW;
+    static constexpr int ROWB = HDP * 2, TILE = TR * ROWB, CPR = HDP / 8, PIECES = TILE / 1024, PPW = PIECES / NW;
     static constexpr int KC = HDP / 16, DB = HDP / 32;
-    static_assert(HDP == 64 || HDP == 32, "tiles are 32 or 64 wide");
+    static_assert(HDP == 96 || HDP == 64 || HDP == 32, "tiles are 32, 64 or 96 wide");
     static __device__ __forceinline__ int swz(int row) { return HDP == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 
@@ -51,7 +53,8 @@ __device__ __forceinline__ void issue_tile(const __bf16* __restrict__ base, long
     using G = Geo<HDP>;
 #pragma unroll
     for (int p = 0; p < G::PPW; ++p) {
-        const int piece = wid + NW * p, row = G::RPP * piece + lane / G::CPR, chunk = (lane % G::CPR) ^ G::swz(row);
+        // the piece's lane i lands at LDS byte 1024 piece + 16 i = row (64 piece + i) / CPR, slot (64 piece + i) % CPR
+        const int piece = wid + NW * p, at = 64 * piece + lane, row = at / G::CPR, chunk = (at % G::CPR) ^ G::swz(row);
         const __bf16* src = base + (long)min(row0 + row, nrows - 1) * ld + 8 * chunk;
         if (8 * chunk < hd) __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(S + piece * 1024), 16, 0, 0);
     }
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_train_bwd_dkv_kernel(Ptrs a) {
 
 int check(const dkd_attn16_args* g, bool bwd) {
     if (!g || !g->q || !g->k || !g->v || !g->m || !g->linv || g->B <= 0 || g->H <= 0 || g->Nq <= 0 || g->Nk <= 0) return DKD_ERR_BAD_ARG;
-    if ((g->hd & 7) || g->hd < 16 || g->hd > 64) return DKD_ERR_UNSUPPORTED;  // 8-wide chunks of a 32- or 64-wide tile (MiT: 40)
+    if ((g->hd & 7) || g->hd < 16 || g->hd > 96) return DKD_ERR_UNSUPPORTED;  // 8-wide chunks of a 32-, 64- or 96-wide tile (MiT: 40, 80)
     if (g->H > 65535 || g->B > 65535) return DKD_ERR_UNSUPPORTED;
     const long w = (long)g->H * g->hd;
     if ((g->ldq & 7) || (g->ldkv & 7) || g->ldq < w || g->ldkv < w) return DKD_ERR_ALIGN;
@@ -435,7 +438,9 @@ static int scale_mode(float c1, float c2) {
 }
 #define DKD_A16_MODE(mode, K, grid, a)                                                                                      \
     do {                                                                                                                    \
-        if (a.hd > 32) {                                                                                                    \
+        if (a.hd > 64) {   /* (no power-of-two scale at these widths: the general logit chain) */                          \
+            hipLaunchKernelGGL((K<96, 0>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                                 \
+        } else if (a.hd > 32) {                                                                                             \
             if ((mode) == 2) hipLaunchKernelGGL((K<64, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                \
             else if ((mode) == 1) hipLaunchKernelGGL((K<64, 1>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);           \
             else hipLaunchKernelGGL((K<64, 0>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a);                            \

@@ -1055,7 +1055,7 @@ class CrossAttn16Fn(Function):
         B, N, D = q.shape
         Nk = kv.shape[1]
         hd = D // heads
-        if hd > 64:   # (MiT-b1 ... b5, third stage: 80) no flash kernel: the materialised path on contiguous copies of k and v
+        if hd > 96:   # no flash kernel past 96-wide heads: the materialised path on contiguous copies of k and v
             k, v = kv[..., :D].contiguous().view(B * Nk, D), kv[..., D:].contiguous().view(B * Nk, D)
             o, S, P = ops.attention16_forward(q.view(B * N, D), k, v, B, heads, N, Nk, hd, scale)
             ctx.save_for_backward(q, k, v, S, P)

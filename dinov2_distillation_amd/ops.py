@@ -1394,7 +1394,7 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-# flash form of the policy attention (csrc/attention16_train.hip, hd 16 / 24 / 32 / 48 / 64): 0 = always the materialised path (A/B, tests)
+# flash form of the policy attention (csrc/attention16_train.hip, head dims 16 ... 96 in steps of 8): 0 = always the materialised path (A/B, tests)
 ATTN16_FLASH = os.environ.get("DKD_ATTN16_FLASH", "1") != "0"
 
 
@@ -1417,7 +1417,7 @@ def attention16_forward(q, k, v, B, H, Nq, Nk, hd, c1, c2=1.0, q_shared=False, l
     L = D if ld is None else ld
     if hd % 8:
         raise _lib.DkdError(f"attention16: the head dim must be a multiple of 8 (got {hd})")
-    if hd in (16, 24, 32, 48, 64) and ATTN16_FLASH:
+    if 16 <= hd <= 96 and ATTN16_FLASH:
         # flash form: O plus the fp32 row statistics (max, 1 / sum) in place of the logit / probability tensors
         a = _attn16_train_args(q, k, v, B, H, Nq, Nk, hd, c1, c2, q_shared, L)
         O = torch.empty((B * Nq, D), dtype=BF16, device=q.device)
@@ -1450,8 +1450,8 @@ def attention16_cross(q, kv, B, H, Nq, Nk, hd, c1, dO=None, stats=None):
     Forward (dO None) -> O [B*Nq, D], (m, linv);  backward (dO, stats from the forward) -> dq [B*Nq, D], dkv [B*Nk, 2 D]"""
     _chk16(q, "q"), _chk16(kv, "kv"), _chk16(dO, "dO")
     D = H * hd
-    if hd % 8 or not 16 <= hd <= 64:
-        raise NotImplementedError(f"attention16_cross: head dim {hd} has no flash kernel (multiples of 8 from 16 to 64)")
+    if hd % 8 or not 16 <= hd <= 96:
+        raise NotImplementedError(f"attention16_cross: head dim {hd} has no flash kernel (multiples of 8 from 16 to 96)")
     kv2 = kv.view(B * Nk, 2 * D)
     a = _attn16_train_args(q, kv2, kv2[:, D:], B, H, Nq, Nk, hd, c1, 1.0, False, D)
     a.ldkv = 2 * D

@@ -214,10 +214,12 @@ def test_frozen_block_reuse_on_1369_tokens_under_the_policy_vs_torch_autocast():
                                                    (2, 3, 1369, 1369, True, 5.0, 64), (2, 2, 64, 64, False, 5.0, 64),
                                                    (2, 16, 256, 256, True, 5.0, 24), (2, 24, 256, 256, False, 5.0, 16),
                                                    (2, 8, 1369, 1369, True, 5.0, 32), (3, 5, 100, 36, False, 1.0, 24),
-                                                   (2, 16, 256, 256, True, 5.0, 48)])
+                                                   (2, 16, 256, 256, True, 5.0, 48), (2, 16, 256, 256, True, 5.0, 96),
+                                                   (2, 4, 1369, 1369, True, 5.0, 96), (3, 4, 196, 49, False, 1.0, 80),
+                                                   (2, 3, 100, 77, False, 5.0, 72), (2, 5, 64, 64, False, 1.0, 40)])
 def test_flash_policy_attention_equals_the_materialised_path(B, H, Nq, Nk, shared, c2, hd):
     """csrc/attention16_train.hip (hd 64: the frozen teacher blocks and the 16-head projector of configs[3]; hd 24 / 16: the projectors of
-    configs[1]; 32: configs[3]'s second level) against the materialised path it replaces (batched bf16 GEMMs around
+    configs[1]; 32: configs[3]'s second level; 96: the 16-head projector on configs[4]'s 1536 channels; 80 / 40: MiT) against the materialised path it replaces (batched bf16 GEMMs around
     dkd_attn16_softmax_*) and against torch.autocast: same rounding points, so the two differ by fp32 summation order only (a
     handful of 1-ulp bf16 flips), far inside the policy's distance from exact attention."""
     from dinov2_distillation_amd import ops
