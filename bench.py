@@ -306,6 +306,50 @@ def cpu_baseline(seconds_budget=25.0, batch=2, max_steps=None):
                       f"{batch} on the host CPU, fp32 torch oracle, {dt:.1f} s"}
 
 
+def input_pipeline(batch, seconds=1.5):
+    """SURVEY 8f-3 beside the step it feeds (never part of `value`: the step's inputs are resident in HBM): `batch` synthetic 500 x 375
+    JPEG files (quality 90, 4:2:0, no restart markers - what an ImageNet folder holds) -> csrc/jpeg.hip -> csrc/augment.hip, and the
+    reference's own decode call (datasets/CustomDataset.py:64, Pillow) on one host core"""
+    import io
+    import numpy as np
+    from PIL import Image
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu, GpuInputPipeline
+    rng = np.random.default_rng(0)
+    files = []
+    for i in range(8):
+        yy, xx = np.mgrid[0:375, 0:500]
+        img = np.stack([127 + 100 * np.sin(xx / (9.0 + i) + yy / 17.0), 127 + 100 * np.cos(xx / 23.0 - i), 127 + 90 * np.sin(yy / 7.0 + xx / 31.0)], 2)
+        img = np.clip(img + rng.normal(0, 10.0, img.shape), 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="JPEG", quality=90)
+        files.append(buf.getvalue())
+    files = (files * ((batch + 7) // 8))[:batch]
+    pipe = GpuInputPipeline(DataAugmentationDINOGpu((0.08, 1.0), 224), host_fallback=False)
+    gen = torch.Generator().manual_seed(0)
+    dec = pipe.decoder.decode(files)
+    ok = all(np.array_equal(im.cpu().numpy(), np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))) for f, im in zip(files[:2], dec.images()[:2]))
+
+    def rate(fn):
+        fn()
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            fn()
+            n += 1
+        torch.cuda.synchronize()
+        return round(n * batch / (time.perf_counter() - t0), 1)
+
+    r_dec, r_all = rate(lambda: pipe.decoder.decode(files)), rate(lambda: pipe(files, generator=gen))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        Image.open(io.BytesIO(files[n % batch])).convert("RGB").load()
+        n += 1
+    r_host = round(n / (time.perf_counter() - t0), 1)
+    return {"files": f"{batch} x JPEG 500x375 q90 4:2:0, {sum(map(len, files)) // batch // 1024} KB each, no restart markers", "unit": "images/s",
+            "gpu_decode": r_dec, "gpu_decode_plus_augment": r_all, "host_pillow_decode_one_core": r_host, "decode_bit_exact_with_pillow": bool(ok),
+            "kernels": "jpeg_entropy_idct_kernel + jpeg_rgb_kernel (csrc/jpeg.hip), then csrc/augment.hip; file bytes in, float32 [B,3,224,224] out"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -625,6 +669,11 @@ def main():
         res["roofline_attention"] = aprof.summary()
         # second roofline class: the HBM-bound ScaleKD loss tail (same single-stream pass; peak = 8 TB/s spec, 6.3 achievable)
         res["roofline_hbm"] = hprof.summary(pmc_kernels)
+    if not args.no_alt and world == 1:
+        try:
+            res["input_pipeline"] = input_pipeline(args.batch)
+        except ImportError as e:   # (no Pillow on the box: the files of the measurement are encoded with it)
+            res["input_pipeline"] = {"skipped": str(e)}
     if not args.no_cpu_baseline and world == 1:
         note("timing the CPU oracle (cpu_baseline) ...")
         res["cpu_baseline"] = cpu_baseline()
