@@ -294,3 +294,27 @@ class GpuInputPipeline:
 
     def __call__(self, files, generator=None, plans=None):
         return self.aug(self.decoder.decode(files), generator=generator, plans=plans)
+
+    def iterate(self, batches, generator=None):
+        """for x in pipe.iterate(loader): ... - batch n + 1 is decoded and augmented on a side stream while the consumer (the training
+        step, on the current stream) works on batch n; one batch of look-ahead.  `batches` yields lists of files."""
+        dev = self.aug.device
+        side = torch.cuda.Stream(device=dev)
+        pending = None
+        for files in batches:
+            side.wait_stream(torch.cuda.current_stream(dev))   # (the side stream's tensors are recycled in the consumer's order)
+            with torch.cuda.stream(side):
+                out = self(files, generator=generator)
+                done = torch.cuda.Event()
+                done.record(side)
+            if pending is not None:
+                yield self._hand_over(*pending)
+            pending = (out, done)
+        if pending is not None:
+            yield self._hand_over(*pending)
+
+    def _hand_over(self, out, done):
+        cur = torch.cuda.current_stream(out.device)
+        cur.wait_event(done)
+        out.record_stream(cur)
+        return out

@@ -56,6 +56,22 @@ def special_cases():
     return out
 
 
+def container_cases():
+    """what real files carry around the scan: EXIF / ICC (multi-segment APP2) / comment segments, JFIF density, bytes behind EOI, 0xFF fill
+    in front of a marker, 16-bit quantisers (an SOF1 frame)"""
+    import warnings
+    img = picture(5, 45, 61)
+    base = encode(img, quality=85, subsampling=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        meta = encode(img, quality=85, exif=b"Exif\x00\x00MM\x00*\x00\x00\x00\x08\x00\x00", comment=b"made for a test",
+                      icc_profile=bytes(range(256)) * 300)
+    q16 = [[min(4 * v, 1000) for v in range(1, 65)], [min(7 * v, 2000) for v in range(1, 65)]]
+    return [("exif_comment_icc", meta), ("trailing_bytes", base + b"\x00\x01garbage\xff\xd8\xff"), ("fill_before_eoi", base[:-2] + b"\xff\xff\xff\xd9"),
+            ("quantisers16", encode(img, qtables=q16)), ("density", encode(img, quality=70, dpi=(300, 300))),
+            ("gray_rows", encode(picture(6, 70, 90, gray=True), quality=80, restart_marker_rows=2, comment=b"x" * 60000))]
+
+
 def unsupported_cases():
     img = picture(3, 40, 56)
     png = io.BytesIO()

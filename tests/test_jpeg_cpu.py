@@ -22,7 +22,7 @@ def test_oracle_matches_pillow_bit_for_bit():
         assert got.shape == ref.shape and np.array_equal(got, ref), name
         n += 1
     assert n == 8 * 4 * 3 * 2
-    for name, data in J.special_cases():     # optimised Huffman tables, one-row restart intervals, quality 100 on noise
+    for name, data in J.special_cases() + J.container_cases():     # optimised Huffman tables, row restart intervals, quality 100 on noise; metadata
         assert np.array_equal(O.decode(data), J.pillow_rgb(data)), name
 
 
@@ -45,7 +45,7 @@ def test_oracle_refuses_what_it_does_not_restate():
 def test_parse_jpeg_headers_and_segments():
     from PIL import Image
     from dinov2_distillation_amd.data.jpeg import parse_jpeg
-    for name, data in J.cases(sizes=((17, 23), (64, 48), (100, 3)), qualities=(75,), restarts=(0, 1, 3)) + J.special_cases():
+    for name, data in J.cases(sizes=((17, 23), (64, 48), (100, 3)), qualities=(75,), restarts=(0, 1, 3)) + J.special_cases() + J.container_cases():
         h = parse_jpeg(data)
         im = Image.open(io.BytesIO(data))
         assert (h.width, h.height) == im.size and h.ncomp == (1 if im.mode == "L" else 3), name

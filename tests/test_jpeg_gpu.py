@@ -46,6 +46,10 @@ def test_optimised_tables_long_codes_and_row_restarts():
     _decode_and_compare(J.special_cases(), chunk=12)
 
 
+def test_metadata_segments_fill_bytes_trailing_bytes_and_16_bit_quantisers():
+    _decode_and_compare(J.container_cases())
+
+
 def test_committed_fixtures_and_the_oracle():
     from oracle import jpeg_oracle as O
     fx = np.load(os.path.join(HERE, "golden", "jpeg_fixtures.npz"))
@@ -101,3 +105,18 @@ def test_input_pipeline_from_files_with_a_png_in_the_batch():
     assert torch.equal(a, b) and pipe.decoder.stats["host_decoded"] == 1
     with pytest.raises(Exception):
         GpuInputPipeline(aug, host_fallback=False)(files)
+
+
+def test_look_ahead_iterator_yields_the_same_batches_in_order():
+    from dinov2_distillation_amd.data import DataAugmentationDINOGpu, GpuInputPipeline
+    batches = [[J.encode(J.picture(10 * b + i, 64 + 8 * i, 96 - 4 * b), quality=85) for i in range(4)] for b in range(5)]
+    aug = DataAugmentationDINOGpu((0.08, 1.0), 224)
+    pipe = GpuInputPipeline(aug)
+    ref = [pipe(files, generator=torch.Generator().manual_seed(3)) for files in batches[:1]]
+    g = torch.Generator().manual_seed(3)
+    ref = [pipe(files, generator=g).clone() for files in batches]
+    g = torch.Generator().manual_seed(3)
+    seen = []
+    for x in pipe.iterate(iter(batches), generator=g):
+        seen.append((x * 1.0).clone())       # (consumer work on the current stream)
+    assert len(seen) == len(batches) and all(torch.equal(a, b) for a, b in zip(seen, ref))
