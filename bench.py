@@ -466,6 +466,11 @@ def main():
                                             "DKD_GEMM_PRECISION=f32"),
             "alt_bf16x3": (ops.PREC_BF16X3, "bf16x3 split (3 x bf16 terms per fp32 operand, 6 MFMA products, fp32 accumulate: "
                                             "fp32-level accuracy) on every GEMM of the step (forward, dgrad, weight gradients)"),
+            "alt_bf16x2": (ops.PREC_BF16X2, "bf16x2 split: each fp32 operand as the sum of TWO bf16 terms, three MFMA products, fp32 accumulate "
+                                            "(csrc/gemm_x3.hip, TERMS = 2) - the arithmetic torch.set_float32_matmul_precision('high') names "
+                                            "('each float32 number as the sum of two bfloat16 numbers'), which the reference sets (train.py:304); "
+                                            "4e-6 ... 6e-6 of an fp64 product where the exact fp32 kernel has 1e-6 ... 2e-6 (scripts/tune_x3.py); "
+                                            "DKD_GEMM_PRECISION=bf16x2"),
             "alt_bf16_operands": (ops.PREC_BF16, "operands rounded to bf16 while staged (activations and master weights stay fp32 "
                                                  "in HBM), fp32 accumulate, on every GEMM of the step incl. the teacher and the "
                                                  "weight gradients - the arithmetic class of the reference's default "
@@ -488,7 +493,7 @@ def main():
                 dta = t.item()
             alts[key] = {"gemm_precision": desc, "value": round(args.batch * world * args.steps / dta, 2), "unit": "images/s",
                          "ms_per_step": round(dta / args.steps * 1e3, 3)}
-            if key == "alt_f32_exact" and not args.no_roofline:
+            if key in ("alt_f32_exact", "alt_bf16x2") and not args.no_roofline:
                 # the exact kernel's own roofline: every launch of two more steps on one stream, HIP events per launch
                 from dinov2_distillation_amd.train import distillation_module as dm
                 n0 = len(prof.records)
@@ -505,10 +510,12 @@ def main():
                 ms_e = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
                 fl_e = sum(f for _, _, f, _ in recs)
                 ach_e = fl_e / (ms_e * 1e-3) / 1e12 if ms_e > 0 else 0.0
-                alts[key]["roofline"] = {"bound": "mfma", "achieved": round(ach_e, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": round(ach_e / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                                         "kernel": "gemm_f32_dma_kernel / gemm_f32_v2_kernel (fp32 MFMA 16x16x4), every dkd_gemm_f32 "
-                                                   "launch of the step on one stream", "launches": len(recs) // 2,
+                pk_e = MFMA_F32_PEAK_TFLOPS if key == "alt_f32_exact" else 2500.0 / 3.0   # (three bf16 products per multiply-add)
+                alts[key]["roofline"] = {"bound": "mfma", "achieved": round(ach_e, 2), "peak": round(pk_e, 1), "unit": "TFLOP/s",
+                                         "frac": round(ach_e / pk_e, 4), "traffic": None,
+                                         "kernel": ("gemm_f32_dma_kernel / gemm_f32_v2_kernel (fp32 MFMA 16x16x4)" if key == "alt_f32_exact" else
+                                                    "gemm_x3_ring_kernel<TERMS = 2> (fp32-equivalent FLOP/s against the dense bf16 peak / 3)") +
+                                                   ", every dkd_gemm_f32 launch of the step on one stream", "launches": len(recs) // 2,
                                          "avg_launch_us": round(ms_e * 1e3 / max(len(recs), 1), 2)}
             ops.GEMM_PRECISION = default_prec
     if not args.no_alt and world == 1:

@@ -185,7 +185,9 @@ __device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(fl
 __device__ __forceinline__ unsigned as_u(float f) { return __builtin_bit_cast(unsigned, f); }
 // Level by level over the fragment's four pairs (four independent chains between two dependent instructions): written pair by pair
 // the 11 instructions of a pair are one dependency chain and every one of them waits for its predecessor (SQ_WAIT_INST_ANY 33 %).
-template <bool TRUNC>
+// TERMS == 2: x ~ h + m only (16 significant bits: the arithmetic class of torch.set_float32_matmul_precision("high") - "each float32
+// number as the sum of two bfloat16 numbers" - which is what the reference sets, train.py:304); 3 VALU per value, l is left alone.
+template <bool TRUNC, int TERMS = 3>
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
     u32x4 hp, mp, lp;
     float r[8], s[8];
@@ -196,10 +198,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m
         for (int e = 0; e < 8; ++e) r[e] = x[e] - as_f(as_u(x[e]) & 0xffff0000u);
 #pragma unroll
         for (int e = 0; e < 4; ++e) mp[e] = __builtin_amdgcn_perm(as_u(r[2 * e + 1]), as_u(r[2 * e]), 0x07060302u);
+        if (TERMS == 3) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = r[e] - as_f(as_u(r[e]) & 0xffff0000u);
+            for (int e = 0; e < 8; ++e) s[e] = r[e] - as_f(as_u(r[e]) & 0xffff0000u);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lp[e] = __builtin_amdgcn_perm(as_u(s[2 * e + 1]), as_u(s[2 * e]), 0x07060302u);
+            for (int e = 0; e < 4; ++e) lp[e] = __builtin_amdgcn_perm(as_u(s[2 * e + 1]), as_u(s[2 * e]), 0x07060302u);
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) hp[e] = cvt2(x[2 * e], x[2 * e + 1]);
@@ -210,17 +214,19 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) mp[e] = cvt2(r[2 * e], r[2 * e + 1]);
+        if (TERMS == 3) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s[2 * e] = r[2 * e] - as_f(mp[e] << 16);
-            s[2 * e + 1] = r[2 * e + 1] - as_f(mp[e] & 0xffff0000u);
+            for (int e = 0; e < 4; ++e) {
+                s[2 * e] = r[2 * e] - as_f(mp[e] << 16);
+                s[2 * e + 1] = r[2 * e + 1] - as_f(mp[e] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lp[e] = cvt2(s[2 * e], s[2 * e + 1]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lp[e] = cvt2(s[2 * e], s[2 * e + 1]);
     }
     h = __builtin_bit_cast(bf16x8, hp);
     m = __builtin_bit_cast(bf16x8, mp);
-    l = __builtin_bit_cast(bf16x8, lp);
+    if (TERMS == 3) l = __builtin_bit_cast(bf16x8, lp);
 }
 
 // WGM x WGN waves, each a (32 TM) x (32 TN) tile; BM = 32 TM WGM, BN = 32 TN WGN; k-tile BK; NS ring stages.
@@ -240,8 +246,9 @@ struct Planes {
 };
 
 // CG = ConvGeomX3: the A operand is gathered from an NHWC image (implicit-GEMM convolution, see ConvRingF); NoConvX3: dense operands.
+// TERMS: 3 = bf16x3 (six products, fp32-level accuracy), 2 = bf16x2 (h + m, three products: ~2^-16 per product).
 template <int WGM, int WGN, int TM, int TN, int BK, int NS, bool A_KC, bool B_KC, int OCC, bool TRUNC, bool PIPE, bool ROWSUM, int KNOCK,
-          class CG = NoConvX3>
+          int TERMS = 3, class CG = NoConvX3>
 __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                                            long ldb, float* C, long ldc, int M, int N, int K, int kchunk,
                                                                            Epilogue epi, float* __restrict__ ws, float* __restrict__ rowsum,
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const 
                 u32x4 t = {as_u(v[0]), as_u(v[1]), as_u(v[2]), as_u(v[3])}, u = {as_u(v[4]), as_u(v[5]), as_u(v[6]), as_u(v[7])};
                 P.ah[i] = __builtin_bit_cast(bf16x8, t), P.am[i] = __builtin_bit_cast(bf16x8, u), P.al[i] = P.ah[i];
             } else {
-                split8<TRUNC>(v, P.ah[i], P.am[i], P.al[i]);
+                split8<TRUNC, TERMS>(v, P.ah[i], P.am[i], P.al[i]);
             }
         }
 #pragma unroll
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const 
                 u32x4 t = {as_u(v[0]), as_u(v[1]), as_u(v[2]), as_u(v[3])}, u = {as_u(v[4]), as_u(v[5]), as_u(v[6]), as_u(v[7])};
                 P.bh[j] = __builtin_bit_cast(bf16x8, t), P.bm[j] = __builtin_bit_cast(bf16x8, u), P.bl[j] = P.bh[j];
             } else {
-                split8<TRUNC>(v, P.bh[j], P.bm[j], P.bl[j]);
+                split8<TRUNC, TERMS>(v, P.bh[j], P.bm[j], P.bl[j]);
             }
         }
     };
@@ -321,13 +328,16 @@ __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {  // D^T: rows = n, lanes = m; smallest cross terms first
                 if (KNOCK & 2) {
-                    asm volatile("" ::"v"(P.ah[i]), "v"(P.am[i]), "v"(P.al[i]), "v"(P.bh[j]), "v"(P.bm[j]), "v"(P.bl[j]));
+                    asm volatile("" ::"v"(P.ah[i]), "v"(P.am[i]), "v"(P.bh[j]), "v"(P.bm[j]));
+                    if (TERMS == 3) asm volatile("" ::"v"(P.al[i]), "v"(P.bl[j]));
                     continue;
                 }
                 f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bh[j], P.al[i], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bl[j], P.ah[i], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bm[j], P.am[i], c, 0, 0, 0);
+                if (TERMS == 3) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bh[j], P.al[i], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bl[j], P.ah[i], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bm[j], P.am[i], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bh[j], P.am[i], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bm[j], P.ah[i], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.bh[j], P.ah[i], c, 0, 0, 0);
@@ -337,8 +347,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const 
 
     if constexpr (PIPE) {
         // one phase = the MFMAs of the current k-block from one register set + the reads and the split of the next into the other
-        constexpr int NMMA = 6 * TM * TN, NREAD = (A_KC ? 2 : 8) * TM + (B_KC ? 2 : 8) * TN;
-        constexpr int NVALU = 44 * (TM + TN) + (ROWSUM ? 8 * TM : 0);
+        constexpr int NMMA = (TERMS == 3 ? 6 : 3) * TM * TN, NREAD = (A_KC ? 2 : 8) * TM + (B_KC ? 2 : 8) * TN;
+        constexpr int NVALU = (TERMS == 3 ? 44 : 24) * (TM + TN) + (ROWSUM ? 8 * TM : 0);
         constexpr int LEAD = NMMA >= 8 ? 2 : 1, PER = (NVALU + NMMA - LEAD - 1) / (NMMA - LEAD);
         auto interleave = [&]() {  // reads first, LEAD MFMAs over their latency, then one MFMA : PER VALU
             if (KNOCK & 3) return;
@@ -354,9 +364,15 @@ __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm_x3_ring_kernel(const 
         // use is the NEXT phase's MFMAs) sinks below the hand-over's barrier into the block of its use and the phase runs its MFMAs bare
         auto pin = [&](Planes<TM, TN>& P) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(P.ah[i]), "+v"(P.am[i]), "+v"(P.al[i]));
+            for (int i = 0; i < TM; ++i) {
+                asm volatile("" : "+v"(P.ah[i]), "+v"(P.am[i]));
+                if (TERMS == 3) asm volatile("" : "+v"(P.al[i]));
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(P.bh[j]), "+v"(P.bm[j]), "+v"(P.bl[j]));
+            for (int j = 0; j < TN; ++j) {
+                asm volatile("" : "+v"(P.bh[j]), "+v"(P.bm[j]));
+                if (TERMS == 3) asm volatile("" : "+v"(P.bl[j]));
+            }
         };
         Planes<TM, TN> P0, P1;
         if (nk > 0) {
@@ -509,9 +525,9 @@ struct X3Cfg {
     static constexpr int RING = NS * (BM + BN) * BK * 4, EPI = NW * 32 * (32 * TN + 4) * 4;
     static constexpr int LDS = RING > EPI ? RING : EPI;
 
-    template <bool AKC, bool BKC, bool RSUM>
+    template <bool AKC, bool BKC, bool RSUM, int TERMS>
     static int launch_layout(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
-        auto kern = gemm_x3_ring_kernel<WGM, WGN, TM, TN, BK, NS, AKC, BKC, OCC, TRUNC, PIPE, RSUM, KNOCK>;
+        auto kern = gemm_x3_ring_kernel<WGM, WGN, TM, TN, BK, NS, AKC, BKC, OCC, TRUNC, PIPE, RSUM, KNOCK, TERMS>;
         static bool attr_done = false;  // (one flag per instantiation; a benign race: the attribute call is idempotent)
         if (!attr_done && LDS > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -526,7 +542,7 @@ struct X3Cfg {
     }
     // the gathered-A form (implicit-GEMM convolution): NT layout only
     static int launch_conv(const dkd_gemm_args* g, const ConvGeomX3& cg, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
-        auto kern = gemm_x3_ring_kernel<WGM, WGN, TM, TN, BK, NS, true, true, OCC, TRUNC, PIPE, false, KNOCK, ConvGeomX3>;
+        auto kern = gemm_x3_ring_kernel<WGM, WGN, TM, TN, BK, NS, true, true, OCC, TRUNC, PIPE, false, KNOCK, 3, ConvGeomX3>;
         if (LDS > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             if (e != hipSuccess) return (int)e;
@@ -537,13 +553,20 @@ struct X3Cfg {
         DKD_LAUNCH_CHECK();
         return DKD_OK;
     }
-    static int launch(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
-        if (g->a_layout == 0 && g->b_layout == 0) return launch_layout<true, true, false>(g, epi, splits, kchunk, vec, st);
-        if (g->a_layout == 0 && g->b_layout == 1) return launch_layout<true, false, false>(g, epi, splits, kchunk, vec, st);
+    template <int TERMS>
+    static int launch_terms(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
+        if (g->a_layout == 0 && g->b_layout == 0) return launch_layout<true, true, false, TERMS>(g, epi, splits, kchunk, vec, st);
+        if (g->a_layout == 0 && g->b_layout == 1) return launch_layout<true, false, false, TERMS>(g, epi, splits, kchunk, vec, st);
         if (g->a_layout == 1 && g->b_layout == 1)
-            return g->rowsum ? launch_layout<false, false, true>(g, epi, splits, kchunk, vec, st)
-                             : launch_layout<false, false, false>(g, epi, splits, kchunk, vec, st);
+            return g->rowsum ? launch_layout<false, false, true, TERMS>(g, epi, splits, kchunk, vec, st)
+                             : launch_layout<false, false, false, TERMS>(g, epi, splits, kchunk, vec, st);
         return DKD_ERR_UNSUPPORTED;
+    }
+    // two-term launches exist for the untuned product configurations only (KNOCK == 0)
+    static int launch(const dkd_gemm_args* g, const Epilogue& epi, int splits, int kchunk, int vec, hipStream_t st) {
+        if constexpr (KNOCK == 0)
+            if (g->precision == DKD_PREC_BF16X2) return launch_terms<2>(g, epi, splits, kchunk, vec, st);
+        return launch_terms<3>(g, epi, splits, kchunk, vec, st);
     }
 };
 

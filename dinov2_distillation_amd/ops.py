@@ -16,8 +16,9 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RED_SUM, RED_DOT, RED_SUMSQ, RED_SQDIFF, RED_DOT_SUM, RED_GELUSQ, RED_DOTGELU_SUM = 0, 1, 2, 3, 4, 5, 6
 
 _ws = {}
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
-PRECISIONS = {None: None, "f32": PREC_F32, "fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X2 = 0, 1, 2, 3
+PRECISIONS = {None: None, "f32": PREC_F32, "fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "bf16x2": PREC_BF16X2}
+SPLIT_PRECISIONS = (PREC_BF16X3, PREC_BF16X2)   # the split-precision ring kernels of csrc/gemm_x3.hip
 # process-wide default of the fp32-operand GEMMs: the bf16x3 split (csrc/gemm_x3.hip: fp32-level accuracy - 5e-7 ... 2e-6 of an fp64 product,
 # the exact kernel's own distance - at 0.77 of its time; the arithmetic class the reference's fp32 mode runs its matmuls in, train.py:304
 # torch.set_float32_matmul_precision('high')).  DKD_GEMM_PRECISION=f32: the exact v_mfma_f32_16x16x4_f32 kernels everywhere.
@@ -90,7 +91,7 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     _chk(out, "out")
     ldc = N if ldc is None else ldc
     prec = GEMM_PRECISION if precision is None else precision
-    wsb = _size("dkd_gemm_x3_workspace_bytes" if prec == PREC_BF16X3 else "dkd_gemm_f32_workspace_bytes", M, N, K, a_layout, b_layout)
+    wsb = _size("dkd_gemm_x3_workspace_bytes" if prec in SPLIT_PRECISIONS else "dkd_gemm_f32_workspace_bytes", M, N, K, a_layout, b_layout)
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     check(_GEMM32(A=_p(a2), lda=lda, B=_p(b2), ldb=ldb, C=_p(out), ldc=ldc, bias=_p(bias), colscale=_p(colscale), residual=_p(residual),
                   preact=_p(preact), workspace=_p(ws), rowsum=_p(rowsum), precision=prec,
@@ -741,7 +742,7 @@ def conv_igemm_fwd(x, w2, k, stride, pad, bias=None, out=None):
     _chk(out, "out")
     wsb = _size("dkd_conv_igemm_f32_workspace_bytes", B, H, W, C, O, k, stride, pad, 0)
     ws = workspace(wsb, x.device) if wsb else None
-    if GEMM_PRECISION == PREC_BF16X3 and CONV_X3 and _size("dkd_conv_igemm_x3_supported", B, H, W, C, O, k, stride, pad):
+    if GEMM_PRECISION in SPLIT_PRECISIONS and CONV_X3 and _size("dkd_conv_igemm_x3_supported", B, H, W, C, O, k, stride, pad):
         # the split-precision kernel with the gathered operand (what it does not take stays on the exact kernel)
         check(_lib.binding().dkd_conv_igemm_x3(_p(x), _p(w2), _p(out), _p(bias), _p(ws), B, H, W, C, O, k, stride, pad, _stream()),
               "dkd_conv_igemm_x3", (B, H, W, C, O, k, stride, pad))

@@ -44,6 +44,7 @@ int dkd_abi_version(void);
  */
 #define DKD_PREC_F32 0
 #define DKD_PREC_BF16X3 1
+#define DKD_PREC_BF16X2 3
 #define DKD_PREC_BF16 2
 typedef struct dkd_gemm_args {
     const float* A;
@@ -73,14 +74,16 @@ typedef struct dkd_gemm_args {
                         anything else: DKD_ERR_BAD_ARG */
     int32_t precision; /* DKD_PREC_F32 (exact fp32 MFMA), DKD_PREC_BF16X3 (3-way bf16 split of each fp32 operand, 6 MFMA products, fp32
                           accumulate: fp32-level accuracy; csrc/gemm_x3.hip, every layout incl. the fused bias gradient; what the Python
-                          side passes by default) or DKD_PREC_BF16 (operands rounded to bf16 while staged, fp32 accumulate: the frozen
-                          teacher's opt-in mode, NT / TN layouts).  A shape a mode does not take (reduction not a multiple of 16, or under
+                          side passes by default), DKD_PREC_BF16X2 (the same kernels with a 2-way split and 3 products: ~16 significant bits per
+                          operand, ~1e-5 of an fp64 product - the arithmetic class torch.set_float32_matmul_precision("high") names, which the
+                          reference sets at train.py:304; opt-in) or DKD_PREC_BF16 (operands rounded to bf16 while staged, fp32 accumulate: the
+                          frozen teacher's opt-in mode, NT / TN layouts).  A shape a mode does not take (reduction not a multiple of 16, or under
                           96: nothing to amortise the split over) silently runs on the exact path */
 } dkd_gemm_args;
 int dkd_gemm_f32(const dkd_gemm_args* args, void* stream);
 int dkd_gemm_f32_splits(int M, int N, int K);
 long dkd_gemm_f32_workspace_bytes(int M, int N, int K, int a_layout, int b_layout);
-/* workspace of a DKD_PREC_BF16X3 launch of this shape (>= dkd_gemm_f32_workspace_bytes: the LDS-DMA ring kernels of csrc/gemm_x3.hip
+/* workspace of a DKD_PREC_BF16X3 / DKD_PREC_BF16X2 launch of this shape (>= dkd_gemm_f32_workspace_bytes: the LDS-DMA ring kernels of csrc/gemm_x3.hip
  * plan their own K-slabs; the precision the reference's fp32 mode runs its matmuls in, train.py:304) */
 long dkd_gemm_x3_workspace_bytes(int M, int N, int K, int a_layout, int b_layout);
 

@@ -1,6 +1,6 @@
 """A/B of the bf16x3 LDS-DMA ring kernels (gemm_x3.hip, variants 31..) against the exact fp32 kernel and the older register-staged bf16x3
 kernel, per GEMM shape of the configs[1] step; error of each against an fp64 product of the same operands.
-    python scripts/tune_x3.py [f,31,32,...]   (f = exact fp32, o = old bf16x3 kernel, a = automatic x3 choice, NN = x3 variant)"""
+    python scripts/tune_x3.py [f,31,32,...]   (f = exact fp32, o = old bf16x3 kernel, a = automatic x3 choice, NN = x3 variant, 2 / 2:NN = bf16x2)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,8 @@ def arm_kw(a):
         return dict(precision=ops.PREC_BF16X3, variant=20)  # (anything outside 0 / 31..39 keeps the older paths)
     if a == "a":
         return dict(precision=ops.PREC_BF16X3, variant=0)
+    if a.startswith("2"):      # "2" / "2:31": the two-term split (bf16x2), automatic / pinned configuration
+        return dict(precision=ops.PREC_BF16X2, variant=int(a.split(":")[1]) if ":" in a else 0)
     return dict(precision=ops.PREC_BF16X3, variant=int(a))
 
 
