@@ -475,9 +475,16 @@ def main():
                                                  "in HBM), fp32 accumulate, on every GEMM of the step incl. the teacher and the "
                                                  "weight gradients - the arithmetic class of the reference's default "
                                                  "precision=16 autocast")}
+        if default_prec == ops.PREC_BF16X3:
+            modes["alt_bf16x3_wgrad_bf16x2"] = ("wgrad_x2", "the default mode with the WEIGHT-GRADIENT launches alone on the two-term split "
+                                                "(DKD_WGRAD_PRECISION=bf16x2): forward and input gradients keep the fp32-level three-term split, dW "
+                                                "carries 5e-6 of an fp64 product, un-propagated (NOTES 10.9)")
+        wgrad_prec_was = ops.WGRAD_PRECISION
         for key, (prec, desc) in modes.items():
             if prec == default_prec:
                 continue
+            if prec == "wgrad_x2":
+                ops.WGRAD_PRECISION, prec = ops.PREC_BF16X2, default_prec
             ops.GEMM_PRECISION = prec
             for _ in range(2):
                 stepper.step(batch)
@@ -517,7 +524,7 @@ def main():
                                                     "gemm_x3_ring_kernel<TERMS = 2> (fp32-equivalent FLOP/s against the dense bf16 peak / 3)") +
                                                    ", every dkd_gemm_f32 launch of the step on one stream", "launches": len(recs) // 2,
                                          "avg_launch_us": round(ms_e * 1e3 / max(len(recs), 1), 2)}
-            ops.GEMM_PRECISION = default_prec
+            ops.GEMM_PRECISION, ops.WGRAD_PRECISION = default_prec, wgrad_prec_was
     if not args.no_alt and world == 1:
         # the frozen teacher in the reference's DEFAULT precision policy (train.py:263 precision=16 == autocast; bf16 here) with
         # bf16 activations in HBM; student, projectors, losses and optimiser exact fp32 as in `value`

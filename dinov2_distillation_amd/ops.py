@@ -23,6 +23,9 @@ SPLIT_PRECISIONS = (PREC_BF16X3, PREC_BF16X2)   # the split-precision ring kerne
 # the exact kernel's own distance - at 0.77 of its time; the arithmetic class the reference's fp32 mode runs its matmuls in, train.py:304
 # torch.set_float32_matmul_precision('high')).  DKD_GEMM_PRECISION=f32: the exact v_mfma_f32_16x16x4_f32 kernels everywhere.
 GEMM_PRECISION = PRECISIONS.get(os.environ.get("DKD_GEMM_PRECISION", "bf16x3").lower(), PREC_BF16X3)
+# opt-in: a different split for the weight-gradient launches (dW = dy^T x) of the default mode only - "bf16x2": their error (5e-6 of an
+# fp64 product) lands on the gradient tensor itself and is not propagated through the network (NOTES 10.9)
+WGRAD_PRECISION = PRECISIONS.get(os.environ.get("DKD_WGRAD_PRECISION", "").lower() or None)
 
 
 _stream = _lib.stream  # the launch stream argument (ctypes binding: the current HIP stream; torch binding: taken inside the op)
@@ -91,6 +94,8 @@ def gemm(a, b, *, a_layout=0, b_layout=0, out=None, bias=None, act=ACT_NONE, col
     _chk(out, "out")
     ldc = N if ldc is None else ldc
     prec = GEMM_PRECISION if precision is None else precision
+    if precision is None and WGRAD_PRECISION is not None and a_layout == 1 and b_layout == 1 and GEMM_PRECISION == PREC_BF16X3:
+        prec = WGRAD_PRECISION
     wsb = _size("dkd_gemm_x3_workspace_bytes" if prec in SPLIT_PRECISIONS else "dkd_gemm_f32_workspace_bytes", M, N, K, a_layout, b_layout)
     ws = workspace(wsb, a.device, slot=ws_slot) if wsb else None
     check(_GEMM32(A=_p(a2), lda=lda, B=_p(b2), ldb=ldb, C=_p(out), ldc=ldc, bias=_p(bias), colscale=_p(colscale), residual=_p(residual),
