@@ -42,7 +42,15 @@ def _align16(n):
 
 
 def parse_jpeg(data):
-    """bytes -> JpegHeader; segments = [(byte offset, length, first MCU, MCU count)] relative to the start of the file"""
+    """bytes -> JpegHeader; segments = [(byte offset, length, first MCU, MCU count)] relative to the start of the file.
+    Anything the kernels do not cover, and any malformed header, raises UnsupportedJpeg."""
+    try:
+        return _parse_jpeg(data)
+    except (IndexError, ValueError) as e:     # a segment shorter than its fields, a table index out of range, ...
+        raise UnsupportedJpeg(f"malformed header ({e})") from None
+
+
+def _parse_jpeg(data):
     n = len(data)
     if n < 4 or data[0] != 0xFF or data[1] != 0xD8:
         raise UnsupportedJpeg("not a JPEG file")
@@ -149,6 +157,10 @@ def parse_jpeg(data):
         raise UnsupportedJpeg("truncated file (no marker behind the scan)")
     end, rst = int(ff[ends[0]]), ff[:ends[0]]
     total = h.mcux * h.mcuy
+    # every block takes at least two bits (a DC code and an end-of-block code): a scan too short for its frame is a truncated or corrupt
+    # file (Pillow refuses those too) - and would keep a wavefront busy decoding padding for every missing MCU
+    if 8 * end < 2 * total * (h.h0 * h.v0 + (2 if nc == 3 else 0)):
+        raise UnsupportedJpeg("the scan is shorter than its frame needs")
     if restart:
         if len(rst) != -(-total // restart) - 1:
             raise UnsupportedJpeg("restart markers do not match the restart interval")

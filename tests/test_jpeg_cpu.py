@@ -84,6 +84,25 @@ def test_parse_jpeg_refuses_other_formats():
         parse_jpeg(good[:len(good) // 2])     # truncated: no marker behind the scan
     with pytest.raises(UnsupportedJpeg):
         parse_jpeg(b"")
+    sof = good.index(b"\xff\xc0")
+    huge = bytearray(good)
+    huge[sof + 5:sof + 9] = b"\xff\xff\xff\xff"          # a 65535 x 65535 frame over a 24 x 24 picture's scan
+    with pytest.raises(UnsupportedJpeg):
+        parse_jpeg(bytes(huge))
+    # malformed headers of every kind end in UnsupportedJpeg, never in another exception: every prefix, and single corrupted header bytes
+    head = good.index(b"\xff\xda")
+    for cut in range(2, head + 14, 3):
+        with pytest.raises(UnsupportedJpeg):
+            parse_jpeg(good[:cut])
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        bad = bytearray(good)
+        bad[int(rng.integers(2, head + 12))] = int(rng.integers(0, 256))
+        try:
+            h = parse_jpeg(bytes(bad))
+        except UnsupportedJpeg:
+            continue
+        assert h.mcux * h.mcuy == sum(s[3] for s in h.segments) and h.ncomp in (1, 3) and (h.h0, h.v0) in ((1, 1), (2, 1), (2, 2))
 
 
 def test_decoder_needs_the_gpu():
