@@ -186,6 +186,11 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
     int wpos = 0;          // bytes staged so far
     unsigned prev_last = 0;
     int pos = 0;           // bits of the (unstuffed) stream consumed so far
+    unsigned w0 = 0, w1 = 0;   // the ring words under bit pos + lane and behind it
+    auto fetch = [&]() {
+        const int wi = (pos + lane) >> 5;
+        w0 = L.ring[wi & (RING / 4 - 1)], w1 = L.ring[(wi + 1) & (RING / 4 - 1)];
+    };
     int pred0 = 0, pred1 = 0, pred2 = 0;
 
     for (int m = 0; m < n_mcu; ++m) {
@@ -229,6 +234,7 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
         }
         __syncthreads();
 
+        if (m == 0) fetch();
         int bi = 0;
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci) {
@@ -241,8 +247,9 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
                 int k = 0;   // next coefficient index; 0: the block's DC difference comes first
                 while (k < 64) {
                     // (1) every lane: the 32 bits that start `lane` bits behind the read position, and what they decode to
+                    // (its two ring words were fetched as soon as `pos` was known - behind the previous walk: the LDS round trip runs
+                    // under the store phase instead of in front of the look-up)
                     const int p = pos + lane;
-                    const unsigned w0 = L.ring[(p >> 5) & (RING / 4 - 1)], w1 = L.ring[((p >> 5) + 1) & (RING / 4 - 1)];
                     const unsigned win = (unsigned)((((unsigned long long)w0 << 32 | w1) << (p & 31)) >> 32);
                     unsigned f = L.lut[ta][win >> (32 - LUT_BITS)];
                     if (k == 0) {
@@ -264,6 +271,8 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
                     } while (!(st & 0xC0C0));
                     const int off = st & 255;
                     k = st >> 8;
+                    pos += off;
+                    fetch();
                     const bool slow = (e & (F_VALUE | F_SLOW)) == F_SLOW;   // the walk ended on a long code (which advanced the offset by nothing)
                     // (3) the lanes on the chain store their coefficients
                     int dc = 0;
@@ -278,7 +287,6 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
                         const int at = (reached >> 8) + (int)((f >> 8) & 127) - 1;
                         if (at <= 63) blk[at] = (short)(k0 == 0 && lane == 0 ? dc : (int)f >> 16);
                     }
-                    pos += off;
                     if (slow) {
                         k -= 64;
                         const unsigned es = slow_symbol(L, k == 0 ? td : ta, __builtin_amdgcn_readlane(win, off));
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(64) void jpeg_entropy_idct_kernel(const unsigned ch
                         }
                         k += (es >> 8) & 127;
                         pos += es & 31;
+                        fetch();
                     }
                 }
             }
