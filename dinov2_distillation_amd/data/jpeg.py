@@ -191,9 +191,12 @@ class DecodedBatch:
 class JpegDecoderGpu:
     PINNED_SLOTS = 3
 
-    def __init__(self, device="cuda", host_fallback=False):
+    def __init__(self, device="cuda", host_fallback=False, single_segment_max_pixels=4 << 20):
+        """single_segment_max_pixels (with host_fallback only): a file WITHOUT restart markers is one sequential chain for one wavefront
+        (~25 Mpixel/s); above this many pixels Pillow on a host core (~150 Mpixel/s) is the faster decoder and takes the file."""
         self.device = torch.device(device)
         self.host_fallback = host_fallback
+        self.single_segment_max_pixels = single_segment_max_pixels
         self.stats = dict(images=0, host_decoded=0, segments=0)
         self._ring, self._slot = [None] * self.PINNED_SLOTS, 0
 
@@ -216,7 +219,10 @@ class JpegDecoderGpu:
         heads, host = [], {}
         for b, f in enumerate(files):
             try:
-                heads.append(parse_jpeg(f))
+                h = parse_jpeg(f)
+                if self.host_fallback and len(h.segments) == 1 and h.width * h.height > self.single_segment_max_pixels:
+                    raise UnsupportedJpeg("a multi-megapixel file without restart markers")
+                heads.append(h)
             except UnsupportedJpeg:
                 if not self.host_fallback:
                     raise

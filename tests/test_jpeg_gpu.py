@@ -77,6 +77,14 @@ def test_other_formats_raise_or_take_the_counted_host_route():
     for (name, data), im in zip(mixed, dec.decode([d for _, d in mixed]).images()):
         assert np.array_equal(im.cpu().numpy(), J.pillow_rgb(data)), name
     assert dec.stats == dict(images=7, host_decoded=4, segments=3)
+    # a large file without restart markers is one long chain for one wavefront: with the host route allowed it goes to Pillow, the same
+    # picture with restart markers stays on the GPU
+    big = J.picture(77, 300, 400)
+    plain, rows = J.encode(big, quality=85), J.encode(big, quality=85, restart_marker_rows=1)
+    dec = JpegDecoderGpu(host_fallback=True, single_segment_max_pixels=100_000)
+    for data, im in zip((plain, rows), dec.decode([plain, rows]).images()):
+        assert np.array_equal(im.cpu().numpy(), J.pillow_rgb(data))
+    assert dec.stats["host_decoded"] == 1 and dec.stats["segments"] > 10
 
 
 def test_decoded_batch_feeds_the_augmentation_pipeline_in_place():
