@@ -686,8 +686,8 @@ def main():
     if not args.no_alt and world == 1:
         try:
             res["input_pipeline"] = input_pipeline(args.batch)
-        except ImportError as e:   # (no Pillow on the box: the files of the measurement are encoded with it)
-            res["input_pipeline"] = {"skipped": str(e)}
+        except Exception as e:   # (e.g. no Pillow on the box: the files of the measurement are encoded with it) - never lose the line over it
+            res["input_pipeline"] = {"skipped": f"{type(e).__name__}: {e}"}
     if not args.no_cpu_baseline and world == 1:
         note("timing the CPU oracle (cpu_baseline) ...")
         res["cpu_baseline"] = cpu_baseline()
